@@ -1,0 +1,90 @@
+/* nerfmae_hip.h -- C ABI of libnerfmae_hip.so: the MI355X (gfx950) kernels of the NeRF-MAE 3-D Swin MAE
+ * pre-training hot path (reference class SwinTransformer_MAE3D_New, nerf_mae/model/mae/swin_mae3d.py:1067-1599).
+ *
+ * The reference has no FFI on this path -- every op is a stock PyTorch call.  This header is therefore
+ * the native-op surface a maintainer would bind in place of those calls (INTEGRATION.md shows the ctypes / pybind
+ * stubs); each entry cites the reference op it replaces.  Conventions:
+ *   - plain device pointers + sizes, no torch types; all launches are asynchronous on `stream` (a hipStream_t);
+ *   - return 0 on success, a hipError_t (>0) or a negative argument-error code otherwise (nmh_error_string);
+ *   - `dt`: storage/compute type of activations and packed weights: 0 = fp32 (exact fp32 MFMA; the 1e-3-parity
+ *     mode), 1 = bf16 (bf16 MFMA, fp32 accumulate).  Parameters, gradients and statistics are always fp32.
+ *   - activations are channels-last token/voxel-major matrices [rows, C]; rows of a (B,A0,A1,A2,C) volume are
+ *     ((b*A0+a0)*A1+a1)*A2+a2 (A2 fastest) -- the reference's (B,H,W,D,C) order;
+ *   - `wm` points to 10 host ints {B, H, W, D, PH, PW, PD, s0, s1, s2}: token grid, grid padded to multiples of 4,
+ *     effective cyclic shifts (0 where window >= padded size; swin_mae3d.py:62-81).
+ * Every line below that starts with NMH_API is parsed by the Python binding and by tests/test_capi_symbols.py.
+ */
+#ifndef NERFMAE_HIP_H
+#define NERFMAE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define NMH_API __attribute__((visibility("default")))
+
+NMH_API int nmh_version(void);
+NMH_API const char* nmh_error_string(int code);
+
+/* C[M,N] = epi(A[M,K] . W[N,K]^T): replaces F.linear (swin_mae3d.py:108,173; torchvision MLP :352-358; PatchMerging.reduction
+ * :413), the patch conv as GEMM (:1120-1126), ConvTranspose3d k=s as GEMM (unetr_block.py:151-158) and 1x1x1 convs (:52-55).
+ * epilogue order: +bias[N]; act 1: C2=pre-activation, exact-erf GELU; act 2: *= gelu'(C2); *= rowscale[row/rows_per_scale]
+ * (stochastic depth, :367-368); += resid; accumulate: += C.  C, C2, resid share ldc. */
+NMH_API int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* C, int64_t ldc, const float* bias, int act, void* C2, const void* resid, const float* rowscale, int rows_per_scale, int accumulate, void* stream);
+/* dW[N,K] += sum_m A[m,N]*rowscale . B[m,K]  (fp32 atomics): weight gradients of the ops above.
+ * omode 0: dW[n*ldo+k]; omode 2: ConvTranspose3d weight [Cin=K][Cout=p0][k3=p1] with n = tap*Cout+co. */
+NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale, int omode, int64_t ldo, int p0, int p1, void* stream);
+/* Y[(b,z,y,x)][Cout] (+)= conv3d(k=3,pad=1) of channels-last X with packed weights [Cout][27][Cin] (nn.Conv3d in
+ * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout]. */
+NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+/* dW[Cout][Cin][3][3][3] (PyTorch layout, fp32) += conv weight gradient */
+NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+
+/* LayerNorm eps over the last dim (swin_mae3d.py:341,351,388,1128) with the surrounding data movement folded in:
+ * src_mode 0 rows as-is (+ optional patch-embed post-ops: + pos[tok], masked tokens <- mask_token; :1459-1463,1375-1380),
+ * src_mode 1 output in window order (pad -> roll -> partition, :62-101; pad rows are zeros),
+ * src_mode 2 patch-merge gather of 8 tokens -> 8C row (:390-402).  mean/rstd are saved per token (modes 0,1) / row (2). */
+NMH_API int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C, const int* wm, const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, void* stream);
+NMH_API int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* stream);
+/* out[tok] = x[tok] + rowscale[b]*yw[window_row(tok)]: window reverse + un-roll + un-pad (:176-196) + residual + stochastic depth */
+NMH_API int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream);
+/* dyw[window_row] = rowscale[b]*dx[tok] (0 for pad rows): adjoint of the above */
+NMH_API int nmh_window_gather_scale(int dt, const void* dx, void* dyw, const float* rowscale, int C, const int* wm, void* stream);
+/* softmax(q k^T / sqrt(32) + bias_table[rel_index] + shift_mask(-100)) v per (window, head): swin_mae3d.py:109-172, 200-211.
+ * qkv [windows*64, 3C] window-ordered ([q|k|v], head-major), out [windows*64, C], lse [windows*heads*64]. head_dim must be 32. */
+NMH_API int nmh_window_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const int* wm, void* stream);
+NMH_API int nmh_window_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C, const int* wm, void* stream);
+
+/* InstanceNorm3d (eps, no affine, biased var) + LeakyReLU(slope) + residual over channels-last [B][V][C] (unetr_block.py:57-71).
+ * stats[b][c] = {mean, rstd}; scratch/sums: fp64 [B][C][2].  rmode 0: lrelu(IN(x)); 1: lrelu(IN(x)+r); 2: lrelu(IN(x)+IN(r)). */
+NMH_API int nmh_instnorm_stats(int dt, const void* x, float* stats, double* scratch, int B, int64_t V, int C, float eps, void* stream);
+NMH_API int nmh_instnorm_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, int64_t V, int C, float slope, void* stream);
+NMH_API int nmh_instnorm_bwd_reduce(int dt, const void* dout, const void* out, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, double* sums, double* sums_r, int B, int64_t V, int C, float slope, void* stream);
+NMH_API int nmh_instnorm_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r, const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, int64_t V, int C, float slope, void* stream);
+
+/* im2row of the 4x4x4 stride-4 patch conv input: x fp32 (B,4,R,R,R) -> A[(b,z,y,x)][256] (swin_mae3d.py:1120-1126) */
+NMH_API int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream);
+/* ConvTranspose3d(k=stride) pixel shuffle + bias + channel concat with the skip (unetr_block.py:193-198) and its adjoint */
+NMH_API int nmh_upconv_shuffle_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, void* stream);
+NMH_API int nmh_upconv_shuffle_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip, void* stream);
+/* UnetOutBlock 1x1 conv (Cd->4) fused with forward_loss (swin_mae3d.py:1513-1549).  target fp32 (B,4,R,R,R); extents [B][3]
+ * valid voxels per axis (replaces the pad_tensor ones-mask, torch_utils.py:56-90); tokmask [g^3] 1 = removed token.
+ * sums fp64[4] = {sum_rgb, n_occ, sum_alpha, n_removed}; losses fp32[3] = {loss, loss_rgb, loss_alpha}; pred optional (B,4,R,R,R). */
+NMH_API int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, double* sums, float* losses, float* pred, void* stream);
+NMH_API int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, const double* sums, void* dd0, void* dpred8, float* dWout, float* dbout, void* stream);
+NMH_API int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream);
+NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream);
+NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
+
+/* fp32 master weights -> compute-dtype GEMM operand layouts, one launch for the whole model.  descs: device array of
+ * {const float* src; void* dst; int mode; int d0,d1,d2; int64 n} (40 bytes, see kernels.hpp PackDesc), one block per 1024 dst elements. */
+NMH_API int nmh_pack_weights(int dt, const void* descs_dev, const int* blk2desc_dev, const int64_t* blkstart_dev, int nblocks, void* stream);
+/* clip_grad_norm_ + AdamW (run_swin_mae3d.py:588-592,665-668) over the flat fp32 parameter buffer; hyper (device fp32[7]) =
+ * {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t}; coef (device) = min(1, max_norm/(norm+1e-6)). */
+NMH_API int nmh_grad_sqnorm(const float* g, int64_t n, double* acc, void* stream);
+NMH_API int nmh_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, void* stream);
+NMH_API int nmh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

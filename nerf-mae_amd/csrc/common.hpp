@@ -1,0 +1,132 @@
+// Shared device primitives for the gfx950 (CDNA4, wave64) kernels of the NeRF-MAE hot path.
+// Everything here is written for gfx950 only: 16x16 MFMA fragments (layouts pinned on hardware by
+// tools/probe/probe_layouts.hip), 128-byte swizzled LDS rows read with ds_read_b128, and
+// ds_read_b64_tr_b16 transpose reads for the weight-gradient (contraction-major) operands.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define NMH_DT_F32 0
+#define NMH_DT_BF16 1
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);  // round-to-nearest-even
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for f32); pointers must be 16-B aligned.
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    uint4 u = *reinterpret_cast<const uint4*>(p);
+    unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// ---- MFMA fragments: one "k-step" = 32 contraction elements for both dtypes -------------------
+// slot (g = lane>>4, j = 0..7) of lane (i = lane&15) holds A[i][slot] / B[slot][i]; C: col = lane&15,
+// row = 4*(lane>>4)+r.  bf16: one v_mfma_f32_16x16x32_bf16; f32: eight exact v_mfma_f32_16x16x4_f32.
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { float v[8]; };
+
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// ---- LDS tiles with 128-byte rows, 16-byte chunks XOR-swizzled by (row>>1)&7 ---------------------
+// bf16 row = 64 elements (two k-steps), f32 row = 32 elements (one k-step).
+template <typename T> struct Row128 { static constexpr int KT = 128 / sizeof(T); static constexpr int KSTEPS = KT / 32; };
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// read the k-step-s fragment of `row` (this lane's group g) from a swizzled tile at byte base `lds`
+__device__ __forceinline__ Frag<bf16_t> lds_frag(const char* lds, int row, int s, int g, bf16_t*) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(lds + swz_off(row, s * 4 + g));
+  return f;
+}
+__device__ __forceinline__ Frag<float> lds_frag(const char* lds, int row, int /*s*/, int g, float*) {
+  Frag<float> f;
+  float4 a = *reinterpret_cast<const float4*>(lds + swz_off(row, 2 * g));
+  float4 b = *reinterpret_cast<const float4*>(lds + swz_off(row, 2 * g + 1));
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+
+// ---- contraction-major ("transposed") fragments for the TN / wgrad kernels ------------------------
+// The LDS tile is stored as loaded from memory: [m (contraction)][cols], row stride RS bytes.
+// k-step covers 32 contraction rows m0..m0+31; slot (g,j): m = m0 + 4g + j (j<4), m0 + 16 + 4g + (j-4).
+// Both operands use the same slot->m map, so the MFMA sums matching m.  (probe: tr-read semantics)
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(__attribute__((address_space(3))) char*)p);
+}
+__device__ __forceinline__ Frag<bf16_t> lds_frag_t(const char* tile, int RS, int m0, int col0, int lane, bf16_t*) {
+  const int g = lane >> 4, p = lane & 15;
+  const char* a = tile + (m0 + 4 * g + (p >> 2)) * RS + (col0 + (p & 3) * 4) * 2;
+  bf16x4 lo = ds_read_tr16(a);
+  bf16x4 hi = ds_read_tr16(a + 16 * RS);
+  Frag<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+__device__ __forceinline__ Frag<float> lds_frag_t(const char* tile, int RS, int m0, int col0, int lane, float*) {
+  const int g = lane >> 4, i = lane & 15;
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int m = m0 + 4 * g + (j & 3) + (j >> 2) * 16;
+    f.v[j] = *reinterpret_cast<const float*>(tile + m * RS + (col0 + i) * 4);
+  }
+  return f;
+}
+
+// ---- misc ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+#define NMH_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

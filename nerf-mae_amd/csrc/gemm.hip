@@ -1,0 +1,456 @@
+// MFMA GEMM engine for the NeRF-MAE hot path (gfx950).
+//
+//  gemm_nt : C[M,N] = epi( A[M,K] . B[N,K]^T )       A rows either direct or the implicit-GEMM view of a
+//            3x3x3 convolution over a channels-last (B,D,H,W,Cin) volume (K = 27*Cin, zero padding).
+//            Used for every Linear forward/dgrad (SURVEY O1,O4,O5,O6,O8), the 1x1 convs and the
+//            3x3x3 decoder convs forward + dgrad (O10; dgrad = same kernel, flipped/transposed pack).
+//  gemm_tn : dW[N,K] += sum_m A[m,N] . B[m,K]         weight gradients (contraction-major operands staged
+//            as loaded, fragments via ds_read_b64_tr_b16), split over m with fp32 atomics; B rows direct
+//            or the conv-tap gather; output index remapped to PyTorch parameter layouts.
+//
+// Both are templated on the storage type: bf16 (v_mfma_f32_16x16x32_bf16) and f32 (exact
+// v_mfma_f32_16x16x4_f32) share all indexing, so the f32 build is the 1e-3-parity mode of the same code.
+#include "common.hpp"
+#include "kernels.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// fast unsigned division by a runtime constant (n < 2^31), host-built
+// ------------------------------------------------------------------------------------------------
+FDiv make_fdiv(unsigned d) {
+  FDiv f;
+  f.d = d;
+  if (d <= 1) { f.M = 0; f.sh = -1; return f; }
+  int cl = 0;
+  while ((1u << cl) < d) ++cl;
+  unsigned long long p2 = 1ull << (31 + cl);
+  f.M = (unsigned)((p2 + d - 1) / d);
+  f.sh = cl - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FDiv& f) { return f.sh < 0 ? n : (__umulhi(n, f.M) >> f.sh); }
+
+// ------------------------------------------------------------------------------------------------
+// A-row providers for gemm_nt.  Row m of the GEMM = (sample b = blockIdx.z, local row).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct ADirect {
+  const T* A; long lda; long rows_per_z;  // rows_per_z = M when gridDim.z == 1
+  struct Row { const T* p; };
+  struct Kst { int k; bool ok; };
+  __device__ __forceinline__ void init_row(Row& r, int m, int M) const {
+    r.p = (m < M) ? A + ((long)blockIdx.z * rows_per_z + m) * lda : nullptr;
+  }
+  __device__ __forceinline__ Kst init_k(int k, int K) const { return Kst{k, k < K}; }
+  __device__ __forceinline__ uint4 load(const Row& r, const Kst& ks) const {
+    if (r.p == nullptr || !ks.ok) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(r.p + ks.k);
+  }
+};
+
+// implicit-GEMM view of conv3d k=3 pad=1 over channels-last X[(b*D+z)*H+y)*W+x][Cin]; k = tap*Cin + ci,
+// tap = (dz+1)*9 + (dy+1)*3 + (dx+1)
+template <typename T> struct AConv3 {
+  const T* X; int Cin, D, H, W; FDiv dW, dH, dC;
+  struct Row { long vox; int z, y, x; bool ok; };
+  struct Kst { int dz, dy, dx, ci; long off; bool ok; };
+  __device__ __forceinline__ void init_row(Row& r, int m, int M) const {
+    r.ok = m < M;
+    unsigned q = fdiv((unsigned)m, dW);
+    r.x = m - q * W;
+    unsigned q2 = fdiv(q, dH);
+    r.y = q - q2 * H;
+    r.z = q2;
+    r.vox = (long)blockIdx.z * ((long)D * H * W) + m;
+  }
+  __device__ __forceinline__ Kst init_k(int k, int K) const {
+    Kst s;
+    s.ok = k < K;
+    int tap = (int)fdiv((unsigned)k, dC);
+    s.ci = k - tap * Cin;
+    int t9 = tap / 9, r9 = tap - t9 * 9, t3 = r9 / 3;
+    s.dz = t9 - 1; s.dy = t3 - 1; s.dx = r9 - t3 * 3 - 1;
+    s.off = ((long)s.dz * H + s.dy) * W + s.dx;
+    return s;
+  }
+  __device__ __forceinline__ uint4 load(const Row& r, const Kst& s) const {
+    int z = r.z + s.dz, y = r.y + s.dy, x = r.x + s.dx;
+    bool ok = r.ok && s.ok && (unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    if (!ok) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(X + (r.vox + s.off) * Cin + s.ci);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// epilogue (runtime-flagged, wave-uniform branches); operates on 8 consecutive columns
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams& ep, long grow, int gcol, float (&v)[8]) {
+  if (ep.bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += ep.bias[gcol + j];
+  }
+  const long o = grow * ep.ldc + gcol;
+  if (ep.act == 1) {
+    Vec8<T>::store((T*)ep.C2 + o, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+  } else if (ep.act == 2) {
+    float a[8];
+    Vec8<T>::load((const T*)ep.C2 + o, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+  }
+  if (ep.rowscale) {
+    float s = ep.rowscale[grow / ep.rows_per_scale];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= s;
+  }
+  if (ep.resid) {
+    float a[8];
+    Vec8<T>::load((const T*)ep.resid + o, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += a[j];
+  }
+  if (ep.accumulate) {
+    float a[8];
+    Vec8<T>::load((const T*)ep.C + o, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += a[j];
+  }
+  Vec8<T>::store((T*)ep.C + o, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt kernel: 256 threads = 4 waves stacked along M, each wave (16*MT) x (16*NT); WG tile (64*MT) x (16*NT)
+// LDS: two stages of swizzled 128-byte rows (A: 64*MT rows, B: 16*NT rows); register prefetch of tile t+1
+// overlaps the MFMAs of tile t (one barrier per K tile); epilogue restaged through LDS for 16-B row stores.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MT, int NT, class AL>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict__ Bw, long ldb, int M, int N, int K, EpiParams ep) {
+  constexpr int BM = 64 * MT, BN = 16 * NT, KT = Row128<T>::KT, KS = Row128<T>::KSTEPS, CE = 16 / (int)sizeof(T);
+  constexpr int AR = BM / 32, BR = (BN + 31) / 32, STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int lc = tid & 7, lr = tid >> 3;
+
+  typename AL::Row arow[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) al.init_row(arow[i], m0 + lr + 32 * i, M);
+  const T* brow[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    int n = n0 + lr + 32 * i;
+    brow[i] = (lr + 32 * i < BN && n < N) ? Bw + (long)n * ldb : nullptr;
+  }
+  uint4 areg[AR], breg[BR];
+  auto gload = [&](int kt) {
+    const int k = kt * KT + lc * CE;
+    typename AL::Kst ks = al.init_k(k, K);
+#pragma unroll
+    for (int i = 0; i < AR; ++i) areg[i] = al.load(arow[i], ks);
+#pragma unroll
+    for (int i = 0; i < BR; ++i) breg[i] = (brow[i] && k < K) ? *reinterpret_cast<const uint4*>(brow[i] + k) : make_uint4(0, 0, 0, 0);
+  };
+  auto sstore = [&](int st) {
+    char* As = smem + st * STAGE;
+    char* Bs = As + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *reinterpret_cast<uint4*>(As + swz_off(lr + 32 * i, lc)) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      if (lr + 32 * i < BN) *reinterpret_cast<uint4*>(Bs + swz_off(lr + 32 * i, lc)) = breg[i];
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + KT - 1) / KT;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + BM * 128;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      Frag<T> bf[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bf[b] = lds_frag(Bs, b * 16 + li, s, g, (T*)nullptr);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        Frag<T> af = lds_frag(As, wave * 16 * MT + a * 16 + li, s, g, (T*)nullptr);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) mma(acc[a][b], af, bf[b]);
+      }
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: per wave, one 16-row m-tile at a time through a private LDS slab ----
+  constexpr int SLD = BN + 4;
+  float* stg = reinterpret_cast<float*>(smem) + wave * 16 * SLD;
+  const long zrow = (long)blockIdx.z * M;
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stg[(4 * g + r) * SLD + b * 16 + li] = acc[a][b][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int it = lane; it < 16 * (BN / 8); it += 64) {
+      const int row = it / (BN / 8), cc = it - row * (BN / 8);
+      const int grow = m0 + wave * 16 * MT + a * 16 + row, gcol = n0 + cc * 8;
+      if (grow < M && gcol < N) {
+        float v[8];
+        float4 x0 = *reinterpret_cast<const float4*>(stg + row * SLD + cc * 8);
+        float4 x1 = *reinterpret_cast<const float4*>(stg + row * SLD + cc * 8 + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        epilogue8<T>(ep, zrow + grow, gcol, v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename T, int MT, int NT, class AL>
+static int launch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st) {
+  constexpr int BM = 64 * MT, BN = 16 * NT;
+  constexpr int lds_main = 2 * (BM + BN) * 128, lds_epi = 4 * 16 * (BN + 4) * 4;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch);
+  static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, MT, NT, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<T, MT, NT, AL>), grid, dim3(256), lds, st, al, (const T*)Bw, ldb, M, N, K, ep);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, class AL>
+static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st) {
+  if (N % 8 != 0 || K % 8 != 0) return -2;
+  const int t16 = (N + 15) / 16;
+  if (t16 <= 3) return launch_nt<T, 4, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  if (t16 == 4) return launch_nt<T, 4, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  if (t16 % 8 == 0 || t16 > 12) {
+    if (M >= 4096) return launch_nt<T, 4, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    return launch_nt<T, 2, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  }
+  if (M >= 4096) return launch_nt<T, 4, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  return launch_nt<T, 2, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+}
+
+int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st) {
+  if (dt == NMH_DT_BF16) {
+    ADirect<bf16_t> al{(const bf16_t*)A, lda, (long)M};
+    return dispatch_nt<bf16_t>(al, Bw, ldb, M, N, K, 1, ep, st);
+  }
+  ADirect<float> al{(const float*)A, lda, (long)M};
+  return dispatch_nt<float>(al, Bw, ldb, M, N, K, 1, ep, st);
+}
+
+int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st) {
+  const int M = D * H * W, K = 27 * Cin;
+  if (dt == NMH_DT_BF16) {
+    AConv3<bf16_t> al{(const bf16_t*)X, Cin, D, H, W, make_fdiv(W), make_fdiv(H), make_fdiv(Cin)};
+    return dispatch_nt<bf16_t>(al, Wp, K, M, Cout, K, B, ep, st);
+  }
+  AConv3<float> al{(const float*)X, Cin, D, H, W, make_fdiv(W), make_fdiv(H), make_fdiv(Cin)};
+  return dispatch_nt<float>(al, Wp, K, M, Cout, K, B, ep, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn: dW[n][k] += sum_m A[m][n] * rs(m) * B[m][k]
+// WG = 4 waves (2x2), wave tile (16*NTW) x (16*KTW); chunk = 64 contraction rows per barrier.
+// grid = (n tiles, k tiles, m splits).  Output via OMap (row,col)->element offset, fp32 atomicAdd.
+// ------------------------------------------------------------------------------------------------
+struct BDirectTN {
+  long ldb;
+  template <typename T> __device__ __forceinline__ uint4 load(const T* B, long mglob, int k, int /*K*/, const TnGeom&) const {
+    return *reinterpret_cast<const uint4*>(B + mglob * ldb + k);
+  }
+};
+struct BConv3TN {
+  // B[m][k] = X[voxel(m)+tap(k)][ci(k)] with zero padding; m is a global voxel index over (b,z,y,x)
+  template <typename T> __device__ __forceinline__ uint4 load(const T* X, long mglob, int k, int /*K*/, const TnGeom& gm) const {
+    unsigned tap = fdiv((unsigned)k, gm.dC);
+    int ci = k - (int)tap * gm.Cin;
+    int t9 = tap / 9, r9 = tap - t9 * 9, t3 = r9 / 3;
+    int dz = t9 - 1, dy = t3 - 1, dx = r9 - t3 * 3 - 1;
+    unsigned b = fdiv((unsigned)mglob, gm.dV);
+    unsigned ml = (unsigned)mglob - b * gm.V;
+    unsigned q = fdiv(ml, gm.dW);
+    int x = ml - q * gm.W + dx;
+    unsigned q2 = fdiv(q, gm.dH);
+    int y = q - q2 * gm.H + dy, z = (int)q2 + dz;
+    if ((unsigned)z >= (unsigned)gm.D || (unsigned)y >= (unsigned)gm.H || (unsigned)x >= (unsigned)gm.W) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(X + (mglob + ((long)dz * gm.H + dy) * gm.W + dx) * gm.Cin + ci);
+  }
+};
+
+__device__ __forceinline__ long omap_index(const TnGeom& gm, int n, int k) {
+  switch (gm.omode) {
+    case 1: {  // conv3 weight [Cout][Cin][27]: n = co, k = tap*Cin + ci
+      unsigned tap = fdiv((unsigned)k, gm.dC);
+      int ci = k - (int)tap * gm.Cin;
+      return ((long)n * gm.Cin + ci) * 27 + tap;
+    }
+    case 2: {  // convT weight [Cin][Cout][k3]: n = tap*Cout + co (tap = n / Cout), k = ci ; gm.Cin := Cout, gm.V := k3
+      unsigned tap = fdiv((unsigned)n, gm.dC);
+      int co = n - (int)tap * gm.Cin;
+      return ((long)k * gm.Cin + co) * gm.V + tap;
+    }
+    default: return (long)n * gm.ldo + k;
+  }
+}
+
+template <int X> struct OddRS { static constexpr int v = ((X + 31) / 32 % 2 == 1) ? (X + 31) / 32 * 32 : ((X + 31) / 32 + 1) * 32; };
+
+template <typename T, int NTW, int KTW, class BL>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, long lda, const T* __restrict__ Bm, BL bl, float* __restrict__ Out,
+                                                       long Mtot, int N, int K, int m_per_split, const float* __restrict__ rowscale, int rows_per_scale, TnGeom gm) {
+  constexpr int BNW = 32 * NTW, BKW = 32 * KTW, CH = 64, CE = 16 / (int)sizeof(T);
+  constexpr int RSA = OddRS<BNW * (int)sizeof(T)>::v, RSB = OddRS<BKW * (int)sizeof(T)>::v;
+  constexpr int CPA = BNW / CE, CPB = BKW / CE;          // 16-B chunks per row
+  constexpr int IA = (CH * CPA + 255) / 256, IB = (CH * CPB + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char sA[CH * RSA];
+  __shared__ __attribute__((aligned(16))) char sB[CH * RSB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave >> 1, wk = wave & 1, g = lane >> 4, li = lane & 15;
+  const int n0 = blockIdx.x * BNW, k0 = blockIdx.y * BKW;
+  const long mbeg = (long)blockIdx.z * m_per_split;
+  long mend = mbeg + m_per_split;
+  if (mend > Mtot) mend = Mtot;
+
+  f32x4 acc[NTW][KTW];
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < KTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[IA], rb[IB];
+  auto gload = [&](long mc) {
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      int it = tid + 256 * i, r = it / CPA, c = it - r * CPA;
+      long m = mc + r;
+      int n = n0 + c * CE;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (it < CH * CPA && m < mend && n < N) {
+        ra[i] = *reinterpret_cast<const uint4*>(A + m * lda + n);
+        if (rowscale) {
+          float s = rowscale[m / rows_per_scale];
+          float v[8];
+          if constexpr (sizeof(T) == 2) {
+            unsigned w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[0] = __uint_as_float(w[q] << 16) * s; v[1] = __uint_as_float(w[q] & 0xffff0000u) * s;
+              w[q] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            }
+            ra[i] = make_uint4(w[0], w[1], w[2], w[3]);
+          } else {
+            ra[i].x = __float_as_uint(__uint_as_float(ra[i].x) * s); ra[i].y = __float_as_uint(__uint_as_float(ra[i].y) * s);
+            ra[i].z = __float_as_uint(__uint_as_float(ra[i].z) * s); ra[i].w = __float_as_uint(__uint_as_float(ra[i].w) * s);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      int it = tid + 256 * i, r = it / CPB, c = it - r * CPB;
+      long m = mc + r;
+      int k = k0 + c * CE;
+      rb[i] = (it < CH * CPB && m < mend && k < K) ? bl.template load<T>(Bm, m, k, K, gm) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      int it = tid + 256 * i, r = it / CPA, c = it - r * CPA;
+      if (it < CH * CPA) *reinterpret_cast<uint4*>(sA + r * RSA + c * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      int it = tid + 256 * i, r = it / CPB, c = it - r * CPB;
+      if (it < CH * CPB) *reinterpret_cast<uint4*>(sB + r * RSB + c * 16) = rb[i];
+    }
+  };
+
+  if (mbeg < mend) gload(mbeg);
+  for (long mc = mbeg; mc < mend; mc += CH) {
+    __syncthreads();  // previous chunk fully consumed
+    sstore();
+    __syncthreads();
+    if (mc + CH < mend) gload(mc + CH);
+#pragma unroll
+    for (int s = 0; s < CH / 32; ++s) {
+      Frag<T> bf[KTW];
+#pragma unroll
+      for (int b = 0; b < KTW; ++b) bf[b] = lds_frag_t(sB, RSB, s * 32, (wk * KTW + b) * 16, lane, (T*)nullptr);
+#pragma unroll
+      for (int a = 0; a < NTW; ++a) {
+        Frag<T> af = lds_frag_t(sA, RSA, s * 32, (wn * NTW + a) * 16, lane, (T*)nullptr);
+#pragma unroll
+        for (int b = 0; b < KTW; ++b) mma(acc[a][b], af, bf[b]);
+      }
+    }
+  }
+  // acc[a][b][r]: row n = n0 + (wn*NTW+a)*16 + 4g + r, col k = k0 + (wk*KTW+b)*16 + li
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < KTW; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n = n0 + (wn * NTW + a) * 16 + 4 * g + r, k = k0 + (wk * KTW + b) * 16 + li;
+        if (n < N && k < K) atomicAdd(Out + omap_index(gm, n, k), acc[a][b][r]);
+      }
+}
+
+template <typename T, int NTW, int KTW, class BL>
+static int launch_tn(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, const float* rs, int rps, const TnGeom& gm, hipStream_t st) {
+  constexpr int BNW = 32 * NTW, BKW = 32 * KTW;
+  int gx = (N + BNW - 1) / BNW, gy = (K + BKW - 1) / BKW;
+  long want = 2048 / ((long)gx * gy);  // aim for ~2k workgroups
+  if (want < 1) want = 1;
+  long mps = (Mtot + want - 1) / want;
+  mps = (mps + 63) / 64 * 64;
+  if (mps < 256) mps = 256;
+  int gz = (int)((Mtot + mps - 1) / mps);
+  hipLaunchKernelGGL((gemm_tn_kernel<T, NTW, KTW, BL>), dim3(gx, gy, gz), dim3(256), 0, st, (const T*)A, lda, (const T*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, class BL>
+static int dispatch_tn(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, const float* rs, int rps, const TnGeom& gm, hipStream_t st) {
+  if (K % 8 != 0 || lda % 8 != 0) return -2;  // N may be ragged: A rows are padded to lda, output guarded by n < N
+  if (N <= 48) return launch_tn<T, 2, 3, BL>(A, lda, Bm, bl, Out, Mtot, N, K, rs, rps, gm, st);   // 64 x 96 tile (N padded)
+  return launch_tn<T, 3, 3, BL>(A, lda, Bm, bl, Out, Mtot, N, K, rs, rps, gm, st);                  // 96 x 96 tile
+}
+
+int k_gemm_tn(int dt, const void* A, long lda, const void* Bm, long ldb, float* Out, long M, int N, int K, const float* rowscale, int rows_per_scale, const TnGeom& gm, hipStream_t st) {
+  BDirectTN bl{ldb};
+  if (dt == NMH_DT_BF16) return dispatch_tn<bf16_t>(A, lda, Bm, bl, Out, M, N, K, rowscale, rows_per_scale, gm, st);
+  return dispatch_tn<float>(A, lda, Bm, bl, Out, M, N, K, rowscale, rows_per_scale, gm, st);
+}
+
+int k_conv3_tn(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st) {
+  TnGeom gm{};
+  gm.omode = 1; gm.Cin = Cin; gm.D = D; gm.H = H; gm.W = W; gm.V = (unsigned)(D * H * W);
+  gm.dC = make_fdiv(Cin); gm.dW = make_fdiv(W); gm.dH = make_fdiv(H); gm.dV = make_fdiv(gm.V);
+  BConv3TN bl;
+  long M = (long)B * D * H * W;
+  if (dt == NMH_DT_BF16) return dispatch_tn<bf16_t>(dY, Cout, X, bl, dW, M, Cout, 27 * Cin, nullptr, 1, gm, st);
+  return dispatch_tn<float>(dY, Cout, X, bl, dW, M, Cout, 27 * Cin, nullptr, 1, gm, st);
+}

@@ -1,0 +1,101 @@
+// Internal launcher declarations shared by the .hip translation units and the C-ABI layer (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct FDiv { unsigned M; int sh; unsigned d; };
+FDiv make_fdiv(unsigned d);
+
+// GEMM epilogue description (all optional, evaluated in this order):
+//   v = acc (+ bias[col]);  act==1: C2 = v, v = gelu(v);  act==2: v *= gelu'(C2);  v *= rowscale[row/rows_per_scale];
+//   v += resid;  accumulate: v += C;  C = v.         C, C2, resid share leading dimension ldc.
+struct EpiParams {
+  void* C; long ldc;
+  const float* bias;
+  int act; void* C2;
+  const void* resid;
+  const float* rowscale; int rows_per_scale;
+  int accumulate;
+};
+
+// geometry for gemm_tn gather / output remap
+struct TnGeom {
+  int omode;            // 0: Out[n*ldo+k]; 1: conv3 weight [Cout][Cin][27]; 2: convT weight [Cin][Cout][k3]
+  long ldo;
+  int Cin, D, H, W; unsigned V;
+  FDiv dC, dW, dH, dV;
+};
+
+// window partition geometry (3-D shifted windows, window edge 4): real dims, padded dims, effective shifts
+struct WinMap { int B, H, W, D, PH, PW, PD, s0, s1, s2; };
+
+int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st);
+int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st);
+int k_gemm_tn(int dt, const void* A, long lda, const void* Bm, long ldb, float* Out, long M, int N, int K, const float* rowscale, int rows_per_scale, const TnGeom& gm, hipStream_t st);
+int k_conv3_tn(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st);
+
+// ---- norm.hip ----
+// src_mode: 0 direct rows, 1 window-ordered output rows (gather tokens, pads -> 0), 2 patch-merge gather (8 tokens -> 8C row)
+struct LnArgs {
+  int dt; int src_mode;
+  const void* x; void* out;             // x: token-major [T,C]; out: [rows, Cout] (Cout = C or 8C)
+  const float* gamma; const float* beta; float eps;
+  float* mean; float* rstd;             // per token (modes 0,1) or per output row (mode 2)
+  long rows; int C;                     // rows = output rows; C = normalized width (8*Cin for mode 2)
+  WinMap wm;                            // modes 1, 2 (mode 2 uses B,H,W,D as the *input* grid)
+  const float* pos; const unsigned char* mask; const float* mask_token; long tokens_per_sample;  // patch-embed post-ops (mode 0)
+};
+int k_ln_fwd(const LnArgs& a, hipStream_t st);
+struct LnBwdArgs {
+  int dt; int src_mode;
+  const void* dy;                       // mode 0: [T,C]; mode 1: window-ordered [Tw,C]; mode 2: [rows, 8C]
+  const void* x; const float* gamma; const float* mean; const float* rstd;
+  const void* dres;                     // optional residual gradient added to dx (modes 0,1)
+  void* dx;                             // token-major [T,C]
+  float* dgamma; float* dbeta;          // fp32 accumulators (atomicAdd)
+  long rows; int C; WinMap wm;
+  const unsigned char* mask; float* dmask_token; long tokens_per_sample;
+};
+int k_ln_bwd(const LnBwdArgs& a, hipStream_t st);
+
+int k_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
+int k_window_gather_scale(int dt, const void* dx, void* dyw, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
+
+// instance norm over channels-last [B, V, C]; stats[b][c] = {mean, rstd}
+int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st);
+// out = lrelu( IN(x) [+ r | + IN(r)] ); rmode 0 none, 1 plain residual, 2 normalized residual (stats_r)
+int k_in_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, long V, int C, float slope, hipStream_t st);
+// sums[b][c] = {sum g, sum g*xhat} (and sums_r for rmode 2), g = dout * lrelu'(out)
+int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, const float* stats, const void* r, const float* stats_r, int rmode,
+                    double* sums, double* sums_r, int B, long V, int C, float slope, hipStream_t st);
+// dx = rstd*(g - S1/V - xhat*S2/V); rmode 1: dr (+)= g ; rmode 2: dr = IN-bwd wrt r
+int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
+                   const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st);
+
+// ---- attn.hip ----
+int k_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st);
+int k_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C, const WinMap& wm, hipStream_t st);
+
+// ---- misc.hip ----
+int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st);
+int k_up_cat_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, hipStream_t st);
+int k_up_cat_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip, hipStream_t st);
+struct LossArgs {
+  int dt; const void* d0; const float* Wout; const float* bout; const float* target;  // d0 [B,R^3,Cd]; target fp32 NCDHW (B,4,R,R,R)
+  const int* extents;                    // [B][3] valid extent per axis (A0,A1,A2)
+  const unsigned char* tokmask;          // [g^3] 1 = removed (shared by the batch)
+  int B, R, Cd;
+  double* sums;                          // [4]: sum_rgb, n_occ, sum_alpha, n_rm
+  float* pred;                           // optional fp32 NCDHW (B,4,R,R,R)
+};
+int k_loss_fwd(const LossArgs& a, hipStream_t st);
+int k_loss_finalize(const double* sums, float* losses, hipStream_t st);
+int k_loss_bwd(const LossArgs& a, void* dd0, void* dpred8, float* dbout, hipStream_t st);
+int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rowscale, int rows_per_scale, hipStream_t st);
+int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st);
+int k_fill_f32(float* p, float v, long n, hipStream_t st);
+
+struct PackDesc { const float* src; void* dst; int mode; int d0, d1, d2; long n; };
+int k_pack_weights(int dt, const PackDesc* descs_dev, const int* blk2desc_dev, const long* blkstart_dev, int nblocks, hipStream_t st);
+int k_sqnorm(const float* g, long n, double* acc, hipStream_t st);
+int k_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, hipStream_t st);
+int k_adamw(float* p, const float* g, float* m, float* v, long n, const float* hyper /*lr,b1,b2,eps,wd,bc1,bc2*/, const float* coef, hipStream_t st);

@@ -1,0 +1,386 @@
+// Remaining HBM-bound kernels of the hot path: patch-embed im2row, transpose-conv pixel shuffle (+skip concat),
+// fused 1x1 output head + masked MSE loss (forward and backward), bias gradients, weight packing (fp32 master ->
+// compute-dtype GEMM operand layouts), and the fused AdamW / grad-clip step.
+// Reference semantics: swin_mae3d.py:1120-1129 (patch conv k=s=4), unetr_block.py:150-158,193-200 (ConvTranspose3d k=s,
+// cat), unetr_block.py:99-105 + swin_mae3d.py:1513-1549 (head + loss), run_swin_mae3d.py:588-598,665-669 (AdamW, clip).
+#include "common.hpp"
+#include "kernels.hpp"
+
+static inline unsigned ew_blocks(long total, int cap = 16384) { long nb = (total + 255) / 256; return (unsigned)(nb > cap ? cap : (nb < 1 ? 1 : nb)); }
+
+// ---- patch embed im2row: A[(b,z,y,x)][ci*64 + kz*16+ky*4+kx] = x[b][ci][4z+kz][4y+ky][4x+kx] ---------------------
+template <typename T> __global__ void embed_gather_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int R) {
+  const int g = R >> 2;
+  const long total = (long)B * g * g * g * 64;  // one thread per (token, ci, kz, ky): 4 contiguous kx
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 63);
+    long tok = i >> 6;
+    const int ci = q >> 4, kz = (q >> 2) & 3, ky = q & 3;
+    const int tx = (int)(tok % g); long t2 = tok / g;
+    const int ty = (int)(t2 % g); t2 /= g;
+    const int tz = (int)(t2 % g);
+    const long b = t2 / g;
+    const float4 v = *reinterpret_cast<const float4*>(x + (((b * 4 + ci) * R + 4 * tz + kz) * R + 4 * ty + ky) * (long)R + 4 * tx);
+    T* o = A + tok * 256 + ci * 64 + kz * 16 + ky * 4;
+    o[0] = from_f<T>(v.x); o[1] = from_f<T>(v.y); o[2] = from_f<T>(v.z); o[3] = from_f<T>(v.w);
+  }
+}
+int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st) {
+  long total = (long)B * (R / 4) * (R / 4) * (R / 4) * 64;
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, x, (bf16_t*)A, B, R);
+  else hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, x, (float*)A, B, R);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- transpose conv (k = stride) pixel shuffle: out[(b,Z,Y,X)][0:Cout] = upre[(b,Z/k,Y/k,X/k)][tap*Cout + c] + bias[c];
+//      out[..][Cout:2Cout] = skip[..]          tap = (Z%k)*k*k + (Y%k)*k + X%k --------------------------------------------
+template <typename T> __global__ void up_cat_fwd_kernel(const T* upre, const float* bias, const T* skip, T* out, int B, int v, int k, int Cout) {
+  const int V = v * k, Cc = skip ? 2 * Cout : Cout, nch = Cc >> 3, uch = Cout >> 3;
+  const long total = (long)B * V * V * V * nch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long vox = i / nch;
+    const int c = (int)(i - vox * nch);
+    float a[8];
+    if (c < uch) {
+      const int X = (int)(vox % V); long t = vox / V;
+      const int Y = (int)(t % V); t /= V;
+      const int Z = (int)(t % V);
+      const long b = t / V;
+      const int tap = ((Z % k) * k + (Y % k)) * k + (X % k);
+      const long m = ((b * v + Z / k) * v + Y / k) * v + X / k;
+      Vec8<T>::load(upre + m * ((long)k * k * k * Cout) + (long)tap * Cout + c * 8, a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += bias[c * 8 + j];
+    } else {
+      Vec8<T>::load(skip + vox * Cout + (c - uch) * 8, a);
+    }
+    Vec8<T>::store(out + vox * Cc + c * 8, a);
+  }
+}
+template <typename T> __global__ void up_cat_bwd_kernel(const T* dcat, T* dupre, T* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip) {
+  extern __shared__ float sdb[];
+  const int V = v * k, Cc = has_skip ? 2 * Cout : Cout, nch = Cc >> 3, uch = Cout >> 3;
+  const long total = (long)B * V * V * V * nch;
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) sdb[i] = 0.f;
+  __syncthreads();
+  // fixed chunk per thread (stride multiple of nch) so bias partials stay in registers
+  const long stride = ((long)gridDim.x * blockDim.x / nch) * nch;
+  float pb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pb[j] = 0.f;
+  const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(start % nch);
+  if (start < stride) {
+    for (long i = start; i < total; i += stride) {
+      const long vox = i / nch;
+      float a[8];
+      Vec8<T>::load(dcat + vox * Cc + c * 8, a);
+      if (c < uch) {
+        const int X = (int)(vox % V); long t = vox / V;
+        const int Y = (int)(t % V); t /= V;
+        const int Z = (int)(t % V);
+        const long b = t / V;
+        const int tap = ((Z % k) * k + (Y % k)) * k + (X % k);
+        const long m = ((b * v + Z / k) * v + Y / k) * v + X / k;
+        Vec8<T>::store(dupre + m * ((long)k * k * k * Cout) + (long)tap * Cout + c * 8, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] += a[j];
+      } else {
+        Vec8<T>::store(dskip + vox * Cout + (c - uch) * 8, a);
+      }
+    }
+    if (c < uch)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&sdb[c * 8 + j], pb[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) atomicAdd(dbias + i, sdb[i]);
+}
+int k_up_cat_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, hipStream_t st) {
+  if (Cout % 8) return -2;
+  long V = (long)v * k;
+  long total = (long)B * V * V * V * ((skip ? 2 : 1) * Cout / 8);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(up_cat_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)upre, bias, (const bf16_t*)skip, (bf16_t*)out, B, v, k, Cout);
+  else hipLaunchKernelGGL(up_cat_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)upre, bias, (const float*)skip, (float*)out, B, v, k, Cout);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_up_cat_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip, hipStream_t st) {
+  if (Cout % 8) return -2;
+  long V = (long)v * k;
+  int nch = (has_skip ? 2 : 1) * Cout / 8;
+  long total = (long)B * V * V * V * nch;
+  unsigned nb = ew_blocks(total, 2048);
+  if ((long)nb * 256 < nch) nb = (unsigned)((nch + 255) / 256);
+  size_t lds = Cout * sizeof(float);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(up_cat_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t*)dcat, (bf16_t*)dupre, (bf16_t*)dskip, dbias, B, v, k, Cout, has_skip);
+  else hipLaunchKernelGGL(up_cat_bwd_kernel<float>, dim3(nb), dim3(256), lds, st, (const float*)dcat, (float*)dupre, (float*)dskip, dbias, B, v, k, Cout, has_skip);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- fused 1x1 head (Cd -> 4) + masked MSE loss ------------------------------------------------------------------------
+// loss_rgb = sum_{rgb}(p-t)^2 [t_a>0.01] / #{t_a>0.01};  loss_a = sum (sigmoid(p_a)-t_a)^2 [valid & removed] / #{valid & removed}
+__device__ __forceinline__ float block_sum_to(float v, float* sh, int slot) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&sh[slot], v);
+  return v;
+}
+template <typename T, int BWD>
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, T* dpred8, float* dbout) {
+  __shared__ float sh[8];
+  if (threadIdx.x < 8) sh[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int R = a.R, Cd = a.Cd, g = R >> 2;
+  const long V = (long)R * R * R, total = (long)a.B * V;
+  const T* d0 = (const T*)a.d0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
+  float inv_occ = 0.f, inv_rm = 0.f;
+  if (BWD) { inv_occ = (float)(1.0 / a.sums[1]); inv_rm = (float)(1.0 / a.sums[3]); }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / V, vox = i - b * V;
+    const int x = (int)(vox % R); const long t = vox / R;
+    const int y = (int)(t % R), z = (int)(t / R);
+    float p[4] = {a.bout[0], a.bout[1], a.bout[2], a.bout[3]};
+    for (int c = 0; c < Cd; c += 8) {
+      float v[8];
+      Vec8<T>::load(d0 + i * Cd + c, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        p[0] += v[j] * a.Wout[c + j]; p[1] += v[j] * a.Wout[Cd + c + j];
+        p[2] += v[j] * a.Wout[2 * Cd + c + j]; p[3] += v[j] * a.Wout[3 * Cd + c + j];
+      }
+    }
+    const float* tg = a.target + b * 4 * V + vox;
+    const float t0 = tg[0], t1 = tg[V], t2 = tg[2 * V], t3 = tg[3 * V];
+    const bool occ = t3 > 0.01f;
+    const bool valid = z < a.extents[b * 3] && y < a.extents[b * 3 + 1] && x < a.extents[b * 3 + 2];
+    const bool rm = valid && a.tokmask[((z >> 2) * g + (y >> 2)) * g + (x >> 2)] != 0;
+    const float sg = 1.0f / (1.0f + __expf(-p[3]));
+    if (!BWD) {
+      if (occ) { acc[0] += (p[0] - t0) * (p[0] - t0) + (p[1] - t1) * (p[1] - t1) + (p[2] - t2) * (p[2] - t2); acc[1] += 1.f; }
+      if (rm) { acc[2] += (sg - t3) * (sg - t3); acc[3] += 1.f; }
+      if (a.pred) { float* pr = a.pred + b * 4 * V + vox; pr[0] = p[0]; pr[V] = p[1]; pr[2 * V] = p[2]; pr[3 * V] = p[3]; }
+    } else {
+      float dp[4];
+      dp[0] = occ ? 2.f * (p[0] - t0) * inv_occ : 0.f;
+      dp[1] = occ ? 2.f * (p[1] - t1) * inv_occ : 0.f;
+      dp[2] = occ ? 2.f * (p[2] - t2) * inv_occ : 0.f;
+      dp[3] = rm ? 2.f * (sg - t3) * sg * (1.f - sg) * inv_rm : 0.f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) accb[o] += dp[o];
+      for (int c = 0; c < Cd; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = dp[0] * a.Wout[c + j] + dp[1] * a.Wout[Cd + c + j] + dp[2] * a.Wout[2 * Cd + c + j] + dp[3] * a.Wout[3 * Cd + c + j];
+        Vec8<T>::store(dd0 + i * Cd + c, v);
+      }
+      float d8[8] = {dp[0], dp[1], dp[2], dp[3], 0.f, 0.f, 0.f, 0.f};
+      Vec8<T>::store(dpred8 + i * 8, d8);
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) block_sum_to(BWD ? accb[o] : acc[o], sh, o);
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    if (!BWD) atomicAdd(&a.sums[threadIdx.x], (double)sh[threadIdx.x]);
+    else atomicAdd(&dbout[threadIdx.x], sh[threadIdx.x]);
+  }
+}
+int k_loss_fwd(const LossArgs& a, hipStream_t st) {
+  if (a.Cd % 8) return -2;
+  hipError_t e = hipMemsetAsync(a.sums, 0, 4 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  long total = (long)a.B * a.R * a.R * a.R;
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 0>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, nullptr, nullptr, nullptr);
+  else hipLaunchKernelGGL((loss_kernel<float, 0>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, nullptr, nullptr, nullptr);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void loss_finalize_kernel(const double* s, float* l) {
+  double lr = s[0] / s[1], la = s[2] / s[3];
+  l[0] = (float)(lr + la); l[1] = (float)lr; l[2] = (float)la;
+}
+int k_loss_finalize(const double* sums, float* losses, hipStream_t st) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, sums, losses);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_loss_bwd(const LossArgs& a, void* dd0, void* dpred8, float* dbout, hipStream_t st) {
+  long total = (long)a.B * a.R * a.R * a.R;
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 1>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, (bf16_t*)dd0, (bf16_t*)dpred8, dbout);
+  else hipLaunchKernelGGL((loss_kernel<float, 1>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, (float*)dd0, (float*)dpred8, dbout);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- column sums of dY (bias gradients) ------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void bias_grad_kernel(const T* dY, float* db, long M, int N, const float* rs, int rps) {
+  extern __shared__ float sdb[];
+  const int nch = N >> 3, NV = 256 / nch;
+  const int c = threadIdx.x % nch, vl = threadIdx.x / nch;
+  for (int i = threadIdx.x; i < N; i += 256) sdb[i] = 0.f;
+  __syncthreads();
+  if (vl < NV) {
+    float p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = 0.f;
+    for (long m = (long)blockIdx.x * NV + vl; m < M; m += (long)gridDim.x * NV) {
+      float v[8];
+      Vec8<T>::load(dY + m * N + c * 8, v);
+      const float s = rs ? rs[m / rps] : 1.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] += v[j] * s;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&sdb[c * 8 + j], p[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += 256) atomicAdd(db + i, sdb[i]);
+}
+template <typename T> __global__ __launch_bounds__(256) void bias_grad_wide_kernel(const T* dY, float* db, long M, int N, const float* rs, int rps) {
+  // N/8 > 256: one thread per 8-column chunk, blockIdx.y strides rows
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c * 8 >= N) return;
+  float p[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = 0.f;
+  for (long m = blockIdx.y; m < M; m += gridDim.y) {
+    float v[8];
+    Vec8<T>::load(dY + m * N + c * 8, v);
+    const float s = rs ? rs[m / rps] : 1.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] += v[j] * s;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(db + c * 8 + j, p[j]);
+}
+int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rs, int rps, hipStream_t st) {
+  if (N % 8) return -2;
+  if (N / 8 <= 256) {
+    int NV = 256 / (N / 8);
+    long nb = (M + NV - 1) / NV;
+    if (nb > 1024) nb = 1024;
+    if (dt == NMH_DT_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), N * sizeof(float), st, (const bf16_t*)dY, db, M, N, rs, rps);
+    else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3((unsigned)nb), dim3(256), N * sizeof(float), st, (const float*)dY, db, M, N, rs, rps);
+  } else {
+    dim3 grid((N / 8 + 255) / 256, (unsigned)(M < 256 ? M : 256));
+    if (dt == NMH_DT_BF16) hipLaunchKernelGGL(bias_grad_wide_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dY, db, M, N, rs, rps);
+    else hipLaunchKernelGGL(bias_grad_wide_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, db, M, N, rs, rps);
+  }
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T> __global__ void add_inplace_kernel(T* a, const T* b, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float x[8], y[8];
+    Vec8<T>::load(a + i * 8, x);
+    Vec8<T>::load(b + i * 8, y);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] += y[j];
+    Vec8<T>::store(a + i * 8, x);
+  }
+}
+int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st) {
+  if (n % 8) return -2;
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (bf16_t*)a, (const bf16_t*)b, n / 8);
+  else hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (float*)a, (const float*)b, n / 8);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void fill_kernel(float* p, float v, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+int k_fill_f32(float* p, float v, long n, hipStream_t st) {
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, v, n);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- weight packing: fp32 master parameters -> compute-dtype GEMM operand layouts, all tensors in ONE launch ------------
+//  mode 0 cast           dst[i] = src[i]
+//  mode 1 transpose 2-D  src [d0][d1] -> dst [d1][d0]
+//  mode 2 conv3 fwd      src [Co=d0][Ci=d1][27] -> dst [Co][27][Ci]
+//  mode 3 conv3 dgrad    dst [Ci][27][Co], tap flipped (26 - t)
+//  mode 4 convT fwd      src [Ci=d0][Co=d1][k3=d2] -> dst [(t*Co+co)][ci]
+//  mode 5 convT dgrad    dst [ci][(t*Co+co)]
+__device__ __forceinline__ long pack_src_index(const PackDesc& d, long i) {
+  switch (d.mode) {
+    case 1: { long c = i / d.d0, r = i - c * d.d0; return r * d.d1 + c; }
+    case 2: { long ci = i % d.d1; long t2 = i / d.d1; long t = t2 % 27, co = t2 / 27; return (co * d.d1 + ci) * 27 + t; }
+    case 3: { long co = i % d.d0; long t2 = i / d.d0; long t = t2 % 27, ci = t2 / 27; return (co * d.d1 + ci) * 27 + (26 - t); }
+    case 4: { long ci = i % d.d0; long t2 = i / d.d0; long co = t2 % d.d1, t = t2 / d.d1; return (ci * d.d1 + co) * d.d2 + t; }
+    case 5: { long n = (long)d.d1 * d.d2; long ci = i / n, r = i - ci * n; long t = r / d.d1, co = r - t * d.d1; return (ci * d.d1 + co) * d.d2 + t; }
+    default: return i;
+  }
+}
+template <typename T> __global__ void pack_kernel(const PackDesc* descs, const int* blk2desc, const long* blkstart) {
+  const PackDesc d = descs[blk2desc[blockIdx.x]];
+  const long base = blkstart[blockIdx.x];
+  T* dst = (T*)d.dst;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    long i = base + u * 256 + threadIdx.x;
+    if (i < d.n) dst[i] = from_f<T>(d.src[pack_src_index(d, i)]);
+  }
+}
+int k_pack_weights(int dt, const PackDesc* descs, const int* blk2desc, const long* blkstart, int nblocks, hipStream_t st) {
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, st, descs, blk2desc, blkstart);
+  else hipLaunchKernelGGL(pack_kernel<float>, dim3(nblocks), dim3(256), 0, st, descs, blk2desc, blkstart);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- global grad norm, clip coefficient, fused AdamW over the flat parameter buffer ----------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, double* acc) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < n) { float4 v = *reinterpret_cast<const float4*>(g + i); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    else for (long j = i; j < n; ++j) s += g[j] * g[j];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, (double)(sh[0] + sh[1] + sh[2] + sh[3]));
+}
+int k_sqnorm(const float* g, long n, double* acc, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(ew_blocks((n + 3) / 4, 2048)), dim3(256), 0, st, g, n, acc);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void clip_coef_kernel(const double* acc, float max_norm, float* coef, float* norm_out) {
+  double nrm = sqrt(*acc);
+  double c = (double)max_norm / (nrm + 1e-6);  // torch.nn.utils.clip_grad_norm_
+  *coef = max_norm > 0.f ? (float)(c < 1.0 ? c : 1.0) : 1.0f;
+  if (norm_out) *norm_out = (float)nrm;
+}
+int k_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, hipStream_t st) {
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, acc, max_norm, coef, norm_out);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+// hyper = {lr, beta1, beta2, eps, weight_decay, bias_correction1, bias_correction2} on device (graph-replayable)
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* coef) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6];
+  const float cf = coef ? *coef : 1.0f;
+  const float step = lr / bc1, isq = 1.0f / sqrtf(bc2);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * cf;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    pi -= step * mi / (sqrtf(vi) * isq + eps);
+    p[i] = pi;
+  }
+}
+int k_adamw(float* p, const float* g, float* m, float* v, long n, const float* hyper, const float* coef, hipStream_t st) {
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n, 4096)), dim3(256), 0, st, p, g, m, v, n, hyper, coef);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,557 @@
+// LayerNorm (with the window-partition / patch-merge gathers folded into its addressing), the
+// window scatter/gather elementwise kernels, and InstanceNorm+LeakyReLU(+residual) forward/backward
+// over channels-last volumes.  All HBM-bound: 16-byte vector accesses, fp32 statistics.
+// Reference semantics: swin_mae3d.py:62-101,176-196 (pad/roll/partition), :341-369 (LN), :390-414 (merge),
+// unetr_block.py:57-71 (IN eps=1e-5, no affine; LeakyReLU 0.01).
+#include "common.hpp"
+#include "kernels.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// window maps.  Window-ordered row m = ((b*nwz+wz)*nwy+wy)*nwx+wx)*64 + tz*16+ty*4+tx.
+// rolled[p] = padded[(p + shift) mod P]  (torch.roll(x, -shift)), padded rows beyond the real dims are zero.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long win_to_tok(const WinMap& w, long m) {
+  const int t = (int)(m & 63);
+  long win = m >> 6;
+  const int nwy = w.PW >> 2, nwx = w.PD >> 2, nwz = w.PH >> 2;
+  int wx = (int)(win % nwx); win /= nwx;
+  int wy = (int)(win % nwy); win /= nwy;
+  int wz = (int)(win % nwz);
+  long b = win / nwz;
+  int sz = wz * 4 + (t >> 4) + w.s0, sy = wy * 4 + ((t >> 2) & 3) + w.s1, sx = wx * 4 + (t & 3) + w.s2;
+  if (sz >= w.PH) sz -= w.PH;
+  if (sy >= w.PW) sy -= w.PW;
+  if (sx >= w.PD) sx -= w.PD;
+  if (sz >= w.H || sy >= w.W || sx >= w.D) return -1;
+  return ((b * w.H + sz) * w.W + sy) * w.D + sx;
+}
+__device__ __forceinline__ long tok_to_win(const WinMap& w, long tok) {
+  int x = (int)(tok % w.D); tok /= w.D;
+  int y = (int)(tok % w.W); tok /= w.W;
+  int z = (int)(tok % w.H);
+  long b = tok / w.H;
+  int pz = z - w.s0, py = y - w.s1, px = x - w.s2;
+  if (pz < 0) pz += w.PH;
+  if (py < 0) py += w.PW;
+  if (px < 0) px += w.PD;
+  long win = ((b * (w.PH >> 2) + (pz >> 2)) * (w.PW >> 2) + (py >> 2)) * (w.PD >> 2) + (px >> 2);
+  return win * 64 + ((pz & 3) << 4) + ((py & 3) << 2) + (px & 3);
+}
+
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// patch-merge source of chunk (8 elements starting at column col) of output row `row`; nullptr = zero pad
+template <typename T> __device__ __forceinline__ const T* merge_src(const T* x, const WinMap& w, long row, int col, int Cin, long* tok_out) {
+  const int H2 = (w.H + 1) >> 1, W2 = (w.W + 1) >> 1, D2 = (w.D + 1) >> 1;
+  long r = row;
+  int x2 = (int)(r % D2); r /= D2;
+  int y2 = (int)(r % W2); r /= W2;
+  int z2 = (int)(r % H2);
+  long b = r / H2;
+  int seg = col / Cin, off = col - seg * Cin;
+  int z = 2 * z2 + (seg & 1), y = 2 * y2 + ((seg >> 1) & 1), xx = 2 * x2 + (seg >> 2);
+  if (z >= w.H || y >= w.W || xx >= w.D) { *tok_out = -1; return nullptr; }
+  long tok = ((b * w.H + z) * w.W + y) * w.D + xx;
+  *tok_out = tok;
+  return x + tok * Cin + off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LPR, int NCH, int MODE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
+  const int sub = threadIdx.x % LPR;
+  const long gstride = (long)gridDim.x * (256 / LPR);
+  const int C = a.C, nch = C >> 3, Cin = C >> 3;  // Cin only meaningful for MODE 2 (C = 8*Cin)
+  const T* x = (const T*)a.x;
+  T* out = (T*)a.out;
+  const float invC = 1.0f / (float)C;
+  for (long row = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; row < a.rows; row += gstride) {
+    long tok = row;
+    bool valid = true;
+    if (MODE == 1) { tok = win_to_tok(a.wm, row); valid = tok >= 0; }
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = sub + i * LPR;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+      if (c < nch && valid) {
+        const T* p;
+        if (MODE == 2) { long tk; p = merge_src<T>(x, a.wm, row, c * 8, Cin, &tk); }
+        else p = x + tok * C + c * 8;
+        if (p) Vec8<T>::load(p, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+      }
+    }
+    const float mean = group_sum<LPR>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      if (sub + i * LPR < nch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float d = v[i][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(group_sum<LPR>(q) * invC + a.eps);
+    bool masked = false;
+    long tl = 0;
+    if (MODE == 0 && a.mask) { tl = row % a.tokens_per_sample; masked = a.mask[tl] != 0; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = sub + i * LPR;
+      if (c < nch) {
+        float o[8];
+        if (!valid) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = 0.f;
+        } else if (masked) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = a.mask_token[c * 8 + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * a.gamma[c * 8 + j] + a.beta[c * 8 + j];
+          if (MODE == 0 && a.pos) {
+            const long tp = a.mask ? tl : row % a.tokens_per_sample;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += a.pos[tp * C + c * 8 + j];
+          }
+        }
+        Vec8<T>::store(out + row * C + c * 8, o);
+      }
+    }
+    if (sub == 0 && valid) { a.mean[tok] = mean; a.rstd[tok] = rstd; }
+  }
+}
+
+template <typename T, int MODE> static int ln_fwd_dispatch(const LnArgs& a, hipStream_t st) {
+  const int nch = a.C / 8;
+  if (a.C % 8) return -2;
+  long rows = a.rows;
+#define LN_LAUNCH(LPR, NCH)                                                                   \
+  {                                                                                           \
+    long nb = (rows + (256 / LPR) - 1) / (256 / LPR);                                         \
+    if (nb > 8192) nb = 8192;                                                                 \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, LPR, NCH, MODE>), dim3((unsigned)nb), dim3(256), 0, st, a); \
+  }
+  if (nch <= 16) LN_LAUNCH(16, 1)
+  else if (nch <= 32) LN_LAUNCH(16, 2)
+  else if (nch <= 48) LN_LAUNCH(16, 3)
+  else if (nch <= 128) LN_LAUNCH(64, 2)
+  else if (nch <= 256) LN_LAUNCH(64, 4)
+  else if (nch <= 512) LN_LAUNCH(64, 8)
+  else return -3;
+#undef LN_LAUNCH
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_ln_fwd(const LnArgs& a, hipStream_t st) {
+  if (a.dt == NMH_DT_BF16) {
+    if (a.src_mode == 0) return ln_fwd_dispatch<bf16_t, 0>(a, st);
+    if (a.src_mode == 1) return ln_fwd_dispatch<bf16_t, 1>(a, st);
+    return ln_fwd_dispatch<bf16_t, 2>(a, st);
+  }
+  if (a.src_mode == 0) return ln_fwd_dispatch<float, 0>(a, st);
+  if (a.src_mode == 1) return ln_fwd_dispatch<float, 1>(a, st);
+  return ln_fwd_dispatch<float, 2>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward: dx = dres + rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;
+// dgamma += dy*xhat, dbeta += dy (register partials -> LDS -> fp32 atomics).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LPR, int NCH, int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+  extern __shared__ float sacc[];  // [3][C]: dgamma, dbeta, dmask_token
+  const int sub = threadIdx.x % LPR;
+  const long gstride = (long)gridDim.x * (256 / LPR);
+  const int C = a.C, nch = C >> 3, Cin = C >> 3;
+  const T* x = (const T*)a.x;
+  const T* dy = (const T*)a.dy;
+  T* dx = (T*)a.dx;
+  const float invC = 1.0f / (float)C;
+  for (int i = threadIdx.x; i < 3 * C; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  // small rows keep dgamma/dbeta partials in registers; wide rows (NCH >= 4) flush per row to LDS
+  constexpr bool FLUSH = NCH >= 4;
+  constexpr int PN = FLUSH ? 1 : NCH, PMN = (MODE == 0 && !FLUSH) ? NCH : 1;
+  float pg[PN][8], pb[PN][8], pm[PMN][8];
+#pragma unroll
+  for (int i = 0; i < PN; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pg[i][j] = 0.f; pb[i][j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < PMN; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pm[i][j] = 0.f;
+
+  for (long row = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; row < a.rows; row += gstride) {
+    long dyrow = row;
+    if (MODE == 1) dyrow = tok_to_win(a.wm, row);
+    bool masked = false;
+    if (MODE == 0 && a.mask) masked = a.mask[row % a.tokens_per_sample] != 0;
+    float xv[NCH][8], gv[NCH][8];
+    long toks[NCH];
+    float s1 = 0.f, s2 = 0.f;
+    const float mean = a.mean[row], rstd = a.rstd[row];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = sub + i * LPR;
+      toks[i] = -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { xv[i][j] = 0.f; gv[i][j] = 0.f; }
+      if (c < nch) {
+        float d[8];
+        Vec8<T>::load(dy + dyrow * C + c * 8, d);
+        if (masked) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (FLUSH) atomicAdd(&sacc[2 * C + c * 8 + j], d[j]);
+            else pm[MODE == 0 ? i : 0][j] += d[j];
+          }
+          continue;
+        }
+        const T* p;
+        if (MODE == 2) p = merge_src<T>(x, a.wm, row, c * 8, Cin, &toks[i]);
+        else p = x + row * C + c * 8;
+        float xr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[j] = 0.f;
+        if (p) Vec8<T>::load(p, xr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (xr[j] - mean) * rstd;
+          xv[i][j] = xh;
+          if (FLUSH) { atomicAdd(&sacc[c * 8 + j], d[j] * xh); atomicAdd(&sacc[C + c * 8 + j], d[j]); }
+          else { pg[i][j] += d[j] * xh; pb[i][j] += d[j]; }
+          const float g = d[j] * a.gamma[c * 8 + j];
+          gv[i][j] = g;
+          s1 += g;
+          s2 += g * xh;
+        }
+      }
+    }
+    const float m1 = group_sum<LPR>(s1) * invC, m2 = group_sum<LPR>(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = sub + i * LPR;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = masked ? 0.f : rstd * (gv[i][j] - m1 - xv[i][j] * m2);
+        if (MODE == 2) {
+          if (toks[i] >= 0) {
+            const int seg = (c * 8) / Cin, off = c * 8 - seg * Cin;
+            Vec8<T>::store(dx + toks[i] * Cin + off, o);
+          }
+        } else {
+          if (a.dres) {
+            float r[8];
+            Vec8<T>::load((const T*)a.dres + row * C + c * 8, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += r[j];
+          }
+          Vec8<T>::store(dx + row * C + c * 8, o);
+        }
+      }
+    }
+  }
+  if (!FLUSH) {
+#pragma unroll
+    for (int i = 0; i < PN; ++i) {
+      const int c = sub + i * LPR;
+      if (c < nch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          atomicAdd(&sacc[c * 8 + j], pg[i][j]);
+          atomicAdd(&sacc[C + c * 8 + j], pb[i][j]);
+          if (MODE == 0 && a.mask) atomicAdd(&sacc[2 * C + c * 8 + j], pm[MODE == 0 ? i : 0][j]);
+        }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(a.dgamma + i, sacc[i]);
+    atomicAdd(a.dbeta + i, sacc[C + i]);
+    if (MODE == 0 && a.mask) atomicAdd(a.dmask_token + i, sacc[2 * C + i]);
+  }
+}
+
+template <typename T, int MODE> static int ln_bwd_dispatch(const LnBwdArgs& a, hipStream_t st) {
+  const int nch = a.C / 8;
+  if (a.C % 8) return -2;
+  const size_t lds = 3 * (size_t)a.C * sizeof(float);
+#define LNB_LAUNCH(LPR, NCH)                                                                        \
+  {                                                                                                 \
+    long nb = (a.rows + (256 / LPR) - 1) / (256 / LPR);                                             \
+    if (nb > 1024) nb = 1024;                                                                       \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NCH, MODE>), dim3((unsigned)nb), dim3(256), lds, st, a); \
+  }
+  if (nch <= 16) LNB_LAUNCH(16, 1)
+  else if (nch <= 32) LNB_LAUNCH(16, 2)
+  else if (nch <= 48) LNB_LAUNCH(16, 3)
+  else if (nch <= 128) LNB_LAUNCH(64, 2)
+  else if (nch <= 256) LNB_LAUNCH(64, 4)
+  else if (nch <= 512) LNB_LAUNCH(64, 8)
+  else return -3;
+#undef LNB_LAUNCH
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
+  if (a.dt == NMH_DT_BF16) {
+    if (a.src_mode == 0) return ln_bwd_dispatch<bf16_t, 0>(a, st);
+    if (a.src_mode == 1) return ln_bwd_dispatch<bf16_t, 1>(a, st);
+    return ln_bwd_dispatch<bf16_t, 2>(a, st);
+  }
+  if (a.src_mode == 0) return ln_bwd_dispatch<float, 0>(a, st);
+  if (a.src_mode == 1) return ln_bwd_dispatch<float, 1>(a, st);
+  return ln_bwd_dispatch<float, 2>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[tok] = x[tok] + s_b * yw[win(tok)]       (window reverse + un-roll + un-pad + residual + stochastic depth)
+// dyw[m]   = s_b * dx[tok(m)] or 0 for pad rows (the adjoint gather)
+// ------------------------------------------------------------------------------------------------
+template <typename T> __global__ void win_scatter_kernel(const T* yw, const T* x, T* out, const float* rs, int C, WinMap wm) {
+  const int nch = C >> 3;
+  const long total = (long)wm.B * wm.H * wm.W * wm.D * nch;
+  const long tps = (long)wm.H * wm.W * wm.D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long tok = i / nch;
+    const int c = (int)(i - tok * nch);
+    const long m = tok_to_win(wm, tok);
+    float a[8], b[8];
+    Vec8<T>::load(yw + m * C + c * 8, a);
+    Vec8<T>::load(x + tok * C + c * 8, b);
+    const float s = rs ? rs[tok / tps] : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] += s * a[j];
+    Vec8<T>::store(out + tok * C + c * 8, b);
+  }
+}
+template <typename T> __global__ void win_gather_kernel(const T* dx, T* dyw, const float* rs, int C, WinMap wm) {
+  const int nch = C >> 3;
+  const long rows = (long)wm.B * (wm.PH >> 2) * (wm.PW >> 2) * (wm.PD >> 2) * 64;
+  const long total = rows * nch;
+  const long tps = (long)wm.H * wm.W * wm.D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / nch;
+    const int c = (int)(i - m * nch);
+    const long tok = win_to_tok(wm, m);
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    if (tok >= 0) {
+      Vec8<T>::load(dx + tok * C + c * 8, a);
+      if (rs) {
+        const float s = rs[tok / tps];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= s;
+      }
+    }
+    Vec8<T>::store(dyw + m * C + c * 8, a);
+  }
+}
+static inline unsigned ew_blocks(long total) { long nb = (total + 255) / 256; return (unsigned)(nb > 16384 ? 16384 : (nb < 1 ? 1 : nb)); }
+
+int k_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rs, int C, const WinMap& wm, hipStream_t st) {
+  long total = (long)wm.B * wm.H * wm.W * wm.D * (C / 8);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(win_scatter_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)yw, (const bf16_t*)x, (bf16_t*)out, rs, C, wm);
+  else hipLaunchKernelGGL(win_scatter_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)yw, (const float*)x, (float*)out, rs, C, wm);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_window_gather_scale(int dt, const void* dx, void* dyw, const float* rs, int C, const WinMap& wm, hipStream_t st) {
+  long total = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4) * 64 * (C / 8);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(win_gather_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)dx, (bf16_t*)dyw, rs, C, wm);
+  else hipLaunchKernelGGL(win_gather_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)dx, (float*)dyw, rs, C, wm);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm over channels-last [B][V][C].  Reductions: each thread owns one 8-channel chunk and
+// strides over voxels; block partials -> LDS atomics -> fp64 global atomics (scratch [B][C][2]).
+// ------------------------------------------------------------------------------------------------
+#define IN_VOX_PER_BLOCK 4096
+
+template <typename T, int BWD>
+__global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dout, const T* outp, const float* stats, const T* r, const float* stats_r, int rmode,
+                                                        double* acc, double* acc_r, long V, int C, float slope) {
+  extern __shared__ float sred[];  // [4][C]
+  const int CL = C >> 3, NV = 256 / CL;
+  const int cl = threadIdx.x % CL, vl = threadIdx.x / CL;
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 4 * C; i += 256) sred[i] = 0.f;
+  __syncthreads();
+  const long v0 = (long)blockIdx.x * IN_VOX_PER_BLOCK;
+  long v1 = v0 + IN_VOX_PER_BLOCK;
+  if (v1 > V) v1 = V;
+  float s1[8], s2[8], t1[8], t2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = t1[j] = t2[j] = 0.f; }
+  float mu[8], rs_[8], mur[8], rsr[8];
+  if (BWD && vl < NV) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = stats[((long)b * C + cl * 8 + j) * 2]; rs_[j] = stats[((long)b * C + cl * 8 + j) * 2 + 1];
+      if (rmode == 2) { mur[j] = stats_r[((long)b * C + cl * 8 + j) * 2]; rsr[j] = stats_r[((long)b * C + cl * 8 + j) * 2 + 1]; }
+    }
+  }
+  if (vl < NV) {
+    for (long v = v0 + vl; v < v1; v += NV) {
+      const long o = ((long)b * V + v) * C + cl * 8;
+      float xv[8];
+      Vec8<T>::load(x + o, xv);
+      if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s1[j] += xv[j]; s2[j] += xv[j] * xv[j]; }
+      } else {
+        float dv[8], ov[8];
+        Vec8<T>::load(dout + o, dv);
+        Vec8<T>::load(outp + o, ov);
+        float rv[8];
+        if (rmode == 2) Vec8<T>::load(r + o, rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float g = dv[j] * (ov[j] > 0.f ? 1.0f : slope);
+          s1[j] += g;
+          s2[j] += g * (xv[j] - mu[j]) * rs_[j];
+          if (rmode == 2) { t1[j] += g; t2[j] += g * (rv[j] - mur[j]) * rsr[j]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&sred[cl * 8 + j], s1[j]);
+      atomicAdd(&sred[C + cl * 8 + j], s2[j]);
+      if (BWD && rmode == 2) { atomicAdd(&sred[2 * C + cl * 8 + j], t1[j]); atomicAdd(&sred[3 * C + cl * 8 + j], t2[j]); }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(&acc[((long)b * C + i) * 2], (double)sred[i]);
+    atomicAdd(&acc[((long)b * C + i) * 2 + 1], (double)sred[C + i]);
+    if (BWD && rmode == 2) {
+      atomicAdd(&acc_r[((long)b * C + i) * 2], (double)sred[2 * C + i]);
+      atomicAdd(&acc_r[((long)b * C + i) * 2 + 1], (double)sred[3 * C + i]);
+    }
+  }
+}
+__global__ void in_finalize_kernel(const double* acc, float* stats, long n, double invV, float eps) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    double m = acc[2 * i] * invV, var = acc[2 * i + 1] * invV - m * m;
+    if (var < 0) var = 0;
+    stats[2 * i] = (float)m;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st) {
+  if (C % 8 || C / 8 > 256) return -2;
+  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B * C, st);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid((unsigned)((V + IN_VOX_PER_BLOCK - 1) / IN_VOX_PER_BLOCK), B);
+  size_t lds = 4 * C * sizeof(float);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 0>), grid, dim3(256), lds, st, (const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f);
+  else hipLaunchKernelGGL((in_reduce_kernel<float, 0>), grid, dim3(256), lds, st, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f);
+  NMH_CHECK_LAUNCH();
+  long n = (long)B * C;
+  hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, stats, n, 1.0 / (double)V, eps);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, const float* stats, const void* r, const float* stats_r, int rmode,
+                    double* sums, double* sums_r, int B, long V, int C, float slope, hipStream_t st) {
+  if (C % 8 || C / 8 > 256) return -2;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * C, st);
+  if (e != hipSuccess) return (int)e;
+  if (rmode == 2) { e = hipMemsetAsync(sums_r, 0, sizeof(double) * 2 * B * C, st); if (e != hipSuccess) return (int)e; }
+  dim3 grid((unsigned)((V + IN_VOX_PER_BLOCK - 1) / IN_VOX_PER_BLOCK), B);
+  size_t lds = 4 * C * sizeof(float);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 1>), grid, dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)out, stats, (const bf16_t*)r, stats_r, rmode, sums, sums_r, V, C, slope);
+  else hipLaunchKernelGGL((in_reduce_kernel<float, 1>), grid, dim3(256), lds, st, (const float*)x, (const float*)dout, (const float*)out, stats, (const float*)r, stats_r, rmode, sums, sums_r, V, C, slope);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+__global__ void in_apply_kernel(const T* x, const float* stats, const T* r, const float* stats_r, int rmode, T* out, long V, int C, float slope, long total) {
+  const int CL = C >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long vox = i / CL;
+    const int c0 = (int)(i - vox * CL) * 8;
+    const long b = vox / V;
+    float xv[8], rv[8];
+    Vec8<T>::load(x + vox * C + c0, xv);
+    if (rmode) Vec8<T>::load(r + vox * C + c0, rv);
+    const float* sp = stats + (b * C + c0) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = (xv[j] - sp[2 * j]) * sp[2 * j + 1];
+      if (rmode == 1) y += rv[j];
+      else if (rmode == 2) y += (rv[j] - stats_r[(b * C + c0 + j) * 2]) * stats_r[(b * C + c0 + j) * 2 + 1];
+      xv[j] = y > 0.f ? y : slope * y;
+    }
+    Vec8<T>::store(out + vox * C + c0, xv);
+  }
+}
+int k_in_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, long V, int C, float slope, hipStream_t st) {
+  long total = (long)B * V * (C / 8);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope, total);
+  else hipLaunchKernelGGL(in_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)x, stats, (const float*)r, stats_r, rmode, (float*)out, V, C, slope, total);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T>
+__global__ void in_bwd_apply_kernel(const T* dout, const T* outp, const T* x, const float* stats, const double* sums, const T* r, const float* stats_r, const double* sums_r,
+                                    int rmode, T* dx, T* dr, int dr_acc, long V, int C, float slope, long total) {
+  const int CL = C >> 3;
+  const float invV = 1.0f / (float)V;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long vox = i / CL;
+    const int c0 = (int)(i - vox * CL) * 8;
+    const long b = vox / V;
+    float dv[8], ov[8], xv[8], rv[8], o[8], orr[8];
+    Vec8<T>::load(dout + vox * C + c0, dv);
+    Vec8<T>::load(outp + vox * C + c0, ov);
+    Vec8<T>::load(x + vox * C + c0, xv);
+    if (rmode == 2) Vec8<T>::load(r + vox * C + c0, rv);
+    if (rmode == 1 && dr_acc) Vec8<T>::load(dr + vox * C + c0, orr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long sc = (b * C + c0 + j) * 2;
+      const float g = dv[j] * (ov[j] > 0.f ? 1.0f : slope);
+      const float mu = stats[sc], rs = stats[sc + 1];
+      const float xh = (xv[j] - mu) * rs;
+      o[j] = rs * (g - (float)sums[sc] * invV - xh * (float)sums[sc + 1] * invV);
+      if (rmode == 1) orr[j] = dr_acc ? orr[j] + g : g;
+      else if (rmode == 2) {
+        const float mr = stats_r[sc], rr = stats_r[sc + 1];
+        const float rh = (rv[j] - mr) * rr;
+        orr[j] = rr * (g - (float)sums_r[sc] * invV - rh * (float)sums_r[sc + 1] * invV);
+      }
+    }
+    Vec8<T>::store(dx + vox * C + c0, o);
+    if (rmode) Vec8<T>::store(dr + vox * C + c0, orr);
+  }
+}
+int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
+                   const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st) {
+  long total = (long)B * V * (C / 8);
+  if (dt == NMH_DT_BF16)
+    hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
+                       (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope, total);
+  else
+    hipLaunchKernelGGL(in_bwd_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, stats, sums,
+                       (const float*)r, stats_r, sums_r, rmode, (float*)dx, (float*)dr, dr_accumulate, V, C, slope, total);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

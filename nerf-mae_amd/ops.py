@@ -1,0 +1,209 @@
+"""Thin tensor-level wrappers over the C ABI (include/nerfmae_hip.h).  PyTorch is used only for device
+memory and the current HIP stream; all arithmetic happens in libnerfmae_hip.so.  Every function raises if
+the library is missing or a tensor is not a contiguous CUDA(HIP) tensor -- there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from ._lib import lib
+
+F32, BF16 = 0, 1
+WS = 4
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("nerf_mae_amd ops need HIP device tensors (no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("nerf_mae_amd ops need contiguous tensors")
+
+
+class WinGeom:
+    """Token grid (B,H,W,D), padded dims and effective shifts for 4x4x4 shifted windows (swin_mae3d.py:62-81)."""
+
+    def __init__(self, B: int, H: int, W: int, D: int, shift: Sequence[int]):
+        self.B, self.H, self.W, self.D = B, H, W, D
+        self.P = [(s + WS - 1) // WS * WS for s in (H, W, D)]
+        self.shift = [0 if WS >= self.P[a] else int(shift[a]) for a in range(3)]
+        self.rows = B * self.P[0] * self.P[1] * self.P[2]  # window-ordered rows (incl. pads)
+        self.tokens = B * H * W * D
+        self.carr = (ctypes.c_int * 10)(B, H, W, D, self.P[0], self.P[1], self.P[2], *self.shift)
+
+
+def gemm_nt(A, W, bias=None, act=0, C2=None, resid=None, rowscale=None, rows_per_scale=1, out=None, accumulate=False,
+            M=None, N=None, K=None):
+    """out[M,N] = epi(A[M,K] @ W[N,K]^T)."""
+    _chk(A, W, bias, C2, resid, rowscale, out)
+    M = A.shape[0] if M is None else M
+    K = A.shape[-1] if K is None else K
+    N = W.shape[0] if N is None else N
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    lib().call("nmh_gemm_nt", dt_of(A), A, A.stride(0) if A.dim() > 1 else K, W, W.stride(0), M, N, K, out, out.stride(0), bias, act, C2,
+               resid, rowscale, rows_per_scale, int(accumulate), _st())
+    return out
+
+
+def gemm_tn(A, B, dW, rowscale=None, rows_per_scale=1, omode=0, ldo=None, p0=0, p1=0, N=None, K=None, M=None):
+    """dW[N,K] += A[M,N]^T @ B[M,K] (fp32 atomics into dW)."""
+    _chk(A, B, dW, rowscale)
+    M = A.shape[0] if M is None else M
+    N = A.shape[1] if N is None else N
+    K = B.shape[1] if K is None else K
+    lib().call("nmh_gemm_tn", dt_of(A), A, A.stride(0), B, B.stride(0), dW, M, N, K, rowscale, rows_per_scale, omode,
+               K if ldo is None else ldo, p0, p1, _st())
+    return dW
+
+
+def conv3d_k3(X, Wp, Cout, out=None, accumulate=False):
+    """X (B,D,H,W,Cin) channels-last, Wp packed [Cout][27][Cin] -> (B,D,H,W,Cout)."""
+    _chk(X, Wp, out)
+    B, D, H, W, Cin = X.shape
+    if out is None:
+        out = torch.empty((B, D, H, W, Cout), dtype=X.dtype, device=X.device)
+    lib().call("nmh_conv3d_k3", dt_of(X), X, Wp, out, B, D, H, W, Cin, Cout, int(accumulate), _st())
+    return out
+
+
+def conv3d_k3_wgrad(dY, X, dW):
+    _chk(dY, X, dW)
+    B, D, H, W, Cin = X.shape
+    lib().call("nmh_conv3d_k3_wgrad", dt_of(X), dY, X, dW, B, D, H, W, Cin, dY.shape[-1], _st())
+    return dW
+
+
+def layernorm_fwd(x, gamma, beta, out, mean, rstd, rows, C, src_mode=0, geom: Optional[WinGeom] = None, eps=1e-5,
+                  pos=None, mask=None, mask_token=None, tokens_per_sample=1):
+    _chk(x, gamma, beta, out, mean, rstd, pos, mask, mask_token)
+    lib().call("nmh_layernorm_fwd", dt_of(x), src_mode, x, out, gamma, beta, eps, mean, rstd, rows, C,
+               geom.carr if geom is not None else None, pos, mask, mask_token, tokens_per_sample, _st())
+    return out
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, src_mode=0, geom: Optional[WinGeom] = None, dres=None,
+                  mask=None, dmask_token=None, tokens_per_sample=1):
+    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dres, mask, dmask_token)
+    lib().call("nmh_layernorm_bwd", dt_of(x), src_mode, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C,
+               geom.carr if geom is not None else None, mask, dmask_token, tokens_per_sample, _st())
+    return dx
+
+
+def window_scatter_residual(yw, x, out, rowscale, C, geom: WinGeom):
+    _chk(yw, x, out, rowscale)
+    lib().call("nmh_window_scatter_residual", dt_of(x), yw, x, out, rowscale, C, geom.carr, _st())
+    return out
+
+
+def window_gather_scale(dx, dyw, rowscale, C, geom: WinGeom):
+    _chk(dx, dyw, rowscale)
+    lib().call("nmh_window_gather_scale", dt_of(dx), dx, dyw, rowscale, C, geom.carr, _st())
+    return dyw
+
+
+def window_attn_fwd(qkv, bias_table, out, lse, heads, C, geom: WinGeom):
+    _chk(qkv, bias_table, out, lse)
+    lib().call("nmh_window_attn_fwd", dt_of(qkv), qkv, bias_table, out, lse, heads, C, geom.carr, _st())
+    return out
+
+
+def window_attn_bwd(qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, geom: WinGeom):
+    _chk(qkv, bias_table, dout, lse, dqkv, dbias_table)
+    lib().call("nmh_window_attn_bwd", dt_of(qkv), qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, geom.carr, _st())
+    return dqkv
+
+
+def instnorm_stats(x, stats, scratch, B, V, C, eps=1e-5):
+    _chk(x, stats, scratch)
+    lib().call("nmh_instnorm_stats", dt_of(x), x, stats, scratch, B, V, C, eps, _st())
+    return stats
+
+
+def instnorm_apply(x, stats, out, B, V, C, r=None, stats_r=None, rmode=0, slope=0.01):
+    _chk(x, stats, out, r, stats_r)
+    lib().call("nmh_instnorm_apply", dt_of(x), x, stats, r, stats_r, rmode, out, B, V, C, slope, _st())
+    return out
+
+
+def instnorm_bwd_reduce(dout, out, x, stats, sums, B, V, C, r=None, stats_r=None, sums_r=None, rmode=0, slope=0.01):
+    _chk(dout, out, x, stats, sums, r, stats_r, sums_r)
+    lib().call("nmh_instnorm_bwd_reduce", dt_of(x), dout, out, x, stats, r, stats_r, rmode, sums, sums_r, B, V, C, slope, _st())
+
+
+def instnorm_bwd_apply(dout, out, x, stats, sums, dx, B, V, C, r=None, stats_r=None, sums_r=None, rmode=0, dr=None,
+                       dr_accumulate=False, slope=0.01):
+    _chk(dout, out, x, stats, sums, dx, r, stats_r, sums_r, dr)
+    lib().call("nmh_instnorm_bwd_apply", dt_of(x), dout, out, x, stats, sums, r, stats_r, sums_r, rmode, dx, dr, int(dr_accumulate),
+               B, V, C, slope, _st())
+
+
+def patch_embed_gather(x, A, B, R):
+    _chk(x, A)
+    lib().call("nmh_patch_embed_gather", dt_of(A), x, A, B, R, _st())
+    return A
+
+
+def upconv_shuffle_fwd(upre, bias, skip, out, B, v, k, Cout):
+    _chk(upre, bias, skip, out)
+    lib().call("nmh_upconv_shuffle_fwd", dt_of(upre), upre, bias, skip, out, B, v, k, Cout, _st())
+    return out
+
+
+def upconv_shuffle_bwd(dcat, dupre, dskip, dbias, B, v, k, Cout, has_skip):
+    _chk(dcat, dupre, dskip, dbias)
+    lib().call("nmh_upconv_shuffle_bwd", dt_of(dcat), dcat, dupre, dskip, dbias, B, v, k, Cout, int(has_skip), _st())
+
+
+def mae_loss_fwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, losses, pred=None):
+    _chk(d0, Wout, bout, target, extents, tokmask, sums, losses, pred)
+    lib().call("nmh_mae_loss_fwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, losses, pred, _st())
+    return losses
+
+
+def mae_loss_bwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, dpred8, dWout, dbout):
+    _chk(d0, Wout, bout, target, extents, tokmask, sums, dd0, dpred8, dWout, dbout)
+    lib().call("nmh_mae_loss_bwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, dpred8, dWout, dbout, _st())
+
+
+def bias_grad(dY, db, M, N, rowscale=None, rows_per_scale=1):
+    _chk(dY, db, rowscale)
+    lib().call("nmh_bias_grad", dt_of(dY), dY, db, M, N, rowscale, rows_per_scale, _st())
+
+
+def add_inplace(a, b):
+    _chk(a, b)
+    lib().call("nmh_add_inplace", dt_of(a), a, b, a.numel(), _st())
+    return a
+
+
+def pack_weights(dt, descs_dev, blk2desc_dev, blkstart_dev, nblocks):
+    lib().call("nmh_pack_weights", dt, descs_dev, blk2desc_dev, blkstart_dev, nblocks, _st())
+
+
+def grad_sqnorm(g, acc):
+    lib().call("nmh_grad_sqnorm", g, g.numel(), acc, _st())
+
+
+def clip_coef(acc, max_norm, coef, norm_out=None):
+    lib().call("nmh_clip_coef", acc, max_norm, coef, norm_out, _st())
+
+
+def adamw_step(p, g, m, v, hyper, coef=None):
+    lib().call("nmh_adamw_step", p, g, m, v, p.numel(), hyper, coef, _st())

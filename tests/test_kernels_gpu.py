@@ -1,0 +1,425 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle / plain fp32 math on the same seeded inputs.
+fp32 mode (exact fp32 MFMA) must agree to 1e-3 relative (north_star tolerance; we assert much tighter),
+bf16 mode to bf16 rounding.  Sizes are small enough that the CPU side finishes in seconds."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTS = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 3e-2}
+
+
+def _ops():
+    from nerf_mae_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 1000)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dt):
+    """round to the storage dtype (so the reference sees the same inputs), back to fp32 on CPU"""
+    return t.to(dt).float()
+
+
+def dev(t, dt=None):
+    return (t if dt is None else t.to(dt)).cuda().contiguous()
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def check(a, b, dt, name="", mult=1.0):
+    e = relerr(a, b)
+    assert e < TOL[dt] * mult, f"{name}: rel err {e:.3e} (dtype {dt})"
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (1000, 384, 96), (517, 288, 96), (2050, 48, 1296), (130, 768, 3072), (64, 64, 256), (4100, 3072, 96)])
+def test_gemm_nt_plain_bias(dt, M, N, K):
+    ops = _ops()
+    A, W, b = q(rnd(M, K), dt), q(rnd(N, K, seed=1, scale=K ** -0.5), dt), rnd(N, seed=2)
+    out = ops.gemm_nt(dev(A, dt), dev(W, dt), bias=dev(b))
+    check(out, A @ W.T + b, dt, "gemm_nt")
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_nt_epilogues(dt):
+    ops = _ops()
+    M, N, K, rps = 640, 384, 96, 320
+    A, W, b = q(rnd(M, K), dt), q(rnd(N, K, seed=1, scale=0.1), dt), rnd(N, seed=2, scale=0.1)
+    # act 1: dual output gelu
+    pre = torch.empty(M, N, dtype=dt, device="cuda")
+    act = ops.gemm_nt(dev(A, dt), dev(W, dt), bias=dev(b), act=1, C2=pre)
+    ref_pre = A @ W.T + b
+    check(pre, ref_pre, dt, "pre")
+    check(act, F.gelu(ref_pre), dt, "gelu")
+    # act 2 + rowscale: v * gelu'(aux) * s
+    aux = q(rnd(M, N, seed=5), dt)
+    rs = torch.tensor([0.0, 1.0 / 0.9])
+    out = ops.gemm_nt(dev(A, dt), dev(W, dt), act=2, C2=dev(aux, dt), rowscale=dev(rs), rows_per_scale=rps)
+    xg = aux.clone().requires_grad_(True)
+    F.gelu(xg).sum().backward()
+    ref = (A @ W.T) * xg.grad * rs.repeat_interleave(rps)[:, None]
+    check(out, ref, dt, "gelu_grad")
+    # residual + rowscale + accumulate
+    res = q(rnd(M, N, seed=6), dt)
+    c0 = q(rnd(M, N, seed=7), dt)
+    out = dev(c0, dt)
+    ops.gemm_nt(dev(A, dt), dev(W, dt), bias=dev(b), resid=dev(res, dt), rowscale=dev(rs), rows_per_scale=rps, out=out, accumulate=True)
+    ref = res + rs.repeat_interleave(rps)[:, None] * (A @ W.T + b) + c0
+    check(out, ref, dt, "resid/accumulate")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(5000, 384, 96), (777, 96, 384), (3000, 48, 48), (900, 1536, 384), (2000, 4, 48)])
+def test_gemm_tn(dt, M, N, K):
+    ops = _ops()
+    lda = (N + 7) // 8 * 8
+    A = torch.zeros(M, lda)
+    A[:, :N] = rnd(M, N)
+    A, B = q(A, dt), q(rnd(M, K, seed=1), dt)
+    rs = torch.tensor([0.5, 2.0, 1.0, 0.0, 1.5])
+    rps = (M + 4) // 5
+    dW = torch.full((N, K), 0.25, device="cuda")
+    ops.gemm_tn(dev(A, dt), dev(B, dt), dW, rowscale=dev(rs), rows_per_scale=rps, N=N)
+    sc = rs.repeat_interleave(rps)[:M, None]
+    ref = 0.25 + (q(A[:, :N] * sc, dt) if dt == torch.bfloat16 else A[:, :N] * sc).T @ B
+    check(dW, ref, dt, "gemm_tn", mult=1.0 if dt == torch.float32 else 1.0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 5, 6, 7, 16, 24), (1, 8, 8, 8, 48, 48), (1, 4, 9, 5, 96, 48), (1, 10, 10, 10, 24, 96)])
+def test_conv3d_fwd_dgrad_wgrad(dt, B, D, H, W, Cin, Cout):
+    ops = _ops()
+    x = q(rnd(B, Cin, D, H, W), dt)
+    w = q(rnd(Cout, Cin, 3, 3, 3, seed=1, scale=(27 * Cin) ** -0.5), dt)
+    dy = q(rnd(B, Cout, D, H, W, seed=2), dt)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv3d(xr, wr, padding=1)
+    y.backward(dy)
+    xcl = dev(x.permute(0, 2, 3, 4, 1), dt)
+    wp_f = dev(w.reshape(Cout, Cin, 27).permute(0, 2, 1), dt)                    # [Co][27][Ci]
+    wp_d = dev(w.reshape(Cout, Cin, 27).flip(2).permute(1, 2, 0), dt)            # [Ci][27 flipped][Co]
+    yk = ops.conv3d_k3(xcl, wp_f, Cout)
+    check(yk.permute(0, 4, 1, 2, 3), y, dt, "conv fwd")
+    dycl = dev(dy.permute(0, 2, 3, 4, 1), dt)
+    dxk = ops.conv3d_k3(dycl, wp_d, Cin)
+    check(dxk.permute(0, 4, 1, 2, 3), xr.grad, dt, "conv dgrad")
+    dW = torch.zeros(Cout, Cin, 3, 3, 3, device="cuda")
+    ops.conv3d_k3_wgrad(dycl, xcl, dW)
+    check(dW, wr.grad, dt, "conv wgrad")
+
+
+def _geom(ops, B, H, W, D, s):
+    return ops.WinGeom(B, H, W, D, [s] * 3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape,shift", [((2, 8, 8, 8), 0), ((2, 8, 8, 8), 2), ((1, 5, 5, 5), 2), ((1, 10, 10, 10), 2), ((1, 2, 2, 2), 2), ((1, 6, 8, 4), 2)])
+def test_layernorm_window_modes(dt, shape, shift):
+    from oracle import mae3d_oracle as O
+    ops = _ops()
+    B, H, W, D = shape
+    C = 96
+    x = q(rnd(B, H, W, D, C), dt)
+    gam, bet = 1 + 0.2 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    geom = _geom(ops, B, H, W, D, shift)
+    T = geom.tokens
+    # forward, window-ordered
+    out = torch.empty(geom.rows, C, dtype=dt, device="cuda")
+    mean, rstd = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    ops.layernorm_fwd(dev(x, dt), dev(gam), dev(bet), out, mean, rstd, geom.rows, C, src_mode=1, geom=geom)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ln = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    pad = [g_ - s for g_, s in zip(geom.P, (H, W, D))]
+    lp = F.pad(ln, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+    if sum(geom.shift) > 0:
+        lp = torch.roll(lp, shifts=[-s for s in geom.shift], dims=(1, 2, 3))
+    ref = O.window_partition(lp).reshape(-1, C)
+    check(out, ref, dt, "ln window fwd")
+    # backward from a window-ordered gradient, with residual grad
+    dyw = q(rnd(geom.rows, C, seed=3), dt)
+    dres = q(rnd(T, C, seed=4), dt)
+    (ref * dyw).sum().backward()
+    dx = torch.empty(T, C, dtype=dt, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.layernorm_bwd(dev(dyw, dt), dev(x, dt), dev(gam), mean, rstd, dx, dg, db, T, C, src_mode=1, geom=geom, dres=dev(dres, dt))
+    check(dx, xr.grad.reshape(T, C) + dres, dt, "ln window bwd dx", mult=2)
+    check(dg, gr.grad, dt, "dgamma", mult=2)
+    check(db, br.grad, dt, "dbeta", mult=2)
+    # scatter/gather adjoint pair
+    yw = q(rnd(geom.rows, C, seed=5), dt)
+    rs = torch.tensor([1.0 / 0.9, 0.0][:B])
+    o2 = torch.empty(T, C, dtype=dt, device="cuda")
+    ops.window_scatter_residual(dev(yw, dt), dev(x.reshape(T, C), dt), o2, dev(rs), C, geom)
+    yv = O.window_reverse(yw.view(-1, 64, C), B, *geom.P)
+    if sum(geom.shift) > 0:
+        yv = torch.roll(yv, shifts=list(geom.shift), dims=(1, 2, 3))
+    ref2 = x + rs.view(B, 1, 1, 1, 1) * yv[:, :H, :W, :D]
+    check(o2, ref2.reshape(T, C), dt, "window scatter")
+    g2 = torch.empty(geom.rows, C, dtype=dt, device="cuda")
+    ops.window_gather_scale(dev(x.reshape(T, C), dt), g2, dev(rs), C, geom)
+    xs = x * rs.view(B, 1, 1, 1, 1)
+    xp = F.pad(xs, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+    if sum(geom.shift) > 0:
+        xp = torch.roll(xp, shifts=[-s for s in geom.shift], dims=(1, 2, 3))
+    check(g2, O.window_partition(xp).reshape(-1, C), dt, "window gather")
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("C", [96, 192, 384])
+def test_layernorm_plain_and_embed_post(dt, C):
+    ops = _ops()
+    B, tps = 2, 130
+    T = B * tps
+    x = q(rnd(T, C), dt)
+    gam, bet = 1 + 0.2 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
+    pos, mt = rnd(tps, C, seed=3), rnd(C, seed=4, scale=0.1)
+    mask = (torch.arange(tps) % 3 == 0).to(torch.uint8)
+    out = torch.empty(T, C, dtype=dt, device="cuda")
+    mean, rstd = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    ops.layernorm_fwd(dev(x, dt), dev(gam), dev(bet), out, mean, rstd, T, C, pos=dev(pos), mask=dev(mask), mask_token=dev(mt), tokens_per_sample=tps)
+    xr, gr, br, mr = [t.clone().requires_grad_(True) for t in (x, gam, bet, mt)]
+    ln = F.layer_norm(xr, (C,), gr, br, 1e-5).view(B, tps, C) + pos
+    ref = torch.where(mask.bool()[None, :, None], mr.view(1, 1, C), ln).reshape(T, C)
+    check(out, ref, dt, "embed post fwd")
+    dy = q(rnd(T, C, seed=5), dt)
+    (ref * dy).sum().backward()
+    dx = torch.empty(T, C, dtype=dt, device="cuda")
+    dg, db, dm = [torch.zeros(C, device="cuda") for _ in range(3)]
+    ops.layernorm_bwd(dev(dy, dt), dev(x, dt), dev(gam), mean, rstd, dx, dg, db, T, C, mask=dev(mask), dmask_token=dm, tokens_per_sample=tps)
+    check(dx, xr.grad, dt, "dx", 2)
+    check(dg, gr.grad, dt, "dgamma", 2)
+    check(db, br.grad, dt, "dbeta", 2)
+    check(dm, mr.grad, dt, "dmask_token", 2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape,C", [((2, 8, 8, 8), 96), ((1, 5, 5, 5), 96), ((1, 6, 5, 4), 192), ((1, 3, 3, 3), 384)])
+def test_patch_merge_layernorm(dt, shape, C):
+    from oracle import mae3d_oracle as O
+    ops = _ops()
+    B, H, W, D = shape
+    x = q(rnd(B, H, W, D, C), dt)
+    gam, bet = 1 + 0.2 * rnd(8 * C, seed=1), 0.1 * rnd(8 * C, seed=2)
+    geom = ops.WinGeom(B, H, W, D, [0, 0, 0])
+    H2, W2, D2 = (H + 1) // 2, (W + 1) // 2, (D + 1) // 2
+    rows = B * H2 * W2 * D2
+    out = torch.empty(rows, 8 * C, dtype=dt, device="cuda")
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(dev(x, dt), dev(gam), dev(bet), out, mean, rstd, rows, 8 * C, src_mode=2, geom=geom)
+    xr, gr, br = [t.clone().requires_grad_(True) for t in (x, gam, bet)]
+    ref = F.layer_norm(O.patch_merge_gather(xr), (8 * C,), gr, br, 1e-5).reshape(rows, 8 * C)
+    check(out, ref, dt, "merge ln fwd")
+    dy = q(rnd(rows, 8 * C, seed=3), dt)
+    (ref * dy).sum().backward()
+    dx = torch.zeros(B * H * W * D, C, dtype=dt, device="cuda")
+    dg, db = torch.zeros(8 * C, device="cuda"), torch.zeros(8 * C, device="cuda")
+    ops.layernorm_bwd(dev(dy, dt), dev(x, dt), dev(gam), mean, rstd, dx, dg, db, rows, 8 * C, src_mode=2, geom=geom)
+    check(dx, xr.grad.reshape(-1, C), dt, "merge dx", 2)
+    check(dg, gr.grad, dt, "merge dgamma", 2)
+    check(db, br.grad, dt, "merge dbeta", 2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape,shift,heads", [((2, 8, 8, 8), 0, 3), ((2, 8, 8, 8), 2, 3), ((1, 5, 5, 5), 2, 6), ((1, 10, 10, 10), 2, 3), ((1, 2, 2, 2), 2, 12), ((1, 6, 8, 4), 2, 3)])
+def test_window_attention_core(dt, shape, shift, heads):
+    """attention core on window-ordered qkv vs the oracle's softmax path (bias + mask + pads as keys)."""
+    from oracle import mae3d_oracle as O
+    ops = _ops()
+    B, H, W, D = shape
+    C = heads * 32
+    geom = _geom(ops, B, H, W, D, shift)
+    nW = geom.rows // 64 // B
+    qkv = q(rnd(geom.rows, 3 * C, scale=1.5), dt)
+    table = rnd(343, heads, seed=1, scale=0.5)
+    dout = q(rnd(geom.rows, C, seed=2), dt)
+    qr, tr = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    t = qr.view(-1, 64, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    attn = (t[0] * 32 ** -0.5) @ t[1].transpose(-2, -1)
+    attn = attn + tr[O.rel_pos_index(4)].view(64, 64, heads).permute(2, 0, 1).unsqueeze(0)
+    if sum(geom.shift) > 0:
+        ids = O.window_partition(O.shift_region_ids(geom.P, geom.shift)[None, ..., None]).view(nW, 64)
+        am = torch.zeros(nW, 64, 64).masked_fill((ids[:, None, :] - ids[:, :, None]) != 0, -100.0)
+        attn = (attn.view(B, nW, heads, 64, 64) + am[None, :, None]).view(-1, heads, 64, 64)
+    p = attn.softmax(-1)
+    ref = (p @ t[2]).transpose(1, 2).reshape(-1, C)
+    ref.backward(dout)
+    out = torch.empty(geom.rows, C, dtype=dt, device="cuda")
+    lse = torch.empty(geom.rows * heads, device="cuda")
+    ops.window_attn_fwd(dev(qkv, dt), dev(table), out, lse, heads, C, geom)
+    check(out, ref, dt, "attn fwd")
+    dqkv = torch.empty(geom.rows, 3 * C, dtype=dt, device="cuda")
+    dtab = torch.zeros(343, heads, device="cuda")
+    ops.window_attn_bwd(dev(qkv, dt), dev(table), dev(dout, dt), lse, dqkv, dtab, heads, C, geom)
+    check(dqkv, qr.grad, dt, "attn dqkv", 2)
+    check(dtab, tr.grad, dt, "attn dbias", 2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,V,C,rmode", [(2, 1000, 48, 0), (2, 343, 96, 1), (1, 5000, 48, 1), (2, 216, 384, 2), (1, 8 ** 3, 192, 2)])
+def test_instnorm_fwd_bwd(dt, B, V, C, rmode):
+    ops = _ops()
+    x = q(rnd(B, V, C) * 1.5 + 0.3, dt)
+    r = q(rnd(B, V, C, seed=1), dt) if rmode else None
+    dout = q(rnd(B, V, C, seed=2), dt)
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if rmode else None
+    inorm = lambda t: F.instance_norm(t.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+    pre = inorm(xr) + (rr if rmode == 1 else inorm(rr) if rmode == 2 else 0)
+    ref = F.leaky_relu(pre, 0.01)
+    ref.backward(dout)
+    xd = dev(x, dt)
+    stats, scratch = torch.empty(B, C, 2, device="cuda"), torch.empty(B, C, 2, dtype=torch.float64, device="cuda")
+    ops.instnorm_stats(xd, stats, scratch, B, V, C)
+    rd, stats_r = (dev(r, dt) if rmode else None), None
+    if rmode == 2:
+        stats_r = torch.empty(B, C, 2, device="cuda")
+        ops.instnorm_stats(rd, stats_r, scratch, B, V, C)
+    out = torch.empty(B, V, C, dtype=dt, device="cuda")
+    ops.instnorm_apply(xd, stats, out, B, V, C, r=rd, stats_r=stats_r, rmode=rmode)
+    check(out, ref, dt, "in fwd")
+    out_ref_dev = dev(ref, dt)  # use the exact forward output so the lrelu sign pattern matches
+    sums = torch.empty(B, C, 2, dtype=torch.float64, device="cuda")
+    sums_r = torch.empty(B, C, 2, dtype=torch.float64, device="cuda") if rmode == 2 else None
+    dd = dev(dout, dt)
+    ops.instnorm_bwd_reduce(dd, out_ref_dev, xd, stats, sums, B, V, C, r=rd, stats_r=stats_r, sums_r=sums_r, rmode=rmode)
+    dx = torch.empty(B, V, C, dtype=dt, device="cuda")
+    dr = torch.empty(B, V, C, dtype=dt, device="cuda") if rmode else None
+    ops.instnorm_bwd_apply(dd, out_ref_dev, xd, stats, sums, dx, B, V, C, r=rd, stats_r=stats_r, sums_r=sums_r, rmode=rmode, dr=dr)
+    check(dx, xr.grad, dt, "in dx", 3)
+    if rmode:
+        check(dr, rr.grad, dt, "in dr", 3)
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("k,Cin,Cout,v,skip", [(2, 96, 48, 3, True), (4, 48, 24, 2, False), (2, 768, 384, 2, True)])
+def test_upconv_block_pieces(dt, k, Cin, Cout, v, skip):
+    """ConvTranspose3d(k=s) = GEMM + pixel shuffle (+bias, +skip concat); backward pieces incl. weight grad remap."""
+    ops = _ops()
+    B = 2
+    x = q(rnd(B, Cin, v, v, v), dt)
+    w = q(rnd(Cin, Cout, k, k, k, seed=1, scale=Cin ** -0.5), dt)
+    b = rnd(Cout, seed=2, scale=0.1)
+    V = v * k
+    sk = q(rnd(B, Cout, V, V, V, seed=3), dt) if skip else None
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    skr = sk.clone().requires_grad_(True) if skip else None
+    y = F.conv_transpose3d(xr, wr, br, stride=k)
+    cat = torch.cat((y, skr), 1) if skip else y
+    dcat = q(rnd(*cat.shape, seed=4), dt)
+    cat.backward(dcat)
+    k3 = k ** 3
+    xcl = dev(x.permute(0, 2, 3, 4, 1).reshape(-1, Cin), dt)
+    wf = dev(w.reshape(Cin, Cout, k3).permute(2, 1, 0).reshape(k3 * Cout, Cin), dt)     # [(t,co)][ci]
+    wd = dev(w.reshape(Cin, Cout, k3).permute(0, 2, 1).reshape(Cin, k3 * Cout), dt)     # [ci][(t,co)]
+    upre = ops.gemm_nt(xcl, wf)
+    Cc = 2 * Cout if skip else Cout
+    out = torch.empty(B * V ** 3, Cc, dtype=dt, device="cuda")
+    skcl = dev(sk.permute(0, 2, 3, 4, 1).reshape(-1, Cout), dt) if skip else None
+    ops.upconv_shuffle_fwd(upre, dev(b), skcl, out, B, v, k, Cout)
+    check(out.view(B, V, V, V, Cc).permute(0, 4, 1, 2, 3), cat, dt, "upconv fwd")
+    dc = dev(dcat.permute(0, 2, 3, 4, 1).reshape(-1, Cc), dt)
+    dupre = torch.empty(B * v ** 3, k3 * Cout, dtype=dt, device="cuda")
+    dskip = torch.empty(B * V ** 3, Cout, dtype=dt, device="cuda") if skip else None
+    dbias = torch.zeros(Cout, device="cuda")
+    ops.upconv_shuffle_bwd(dc, dupre, dskip, dbias, B, v, k, Cout, skip)
+    check(dbias, br.grad, dt, "upconv dbias", 2)
+    if skip:
+        check(dskip.view(B, V, V, V, Cout).permute(0, 4, 1, 2, 3), skr.grad, dt, "dskip")
+    dx = ops.gemm_nt(dupre, wd)
+    check(dx.view(B, v, v, v, Cin).permute(0, 4, 1, 2, 3), xr.grad, dt, "upconv dx", 2)
+    dW = torch.zeros(Cin, Cout, k, k, k, device="cuda")
+    ops.gemm_tn(dupre, xcl, dW, omode=2, p0=Cout, p1=k3)
+    check(dW, wr.grad, dt, "upconv dW", 2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_loss_head(dt):
+    from oracle import mae3d_oracle as O
+    ops = _ops()
+    B, R, Cd = 2, 32, 48
+    x = torch.stack([O.synthetic_grid((32, 32, 32), 3), O.synthetic_grid((32, 32, 32), 4)])
+    valid = torch.ones_like(x)
+    valid[1, :, 28:] = 0
+    valid[1, :, :, 24:] = 0
+    x = x * valid
+    ext = torch.tensor([[32, 32, 32], [28, 24, 32]], dtype=torch.int32)
+    d0 = q(rnd(B, R, R, R, Cd), dt)
+    Wo, bo = rnd(4, Cd, seed=1, scale=0.2), rnd(4, seed=2, scale=0.1)
+    tm = O.draw_block_mask((8, 8, 8), 0.6, rng=__import__("random").Random(5))
+    d0r, Wr, br_ = d0.clone().requires_grad_(True), Wo.clone().requires_grad_(True), bo.clone().requires_grad_(True)
+    pred = (d0r @ Wr.T + br_).permute(0, 4, 1, 2, 3)
+    tmask = tm[None, ..., None].expand(B, -1, -1, -1, 1)
+    l, lr, la, *_ = O.mae_loss(x, pred, valid, tmask)
+    l.backward()
+    sums = torch.empty(4, dtype=torch.float64, device="cuda")
+    losses = torch.empty(3, device="cuda")
+    predk = torch.empty(B, 4, R, R, R, device="cuda")
+    args = (dev(d0, dt), dev(Wo), dev(bo), dev(x), dev(ext), dev(tm.to(torch.uint8)), B, R, Cd, sums)
+    ops.mae_loss_fwd(*args, losses, predk)
+    check(predk, pred, dt, "pred")
+    np.testing.assert_allclose(losses.cpu().numpy(), [l.item(), lr.item(), la.item()], rtol=TOL[dt])
+    dd0 = torch.empty(B * R ** 3, Cd, dtype=dt, device="cuda")
+    dp8 = torch.empty(B * R ** 3, 8, dtype=dt, device="cuda")
+    dW, db = torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda")
+    ops.mae_loss_bwd(*args, dd0, dp8, dW, db)
+    check(dd0, d0r.grad.reshape(-1, Cd), dt, "dd0", 2)
+    check(dW, Wr.grad, dt, "dWout", 2)
+    check(db, br_.grad, dt, "dbout", 2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_patch_embed_gather_and_bias_grad(dt):
+    ops = _ops()
+    B, R, C = 2, 16, 96
+    x = rnd(B, 4, R, R, R)
+    w, b = q(rnd(C, 4, 4, 4, 4, seed=1, scale=1 / 16), dt), rnd(C, seed=2)
+    A = torch.empty(B * (R // 4) ** 3, 256, dtype=dt, device="cuda")
+    ops.patch_embed_gather(dev(x), A, B, R)
+    y = ops.gemm_nt(A, dev(w.reshape(C, 256), dt), bias=dev(b))
+    ref = F.conv3d(q(x, dt), w, b, stride=4).permute(0, 2, 3, 4, 1).reshape(-1, C)
+    check(y, ref, dt, "patch embed")
+    dY = q(rnd(1234, 768, seed=3), dt)
+    db = torch.zeros(768, device="cuda")
+    ops.bias_grad(dev(dY, dt), db, 1234, 768)
+    check(db, dY.sum(0), dt, "bias grad")
+    dY2 = q(rnd(333, 3072, seed=4), dt)
+    db2 = torch.zeros(3072, device="cuda")
+    ops.bias_grad(dev(dY2, dt), db2, 333, 3072)
+    check(db2, dY2.sum(0), dt, "bias grad wide")
+
+
+def test_adamw_and_clip_match_torch():
+    ops = _ops()
+    n = 10007
+    p0, g0 = rnd(n), rnd(n, seed=1) * 3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=1e-2, betas=(0.9, 0.999))
+    p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    coef, nrm = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    for step in range(1, 4):
+        g = g0 * step
+        pr.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 0.1)
+        opt.step()
+        gd = dev(g)
+        ops.grad_sqnorm(gd, acc)
+        ops.clip_coef(acc, 0.1, coef, nrm)
+        hyper = dev(torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1e-2, 1 - 0.9 ** step, 1 - 0.999 ** step]))
+        ops.adamw_step(p, gd, m, v, hyper, coef)
+        assert abs(nrm.item() - tn.item()) / tn.item() < 1e-5
+    assert relerr(p, pr) < 1e-5
