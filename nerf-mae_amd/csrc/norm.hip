@@ -396,7 +396,8 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dou
   float s1[8], s2[8], t1[8], t2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = t1[j] = t2[j] = 0.f; }
-  float mu[8], rs_[8], mur[8], rsr[8];
+  float mu[8], rs_[8], mur[8], rsr[8], cref[8];
+  if (!BWD && vl < NV) Vec8<T>::load(x + ((long)b * V) * C + cl * 8, cref);  // per-channel shift kills the E[x^2]-mean^2 cancellation
   if (BWD && vl < NV) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dou
       Vec8<T>::load(x + o, xv);
       if (!BWD) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s1[j] += xv[j]; s2[j] += xv[j] * xv[j]; }
+        for (int j = 0; j < 8; ++j) { const float d = xv[j] - cref[j]; s1[j] += d; s2[j] += d * d; }
       } else {
         float dv[8], ov[8];
         Vec8<T>::load(dout + o, dv);
@@ -444,11 +445,14 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dou
     }
   }
 }
-__global__ void in_finalize_kernel(const double* acc, float* stats, long n, double invV, float eps) {
+template <typename T>
+__global__ void in_finalize_kernel(const double* acc, float* stats, const T* x, long n, long V, int C, double invV, float eps) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
+    const long b = i / C, c = i - b * C;
     double m = acc[2 * i] * invV, var = acc[2 * i + 1] * invV - m * m;
     if (var < 0) var = 0;
+    m += (double)to_f<T>(x[b * V * C + c]);
     stats[2 * i] = (float)m;
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
@@ -463,7 +467,8 @@ int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long
   else hipLaunchKernelGGL((in_reduce_kernel<float, 0>), grid, dim3(256), lds, st, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f);
   NMH_CHECK_LAUNCH();
   long n = (long)B * C;
-  hipLaunchKernelGGL(in_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, stats, n, 1.0 / (double)V, eps);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_finalize_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, stats, (const bf16_t*)x, n, V, C, 1.0 / (double)V, eps);
+  else hipLaunchKernelGGL(in_finalize_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, stats, (const float*)x, n, V, C, 1.0 / (double)V, eps);
   NMH_CHECK_LAUNCH();
   return 0;
 }

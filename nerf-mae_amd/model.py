@@ -1,0 +1,695 @@
+"""Host-side mirror of the reference's `SwinTransformer_MAE3D_New` (nerf_mae/model/mae/swin_mae3d.py:1067-1599;
+imported there under the alias `SwinTransformer_MAE3D`, run_swin_mae3d.py:22).
+
+Same constructor kwargs, `forward(list_of_grids, is_eval)` tuple contract, attribute contract used by nerf_rpn
+(`patch_partition`, `pos_embed`, `stages`, deletable `decoder*`/`out`/`mask_token`; feature_extractor.py:1127-1187)
+and `state_dict()` keys/shapes, so reference checkpoints load with strict=True and checkpoints written here load
+into the reference.  The nn.Linear/Conv3d/LayerNorm children are *parameter holders only*: every forward and
+backward op is a hand-written HIP kernel called through the C ABI (ops.py); activations stay channels-last
+(B,A0,A1,A2,C) token-major matrices end to end (the reference's NCDHW round trips, swin_mae3d.py:1470, are gone).
+
+Gradients: each block is one torch.autograd.Function with an explicit backward that launches the dgrad/wgrad
+kernels; parameter gradients are accumulated by the kernels (fp32 atomics) straight into `param.grad`, which are
+views of one flat fp32 buffer (likewise the parameters), so the optimizer and the data-parallel all-reduce work on
+two flat buffers."""
+from __future__ import annotations
+
+import math
+import random
+import struct
+from functools import partial
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .ops import WinGeom
+
+WS = 4
+
+
+# --------------------------------------------------------------------------------------------------
+# fixed tables (restated from the reference's formulas; validated against golden vectors in tests)
+# --------------------------------------------------------------------------------------------------
+def _sincos_1d(dim: int, pos: np.ndarray) -> np.ndarray:
+    omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+    ang = pos.reshape(-1).astype(np.float64)[:, None] * omega[None, :]
+    return np.concatenate([np.sin(ang), np.cos(ang)], axis=1)
+
+
+def sincos_pos_embed_3d(embed_dim: int, g: int) -> np.ndarray:
+    """torch_utils.py:5-31: channel thirds encode (a1, a0, a2) of token (a0,a1,a2); zero-padded when 3*(C//3) < C
+    (the defined swin_b deviation)."""
+    third = embed_dim // 3
+    third -= third % 2
+    i, j, k = np.meshgrid(np.arange(g), np.arange(g), np.arange(g), indexing="ij")
+    emb = np.concatenate([_sincos_1d(third, j), _sincos_1d(third, i), _sincos_1d(third, k)], axis=1)
+    if emb.shape[1] < embed_dim:
+        emb = np.concatenate([emb, np.zeros((emb.shape[0], embed_dim - emb.shape[1]))], axis=1)
+    return emb.reshape(1, g, g, g, embed_dim)
+
+
+def relative_position_index(ws: int = WS) -> Tensor:
+    c = torch.stack(torch.meshgrid(*[torch.arange(ws)] * 3, indexing="ij")).flatten(1)
+    rel = (c[:, :, None] - c[:, None, :]) + (ws - 1)
+    m = 2 * ws - 1
+    return (rel[0] * m * m + rel[1] * m + rel[2]).flatten()
+
+
+def draw_block_mask(g: Sequence[int], p_remove: float, block: int = 4, rng=random) -> Tensor:
+    """swin_mae3d.py:1366-1373: one python-`random` draw per 4x4x4-token block in raster order -> uint8 (g0,g1,g2), 1 = removed."""
+    m = torch.zeros(tuple(g), dtype=torch.uint8)
+    for h in range(0, g[0] - block + 1, block):
+        for w in range(0, g[1] - block + 1, block):
+            for d in range(0, g[2] - block + 1, block):
+                if rng.random() < p_remove:
+                    m[h:h + block, w:w + block, d:d + block] = 1
+    return m
+
+
+# --------------------------------------------------------------------------------------------------
+# packed compute-dtype weights
+# --------------------------------------------------------------------------------------------------
+class _Packer:
+    """Owns the flat compute-dtype buffer holding every GEMM operand layout derived from the fp32 master
+    parameters, and the device descriptor table for the single-launch pack kernel."""
+
+    CAST, TRANS, CONV_F, CONV_D, CONVT_F, CONVT_D = 0, 1, 2, 3, 4, 5
+
+    def __init__(self):
+        self.items = []  # (key, param, mode, dims, numel)
+        self.views = {}
+
+    def add(self, key: str, p: nn.Parameter, mode: int):
+        sh = tuple(p.shape)
+        if mode in (self.CAST,):
+            dims = (0, 0, 0)
+        elif mode == self.TRANS:
+            dims = (sh[0], int(np.prod(sh[1:])), 0)
+        elif mode in (self.CONV_F, self.CONV_D):
+            dims = (sh[0], sh[1], 27)
+        else:
+            dims = (sh[0], sh[1], int(np.prod(sh[2:])))
+        self.items.append((key, p, mode, dims, p.numel()))
+
+    def build(self, dtype: torch.dtype, device):
+        total = sum((n + 63) // 64 * 64 for *_, n in self.items)
+        self.buf = torch.empty(total, dtype=dtype, device=device)
+        esz = self.buf.element_size()
+        descs, blk2desc, blkstart = b"", [], []
+        off = 0
+        for i, (key, p, mode, dims, n) in enumerate(self.items):
+            self.views[key] = self.buf[off:off + n]
+            descs += struct.pack("<QQiiiiq", p.data_ptr(), self.buf.data_ptr() + off * esz, mode, dims[0], dims[1], dims[2], n)
+            for s in range(0, n, 1024):
+                blk2desc.append(i)
+                blkstart.append(s)
+            off += (n + 63) // 64 * 64
+        self.descs = torch.frombuffer(bytearray(descs), dtype=torch.uint8).to(device)
+        self.blk2desc = torch.tensor(blk2desc, dtype=torch.int32, device=device)
+        self.blkstart = torch.tensor(blkstart, dtype=torch.int64, device=device)
+        self.dt = ops.BF16 if dtype == torch.bfloat16 else ops.F32
+
+    def run(self):
+        ops.pack_weights(self.dt, self.descs, self.blk2desc, self.blkstart, self.blk2desc.numel())
+
+    def __getitem__(self, key):
+        return self.views[key]
+
+
+def _gradbuf(p: nn.Parameter) -> Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd Functions (one per block; explicit backward launching the HIP dgrad/wgrad kernels)
+# --------------------------------------------------------------------------------------------------
+class _EmbedFn(torch.autograd.Function):
+    """patch conv (im2row + GEMM) -> LayerNorm -> + pos_embed -> masked tokens <- mask_token (swin_mae3d.py:1455-1463)."""
+
+    @staticmethod
+    def forward(ctx, anchor, mod, xb, mask_dev):
+        m: "SwinTransformer_MAE3D_New" = mod
+        B, R = xb.shape[0], xb.shape[2]
+        g = R // 4
+        T, C, dtype = B * g ** 3, m.embed_dim, m.compute_dtype
+        A = torch.empty((T, 256), dtype=dtype, device=xb.device)
+        ops.patch_embed_gather(xb, A, B, R)
+        conv, ln = m.patch_partition[0], m.patch_partition[2]
+        y0 = ops.gemm_nt(A, m._pk["pe.w"].view(C, 256), bias=conv.bias)
+        tok = torch.empty((T, C), dtype=dtype, device=xb.device)
+        mean, rstd = torch.empty(T, device=xb.device), torch.empty(T, device=xb.device)
+        use_mask = mask_dev is not None
+        ops.layernorm_fwd(y0, ln.weight, ln.bias, tok, mean, rstd, T, C, pos=m.pos_embed.view(-1, C) if m._add_pos else None,
+                          mask=mask_dev, mask_token=m.mask_token if use_mask else None, tokens_per_sample=g ** 3)
+        ctx.m, ctx.saved, ctx.dims = m, (A, y0, mean, rstd, mask_dev), (T, C, g)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        m = ctx.m
+        A, y0, mean, rstd, mask_dev = ctx.saved
+        T, C, g = ctx.dims
+        conv, ln = m.patch_partition[0], m.patch_partition[2]
+        dy0 = torch.empty_like(y0)
+        ops.layernorm_bwd(dtok.contiguous(), y0, ln.weight, mean, rstd, dy0, _gradbuf(ln.weight), _gradbuf(ln.bias), T, C,
+                          mask=mask_dev, dmask_token=_gradbuf(m.mask_token) if mask_dev is not None else None, tokens_per_sample=g ** 3)
+        ops.gemm_tn(dy0, A, _gradbuf(conv.weight))
+        ops.bias_grad(dy0, _gradbuf(conv.bias), T, C)
+        return None, None, None, None
+
+
+class _BlockFn(torch.autograd.Function):
+    """x + SD(attn(LN1 x)); x + SD(MLP(LN2 x))  (swin_mae3d.py:366-369)."""
+
+    @staticmethod
+    def forward(ctx, x, blk, geom, sd1, sd2):
+        b: "SwinBlock3D" = blk
+        pk, key = b._pk, b._key
+        T, C, heads = geom.tokens, b.dim, b.num_heads
+        dev, dtype = x.device, x.dtype
+        tps = T // geom.B
+        xnw = torch.empty((geom.rows, C), dtype=dtype, device=dev)
+        mean1, rstd1 = torch.empty(T, device=dev), torch.empty(T, device=dev)
+        ops.layernorm_fwd(x, b.norm1.weight, b.norm1.bias, xnw, mean1, rstd1, geom.rows, C, src_mode=1, geom=geom)
+        qkv = ops.gemm_nt(xnw, pk[key + "qkv.w"].view(3 * C, C), bias=b.attn.qkv.bias)
+        o = torch.empty((geom.rows, C), dtype=dtype, device=dev)
+        lse = torch.empty(geom.rows * heads, device=dev)
+        ops.window_attn_fwd(qkv, b.attn.relative_position_bias_table, o, lse, heads, C, geom)
+        yw = ops.gemm_nt(o, pk[key + "proj.w"].view(C, C), bias=b.attn.proj.bias)
+        x1 = torch.empty_like(x)
+        ops.window_scatter_residual(yw, x, x1, sd1, C, geom)
+        x1n = torch.empty_like(x)
+        mean2, rstd2 = torch.empty(T, device=dev), torch.empty(T, device=dev)
+        ops.layernorm_fwd(x1, b.norm2.weight, b.norm2.bias, x1n, mean2, rstd2, T, C)
+        h_pre = torch.empty((T, 4 * C), dtype=dtype, device=dev)
+        h_act = ops.gemm_nt(x1n, pk[key + "fc1.w"].view(4 * C, C), bias=b.mlp[0].bias, act=1, C2=h_pre)
+        x2 = ops.gemm_nt(h_act, pk[key + "fc2.w"].view(C, 4 * C), bias=b.mlp[3].bias, resid=x1, rowscale=sd2, rows_per_scale=tps)
+        ctx.b, ctx.geom = b, geom
+        ctx.saved = (x, xnw, mean1, rstd1, qkv, o, lse, x1, x1n, mean2, rstd2, h_pre, h_act, sd1, sd2)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        b, geom = ctx.b, ctx.geom
+        x, xnw, mean1, rstd1, qkv, o, lse, x1, x1n, mean2, rstd2, h_pre, h_act, sd1, sd2 = ctx.saved
+        pk, key = b._pk, b._key
+        T, C, heads = geom.tokens, b.dim, b.num_heads
+        tps = T // geom.B
+        dx2 = dx2.contiguous()
+        # ---- MLP branch
+        dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
+        ops.gemm_tn(dx2, h_act, _gradbuf(b.mlp[3].weight), rowscale=sd2, rows_per_scale=tps)
+        ops.bias_grad(dx2, _gradbuf(b.mlp[3].bias), T, C, rowscale=sd2, rows_per_scale=tps)
+        dx1n = ops.gemm_nt(dh, pk[key + "fc1.wT"].view(C, 4 * C))
+        ops.gemm_tn(dh, x1n, _gradbuf(b.mlp[0].weight))
+        ops.bias_grad(dh, _gradbuf(b.mlp[0].bias), T, 4 * C)
+        dx1 = torch.empty_like(x)
+        ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2)
+        # ---- attention branch
+        dyw = torch.empty_like(xnw)
+        ops.window_gather_scale(dx1, dyw, sd1, C, geom)
+        do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
+        ops.gemm_tn(dyw, o, _gradbuf(b.attn.proj.weight))
+        ops.bias_grad(dyw, _gradbuf(b.attn.proj.bias), geom.rows, C)
+        dqkv = torch.empty_like(qkv)
+        ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
+        dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
+        ops.gemm_tn(dqkv, xnw, _gradbuf(b.attn.qkv.weight))
+        ops.bias_grad(dqkv, _gradbuf(b.attn.qkv.bias), geom.rows, 3 * C)
+        dx = torch.empty_like(x)
+        ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
+        return dx, None, None, None, None
+
+
+class _MergeFn(torch.autograd.Function):
+    """2x2x2 gather -> LayerNorm(8C) -> Linear(8C,2C,no bias)  (swin_mae3d.py:390-414)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, geom):
+        m: "PatchMerging3D" = mod
+        Cin = m.dim
+        H2, W2, D2 = (geom.H + 1) // 2, (geom.W + 1) // 2, (geom.D + 1) // 2
+        rows = geom.B * H2 * W2 * D2
+        xg = torch.empty((rows, 8 * Cin), dtype=x.dtype, device=x.device)
+        mean, rstd = torch.empty(rows, device=x.device), torch.empty(rows, device=x.device)
+        ops.layernorm_fwd(x, m.norm.weight, m.norm.bias, xg, mean, rstd, rows, 8 * Cin, src_mode=2, geom=geom)
+        y = ops.gemm_nt(xg, m._pk[m._key + "red.w"].view(2 * Cin, 8 * Cin))
+        ctx.m, ctx.geom, ctx.saved, ctx.rows = m, geom, (x, xg, mean, rstd), rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m, geom, rows = ctx.m, ctx.geom, ctx.rows
+        x, xg, mean, rstd = ctx.saved
+        Cin = m.dim
+        dy = dy.contiguous()
+        dxg = ops.gemm_nt(dy, m._pk[m._key + "red.wT"].view(8 * Cin, 2 * Cin))
+        ops.gemm_tn(dy, xg, _gradbuf(m.reduction.weight))
+        dx = torch.empty_like(x)
+        ops.layernorm_bwd(dxg, x, m.norm.weight, mean, rstd, dx, _gradbuf(m.norm.weight), _gradbuf(m.norm.bias), rows, 8 * Cin, src_mode=2, geom=geom)
+        return dx, None, None
+
+
+class _UpBlockFn(torch.autograd.Function):
+    """ConvTranspose3d(k=s) -> cat(skip) -> UnetResBlock (unetr_block.py:57-71,193-200), channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, skip, mod, B, v):
+        m: "UpBlock3D" = mod
+        pk, key = m._pk, m._key
+        k, Cin, Cout = m.k, m.cin, m.cout
+        k3, V = k ** 3, (v * k) ** 3
+        dev, dtype = x.device, x.dtype
+        has_skip = skip is not None
+        Cc = 2 * Cout if has_skip else Cout
+        upre = ops.gemm_nt(x, pk[key + "t.w"].view(k3 * Cout, Cin))
+        cat = torch.empty((B * V, Cc), dtype=dtype, device=dev)
+        ops.upconv_shuffle_fwd(upre, m.transp_conv.bias, skip, cat, B, v, k, Cout)
+        del upre
+        S = v * k
+        scratch = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
+        y1 = ops.conv3d_k3(cat.view(B, S, S, S, Cc), pk[key + "c1.w"], Cout).view(B * V, Cout)
+        st1 = torch.empty((B, Cout, 2), device=dev)
+        ops.instnorm_stats(y1, st1, scratch, B, V, Cout)
+        a1 = torch.empty_like(y1)
+        ops.instnorm_apply(y1, st1, a1, B, V, Cout)
+        y2 = ops.conv3d_k3(a1.view(B, S, S, S, Cout), pk[key + "c2.w"], Cout).view(B * V, Cout)
+        st2 = torch.empty((B, Cout, 2), device=dev)
+        ops.instnorm_stats(y2, st2, scratch, B, V, Cout)
+        out = torch.empty_like(y2)
+        y3 = st3 = None
+        if m.has_proj:
+            y3 = ops.gemm_nt(cat, pk[key + "c3.w"].view(Cout, Cc))
+            st3 = torch.empty((B, Cout, 2), device=dev)
+            ops.instnorm_stats(y3, st3, scratch, B, V, Cout)
+            ops.instnorm_apply(y2, st2, out, B, V, Cout, r=y3, stats_r=st3, rmode=2)
+        else:
+            ops.instnorm_apply(y2, st2, out, B, V, Cout, r=cat, rmode=1)
+        ctx.m, ctx.dims = m, (B, v, has_skip)
+        ctx.saved = (x, cat, y1, st1, a1, y2, st2, y3, st3, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.m
+        B, v, has_skip = ctx.dims
+        x, cat, y1, st1, a1, y2, st2, y3, st3, out = ctx.saved
+        pk, key = m._pk, m._key
+        k, Cin, Cout = m.k, m.cin, m.cout
+        k3, S = k ** 3, v * k
+        V = S ** 3
+        Cc = cat.shape[1]
+        dev, dtype = x.device, x.dtype
+        dout = dout.contiguous()
+        sums2 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
+        dy2 = torch.empty_like(y2)
+        dcat = torch.empty_like(cat)
+        if m.has_proj:
+            sums3 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
+            dy3 = torch.empty_like(y3)
+            ops.instnorm_bwd_reduce(dout, out, y2, st2, sums2, B, V, Cout, r=y3, stats_r=st3, sums_r=sums3, rmode=2)
+            ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, r=y3, stats_r=st3, sums_r=sums3, rmode=2, dr=dy3)
+        else:
+            ops.instnorm_bwd_reduce(dout, out, y2, st2, sums2, B, V, Cout, rmode=1)
+            ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, rmode=1, dr=dcat)  # dcat <- g (plain residual)
+        da1 = ops.conv3d_k3(dy2.view(B, S, S, S, Cout), pk[key + "c2.wd"], Cout).view(B * V, Cout)
+        ops.conv3d_k3_wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
+        sums1 = sums2
+        ops.instnorm_bwd_reduce(da1, a1, y1, st1, sums1, B, V, Cout, rmode=0)
+        dy1 = dy2  # reuse
+        ops.instnorm_bwd_apply(da1, a1, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
+        ops.conv3d_k3(dy1.view(B, S, S, S, Cout), pk[key + "c1.wd"], Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
+        ops.conv3d_k3_wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
+        if m.has_proj:
+            ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
+            ops.gemm_tn(dy3, cat, _gradbuf(m.conv_block.conv3.weight))
+        dupre = torch.empty((B * v ** 3, k3 * Cout), dtype=dtype, device=dev)
+        dskip = torch.empty((B * V, Cout), dtype=dtype, device=dev) if has_skip else None
+        ops.upconv_shuffle_bwd(dcat, dupre, dskip, _gradbuf(m.transp_conv.bias), B, v, k, Cout, has_skip)
+        dx = ops.gemm_nt(dupre, pk[key + "t.wd"].view(Cin, k3 * Cout))
+        ops.gemm_tn(dupre, x, _gradbuf(m.transp_conv.weight), omode=2, p0=Cout, p1=k3)
+        return dx, dskip, None, None, None
+
+
+class _LossFn(torch.autograd.Function):
+    """UnetOutBlock 1x1 conv + forward_loss (swin_mae3d.py:1513-1549) fused; outputs (loss, loss_rgb, loss_alpha)."""
+
+    @staticmethod
+    def forward(ctx, d0, mod, xb, extents, tokmask, pred_out):
+        m = mod
+        B, R, Cd = xb.shape[0], xb.shape[2], d0.shape[1]
+        sums = torch.empty(4, dtype=torch.float64, device=d0.device)
+        losses = torch.empty(3, device=d0.device)
+        ops.mae_loss_fwd(d0, m.out.conv.weight, m.out.conv.bias, xb, extents, tokmask, B, R, Cd, sums, losses, pred_out)
+        ctx.m, ctx.saved, ctx.dims = m, (d0, xb, extents, tokmask, sums), (B, R, Cd)
+        return losses
+
+    @staticmethod
+    def backward(ctx, dl):
+        m = ctx.m
+        d0, xb, extents, tokmask, sums = ctx.saved
+        B, R, Cd = ctx.dims
+        dd0 = torch.empty_like(d0)
+        dp8 = torch.empty((d0.shape[0], 8), dtype=d0.dtype, device=d0.device)
+        ops.mae_loss_bwd(d0, m.out.conv.weight, m.out.conv.bias, xb, extents, tokmask, B, R, Cd, sums, dd0, dp8,
+                         _gradbuf(m.out.conv.weight), _gradbuf(m.out.conv.bias))
+        return dd0, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# modules (parameter names/shapes == reference)
+# --------------------------------------------------------------------------------------------------
+class _Permute(nn.Module):  # placeholder for torchvision Permute (index 1 of patch_partition; no parameters)
+    def __init__(self, dims):
+        super().__init__()
+        self.dims = dims
+
+
+class PatchPartition(nn.Sequential):
+    """Conv3d(4,C,k=4,s=4) -> channels-last -> LayerNorm (swin_mae3d.py:1120-1129); callable on (B,4,R,R,R) -> (B,g,g,g,C)
+    as nerf_rpn uses it (feature_extractor.py:1179)."""
+
+    def forward(self, x):
+        m = self._owner()
+        m._ensure_ready(x.device)
+        m._add_pos = False
+        try:
+            tok = _EmbedFn.apply(m._anchor, m, x.float().contiguous(), None)
+        finally:
+            m._add_pos = True
+        g = x.shape[2] // 4
+        return tok.view(x.shape[0], g, g, g, -1)
+
+
+class WindowAttention3D(nn.Module):
+    def __init__(self, dim, window_size, shift_size, num_heads):
+        super().__init__()
+        self.window_size, self.shift_size, self.num_heads = window_size, shift_size, num_heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * WS - 1) ** 3, num_heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.register_buffer("relative_position_index", relative_position_index(WS))
+
+
+class SwinBlock3D(nn.Module):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio=4.0, stochastic_depth_prob=0.0, eps=1e-5):
+        super().__init__()
+        self.dim, self.num_heads, self.shift_size, self.sd_prob = dim, num_heads, list(shift_size), stochastic_depth_prob
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = WindowAttention3D(dim, window_size, shift_size, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        hid = int(dim * mlp_ratio)
+        self.mlp = nn.Sequential(nn.Linear(dim, hid), nn.GELU(), nn.Dropout(0.0), nn.Linear(hid, dim), nn.Dropout(0.0))
+
+    def _sd_noise(self, B, device):
+        if not self.training or self.sd_prob == 0.0:
+            return None
+        keep = 1.0 - self.sd_prob
+        return torch.empty(B, device=device).bernoulli_(keep).div_(keep)
+
+    def forward(self, x, sd_noise=None):
+        """x: (B,H,W,D,C) channels-last."""
+        B, H, W, D, C = x.shape
+        geom = WinGeom(B, H, W, D, self.shift_size)
+        if sd_noise is None:
+            sd_noise = (self._sd_noise(B, x.device), self._sd_noise(B, x.device))
+        y = _BlockFn.apply(x.reshape(-1, C), self, geom, sd_noise[0], sd_noise[1])
+        return y.view(B, H, W, D, C)
+
+
+class PatchMerging3D(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(8 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(8 * dim, eps=eps)
+
+    def forward(self, x):
+        B, H, W, D, C = x.shape
+        geom = WinGeom(B, H, W, D, [0, 0, 0])
+        y = _MergeFn.apply(x.reshape(-1, C), self, geom)
+        return y.view(B, (H + 1) // 2, (W + 1) // 2, (D + 1) // 2, 2 * C)
+
+
+class _Stage(nn.Sequential):
+    def forward(self, x):
+        m = self._owner()
+        m._ensure_ready(x.device)
+        if x.dtype != m.compute_dtype:
+            x = x.to(m.compute_dtype)
+        for mod in self:
+            x = mod(x.contiguous())
+        return x
+
+
+class ResBlock3D(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv3d(cin, cout, 3, 1, 1)
+        self.conv2 = nn.Conv3d(cout, cout, 3, 1, 1)
+        if cin != cout:
+            self.conv3 = nn.Conv3d(cin, cout, 1, 1)
+
+
+class UpBlock3D(nn.Module):
+    def __init__(self, cin, cout, k, use_skip=True):
+        super().__init__()
+        self.cin, self.cout, self.k, self.use_skip = cin, cout, k, use_skip
+        self.transp_conv = nn.ConvTranspose3d(cin, cout, k, stride=k)
+        self.conv_block = ResBlock3D(2 * cout if use_skip else cout, cout)
+        self.has_proj = use_skip
+
+    def forward(self, x, skip=None):
+        """channels-last (B,v,v,v,Cin) [+ skip (B,kv,kv,kv,Cout)] -> (B,kv,kv,kv,Cout)"""
+        B, v = x.shape[0], x.shape[1]
+        S = v * self.k
+        out = _UpBlockFn.apply(x.reshape(-1, self.cin), skip.reshape(-1, self.cout) if self.use_skip else None, self, B, v)
+        return out.view(B, S, S, S, self.cout)
+
+
+class OutBlock3D(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, 1)
+
+
+class SwinTransformer_MAE3D_New(nn.Module):
+    def __init__(self, patch_size: List[int], embed_dim: int, depths: List[int], num_heads: List[int], window_size: List[int],
+                 mlp_ratio: float = 4.0, dropout: float = 0.0, attention_dropout: float = 0.0, stochastic_depth_prob: float = 0.1,
+                 norm_layer: Optional[Callable[..., nn.Module]] = None, block: Optional[Callable[..., nn.Module]] = None,
+                 downsample_layer: Optional[Callable[..., nn.Module]] = None, expand_dim: bool = True, out_channels: int = 4,
+                 input_ch_dim: int = 4, decoder_embed_dim: int = 768, masking_prob=0.50, resolution=160, drop_rate=0.10,
+                 masking_strategy="random", compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        if list(patch_size) != [4, 4, 4] or list(window_size) != [WS] * 3 or not expand_dim or input_ch_dim != 4 or out_channels != 4:
+            raise ValueError("the HIP path implements the configuration the reference trains: patch 4^3, window 4^3, expand_dim, 4->4 channels")
+        if dropout != 0.0 or attention_dropout != 0.0:
+            raise ValueError("dropout/attention_dropout are 0 in every reference config (run_swin_mae3d.py:400-411)")
+        if any(embed_dim * 2 ** s != num_heads[s] * 32 for s in range(len(depths))):
+            raise ValueError("head_dim must be 32 (all reference backbones; swin_b uses heads [4,8,16,32], SURVEY 8(c))")
+        if embed_dim % 16:
+            raise ValueError("embed_dim must be a multiple of 16")
+        self.out_channels, self.embed_dim, self.patch_size = out_channels, embed_dim, list(patch_size)
+        self.masking_prob, self.resolution, self.compute_dtype = masking_prob, resolution, compute_dtype
+        owner = lambda: self  # noqa: E731  (children reach the model without registering it as a submodule)
+        self.patch_partition = PatchPartition(nn.Conv3d(4, embed_dim, 4, 4), _Permute([0, 2, 3, 4, 1]), nn.LayerNorm(embed_dim, eps=1e-5))
+        self.patch_partition._owner = owner
+        self.stages = nn.ModuleList()
+        total, bid = sum(depths), 0
+        for s, depth in enumerate(depths):
+            dim = embed_dim * 2 ** s
+            mods: List[nn.Module] = [PatchMerging3D(dim // 2)] if s > 0 else []
+            for i in range(depth):
+                sd = stochastic_depth_prob * float(bid) / (total - 1)
+                mods.append(SwinBlock3D(dim, num_heads[s], list(window_size), [0] * 3 if i % 2 == 0 else [WS // 2] * 3, mlp_ratio, sd))
+                bid += 1
+            st = _Stage(*mods)
+            st._owner = owner
+            self.stages.append(st)
+        E = embed_dim
+        self.decoder4 = UpBlock3D(8 * E, 4 * E, 2)
+        self.decoder3 = UpBlock3D(4 * E, 2 * E, 2)
+        self.decoder2 = UpBlock3D(2 * E, E, 2)
+        self.decoder1 = UpBlock3D(E, E // 2, 4, use_skip=False)
+        self.out = OutBlock3D(E // 2, out_channels)
+        self.num_patches = g = resolution // patch_size[0]
+        self.pos_embed = nn.Parameter(torch.zeros(1, g, g, g, E), requires_grad=False)
+        self.mask_token = nn.Parameter(torch.zeros(E))
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+        self.pos_embed.data.copy_(torch.from_numpy(sincos_pos_embed_3d(E, g)).float())
+        nn.init.normal_(self.mask_token, std=0.02)
+        self._flat = self._flat_grad = None
+        self._packer = None
+        self._add_pos = True
+        self._anchor = None
+
+    # ---- flat buffers + packed weights ------------------------------------------------------------
+    def _trainable(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def flatten_parameters(self, device=None):
+        """Re-home every trainable parameter (and its .grad) as a view of one flat fp32 buffer."""
+        ps = self._trainable()
+        device = device or ps[0].device
+        n = sum((p.numel() + 3) // 4 * 4 for p in ps)
+        flat = torch.zeros(n, device=device)
+        fg = torch.zeros(n, device=device)
+        off = 0
+        self._offsets = {}
+        for p in ps:
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + k].view(p.shape)
+            p.grad = fg[off:off + k].view(p.shape)
+            self._offsets[id(p)] = off
+            off += (k + 3) // 4 * 4
+        self._flat, self._flat_grad = flat, fg
+        self._build_packer(device)
+        return flat, fg
+
+    def _build_packer(self, device):
+        P = _Packer()
+        P.add("pe.w", self.patch_partition[0].weight, P.CAST)
+        for s, st in enumerate(self.stages):
+            for i, mod in enumerate(st):
+                key = f"s{s}.{i}."
+                mod._key = key
+                if isinstance(mod, PatchMerging3D):
+                    P.add(key + "red.w", mod.reduction.weight, P.CAST)
+                    P.add(key + "red.wT", mod.reduction.weight, P.TRANS)
+                else:
+                    for nm, lin in (("qkv", mod.attn.qkv), ("proj", mod.attn.proj), ("fc1", mod.mlp[0]), ("fc2", mod.mlp[3])):
+                        P.add(key + nm + ".w", lin.weight, P.CAST)
+                        P.add(key + nm + ".wT", lin.weight, P.TRANS)
+        for name in ("decoder4", "decoder3", "decoder2", "decoder1"):
+            if not hasattr(self, name):
+                continue
+            d = getattr(self, name)
+            key = name + "."
+            d._key = key
+            P.add(key + "t.w", d.transp_conv.weight, P.CONVT_F)
+            P.add(key + "t.wd", d.transp_conv.weight, P.CONVT_D)
+            for cn in ("c1", "c2"):
+                conv = getattr(d.conv_block, "conv" + cn[1])
+                P.add(key + cn + ".w", conv.weight, P.CONV_F)
+                P.add(key + cn + ".wd", conv.weight, P.CONV_D)
+            if d.has_proj:
+                P.add(key + "c3.w", d.conv_block.conv3.weight, P.CAST)
+                P.add(key + "c3.wT", d.conv_block.conv3.weight, P.TRANS)
+        P.build(self.compute_dtype, device)
+        self._packer = P
+        self._pk = P
+        for mod in self.modules():
+            if isinstance(mod, (SwinBlock3D, PatchMerging3D, UpBlock3D)):
+                mod._pk = P
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+
+    def _ensure_ready(self, device):
+        ps = self._trainable()
+        stale = (self._flat is None or self._flat.device != ps[0].device or
+                 any(p.data_ptr() != self._flat.data_ptr() + 4 * self._offsets.get(id(p), -1) for p in ps))
+        if stale:
+            if not ps[0].is_cuda:
+                raise RuntimeError("SwinTransformer_MAE3D (HIP) needs its parameters on a HIP device: call .cuda() first (no CPU fallback)")
+            self.flatten_parameters()
+        self._packer.run()
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self._flat_grad is not None:
+            self._flat_grad.zero_()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def transform(self, x: List[Tensor], device):
+        """pad_tensor semantics (torch_utils.py:56-90) without materialising the ones-mask: returns the padded
+        batch (B,4,R,R,R) fp32 and the valid extents [B,3] (the analytic mask)."""
+        R = self.resolution
+        xb = torch.zeros((len(x), 4, R, R, R), dtype=torch.float32, device=device)
+        ext = []
+        for i, t in enumerate(x):
+            a0, a1, a2 = t.shape[1:]
+            xb[i, :, :a0, :a1, :a2] = t.to(device=device, dtype=torch.float32, non_blocking=True)
+            ext.append([a0, a1, a2])
+        return xb, torch.tensor(ext, dtype=torch.int32).to(device, non_blocking=True)
+
+    def forward_encoder(self, tok: Tensor, sd_noise=None):
+        feats, x, bi = [], tok, 0
+        for st in self.stages:
+            for mod in st:
+                if isinstance(mod, SwinBlock3D):
+                    x = mod(x, None if sd_noise is None else sd_noise[bi])
+                    bi += 1
+                else:
+                    x = mod(x)
+            feats.append(x)
+        return feats
+
+    def forward_decoder(self, feats: List[Tensor]) -> Tensor:
+        d = self.decoder4(feats[3], feats[2])
+        d = self.decoder3(d, feats[1])
+        d = self.decoder2(d, feats[0])
+        return self.decoder1(d)
+
+    def forward(self, x: List[Tensor], is_eval: bool = False, block_mask: Optional[Tensor] = None, sd_noise=None, return_pred: bool = False):
+        device = self.mask_token.device
+        self._ensure_ready(device)
+        xb, ext = self.transform(x, device)
+        B, R = xb.shape[0], self.resolution
+        g = R // 4
+        if block_mask is None:
+            block_mask = draw_block_mask((g, g, g), self.masking_prob)
+        mask_dev = block_mask.to(torch.uint8).contiguous().view(-1).to(device, non_blocking=True)
+        tok = _EmbedFn.apply(self._anchor, self, xb, mask_dev).view(B, g, g, g, self.embed_dim)
+        feats = self.forward_encoder(tok, sd_noise)
+        d0 = self.forward_decoder(feats)
+        want_pred = is_eval or return_pred
+        pred = torch.empty((B, 4, R, R, R), device=device) if want_pred else None
+        losses = _LossFn.apply(d0.reshape(-1, d0.shape[-1]), self, xb, ext, mask_dev, pred)
+        loss, loss_rgb, loss_alpha = losses[0], losses[1], losses[2]
+        if return_pred:
+            return loss, loss_rgb, loss_alpha, pred
+        if is_eval:
+            patch = lambda t: t.reshape(B, 4, g, 4, g, 4, g, 4).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B, g, g, g, 64, 4)  # noqa: E731
+            tgt = patch(xb)
+            return loss, loss_rgb, loss_alpha, patch(pred), tgt[..., 3:] > 0.01, tgt
+        return loss, loss_rgb, loss_alpha
+
+    def encoder_features(self, xb: Tensor) -> List[Tensor]:
+        """nerf_rpn contract (feature_extractor.py:1176-1187): NCDHW feature list [C,2C,4C,8C]."""
+        t = self.patch_partition(xb)
+        t = t + self.pos_embed.to(t.dtype)
+        feats = []
+        for st in self.stages:
+            t = st(t)
+            feats.append(t.permute(0, 4, 1, 2, 3).contiguous())
+        return feats
+
+
+SwinTransformer_MAE3D = SwinTransformer_MAE3D_New  # the alias run_swin_mae3d.py:22 imports
+
+SWIN_CONFIGS = {
+    "swin_t": dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24]),
+    "swin_s": dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24]),
+    "swin_b": dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32]),  # defined deviation, SURVEY 8(c)
+    "swin_l": dict(embed_dim=192, depths=[2, 2, 18, 2], num_heads=[6, 12, 24, 48]),
+}
+
+
+def build_model(backbone_type: str = "swin_s", resolution: int = 160, masking_prob: float = 0.75, stochastic_depth_prob: float = 0.1,
+                compute_dtype: torch.dtype = torch.bfloat16) -> SwinTransformer_MAE3D_New:
+    """The config dict of run_swin_mae3d.py:378-411."""
+    cfg = SWIN_CONFIGS[backbone_type]
+    return SwinTransformer_MAE3D_New(patch_size=[4, 4, 4], embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                                     window_size=[4, 4, 4], stochastic_depth_prob=stochastic_depth_prob, expand_dim=True,
+                                     resolution=resolution, masking_prob=masking_prob, compute_dtype=compute_dtype)

@@ -40,6 +40,8 @@ def relerr(a, b):
 
 def check(a, b, dt, name="", mult=1.0):
     e = relerr(a, b)
+    if __import__("os").environ.get("NMH_PRINT_ERR"):
+        print(f"  [{name}] {dt} relerr {e:.2e}")
     assert e < TOL[dt] * mult, f"{name}: rel err {e:.3e} (dtype {dt})"
 
 

@@ -1,0 +1,180 @@
+"""GPU: whole hot path (SwinTransformer_MAE3D forward + backward through the C ABI) vs the CPU oracle on identical
+weights (strict state_dict transplant), inputs and masks.  fp32 mode must meet the north-star 1e-3 relative bar."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def _pair(cfg, dtype, res=32, sd=0.0, mask_p=0.75, init="formula"):
+    from nerf_mae_amd.model import SwinTransformer_MAE3D
+    from oracle import mae3d_oracle as O
+    torch.manual_seed(1234)
+    ora = O.MAE3DOracle(resolution=res, masking_prob=mask_p, stochastic_depth_prob=sd, pad_pos_embed=cfg['embed_dim'] % 6 != 0, **cfg)
+    if init == "formula":
+        O.formula_fill_(ora)
+    else:  # the reference's own initialisation (trunc_normal .02 linears, kaiming convs) + non-trivial biases/bias tables
+        with torch.no_grad():
+            for n, p in ora.named_parameters():
+                if p.requires_grad and (n.endswith("bias") or "relative_position_bias_table" in n):
+                    p.add_(0.02 * torch.randn_like(p))
+    hip = SwinTransformer_MAE3D(patch_size=[4] * 3, window_size=[4] * 3, resolution=res, masking_prob=mask_p, stochastic_depth_prob=sd,
+                                compute_dtype=dtype, **cfg)
+    missing = hip.load_state_dict(ora.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return ora, hip.cuda()
+
+
+TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8])
+SWIN_T = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24])
+
+
+def _run_both(ora, hip, xs, seed):
+    from oracle import mae3d_oracle as O
+    g = ora.resolution // 4
+    bm = O.draw_block_mask((g, g, g), ora.masking_prob, rng=random.Random(seed))
+    lo = ora(xs, block_mask=bm, return_pred=True)
+    lo[0].backward()
+    hip.zero_grad()
+    lh = hip([t.cuda() for t in xs], block_mask=bm, return_pred=True)
+    lh[0].backward()
+    torch.cuda.synchronize()
+    return lo, lh
+
+
+def _grads_vs_fp64(ora, hip, xs, seed):
+    """returns loss/pred tuples and per-parameter (hip error, reference-fp32 error) measured against an fp64 oracle"""
+    import copy
+    from oracle import mae3d_oracle as O
+    lo, lh = _run_both(ora, hip, xs, seed)
+    o64 = copy.deepcopy(ora).double()
+    o64.zero_grad()
+    g = ora.resolution // 4
+    bm = O.draw_block_mask((g, g, g), ora.masking_prob, rng=random.Random(seed))
+    l64 = o64([t.double() for t in xs], block_mask=bm.double(), return_pred=True)
+    l64[0].backward()
+    p64, po, ph = dict(o64.named_parameters()), dict(ora.named_parameters()), dict(hip.named_parameters())
+    rows = {}
+    for n, p in p64.items():
+        if p.grad is None:
+            continue
+        if n.endswith(("conv1.bias", "conv2.bias", "conv3.bias")):
+            # bias feeding an InstanceNorm: gradient identically zero in exact arithmetic (rounding noise in the reference,
+            # exactly 0 here because the bias add is skipped) -- DESIGN.md "conv biases"
+            assert ph[n].grad.abs().max().item() == 0.0 and p.grad.abs().max().item() < 1e-9  # fp64 truth is ~0
+            continue
+        a, b = ph[n].grad.float().cpu().flatten(), p.grad.float().flatten()
+        rows[n] = (relerr(a, b), relerr(po[n].grad, p.grad), (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item())
+    return lo, lh, l64, rows
+
+
+def test_fp32_formula_weights_forward_matches_oracle():
+    """north-star bar: reconstructed grids within 1e-3 relative of the reference fp32 path on identical inputs
+    (formula-filled weights = the same tensors the golden fixtures pin the oracle with)."""
+    from oracle import mae3d_oracle as O
+    for cfg in (TINY, SWIN_T):
+        ora, hip = _pair(cfg, torch.float32)
+        xs = [O.synthetic_grid((32, 32, 32), 11), O.synthetic_grid((30, 28, 32), 12)]   # second sample exercises pad_tensor
+        lo, lh = _run_both(ora, hip, xs, 42)
+        for a, b, n in zip(lh[:3], lo[:3], ("loss", "loss_rgb", "loss_alpha")):
+            assert abs(a.item() - b.item()) / abs(b.item()) < 1e-4, (n, a.item(), b.item())
+        assert relerr(lh[3], lo[3]) < 1e-3, "reconstructed grid"
+
+
+@pytest.mark.parametrize("cfg,name,res", [(SWIN_T, "swin_t", 32), (TINY, "tiny", 96)])
+def test_fp32_forward_backward_matches_oracle(cfg, name, res):
+    """reference-style initialisation; gradients are judged against an fp64 oracle: the HIP fp32 path must be as close to
+    it as the reference's own fp32 arithmetic is (the gradient map amplifies 1e-7 noise ~1e3-1e4x)."""
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(cfg, torch.float32, res=res, init="default")
+    xs = [O.synthetic_grid((res, res, res), 11), O.synthetic_grid((res - 2, res - 4, res), 12)]
+    lo, lh, l64, rows = _grads_vs_fp64(ora, hip, xs, 42)
+    for a, b in zip(lh[:3], lo[:3]):
+        assert abs(a.item() - b.item()) / abs(b.item()) < 1e-5
+    assert relerr(lh[3], lo[3]) < 1e-4, "reconstructed grid"
+    worst = max(rows.items(), key=lambda kv: kv[1][0])
+    print(f"[{name}] worst grad err vs fp64: hip {worst[1][0]:.2e} (reference fp32 {worst[1][1]:.2e}) at {worst[0]}")
+    ref_noise = max(r[1] for r in rows.values())
+    for n, (eh, er, cos) in rows.items():
+        assert eh < max(1e-3, 6 * ref_noise), f"{name} grad {n}: {eh:.3e} vs reference-fp32 noise {ref_noise:.3e}"
+        assert cos > 0.9999, (n, cos)
+
+
+def test_bf16_close_to_oracle_and_eval_contract():
+    from oracle import mae3d_oracle as O
+    res = 96
+    ora, hip = _pair(TINY, torch.bfloat16, res=res, init="default")
+    xs = [O.synthetic_grid((res, res, res), 21), O.synthetic_grid((res, 80, 91), 22)]
+    lo, lh, l64, rows = _grads_vs_fp64(ora, hip, xs, 7)
+    for a, b in zip(lh[:3], lo[:3]):
+        assert abs(a.item() - b.item()) / abs(b.item()) < 1e-2
+    assert relerr(lh[3], lo[3]) < 5e-2
+    assert min(r[2] for r in rows.values()) > 0.95, min(rows.items(), key=lambda kv: kv[1][2])
+    po, ph = dict(ora.named_parameters()), dict(hip.named_parameters())
+    fa = torch.cat([ph[n].grad.float().cpu().flatten() for n in rows])
+    fb = torch.cat([po[n].grad.flatten() for n in rows])
+    assert (torch.dot(fa, fb) / (fa.norm() * fb.norm())).item() > 0.999
+    # eval contract (swin_mae3d.py:1578-1594): 6-tuple, patchified shapes
+    hip.eval()
+    g = res // 4
+    with torch.no_grad():
+        out = hip([t.cuda() for t in xs], is_eval=True)
+    assert len(out) == 6 and out[3].shape == (2, g, g, g, 64, 4) and out[4].shape == (2, g, g, g, 64, 1) and out[4].dtype == torch.bool
+    assert out[5].shape == (2, g, g, g, 64, 4)
+
+
+def test_stochastic_depth_and_train_step_decreases_loss():
+    """train mode with SD noise injected identically on both sides; then a few fused AdamW steps reduce the loss."""
+    from oracle import mae3d_oracle as O
+    from nerf_mae_amd.trainer import FusedAdamW
+    ora, hip = _pair(TINY, torch.float32, sd=0.2)
+    xs = [O.synthetic_grid((32, 32, 32), 31), O.synthetic_grid((32, 32, 32), 32)]
+    nblk = 8
+    gen = torch.Generator().manual_seed(3)
+    noise = [(torch.bernoulli(torch.full((2,), 0.8), generator=gen) / 0.8, torch.bernoulli(torch.full((2,), 0.8), generator=gen) / 0.8) for _ in range(nblk)]
+    bm = O.draw_block_mask((8, 8, 8), 0.75, rng=random.Random(1))
+    # oracle with the same per-block noise: patch its RowStochasticDepth modules
+    it = iter([n for pair in noise for n in pair])
+    for mod in ora.modules():
+        if isinstance(mod, O.RowStochasticDepth):
+            mod.forward = (lambda x, _it=it: x * next(_it).view(-1, 1, 1, 1, 1))
+    lo = ora(xs, block_mask=bm)
+    lh = hip([t.cuda() for t in xs], block_mask=bm, sd_noise=[(a.cuda(), b.cuda()) for a, b in noise])
+    assert abs(lh[0].item() - lo[0].item()) / lo[0].item() < 1e-4
+    opt = FusedAdamW(hip, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1)
+    first = last = None
+    for step in range(6):
+        hip.zero_grad()
+        l = hip([t.cuda() for t in xs], block_mask=bm, sd_noise=[(torch.ones(2).cuda(), torch.ones(2).cuda())] * nblk)[0]
+        l.backward()
+        opt.step()
+        first = l.item() if first is None else first
+        last = l.item()
+    assert last < first
+
+
+def test_nerf_rpn_encoder_contract():
+    """feature_extractor.py:1155-1187: strict load, delete decoder/out/mask_token, encoder-only NCDHW features."""
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(TINY, torch.float32)
+    del hip.decoder4, hip.decoder3, hip.decoder2, hip.decoder1, hip.out, hip.mask_token
+    xb = torch.stack([O.synthetic_grid((32, 32, 32), 5), O.synthetic_grid((32, 32, 32), 6)])
+    with torch.no_grad():
+        fo = ora.encoder_features(xb)
+        x = hip.patch_partition(xb.cuda())
+        x = x + hip.pos_embed
+        fh = []
+        for i in range(len(hip.stages)):
+            x = hip.stages[i](x)
+            fh.append(torch.permute(x, [0, 4, 1, 2, 3]).contiguous())
+    assert [tuple(f.shape) for f in fh] == [(2, 32, 8, 8, 8), (2, 64, 4, 4, 4), (2, 128, 2, 2, 2), (2, 256, 1, 1, 1)]
+    for a, b in zip(fh, fo):
+        assert relerr(a, b) < 1e-3
