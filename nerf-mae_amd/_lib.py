@@ -6,6 +6,8 @@ fail loudly without the HIP extension)."""
 from __future__ import annotations
 
 import ctypes
+
+import torch  # noqa: F401  (must be imported BEFORE the .so is dlopen-ed: torch bundles its own libamdhip64; loading ours first would put two HIP runtimes in one process)
 import os
 import re
 from typing import Dict, List, Tuple

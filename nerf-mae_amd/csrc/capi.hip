@@ -9,6 +9,9 @@ static inline WinMap to_wm(const int* w) {
   return m;
 }
 #define ST ((hipStream_t)stream)
+// hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left behind, so that the
+// post-launch check in the k_* launchers reports only this call's launch status
+#define CLR() (void)hipGetLastError()
 
 extern "C" {
 int nmh_version(void) { return 100; }
@@ -22,12 +25,14 @@ const char* nmh_error_string(int code) {
 }
 int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* C, int64_t ldc, const float* bias, int act, void* C2,
                 const void* resid, const float* rowscale, int rows_per_scale, int accumulate, void* stream) {
+  CLR();
   if (M <= 0) return 0;
   EpiParams ep{C, ldc, bias, act, C2, resid, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, accumulate};
   return k_gemm_nt(dt, A, lda, W, ldw, M, N, K, ep, ST);
 }
 int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale,
                 int omode, int64_t ldo, int p0, int p1, void* stream) {
+  CLR();
   if (M <= 0) return 0;
   TnGeom gm{};
   gm.omode = omode; gm.ldo = ldo;
@@ -35,60 +40,76 @@ int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, 
   return k_gemm_tn(dt, A, lda, B, ldb, dW, M, N, K, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, gm, ST);
 }
 int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+  CLR();
   EpiParams ep{Y, Cout, nullptr, 0, nullptr, nullptr, nullptr, 1, accumulate};
   return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
 }
 int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
+  CLR();
   return k_conv3_tn(dt, dY, X, dW, B, D, H, W, Cin, Cout, ST);
 }
 int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C,
                       const int* wm, const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, void* stream) {
+  CLR();
   if (rows <= 0) return 0;
   LnArgs a{dt, src_mode, x, out, gamma, beta, eps, mean, rstd, (long)rows, C, to_wm(wm), pos, mask, mask_token, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1)};
   return k_ln_fwd(a, ST);
 }
 int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx,
                       float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* stream) {
+  CLR();
   if (rows <= 0) return 0;
   LnBwdArgs a{dt, src_mode, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, C, to_wm(wm), mask, dmask_token, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1)};
   return k_ln_bwd(a, ST);
 }
 int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream) {
+  CLR();
   return k_window_scatter_residual(dt, yw, x, out, rowscale, C, to_wm(wm), ST);
 }
 int nmh_window_gather_scale(int dt, const void* dx, void* dyw, const float* rowscale, int C, const int* wm, void* stream) {
+  CLR();
   return k_window_gather_scale(dt, dx, dyw, rowscale, C, to_wm(wm), ST);
 }
 int nmh_window_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const int* wm, void* stream) {
+  CLR();
   return k_attn_fwd(dt, qkv, bias_table, out, lse, heads, C, to_wm(wm), ST);
 }
 int nmh_window_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C,
                         const int* wm, void* stream) {
+  CLR();
   return k_attn_bwd(dt, qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, to_wm(wm), ST);
 }
 int nmh_instnorm_stats(int dt, const void* x, float* stats, double* scratch, int B, int64_t V, int C, float eps, void* stream) {
+  CLR();
   return k_in_stats(dt, x, stats, scratch, B, (long)V, C, eps, ST);
 }
 int nmh_instnorm_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, int64_t V, int C, float slope, void* stream) {
+  CLR();
   return k_in_apply(dt, x, stats, r, stats_r, rmode, out, B, (long)V, C, slope, ST);
 }
 int nmh_instnorm_bwd_reduce(int dt, const void* dout, const void* out, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, double* sums,
                             double* sums_r, int B, int64_t V, int C, float slope, void* stream) {
+  CLR();
   return k_in_bwd_reduce(dt, dout, out, x, stats, r, stats_r, rmode, sums, sums_r, B, (long)V, C, slope, ST);
 }
 int nmh_instnorm_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
                            const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, int64_t V, int C, float slope, void* stream) {
+  CLR();
   return k_in_bwd_apply(dt, dout, out, x, stats, sums, r, stats_r, sums_r, rmode, dx, dr, dr_accumulate, B, (long)V, C, slope, ST);
 }
-int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream) { return k_embed_gather(dt, x, A, B, R, ST); }
+int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream) {
+  CLR(); return k_embed_gather(dt, x, A, B, R, ST); }
 int nmh_upconv_shuffle_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, void* stream) {
+  CLR();
   return k_up_cat_fwd(dt, upre, bias, skip, out, B, v, k, Cout, ST);
 }
 int nmh_upconv_shuffle_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip, void* stream) {
+  CLR();
   return k_up_cat_bwd(dt, dcat, dupre, dskip, dbias, B, v, k, Cout, has_skip, ST);
 }
 int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R,
                      int Cd, double* sums, float* losses, float* pred, void* stream) {
+  CLR();
   LossArgs a{dt, d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, pred};
   int rc = k_loss_fwd(a, ST);
   if (rc) return rc;
@@ -96,6 +117,7 @@ int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bou
 }
 int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R,
                      int Cd, const double* sums, void* dd0, void* dpred8, float* dWout, float* dbout, void* stream) {
+  CLR();
   LossArgs a{dt, d0, Wout, bout, target, extents, tokmask, B, R, Cd, const_cast<double*>(sums), nullptr};
   int rc = k_loss_bwd(a, dd0, dpred8, dbout, ST);
   if (rc) return rc;
@@ -104,17 +126,24 @@ int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bou
   return k_gemm_tn(dt, dpred8, 8, d0, Cd, dWout, (long)B * R * R * R, 4, Cd, nullptr, 1, gm, ST);
 }
 int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream) {
+  CLR();
   if (M <= 0) return 0;
   return k_bias_grad(dt, dY, db, (long)M, N, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, ST);
 }
-int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream) { return k_add_inplace(dt, a, b, (long)n, ST); }
-int nmh_fill_f32(float* p, float v, int64_t n, void* stream) { return k_fill_f32(p, v, (long)n, ST); }
+int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream) {
+  CLR(); return k_add_inplace(dt, a, b, (long)n, ST); }
+int nmh_fill_f32(float* p, float v, int64_t n, void* stream) {
+  CLR(); return k_fill_f32(p, v, (long)n, ST); }
 int nmh_pack_weights(int dt, const void* descs_dev, const int* blk2desc_dev, const int64_t* blkstart_dev, int nblocks, void* stream) {
+  CLR();
   static_assert(sizeof(PackDesc) == 40 || sizeof(PackDesc) == 48, "PackDesc layout");
   if (nblocks <= 0) return 0;
   return k_pack_weights(dt, (const PackDesc*)descs_dev, blk2desc_dev, (const long*)blkstart_dev, nblocks, ST);
 }
-int nmh_grad_sqnorm(const float* g, int64_t n, double* acc, void* stream) { return k_sqnorm(g, (long)n, acc, ST); }
-int nmh_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, void* stream) { return k_clip_coef(acc, max_norm, coef, norm_out, ST); }
-int nmh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* coef, void* stream) { return k_adamw(p, g, m, v, (long)n, hyper, coef, ST); }
+int nmh_grad_sqnorm(const float* g, int64_t n, double* acc, void* stream) {
+  CLR(); return k_sqnorm(g, (long)n, acc, ST); }
+int nmh_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, void* stream) {
+  CLR(); return k_clip_coef(acc, max_norm, coef, norm_out, ST); }
+int nmh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* coef, void* stream) {
+  CLR(); return k_adamw(p, g, m, v, (long)n, hyper, coef, ST); }
 }

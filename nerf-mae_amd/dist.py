@@ -1,0 +1,101 @@
+"""Data-parallel gradient exchange for the MAE path: one process per GPU, RCCL (torch.distributed "nccl") over xGMI.
+
+The reference wraps the model in DDP (run_swin_mae3d.py:355-357).  Here the gradients already live in ONE flat fp32 buffer
+laid out in forward order (embed, stage0..3, decoder4..1, head), so the exchange is a handful of large contiguous
+all-reduces launched from inside backward as soon as a segment is complete -- decoder first (it finishes first and carries
+91 % of the FLOPs' worth of backward time behind it), then stage 3..0, then the embed tail -- on a side stream so they
+overlap the remaining backward kernels.  xGMI is point-to-point (7 links/GPU), so few large messages beat many small
+buckets.  AVG reduction = DDP's gradient averaging; no per-step barrier or scalar loss all-reduce (the reference's
+:676-686) -- losses are reduced only when logged."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _Trigger(torch.autograd.Function):
+    """identity in forward; in backward (everything downstream has produced its gradients) launches the all-reduce of a segment"""
+
+    @staticmethod
+    def forward(ctx, x, reducer, seg):
+        ctx.reducer, ctx.seg = reducer, seg
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.reducer.launch(ctx.seg)
+        return g, None, None
+
+
+class GradReducer:
+    def __init__(self, model, process_group=None, comm_dtype: Optional[torch.dtype] = None):
+        self.model, self.group = model, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if model._flat is None:
+            model.flatten_parameters()
+        off = model._offsets
+        first = lambda mod: min(off[id(p)] for p in mod.parameters() if p.requires_grad)  # noqa: E731
+        n = model._flat_grad.numel()
+        # forward-order boundaries: [embed | stage0 | stage1 | stage2 | stage3 | decoders+head(+mask_token)]
+        b = [0] + [first(st) for st in model.stages] + [first(model.decoder4), n]
+        self.bounds = b
+        self.nseg = len(b) - 1
+        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        self.pending: List = []
+        self.comm_dtype = comm_dtype
+        self.staging = torch.empty(n, dtype=comm_dtype, device=model._flat_grad.device) if (comm_dtype and self.world > 1) else None
+
+    def trigger(self, x, seg: int):
+        """insert after the forward op whose *inputs* bound segment `seg` from below (see model.forward)"""
+        if self.world == 1 or not torch.is_grad_enabled():
+            return x
+        return _Trigger.apply(x, self, seg)
+
+    def launch(self, seg: int):
+        if self.world == 1:
+            return
+        lo, hi = self.bounds[seg], self.bounds[seg + 1]
+        g = self.model._flat_grad[lo:hi]
+        cur = torch.cuda.current_stream()
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            if self.staging is not None:
+                s = self.staging[lo:hi]
+                s.copy_(g)
+                dist.all_reduce(s, op=dist.ReduceOp.AVG, group=self.group)
+                g.copy_(s)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+        self.pending.append(seg)
+
+    def finish(self):
+        """call after backward: reduce any segment whose trigger did not fire, then join the comm stream"""
+        if self.world == 1:
+            return
+        for seg in range(self.nseg):
+            if seg not in self.pending:
+                self.launch(seg)
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.pending = []
+
+
+def broadcast_parameters(model, src: int = 0, group=None):
+    """DDP's initial parameter broadcast: one flat message."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if model._flat is None:
+            model.flatten_parameters()
+        dist.broadcast(model._flat, src=src, group=group)
+        dist.broadcast(model.pos_embed.data, src=src, group=group)
+
+
+def shard_indices(n: int, rank: int, world: int, epoch: int, shuffle: bool = True, seed: int = 0):
+    """torch DistributedSampler semantics (run_swin_mae3d.py:578-586,614): epoch-seeded permutation, padded to a multiple
+    of world size, rank r takes r::world."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    idx = torch.randperm(n, generator=g).tolist() if shuffle else list(range(n))
+    total = (n + world - 1) // world * world
+    idx += idx[: total - n]
+    return idx[rank:total:world]

@@ -532,10 +532,19 @@ class SwinTransformer_MAE3D_New(nn.Module):
         self._packer = None
         self._add_pos = True
         self._anchor = None
+        self._reducer = None  # dist.GradReducer when data-parallel
 
     # ---- flat buffers + packed weights ------------------------------------------------------------
     def _trainable(self):
-        return [p for p in self.parameters() if p.requires_grad]
+        """trainable parameters in *gradient-completion-friendly* order: [mask_token, patch embed | stage0..3 | decoders, head]
+        (mask_token's gradient is produced by the embed backward, i.e. last, so it sits with the embed segment)"""
+        ps = [self.mask_token] if "mask_token" in self._parameters else []
+        seen = {id(p) for p in ps}
+        for p in self.parameters():
+            if p.requires_grad and id(p) not in seen:
+                ps.append(p)
+                seen.add(id(p))
+        return ps
 
     def flatten_parameters(self, device=None):
         """Re-home every trainable parameter (and its .grad) as a view of one flat fp32 buffer."""
@@ -625,7 +634,10 @@ class SwinTransformer_MAE3D_New(nn.Module):
 
     def forward_encoder(self, tok: Tensor, sd_noise=None):
         feats, x, bi = [], tok, 0
-        for st in self.stages:
+        red = self._reducer
+        for si, st in enumerate(self.stages):
+            if red is not None:
+                x = red.trigger(x, si + 1)  # backward reaching here => stage si gradients are complete
             for mod in st:
                 if isinstance(mod, SwinBlock3D):
                     x = mod(x, None if sd_noise is None else sd_noise[bi])
@@ -636,7 +648,10 @@ class SwinTransformer_MAE3D_New(nn.Module):
         return feats
 
     def forward_decoder(self, feats: List[Tensor]) -> Tensor:
-        d = self.decoder4(feats[3], feats[2])
+        f3 = feats[3]
+        if self._reducer is not None:
+            f3 = self._reducer.trigger(f3, len(self.stages) + 1)  # decoder4 is the last decoder op in backward order
+        d = self.decoder4(f3, feats[2])
         d = self.decoder3(d, feats[1])
         d = self.decoder2(d, feats[0])
         return self.decoder1(d)
@@ -664,6 +679,17 @@ class SwinTransformer_MAE3D_New(nn.Module):
             tgt = patch(xb)
             return loss, loss_rgb, loss_alpha, patch(pred), tgt[..., 3:] > 0.01, tgt
         return loss, loss_rgb, loss_alpha
+
+    def forward_static(self, xb: Tensor, ext: Tensor, mask_dev: Tensor):
+        """graph-capturable training forward: everything already on the device (padded batch (B,4,R,R,R) fp32, extents [B,3]
+        int32, token mask [g^3] uint8); no host<->device traffic, no python RNG."""
+        B, R = xb.shape[0], self.resolution
+        g = R // 4
+        self._packer.run()
+        tok = _EmbedFn.apply(self._anchor, self, xb, mask_dev).view(B, g, g, g, self.embed_dim)
+        d0 = self.forward_decoder(self.forward_encoder(tok))
+        losses = _LossFn.apply(d0.reshape(-1, d0.shape[-1]), self, xb, ext, mask_dev, None)
+        return losses[0], losses[1], losses[2]
 
     def encoder_features(self, xb: Tensor) -> List[Tensor]:
         """nerf_rpn contract (feature_extractor.py:1176-1187): NCDHW feature list [C,2C,4C,8C]."""

@@ -12,6 +12,16 @@ from ._lib import lib
 
 F32, BF16 = 0, 1
 WS = 4
+PROFILE = None  # set to a dict by bench.py: {(op, dims...): [(start_event, end_event), ...]} recorded on the launch stream
+
+
+def _prof(key):
+    if PROFILE is None:
+        return None
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    PROFILE.setdefault(key, []).append((a, b))
+    a.record(torch.cuda.current_stream())
+    return b
 
 
 def dt_of(t: torch.Tensor) -> int:
@@ -79,14 +89,20 @@ def conv3d_k3(X, Wp, Cout, out=None, accumulate=False):
     B, D, H, W, Cin = X.shape
     if out is None:
         out = torch.empty((B, D, H, W, Cout), dtype=X.dtype, device=X.device)
+    ev = _prof(("conv3d_k3", B, D, Cin, Cout))
     lib().call("nmh_conv3d_k3", dt_of(X), X, Wp, out, B, D, H, W, Cin, Cout, int(accumulate), _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
     return out
 
 
 def conv3d_k3_wgrad(dY, X, dW):
     _chk(dY, X, dW)
     B, D, H, W, Cin = X.shape
+    ev = _prof(("conv3d_k3_wgrad", B, D, Cin, dY.shape[-1]))
     lib().call("nmh_conv3d_k3_wgrad", dt_of(X), dY, X, dW, B, D, H, W, Cin, dY.shape[-1], _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
     return dW
 
 
