@@ -42,7 +42,8 @@ class GradReducer:
         b = [0] + [first(st) for st in model.stages] + [first(model.decoder4), n]
         self.bounds = b
         self.nseg = len(b) - 1
-        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
+        self.on_gpu = model._flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.on_gpu) else None
         self.pending: List = []
         self.comm_dtype = comm_dtype
         self.staging = torch.empty(n, dtype=comm_dtype, device=model._flat_grad.device) if (comm_dtype and self.world > 1) else None
@@ -58,6 +59,11 @@ class GradReducer:
             return
         lo, hi = self.bounds[seg], self.bounds[seg + 1]
         g = self.model._flat_grad[lo:hi]
+        if not self.on_gpu:  # CPU/gloo (tests): synchronous
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.div_(self.world)
+            self.pending.append(seg)
+            return
         cur = torch.cuda.current_stream()
         self.comm_stream.wait_stream(cur)
         with torch.cuda.stream(self.comm_stream):
@@ -77,7 +83,8 @@ class GradReducer:
         for seg in range(self.nseg):
             if seg not in self.pending:
                 self.launch(seg)
-        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         self.pending = []
 
 
