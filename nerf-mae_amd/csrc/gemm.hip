@@ -240,6 +240,13 @@ template <typename T, class AL>
 static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st) {
   if (N % 8 != 0 || K % 8 != 0) return -2;
   const int t16 = (N + 15) / 16;
+  // small problems (stage 2/3 tokens, 10^3..20^3 decoder volumes): 64-row tiles so that more than a few dozen CUs get work
+  if ((long)M * batch <= 4096 && t16 >= 4) {
+    if (t16 % 4 == 0) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (t16 % 6 == 0) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (t16 % 3 == 0) return launch_nt<T, 1, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  }
   if (t16 <= 3) return launch_nt<T, 4, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
   if (t16 == 4) return launch_nt<T, 4, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
   if (t16 % 8 == 0 || t16 > 12) {
@@ -425,11 +432,11 @@ template <typename T, int NTW, int KTW, class BL>
 static int launch_tn(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, const float* rs, int rps, const TnGeom& gm, hipStream_t st) {
   constexpr int BNW = 32 * NTW, BKW = 32 * KTW;
   int gx = (N + BNW - 1) / BNW, gy = (K + BKW - 1) / BKW;
-  long want = 1024 / ((long)gx * gy);  // aim for ~1k workgroups; many output tiles => no split (and no atomics)
+  long want = 512 / ((long)gx * gy);  // aim for ~512 workgroups; many output tiles => no split (and no atomics)
   if (want < 1) want = 1;
   long mps = (Mtot + want - 1) / want;
   mps = (mps + 63) / 64 * 64;
-  if (mps < 256) mps = 256;
+  if (mps < 1024) mps = 1024;          // every split ends in BNW*BKW atomics: give it >= 16 chunks of MFMA work first
   int gz = (int)((Mtot + mps - 1) / mps);
   hipLaunchKernelGGL((gemm_tn_kernel<T, NTW, KTW, BL>), dim3(gx, gy, gz), dim3(256), 0, st, (const T*)A, lda, (const T*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
   NMH_CHECK_LAUNCH();

@@ -260,8 +260,9 @@ int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* r
   if (N % 8) return -2;
   if (N / 8 <= 256) {
     int NV = 256 / (N / 8);
-    long nb = (M + NV - 1) / NV;
+    long nb = (M + (long)NV * 32 - 1) / ((long)NV * 32);  // >= 32 rows per thread before the block touches its N atomics
     if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
     if (dt == NMH_DT_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), N * sizeof(float), st, (const bf16_t*)dY, db, M, N, rs, rps);
     else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3((unsigned)nb), dim3(256), N * sizeof(float), st, (const float*)dY, db, M, N, rs, rps);
   } else {

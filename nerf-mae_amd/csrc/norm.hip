@@ -406,25 +406,39 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dou
     }
   }
   if (vl < NV) {
-    for (long v = v0 + vl; v < v1; v += NV) {
-      const long o = ((long)b * V + v) * C + cl * 8;
-      float xv[8];
-      Vec8<T>::load(x + o, xv);
-      if (!BWD) {
+    // U independent voxels per iteration: keeps several 16-B loads per tensor in flight per thread (HBM latency-bound otherwise)
+    constexpr int U = 4;
+    for (long vb = v0 + vl; vb < v1; vb += (long)NV * U) {
+      float xv[U][8], dv[U][8], ov[U][8], rv[U][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = xv[j] - cref[j]; s1[j] += d; s2[j] += d * d; }
-      } else {
-        float dv[8], ov[8];
-        Vec8<T>::load(dout + o, dv);
-        Vec8<T>::load(outp + o, ov);
-        float rv[8];
-        if (rmode == 2) Vec8<T>::load(r + o, rv);
+      for (int u = 0; u < U; ++u) {
+        const long v = vb + (long)u * NV;
+        if (v < v1) {
+          const long o = ((long)b * V + v) * C + cl * 8;
+          Vec8<T>::load(x + o, xv[u]);
+          if (BWD) {
+            Vec8<T>::load(dout + o, dv[u]);
+            Vec8<T>::load(outp + o, ov[u]);
+            if (rmode == 2) Vec8<T>::load(r + o, rv[u]);
+          }
+        }
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float g = dv[j] * (ov[j] > 0.f ? 1.0f : slope);
-          s1[j] += g;
-          s2[j] += g * (xv[j] - mu[j]) * rs_[j];
-          if (rmode == 2) { t1[j] += g; t2[j] += g * (rv[j] - mur[j]) * rsr[j]; }
+      for (int u = 0; u < U; ++u) {
+        const long v = vb + (long)u * NV;
+        if (v < v1) {
+          if (!BWD) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = xv[u][j] - cref[j]; s1[j] += d; s2[j] += d * d; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float g = dv[u][j] * (ov[u][j] > 0.f ? 1.0f : slope);
+              s1[j] += g;
+              s2[j] += g * (xv[u][j] - mu[j]) * rs_[j];
+              if (rmode == 2) { t1[j] += g; t2[j] += g * (rv[u][j] - mur[j]) * rsr[j]; }
+            }
+          }
         }
       }
     }
