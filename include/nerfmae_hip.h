@@ -36,6 +36,9 @@ NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64
 /* Y[(b,z,y,x)][Cout] (+)= conv3d(k=3,pad=1) of channels-last X with packed weights [Cout][27][Cin] (nn.Conv3d in
  * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout]. */
 NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+/* The same convolution specialised for Cin = Cout = 48, bf16 (decoder1.conv_block at 160^3 -- 75 % of the model's FLOPs): persistent
+ * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad). */
+NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, void* stream);
 /* dW[Cout][Cin][3][3][3] (PyTorch layout, fp32) += conv weight gradient */
 NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 

@@ -44,6 +44,10 @@ int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, 
   EpiParams ep{Y, Cout, nullptr, 0, nullptr, nullptr, nullptr, 1, accumulate};
   return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
 }
+int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, void* stream) {
+  CLR();
+  return k_conv48(X, Wk, Y, B, D, H, W, accumulate, ST);
+}
 int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
   CLR();
   return k_conv3_tn(dt, dY, X, dW, B, D, H, W, Cin, Cout, ST);

@@ -1,0 +1,224 @@
+// Specialised 3x3x3 convolution for the decoder1 layers (Cin = Cout = 48, bf16, 160^3): the roofline kernel.
+//
+// One persistent 512-thread workgroup per CU walks 4x8x16 output tiles (XCD-contiguous tile ranges so halo overlap hits
+// the same L2).  Per tile:
+//   * the 6x10x18x48 input halo sits in LDS (104.7 KB; line stride 1744 B and plane stride 17456 B are = 16 mod 32 so the
+//     two 8-lane halves of every ds_read_b128 service group land on complementary bank halves -> conflict-free);
+//   * K = 27*48 = 1296 is walked in 41 MFMA k-steps of 32: 36 "row-quad" steps (lane group g reads tap-row 4q+g, all
+//     groups the same 8-channel vector c of that row: address = base + rowoff_q[g] + immediate) + 5 steps for tap-row 8;
+//     only 2 of 164 slots are padding (1.2 % waste instead of 33 % for channel padding to 64);
+//   * weights are pre-packed on the host side in exact B-fragment order [step][ntile][lane][8] and streamed through a
+//     2 x 27 KB LDS ring in 5 chunks (global -> registers under the MFMAs -> LDS);
+//   * the NEXT tile's halo is prefetched into 13 x 16 B registers per thread while the current tile computes, then
+//     written to LDS between tiles (HBM/L2 latency fully hidden, only the ds_write pass is exposed);
+//   * epilogue: accumulators -> bf16 -> wave-private slice of the (now free) halo region -> 16-B row stores.
+// The same kernel computes input gradients with the flipped/transposed pack.  LDS use 160,032 B of 163,840.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace c48 {
+constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
+constexpr int LINE = HX * 96 + 16, PLANE = HY * LINE + 16, HALO = (TZ + 2) * PLANE;
+constexpr int NSTEP = 41, CSTEPS = 9, WCHUNK = CSTEPS * 3 * 1024;
+constexpr int LDS_BYTES = HALO + 2 * WCHUNK;
+constexpr int HCH = (TZ + 2) * HY * HX * 6;  // 16-B chunks in the halo (6480)
+constexpr int HREG = (HCH + 511) / 512;      // 13
+static_assert(LINE % 32 == 16 && PLANE % 32 == 16, "bank-half alternation");
+static_assert(LDS_BYTES <= 163840, "LDS budget");
+}  // namespace c48
+
+struct C48Args {
+  const bf16_t* X; const bf16_t* Wk; bf16_t* Y;
+  int B, D, H, W, tz, ty, tx;  // tiles per axis
+  long total;                  // B*tz*ty*tx
+  int accumulate;
+};
+
+__device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
+  int xt = (int)(t % a.tx); long r = t / a.tx;
+  int yt = (int)(r % a.ty); r /= a.ty;
+  int zt = (int)(r % a.tz);
+  b = (int)(r / a.tz);
+  z0 = zt * c48::TZ; y0 = yt * c48::TY; x0 = xt * c48::TX;
+}
+
+__global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
+  using namespace c48;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + HALO;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+
+  // XCD-contiguous tile ranges: block b runs on XCD b%8 (speed only); its tiles are xcd*per + j, j = b/8, stride gridDim/8
+  const int nx = 8, xcd = blockIdx.x % nx, jb = blockIdx.x / nx, jstride = gridDim.x / nx;
+  const long per = (a.total + nx - 1) / nx;
+  const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
+
+  uint4 hreg[HREG];
+  auto halo_gload = [&](long t) {
+    int b, z0, y0, x0;
+    c48_tile_origin(a, t, b, z0, y0, x0);
+#pragma unroll
+    for (int i = 0; i < HREG; ++i) {
+      const int cid = tid + 512 * i;
+      hreg[i] = make_uint4(0, 0, 0, 0);
+      if (cid < HCH) {
+        const int line = cid / (HX * 6), within = cid - line * (HX * 6);
+        const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
+        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+        if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+          hreg[i] = *reinterpret_cast<const uint4*>(a.X + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8);
+      }
+    }
+  };
+  auto halo_sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < HREG; ++i) {
+      const int cid = tid + 512 * i;
+      if (cid < HCH) {
+        const int line = cid / (HX * 6), within = cid - line * (HX * 6);
+        const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
+        *reinterpret_cast<uint4*>(halo + hz * PLANE + hy * LINE + hx * 96 + c6 * 16) = hreg[i];
+      }
+    }
+  };
+  // weight chunk ck (steps [9ck, min(9ck+9,41))) -> LDS ring slot `buf` by LDS-DMA: the image is lane-linear
+  // (dst = wave-uniform base + lane*16), so no VGPR staging and no ds_write pass; completes before the next barrier.
+  auto w_dma = [&](int ck, int buf) {
+    const int nunits = ((ck < 4) ? CSTEPS : (NSTEP - 4 * CSTEPS)) * 192;  // 16-B units, multiple of 64
+    const char* src = reinterpret_cast<const char*>(a.Wk) + (long)ck * CSTEPS * 3072;
+    char* dst = wbuf + buf * WCHUNK;
+    for (int u0 = wave * 64; u0 < nunits; u0 += 512) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(u0 + lane) * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + u0 * 16), 16, 0, 0);
+    }
+  };
+
+  // zero the 16-B pads once (they are only ever multiplied by zero weights, but must not hold NaN patterns)
+  for (int i = tid; i < HALO / 16; i += 512) reinterpret_cast<uint4*>(halo)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  long t = tbeg + jb;
+  if (t >= tend) return;
+  halo_gload(t);
+  w_dma(0, 0);
+  halo_sstore();
+  __syncthreads();
+  int wb = 0;  // LDS buffer holding chunk 0 of the current tile
+
+  // per-lane A addressing: m-tile i = x-line (z_l, y_l + i), lanes li = x
+  const int z_l = wave >> 1, y_l = (wave & 1) * 4;
+  const int base0 = z_l * PLANE + y_l * LINE + li * 96;
+  int rowoff[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) { const int r = 4 * q + g; rowoff[q] = (r / 3) * PLANE + (r % 3) * LINE; }
+  const int row8 = 2 * PLANE + 2 * LINE;
+
+  for (; t < tend; t += jstride) {
+    const long tn = t + jstride;
+    const bool has_next = tn < tend;
+    if (has_next) halo_gload(tn);
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one k-step: 3 B fragments (linear, lane*16) + 4 A fragments (4 x-lines) -> 12 MFMAs
+    auto kstep = [&](const char* wsrc, int sl, int aoff) {
+      Frag<bf16_t> bf[3], af[4];
+#pragma unroll
+      for (int n = 0; n < 3; ++n) bf[n].v = *reinterpret_cast<const bf16x8*>(wsrc + (sl * 3 + n) * 1024 + lane * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i].v = *reinterpret_cast<const bf16x8*>(halo + aoff + i * LINE);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) mma(acc[i][n], af[i], bf[n]);
+    };
+#pragma unroll
+    for (int ck = 0; ck < 5; ++ck) {
+      const int nxt = (ck < 4) ? ck + 1 : 0;
+      if (ck < 4 || has_next) w_dma(nxt, (wb + ck + 1) & 1);
+      const char* wsrc = wbuf + ((wb + ck) & 1) * WCHUNK;
+      if (ck < 4) {
+        // row-quad steps s = 9ck .. 9ck+8 (< 36): q = s/18, c = s%18 are wave-uniform scalars
+#pragma unroll 3
+        for (int sl = 0; sl < CSTEPS; ++sl) {
+          const int s = ck * CSTEPS + sl;
+          const int q = s >= 18 ? 1 : 0, c = s - 18 * q, c6 = (c * 43) >> 8;
+          kstep(wsrc, sl, base0 + (q ? rowoff[1] : rowoff[0]) + c6 * 96 + (c - 6 * c6) * 16);
+        }
+      } else {
+#pragma unroll
+        for (int sl = 0; sl < NSTEP - 4 * CSTEPS; ++sl) {
+          int c = 4 * sl + g;
+          c = c > 17 ? 17 : c;  // padded slots: weights are zero there, any finite operand will do
+          const int c6 = (c * 43) >> 8;
+          kstep(wsrc, sl, base0 + row8 + c6 * 96 + (c - 6 * c6) * 16);
+        }
+      }
+      __syncthreads();
+    }
+    wb ^= 1;  // 5 chunks: chunk 0 of the next tile landed in the other buffer
+
+    // ---- epilogue: wave-private slice of the halo region (all waves are past the last barrier: halo is free) ----
+    {
+      char* sl = halo + wave * 6144;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<bf16_t*>(sl + (i * 16 + 4 * g + r) * 96 + (n * 16 + li) * 2) = f2bf(acc[i][n][r]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      int b, z0, y0, x0;
+      c48_tile_origin(a, t, b, z0, y0, x0);
+      const int z = z0 + z_l;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int it = lane + 64 * k, row = it / 6, c6 = it - row * 6;
+        const int y = y0 + y_l + (row >> 4), x = x0 + (row & 15);
+        if (z < a.D && y < a.H && x < a.W) {
+          uint4 v = *reinterpret_cast<const uint4*>(sl + row * 96 + c6 * 16);
+          bf16_t* dst = a.Y + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8;
+          if (a.accumulate) {
+            float o[8], n8[8];
+            Vec8<bf16_t>::load(dst, o);
+            unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { n8[2 * j] = __uint_as_float(w4[j] << 16) + o[2 * j]; n8[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u) + o[2 * j + 1]; }
+            Vec8<bf16_t>::store(dst, n8);
+          } else {
+            *reinterpret_cast<uint4*>(dst) = v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (has_next) halo_sstore();
+    __syncthreads();
+  }
+}
+
+int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, hipStream_t st) {
+  using namespace c48;
+  C48Args a;
+  a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
+  a.B = B; a.D = D; a.H = H; a.W = W;
+  a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
+  a.total = (long)B * a.tz * a.ty * a.tx;
+  a.accumulate = accumulate;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  long nb = a.total < 256 ? ((a.total + 7) / 8 * 8) : 256;
+  hipLaunchKernelGGL(conv48_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

@@ -432,7 +432,9 @@ template <typename T, int NTW, int KTW, class BL>
 static int launch_tn(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, const float* rs, int rps, const TnGeom& gm, hipStream_t st) {
   constexpr int BNW = 32 * NTW, BKW = 32 * KTW;
   int gx = (N + BNW - 1) / BNW, gy = (K + BKW - 1) / BKW;
-  long want = 512 / ((long)gx * gy);  // aim for ~512 workgroups; many output tiles => no split (and no atomics)
+  // the load->LDS->MFMA chain of one workgroup is not software-pipelined: latency is hidden by co-resident workgroups, so a
+  // long contraction (conv wgrad over 4M voxels) wants ~4 workgroups per CU; short ones are bounded by the atomics instead
+  long want = (Mtot >= (1L << 20) ? 1024 : 512) / ((long)gx * gy);  // aim for ~512 workgroups; many output tiles => no split (and no atomics)
   if (want < 1) want = 1;
   long mps = (Mtot + want - 1) / want;
   mps = (mps + 63) / 64 * 64;

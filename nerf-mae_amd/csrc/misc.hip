@@ -307,6 +307,9 @@ int k_fill_f32(float* p, float v, long n, hipStream_t st) {
 //  mode 3 conv3 dgrad    dst [Ci][27][Co], tap flipped (26 - t)
 //  mode 4 convT fwd      src [Ci=d0][Co=d1][k3=d2] -> dst [(t*Co+co)][ci]
 //  mode 5 convT dgrad    dst [ci][(t*Co+co)]
+//  mode 6/7 conv48 fragment order (conv48.hip): dst [step 41][ntile 3][lane 64][8] from the mode-2 (fwd) / mode-3 (dgrad) view
+//           W'[n][tap][k]: lane (li = n%16, g), slot j; steps < 36: tap-row r = 4*(s/18)+g, vector c = s%18; steps >= 36: row 8,
+//           c = 4*(s-36)+g (c >= 18 -> zero padding)
 __device__ __forceinline__ long pack_src_index(const PackDesc& d, long i) {
   switch (d.mode) {
     case 1: { long c = i / d.d0, r = i - c * d.d0; return r * d.d1 + c; }
@@ -314,6 +317,17 @@ __device__ __forceinline__ long pack_src_index(const PackDesc& d, long i) {
     case 3: { long co = i % d.d0; long t2 = i / d.d0; long t = t2 % 27, ci = t2 / 27; return (co * d.d1 + ci) * 27 + (26 - t); }
     case 4: { long ci = i % d.d0; long t2 = i / d.d0; long co = t2 % d.d1, t = t2 / d.d1; return (ci * d.d1 + co) * d.d2 + t; }
     case 5: { long n = (long)d.d1 * d.d2; long ci = i / n, r = i - ci * n; long t = r / d.d1, co = r - t * d.d1; return (ci * d.d1 + co) * d.d2 + t; }
+    case 6: case 7: {
+      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+      const long sn = i >> 9;
+      const int nt = (int)(sn % 3), st = (int)(sn / 3), g = lane >> 4, n = nt * 16 + (lane & 15);
+      int r, c;
+      if (st < 36) { r = 4 * (st / 18) + g; c = st % 18; } else { r = 8; c = 4 * (st - 36) + g; }
+      if (c >= 18) return -1;
+      const int tap = r * 3 + c / 6, k = (c % 6) * 8 + j;  // tap = (dz+1)*9+(dy+1)*3+(dx+1), r = (dz+1)*3+(dy+1)
+      // W'[n][tap][k]: fwd  = W[co=n][ci=k][tap];  dgrad = W[co=k][ci=n][26-tap]
+      return d.mode == 6 ? ((long)n * 48 + k) * 27 + tap : ((long)k * 48 + n) * 27 + (26 - tap);
+    }
     default: return i;
   }
 }
@@ -324,7 +338,7 @@ template <typename T> __global__ void pack_kernel(const PackDesc* descs, const i
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     long i = base + u * 256 + threadIdx.x;
-    if (i < d.n) dst[i] = from_f<T>(d.src[pack_src_index(d, i)]);
+    if (i < d.n) { const long si = pack_src_index(d, i); dst[i] = from_f<T>(si >= 0 ? d.src[si] : 0.f); }
   }
 }
 int k_pack_weights(int dt, const PackDesc* descs, const int* blk2desc, const long* blkstart, int nblocks, hipStream_t st) {

@@ -76,7 +76,8 @@ class _Packer:
     """Owns the flat compute-dtype buffer holding every GEMM operand layout derived from the fp32 master
     parameters, and the device descriptor table for the single-launch pack kernel."""
 
-    CAST, TRANS, CONV_F, CONV_D, CONVT_F, CONVT_D = 0, 1, 2, 3, 4, 5
+    CAST, TRANS, CONV_F, CONV_D, CONVT_F, CONVT_D, C48_F, C48_D = 0, 1, 2, 3, 4, 5, 6, 7
+    C48_NUMEL = 41 * 3 * 64 * 8  # conv48.hip fragment order [step][ntile][lane][8]
 
     def __init__(self):
         self.items = []  # (key, param, mode, dims, numel)
@@ -88,11 +89,11 @@ class _Packer:
             dims = (0, 0, 0)
         elif mode == self.TRANS:
             dims = (sh[0], int(np.prod(sh[1:])), 0)
-        elif mode in (self.CONV_F, self.CONV_D):
+        elif mode in (self.CONV_F, self.CONV_D, self.C48_F, self.C48_D):
             dims = (sh[0], sh[1], 27)
         else:
             dims = (sh[0], sh[1], int(np.prod(sh[2:])))
-        self.items.append((key, p, mode, dims, p.numel()))
+        self.items.append((key, p, mode, dims, self.C48_NUMEL if mode in (self.C48_F, self.C48_D) else p.numel()))
 
     def build(self, dtype: torch.dtype, device):
         total = sum((n + 63) // 64 * 64 for *_, n in self.items)
@@ -273,12 +274,17 @@ class _UpBlockFn(torch.autograd.Function):
         del upre
         S = v * k
         scratch = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
-        y1 = ops.conv3d_k3(cat.view(B, S, S, S, Cc), pk[key + "c1.w"], Cout).view(B * V, Cout)
+        c48 = (key + "c1.wk") in pk.views and (key + "c2.wk") in pk.views
+        if c48:   # Cin = Cout = 48 in bf16: LDS-halo kernel with fragment-ordered weights ("c1.w" -> "c1.wk", "c1.wd" -> "c1.wkd")
+            conv = lambda X, nm, co, **kw: ops.conv3d_k3_c48(X, pk[key + nm.replace(".w", ".wk")], **kw)  # noqa: E731
+        else:
+            conv = lambda X, nm, co, **kw: ops.conv3d_k3(X, pk[key + nm], co, **kw)  # noqa: E731
+        y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout).view(B * V, Cout)
         st1 = torch.empty((B, Cout, 2), device=dev)
         ops.instnorm_stats(y1, st1, scratch, B, V, Cout)
         a1 = torch.empty_like(y1)
         ops.instnorm_apply(y1, st1, a1, B, V, Cout)
-        y2 = ops.conv3d_k3(a1.view(B, S, S, S, Cout), pk[key + "c2.w"], Cout).view(B * V, Cout)
+        y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout).view(B * V, Cout)
         st2 = torch.empty((B, Cout, 2), device=dev)
         ops.instnorm_stats(y2, st2, scratch, B, V, Cout)
         out = torch.empty_like(y2)
@@ -290,7 +296,7 @@ class _UpBlockFn(torch.autograd.Function):
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=y3, stats_r=st3, rmode=2)
         else:
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=cat, rmode=1)
-        ctx.m, ctx.dims = m, (B, v, has_skip)
+        ctx.m, ctx.dims, ctx.conv = m, (B, v, has_skip), conv
         ctx.saved = (x, cat, y1, st1, a1, y2, st2, y3, st3, out)
         return out
 
@@ -317,13 +323,14 @@ class _UpBlockFn(torch.autograd.Function):
         else:
             ops.instnorm_bwd_reduce(dout, out, y2, st2, sums2, B, V, Cout, rmode=1)
             ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, rmode=1, dr=dcat)  # dcat <- g (plain residual)
-        da1 = ops.conv3d_k3(dy2.view(B, S, S, S, Cout), pk[key + "c2.wd"], Cout).view(B * V, Cout)
+        conv = ctx.conv
+        da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
         ops.conv3d_k3_wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
         sums1 = sums2
         ops.instnorm_bwd_reduce(da1, a1, y1, st1, sums1, B, V, Cout, rmode=0)
         dy1 = dy2  # reuse
         ops.instnorm_bwd_apply(da1, a1, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
-        ops.conv3d_k3(dy1.view(B, S, S, S, Cout), pk[key + "c1.wd"], Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
+        conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
         ops.conv3d_k3_wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
         if m.has_proj:
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
@@ -592,6 +599,9 @@ class SwinTransformer_MAE3D_New(nn.Module):
                 conv = getattr(d.conv_block, "conv" + cn[1])
                 P.add(key + cn + ".w", conv.weight, P.CONV_F)
                 P.add(key + cn + ".wd", conv.weight, P.CONV_D)
+                if self.compute_dtype == torch.bfloat16 and tuple(conv.weight.shape[:2]) == (48, 48):
+                    P.add(key + cn + ".wk", conv.weight, P.C48_F)     # specialised LDS-halo kernel (decoder1 @160^3)
+                    P.add(key + cn + ".wkd", conv.weight, P.C48_D)
             if d.has_proj:
                 P.add(key + "c3.w", d.conv_block.conv3.weight, P.CAST)
                 P.add(key + "c3.wT", d.conv_block.conv3.weight, P.TRANS)

@@ -96,6 +96,21 @@ def conv3d_k3(X, Wp, Cout, out=None, accumulate=False):
     return out
 
 
+def conv3d_k3_c48(X, Wk, out=None, accumulate=False):
+    """specialised Cin=Cout=48 bf16 conv (fragment-ordered weights Wk, pack modes 6/7)"""
+    _chk(X, Wk, out)
+    B, D, H, W, Cin = X.shape
+    if Cin != 48 or X.dtype != torch.bfloat16:
+        raise RuntimeError("conv3d_k3_c48 needs bf16 activations with 48 channels")
+    if out is None:
+        out = torch.empty((B, D, H, W, 48), dtype=X.dtype, device=X.device)
+    ev = _prof(("conv3d_k3_c48", B, D, 48, 48))
+    lib().call("nmh_conv3d_k3_c48", X, Wk, out, B, D, H, W, int(accumulate), _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 def conv3d_k3_wgrad(dY, X, dW):
     _chk(dY, X, dW)
     B, D, H, W, Cin = X.shape

@@ -425,3 +425,54 @@ def test_adamw_and_clip_match_torch():
         ops.adamw_step(p, gd, m, v, hyper, coef)
         assert abs(nrm.item() - tn.item()) / tn.item() < 1e-5
     assert relerr(p, pr) < 1e-5
+
+
+def _pack_via_kernel(w, mode, dt, n_out):
+    """run the single-launch pack kernel for one tensor (descriptor table of 1)"""
+    import struct
+    ops = _ops()
+    src = w.float().cuda().contiguous()
+    dst = torch.empty(n_out, dtype=dt, device="cuda")
+    sh = list(w.shape)
+    d = (sh[0], sh[1], int(np.prod(sh[2:])) if len(sh) > 2 else 0)
+    descs = torch.frombuffer(bytearray(struct.pack("<QQiiiiq", src.data_ptr(), dst.data_ptr(), mode, d[0], d[1], d[2], n_out)), dtype=torch.uint8).cuda()
+    nb = (n_out + 1023) // 1024
+    b2d = torch.zeros(nb, dtype=torch.int32, device="cuda")
+    bst = (torch.arange(nb, dtype=torch.int64) * 1024).cuda()
+    ops.pack_weights(1 if dt == torch.bfloat16 else 0, descs, b2d, bst, nb)
+    torch.cuda.synchronize()
+    return dst
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_pack_weight_modes(dt):
+    w2 = rnd(24, 40)
+    check(_pack_via_kernel(w2, 1, dt, w2.numel()).view(40, 24), q(w2, dt).T, dt, "transpose")
+    wc = rnd(16, 24, 3, 3, 3)
+    check(_pack_via_kernel(wc, 2, dt, wc.numel()).view(16, 27, 24), q(wc, dt).reshape(16, 24, 27).permute(0, 2, 1), dt, "conv fwd pack")
+    check(_pack_via_kernel(wc, 3, dt, wc.numel()).view(24, 27, 16), q(wc, dt).reshape(16, 24, 27).flip(2).permute(1, 2, 0), dt, "conv dgrad pack")
+    wt = rnd(24, 16, 2, 2, 2)
+    check(_pack_via_kernel(wt, 4, dt, wt.numel()).view(8 * 16, 24), q(wt, dt).reshape(24, 16, 8).permute(2, 1, 0).reshape(128, 24), dt, "convT fwd pack")
+    check(_pack_via_kernel(wt, 5, dt, wt.numel()).view(24, 8 * 16), q(wt, dt).reshape(24, 16, 8).permute(0, 2, 1).reshape(24, 128), dt, "convT dgrad pack")
+
+
+@pytest.mark.parametrize("B,D,H,W", [(1, 8, 16, 32), (2, 4, 8, 16), (1, 12, 24, 48), (1, 6, 10, 20), (1, 40, 40, 40)])
+def test_conv48_specialised_matches_reference_conv(B, D, H, W):
+    """LDS-halo Cin=Cout=48 bf16 kernel (forward pack and dgrad pack, accumulate) vs F.conv3d; incl. ragged tiles"""
+    ops = _ops()
+    dt = torch.bfloat16
+    x = q(rnd(B, 48, D, H, W), dt)
+    w = q(rnd(48, 48, 3, 3, 3, seed=1, scale=(27 * 48) ** -0.5), dt)
+    dy = q(rnd(B, 48, D, H, W, seed=2), dt)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv3d(xr, w, padding=1)
+    y.backward(dy)
+    n = 41 * 3 * 64 * 8
+    wk_f, wk_d = _pack_via_kernel(w, 6, dt, n), _pack_via_kernel(w, 7, dt, n)
+    xcl = dev(x.permute(0, 2, 3, 4, 1), dt)
+    yk = ops.conv3d_k3_c48(xcl, wk_f)
+    check(yk.permute(0, 4, 1, 2, 3), y, dt, "conv48 fwd")
+    base = q(rnd(B, D, H, W, 48, seed=3), dt)
+    out = dev(base, dt)
+    ops.conv3d_k3_c48(dev(dy.permute(0, 2, 3, 4, 1), dt), wk_d, out=out, accumulate=True)
+    check(out.permute(0, 4, 1, 2, 3), xr.grad + base.permute(0, 4, 1, 2, 3), dt, "conv48 dgrad+accumulate")
