@@ -39,6 +39,9 @@ NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B,
 /* The same convolution specialised for Cin = Cout = 48, bf16 (decoder1.conv_block at 160^3 -- 75 % of the model's FLOPs): persistent
  * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad). */
 NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, void* stream);
+/* weight gradient of the specialised layer; ws = fp32 scratch of nmh_conv3d_k3_c48_wgrad_ws_floats() elements (per-workgroup partials) */
+NMH_API int nmh_conv3d_k3_c48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, void* stream);
+NMH_API int64_t nmh_conv3d_k3_c48_wgrad_ws_floats(void);
 /* dW[Cout][Cin][3][3][3] (PyTorch layout, fp32) += conv weight gradient */
 NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 

@@ -59,7 +59,7 @@ class _Lib:
         self.sigs = parse_header()
         for name, (ret, args) in self.sigs.items():
             fn = getattr(self.cdll, name)
-            fn.restype = _ctype(ret) if ret != "int" else ctypes.c_int
+            fn.restype = _ctype(ret)
             fn.argtypes = [_ctype(t) for t, _ in args]
         self.cdll.nmh_error_string.restype = ctypes.c_char_p
 
@@ -84,7 +84,7 @@ class _Lib:
             else:
                 conv.append(int(a))
         rc = getattr(self.cdll, name)(*conv)
-        if ret == "int" and name != "nmh_version" and rc != 0:
+        if ret == "int" and name != "nmh_version" and rc != 0:  # int64_t/char* returns are values, not status codes
             raise NmhError(f"{name} failed with code {rc}: {self.cdll.nmh_error_string(rc).decode()}")
         return rc
 

@@ -222,3 +222,203 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   NMH_CHECK_LAUNCH();
   return 0;
 }
+
+// ================================================================================================================
+// Weight gradient of the same layer: dW[co][ci][tap] += sum_v dY[v][co] * X[v + tap][ci]      (Cin = Cout = 48, bf16)
+//
+// Persistent 1024-thread workgroups (16 waves, 4 per SIMD, <=128 VGPRs) walk 4x4x16 voxel tiles.  Per tile the X halo
+// (6x6x18 voxels, 62 KB) and the dY tile (256 voxels, 24 KB, double-buffered by LDS-DMA) sit in LDS exactly as they lie in
+// memory ([voxel][channel], 96-B rows), and BOTH MFMA operands are contraction-major, i.e. read with ds_read_b64_tr_b16
+// (rows = 8 consecutive x, conflict-free at a 96-B stride).  A k-step is 32 voxels = two adjacent x-lines.  The 27 taps x 3
+// ci-tiles = 81 output column blocks are dealt round-robin to the 16 waves (5-6 blocks x 3 co-tiles = <=18 accumulator tiles
+// per wave); a tap shift is just a different LDS base address.  Accumulators persist across all tiles of the workgroup and
+// are flushed once to a per-workgroup fp32 partial, summed into the PyTorch-layout gradient by a second tiny kernel.
+// ================================================================================================================
+namespace w48 {
+constexpr int TZ = 4, TY = 4, TX = 16, HY = TY + 2, HX = TX + 2;
+constexpr int LINE = HX * 96, PLANE = HY * LINE, HALO = (TZ + 2) * PLANE;  // 1728, 10368, 62208
+constexpr int DYT = TZ * TY * TX * 96;                                     // 24576
+constexpr int LDS_BYTES = HALO + 2 * DYT;
+constexpr int HCH = HALO / 16, HREG = (HCH + 1023) / 1024;                 // 3888 chunks, 4 per thread
+constexpr int DCH = DYT / 16;                                              // 1536
+constexpr int NUNIT = 81, UPW = 5, PARTIAL = NUNIT * 3 * 256;              // 62208 floats per workgroup
+}  // namespace w48
+
+__device__ uint4 g_zero16[4];  // zero source for out-of-range LDS-DMA lanes
+
+struct W48Args {
+  const bf16_t* X; const bf16_t* dY; float* ws;
+  int B, D, H, W, tz, ty, tx;
+  long total;
+};
+
+__device__ __forceinline__ void w48_tile_origin(const W48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
+  int xt = (int)(t % a.tx); long r = t / a.tx;
+  int yt = (int)(r % a.ty); r /= a.ty;
+  int zt = (int)(r % a.tz);
+  b = (int)(r / a.tz);
+  z0 = zt * w48::TZ; y0 = yt * w48::TY; x0 = xt * w48::TX;
+}
+
+__global__ __launch_bounds__(1024) void conv48_wgrad_kernel(W48Args a) {
+  using namespace w48;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* dyb = smem + HALO;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, p = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int nx = 8, xcd = blockIdx.x % nx, jb = blockIdx.x / nx, jstride = gridDim.x / nx;
+  const long per = (a.total + nx - 1) / nx;
+  const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
+
+  uint4 hreg[HREG];
+  auto halo_gload = [&](long t) {
+    int b, z0, y0, x0;
+    w48_tile_origin(a, t, b, z0, y0, x0);
+#pragma unroll
+    for (int i = 0; i < HREG; ++i) {
+      const int cid = tid + 1024 * i;
+      hreg[i] = make_uint4(0, 0, 0, 0);
+      if (cid < HCH) {
+        const int line = cid / (HX * 6), within = cid - line * (HX * 6);
+        const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
+        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+        if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
+          hreg[i] = *reinterpret_cast<const uint4*>(a.X + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8);
+      }
+    }
+  };
+  auto halo_sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < HREG; ++i) {
+      const int cid = tid + 1024 * i;
+      if (cid < HCH) reinterpret_cast<uint4*>(halo)[cid] = hreg[i];  // halo image is dense: chunk id == LDS chunk index
+    }
+  };
+  auto dy_dma = [&](long t, int buf) {
+    int b, z0, y0, x0;
+    w48_tile_origin(a, t, b, z0, y0, x0);
+    for (int u0 = wave * 64; u0 < DCH; u0 += 1024) {
+      const int u = u0 + lane, v = u / 6, c6 = u - v * 6;
+      const int line = v >> 4, x = x0 + (v & 15), z = z0 + (line >> 2), y = y0 + (line & 3);
+      const void* src = (z < a.D && y < a.H && x < a.W)
+                            ? (const void*)(a.dY + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8)
+                            : (const void*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dyb + buf * DYT + u0 * 16), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[UPW][3];
+#pragma unroll
+  for (int i = 0; i < UPW; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // this wave's output blocks: unit u = wave + 16*idx -> (tap = u/3, ci-tile = u%3); LDS byte offset of the shifted window
+  int uoff[UPW];
+#pragma unroll
+  for (int i = 0; i < UPW; ++i) {
+    const int u = wave + 16 * i, tap = u / 3, cit = u - tap * 3;
+    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;  // already +1 biased
+    uoff[i] = dz * PLANE + dy * LINE + dx * 96 + cit * 32;
+  }
+  // 81 = 16*5 + 1: the last block (tap 26, ci-tile 2) is split by co-tile over waves 1..3 (one extra accumulator tile each)
+  f32x4 accx = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xoff = 2 * PLANE + 2 * LINE + 2 * 96 + 2 * 32;
+  const bool has_x = wave >= 1 && wave <= 3;
+  const int lane_off = (4 * g + (p >> 2)) * 96 + (p & 3) * 8;  // row (x) and 8-byte column piece supplied by this lane
+
+  long t = tbeg + jb;
+  int cur = 0;
+  if (t < tend) {
+    dy_dma(t, 0);
+    halo_gload(t);
+    halo_sstore();
+  }
+  __syncthreads();
+  for (; t < tend; t += jstride) {
+    const long tn = t + jstride;
+    const bool has_next = tn < tend;
+    if (has_next) { dy_dma(tn, cur ^ 1); halo_gload(tn); }
+    const char* dyc = dyb + cur * DYT;
+#pragma unroll 1
+    for (int ks = 0; ks < 8; ++ks) {
+      // lines 2ks, 2ks+1 of the tile: (z_l, y_l) = (ks>>1, (ks&1)*2) and y_l+1
+      const int lbase = (ks >> 1) * PLANE + ((ks & 1) * 2) * LINE + lane_off;
+      Frag<bf16_t> af[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) af[c] = lds_frag_t(dyc, 96, ks * 32, c * 16, lane, (bf16_t*)nullptr);
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) {
+        const char* pb = halo + lbase + uoff[i];
+        bf16x4 lo = ds_read_tr16(pb), hi = ds_read_tr16(pb + LINE);
+        Frag<bf16_t> bfr;
+        bfr.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mma(acc[i][c], af[c], bfr);
+      }
+      if (has_x) {
+        const char* pb = halo + lbase + xoff;
+        bf16x4 lo = ds_read_tr16(pb), hi = ds_read_tr16(pb + LINE);
+        Frag<bf16_t> bfr;
+        bfr.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (wave == 1) mma(accx, af[0], bfr);
+        else if (wave == 2) mma(accx, af[1], bfr);
+        else mma(accx, af[2], bfr);
+      }
+    }
+    __syncthreads();  // everyone is done with halo / dY[cur]; the barrier also drains this wave's DMA + prefetch loads
+    if (has_next) halo_sstore();
+    __syncthreads();
+    cur ^= 1;
+  }
+  // flush: ws[block][u][ct][row 16][col 16]
+  float* wsb = a.ws + (long)blockIdx.x * PARTIAL;
+#pragma unroll
+  for (int i = 0; i < UPW; ++i) {
+    const int u = wave + 16 * i;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wsb[(u * 3 + c) * 256 + (4 * g + r) * 16 + p] = acc[i][c][r];
+  }
+  if (has_x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wsb[(80 * 3 + (wave - 1)) * 256 + (4 * g + r) * 16 + p] = accx[r];
+  }
+}
+
+// dW[(co*48+ci)*27+tap] += sum_blocks ws[block][u = tap*3+cit][ct][row][col], co = ct*16+row, ci = cit*16+col
+__global__ void conv48_wgrad_reduce_kernel(const float* ws, float* dW, int nblocks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w48::PARTIAL) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += ws[(long)b * w48::PARTIAL + i];
+  const int col = i & 15, row = (i >> 4) & 15, uc = i >> 8, ct = uc % 3, u = uc / 3, tap = u / 3, cit = u - tap * 3;
+  dW[((ct * 16 + row) * 48 + cit * 16 + col) * 27 + tap] += s;
+}
+
+long k_conv48_wgrad_ws_floats() { return 256L * w48::PARTIAL; }
+
+int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st) {
+  using namespace w48;
+  W48Args a;
+  a.X = (const bf16_t*)X; a.dY = (const bf16_t*)dY; a.ws = ws;
+  a.B = B; a.D = D; a.H = H; a.W = W;
+  a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
+  a.total = (long)B * a.tz * a.ty * a.tx;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv48_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int nb = a.total < 256 ? (int)((a.total + 7) / 8 * 8) : 256;
+  hipLaunchKernelGGL(conv48_wgrad_kernel, dim3(nb), dim3(1024), LDS_BYTES, st, a);
+  NMH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(conv48_wgrad_reduce_kernel, dim3((PARTIAL + 255) / 256), dim3(256), 0, st, ws, dW, nb);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

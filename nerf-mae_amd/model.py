@@ -296,7 +296,7 @@ class _UpBlockFn(torch.autograd.Function):
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=y3, stats_r=st3, rmode=2)
         else:
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=cat, rmode=1)
-        ctx.m, ctx.dims, ctx.conv = m, (B, v, has_skip), conv
+        ctx.m, ctx.dims, ctx.conv, ctx.c48 = m, (B, v, has_skip), conv, c48
         ctx.saved = (x, cat, y1, st1, a1, y2, st2, y3, st3, out)
         return out
 
@@ -325,13 +325,14 @@ class _UpBlockFn(torch.autograd.Function):
             ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, rmode=1, dr=dcat)  # dcat <- g (plain residual)
         conv = ctx.conv
         da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
-        ops.conv3d_k3_wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
+        wgrad = ops.conv3d_k3_c48_wgrad if ctx.c48 else ops.conv3d_k3_wgrad
+        wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
         sums1 = sums2
         ops.instnorm_bwd_reduce(da1, a1, y1, st1, sums1, B, V, Cout, rmode=0)
         dy1 = dy2  # reuse
         ops.instnorm_bwd_apply(da1, a1, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
-        ops.conv3d_k3_wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
+        wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
         if m.has_proj:
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
             ops.gemm_tn(dy3, cat, _gradbuf(m.conv_block.conv3.weight))

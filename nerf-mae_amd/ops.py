@@ -111,6 +111,23 @@ def conv3d_k3_c48(X, Wk, out=None, accumulate=False):
     return out
 
 
+_C48_WS = {}
+
+
+def conv3d_k3_c48_wgrad(dY, X, dW):
+    """dW[48][48][3][3][3] += weight gradient (specialised LDS-halo kernel + per-workgroup partial reduce)"""
+    _chk(dY, X, dW)
+    B, D, H, W, Cin = X.shape
+    key = X.device.index
+    if key not in _C48_WS:
+        _C48_WS[key] = torch.empty(lib().call("nmh_conv3d_k3_c48_wgrad_ws_floats"), dtype=torch.float32, device=X.device)
+    ev = _prof(("conv3d_k3_c48_wgrad", B, D, 48, 48))
+    lib().call("nmh_conv3d_k3_c48_wgrad", dY, X, dW, _C48_WS[key], B, D, H, W, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return dW
+
+
 def conv3d_k3_wgrad(dY, X, dW):
     _chk(dY, X, dW)
     B, D, H, W, Cin = X.shape

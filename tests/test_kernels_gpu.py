@@ -474,5 +474,11 @@ def test_conv48_specialised_matches_reference_conv(B, D, H, W):
     check(yk.permute(0, 4, 1, 2, 3), y, dt, "conv48 fwd")
     base = q(rnd(B, D, H, W, 48, seed=3), dt)
     out = dev(base, dt)
-    ops.conv3d_k3_c48(dev(dy.permute(0, 2, 3, 4, 1), dt), wk_d, out=out, accumulate=True)
+    dycl = dev(dy.permute(0, 2, 3, 4, 1), dt)
+    ops.conv3d_k3_c48(dycl, wk_d, out=out, accumulate=True)
     check(out.permute(0, 4, 1, 2, 3), xr.grad + base.permute(0, 4, 1, 2, 3), dt, "conv48 dgrad+accumulate")
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(x, wr, padding=1).backward(dy)
+    dW = torch.full((48, 48, 3, 3, 3), 0.5, device="cuda")
+    ops.conv3d_k3_c48_wgrad(dycl, xcl, dW)
+    check(dW, wr.grad + 0.5, dt, "conv48 wgrad")
