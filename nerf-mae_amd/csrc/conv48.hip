@@ -23,6 +23,7 @@ constexpr int NSTEP = 41, CSTEPS = 9, WCHUNK = CSTEPS * 3 * 1024;
 constexpr int LDS_BYTES = HALO + 2 * WCHUNK;
 constexpr int HCH = (TZ + 2) * HY * HX * 6;  // 16-B chunks in the halo (6480)
 constexpr int HREG = (HCH + 511) / 512;      // 13
+constexpr int PF_CHUNK = 0;                  // weight chunk at whose start the next tile's halo is requested
 static_assert(LINE % 32 == 16 && PLANE % 32 == 16, "bank-half alternation");
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 }  // namespace c48
@@ -55,26 +56,34 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
 
   uint4 hreg[HREG];
-  auto halo_gload = [&](long t) {
+  const unsigned sample_bytes = (unsigned)a.D * a.H * a.W * 96u;  // one sample of X (< 4 GiB)
+  // loads hreg[i0 .. i1) of tile t.  __syncthreads() drains vmcnt(0), so the prefetch is spread over the weight chunks:
+  // each barrier then only waits for loads that had a whole chunk of MFMAs (~1.6 us) to land.
+  auto halo_gload = [&](long t, int i0, int i1) {
     int b, z0, y0, x0;
     c48_tile_origin(a, t, b, z0, y0, x0);
+    int tv = tid;
+    asm volatile("" : "+v"(tv));  // opaque: keep the index math below inside the tile loop (no LICM -> no long-lived VGPRs)
+    // buffer resource over sample b: offsets are 32-bit, and an offset >= num_records reads as zero (the conv's zero padding)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * (sample_bytes / 2)), 0, (int)sample_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < HREG; ++i) {
-      const int cid = tid + 512 * i;
-      hreg[i] = make_uint4(0, 0, 0, 0);
-      if (cid < HCH) {
-        const int line = cid / (HX * 6), within = cid - line * (HX * 6);
-        const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
-        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-        if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-          hreg[i] = *reinterpret_cast<const uint4*>(a.X + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8);
-      }
+      if (i < i0 || i >= i1) continue;
+      const int cid = tv + 512 * i;
+      const int line = cid / (HX * 6), within = cid - line * (HX * 6);
+      const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
+      const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = cid < HCH && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * 96 + c6 * 16) : 0xFFFFFFF0u;
+      hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
     }
   };
   auto halo_sstore = [&]() {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
 #pragma unroll
     for (int i = 0; i < HREG; ++i) {
-      const int cid = tid + 512 * i;
+      const int cid = tv + 512 * i;
       if (cid < HCH) {
         const int line = cid / (HX * 6), within = cid - line * (HX * 6);
         const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 
   long t = tbeg + jb;
   if (t >= tend) return;
-  halo_gload(t);
+  halo_gload(t, 0, HREG);
   w_dma(0, 0);
   halo_sstore();
   __syncthreads();
@@ -117,87 +126,85 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   for (; t < tend; t += jstride) {
     const long tn = t + jstride;
     const bool has_next = tn < tend;
-    if (has_next) halo_gload(tn);
     f32x4 acc[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int n = 0; n < 3; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one k-step: 3 B fragments (linear, lane*16) + 4 A fragments (4 x-lines) -> 12 MFMAs
-    auto kstep = [&](const char* wsrc, int sl, int aoff) {
-      Frag<bf16_t> bf[3], af[4];
+    // k-steps are software-pipelined inside a weight chunk: the fragments of step s+1 (3 B, linear lane*16; 4 A, one per x-line)
+    // are in flight while the 12 MFMAs of step s issue.  aoff(s): LDS byte offset of the A fragment of x-line 0.
+    auto a_off = [&](int s) -> int {
+      if (s < 36) {
+        const int q = s / 18, c = s % 18;
+        return base0 + rowoff[q] + (c / 6) * 96 + (c % 6) * 16;
+      }
+      int c = 4 * (s - 36) + g;
+      c = c > 17 ? 17 : c;  // padded slots: weights are zero there, any finite operand will do
+      const int c6 = (c * 43) >> 8;
+      return base0 + row8 + c6 * 96 + (c - 6 * c6) * 16;
+    };
+    Frag<bf16_t> bf[2][3], af[2][4];
+    auto ld_frags = [&](int buf, const char* wsrc, int sl, int s) {
+      const int ao = a_off(s);
 #pragma unroll
-      for (int n = 0; n < 3; ++n) bf[n].v = *reinterpret_cast<const bf16x8*>(wsrc + (sl * 3 + n) * 1024 + lane * 16);
+      for (int n = 0; n < 3; ++n) bf[buf][n].v = *reinterpret_cast<const bf16x8*>(wsrc + (sl * 3 + n) * 1024 + lane * 16);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i].v = *reinterpret_cast<const bf16x8*>(halo + aoff + i * LINE);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int n = 0; n < 3; ++n) mma(acc[i][n], af[i], bf[n]);
+      for (int i = 0; i < 4; ++i) af[buf][i].v = *reinterpret_cast<const bf16x8*>(halo + ao + i * LINE);
     };
 #pragma unroll
     for (int ck = 0; ck < 5; ++ck) {
       const int nxt = (ck < 4) ? ck + 1 : 0;
+      // the next tile's halo (13 x 16 B per thread) is requested only now, so its registers are live across the last 5 k-steps
+      // and the epilogue instead of the whole tile (the k-loop of chunks 0-3 keeps its fragment double-buffering)
+      if (ck == PF_CHUNK && has_next) halo_gload(tn, 0, HREG);  // (spreading the 13 loads over chunks 0-3 measured 4 % slower)
       if (ck < 4 || has_next) w_dma(nxt, (wb + ck + 1) & 1);
       const char* wsrc = wbuf + ((wb + ck) & 1) * WCHUNK;
-      if (ck < 4) {
-        // row-quad steps s = 9ck .. 9ck+8 (< 36): q = s/18, c = s%18 are wave-uniform scalars
-#pragma unroll 3
-        for (int sl = 0; sl < CSTEPS; ++sl) {
-          const int s = ck * CSTEPS + sl;
-          const int q = s >= 18 ? 1 : 0, c = s - 18 * q, c6 = (c * 43) >> 8;
-          kstep(wsrc, sl, base0 + (q ? rowoff[1] : rowoff[0]) + c6 * 96 + (c - 6 * c6) * 16);
-        }
-      } else {
+      constexpr int NST4 = NSTEP - 4 * CSTEPS;
+      const int nst = (ck < 4) ? CSTEPS : NST4;
+      ld_frags(0, wsrc, 0, ck * CSTEPS);
 #pragma unroll
-        for (int sl = 0; sl < NSTEP - 4 * CSTEPS; ++sl) {
-          int c = 4 * sl + g;
-          c = c > 17 ? 17 : c;  // padded slots: weights are zero there, any finite operand will do
-          const int c6 = (c * 43) >> 8;
-          kstep(wsrc, sl, base0 + row8 + c6 * 96 + (c - 6 * c6) * 16);
+      for (int sl = 0; sl < CSTEPS; ++sl) {
+        if (sl < nst) {
+          if (sl + 1 < nst) ld_frags((sl + 1) & 1, wsrc, sl + 1, ck * CSTEPS + sl + 1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) mma(acc[i][n], bf[sl & 1][n], af[sl & 1][i]);  // acc = (W . X^T) tile: rows co, cols voxel
         }
       }
       __syncthreads();
     }
     wb ^= 1;  // 5 chunks: chunk 0 of the next tile landed in the other buffer
 
-    // ---- epilogue: wave-private slice of the halo region (all waves are past the last barrier: halo is free) ----
+    // ---- epilogue: transposed accumulators (row = co = 16n + 4g + r, col = voxel x = li): every lane owns 4 consecutive
+    //      channels of one voxel per (x-line, co-tile) -> 8-byte bf16 stores straight from registers, no LDS restaging ----
     {
-      char* sl = halo + wave * 6144;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int n = 0; n < 3; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<bf16_t*>(sl + (i * 16 + 4 * g + r) * 96 + (n * 16 + li) * 2) = f2bf(acc[i][n][r]);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
       int b, z0, y0, x0;
       c48_tile_origin(a, t, b, z0, y0, x0);
-      const int z = z0 + z_l;
+      const int z = z0 + z_l, x = x0 + li;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int it = lane + 64 * k, row = it / 6, c6 = it - row * 6;
-        const int y = y0 + y_l + (row >> 4), x = x0 + (row & 15);
+      for (int i = 0; i < 4; ++i) {
+        const int y = y0 + y_l + i;
         if (z < a.D && y < a.H && x < a.W) {
-          uint4 v = *reinterpret_cast<const uint4*>(sl + row * 96 + c6 * 16);
-          bf16_t* dst = a.Y + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8;
-          if (a.accumulate) {
-            float o[8], n8[8];
-            Vec8<bf16_t>::load(dst, o);
-            unsigned w4[4] = {v.x, v.y, v.z, v.w};
+          bf16_t* dst = a.Y + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + 4 * g;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { n8[2 * j] = __uint_as_float(w4[j] << 16) + o[2 * j]; n8[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u) + o[2 * j + 1]; }
-            Vec8<bf16_t>::store(dst, n8);
-          } else {
-            *reinterpret_cast<uint4*>(dst) = v;
+          for (int n = 0; n < 3; ++n) {
+            float v0 = acc[i][n][0], v1 = acc[i][n][1], v2 = acc[i][n][2], v3 = acc[i][n][3];
+            if (a.accumulate) {
+              const uint2 o = *reinterpret_cast<const uint2*>(dst + 16 * n);
+              v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xffff0000u);
+              v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xffff0000u);
+            }
+            uint2 w2;
+            w2.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+            w2.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+            *reinterpret_cast<uint2*>(dst + 16 * n) = w2;
           }
         }
       }
     }
-    __syncthreads();
+    // (the barrier closing weight chunk 4 already guarantees every wave is done reading the halo)
     if (has_next) halo_sstore();
     __syncthreads();
   }

@@ -1,0 +1,25 @@
+"""micro-benchmark of the specialised decoder1 conv kernels (forward/dgrad and wgrad) at 160^3 x 48, bf16"""
+import sys, time, torch
+sys.path.insert(0, '.')
+from nerf_mae_amd import ops
+from tests.test_kernels_gpu import _pack_via_kernel
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+R = 160
+dt = torch.bfloat16
+x = torch.randn(B, R, R, R, 48, device='cuda').to(dt)
+dy = torch.randn(B, R, R, R, 48, device='cuda').to(dt)
+w = torch.randn(48, 48, 3, 3, 3) * (27 * 48) ** -0.5
+wk = _pack_via_kernel(w, 6, dt, 41 * 3 * 64 * 8)
+y = torch.empty_like(x)
+dW = torch.zeros(48, 48, 3, 3, 3, device='cuda')
+fl = 2.0 * 27 * 48 * 48 * R ** 3 * B
+for name, fn in (("conv48 fwd", lambda: ops.conv3d_k3_c48(x, wk, out=y)), ("conv48 wgrad", lambda: ops.conv3d_k3_c48_wgrad(dy, x, dW))):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    n = 20
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
+    print(f"{name}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s ({fl / ms / 1e9 / 2500 * 100:.1f}% of bf16 MFMA peak)")
