@@ -161,6 +161,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
   __shared__ __attribute__((aligned(16))) char sK[NW][64 * RS];
   __shared__ __attribute__((aligned(16))) char sO[NW][64 * RS];
   __shared__ float sB[NW][344], sDB[NW][344], sD[NW][64], sL[NW][64];
+  // d(bias) of one (query,key) pair always comes from the same lane/register, so it is accumulated over all windows of this
+  // wave in a private 64x64 LDS tile (conflict-free adds) and folded into the 343 bins once at the end (was: 4096 colliding
+  // LDS atomics per window)
+  __shared__ float sDS[NW][64 * 64];
   __shared__ int sR[NW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const int h = blockIdx.y;
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
   const long ld = 3L * C;
   const float scale = 0.17677669529663689f;
   for (int t = lane; t < 344; t += 64) { sB[wave][t] = t < 343 ? table[t * heads + h] : 0.f; sDB[wave][t] = 0.f; }
+  for (int t = lane; t < 64 * 64; t += 64) sDS[wave][t] = 0.f;
 
   for (long win = (long)blockIdx.x * NW + wave; win < nwin; win += (long)gridDim.x * NW) {
     const T* qb = qkv + win * 64 * ld + h * 32;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
             const int j = 16 * jt + 4 * g + r;
             const float ds = p[jt][it][r] * (dp[jt][it][r] - dsum);
             dp[jt][it][r] = ds;
-            atomicAdd(&sDB[wave][relidx(i, j)], ds);
+            sDS[wave][j * 64 + i] += ds;  // lanes li = consecutive i: conflict-free
           }
         // dQ rows of this query tile: sum_j dS[i][j] K[j][d]
         f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -298,6 +303,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
       }
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int t = lane; t < 64 * 64; t += 64) atomicAdd(&sDB[wave][relidx(t & 63, t >> 6)], sDS[wave][t]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int t = lane; t < 343; t += 64) atomicAdd(dtable + t * heads + h, sDB[wave][t]);

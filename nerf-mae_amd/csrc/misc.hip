@@ -37,18 +37,18 @@ int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st
 //      out[..][Cout:2Cout] = skip[..]          tap = (Z%k)*k*k + (Y%k)*k + X%k --------------------------------------------
 template <typename T> __global__ void up_cat_fwd_kernel(const T* upre, const float* bias, const T* skip, T* out, int B, int v, int k, int Cout) {
   const int V = v * k, Cc = skip ? 2 * Cout : Cout, nch = Cc >> 3, uch = Cout >> 3;
-  const long total = (long)B * V * V * V * nch;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long vox = i / nch;
-    const int c = (int)(i - vox * nch);
+  const unsigned total = (unsigned)V * V * V * nch, Vu = (unsigned)V, ku = (unsigned)k;
+  const long b = blockIdx.y, boff = b * ((long)V * V * V);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned voxl = i / (unsigned)nch;
+    const int c = (int)(i - voxl * nch);
+    const long vox = boff + voxl;
     float a[8];
     if (c < uch) {
-      const int X = (int)(vox % V); long t = vox / V;
-      const int Y = (int)(t % V); t /= V;
-      const int Z = (int)(t % V);
-      const long b = t / V;
-      const int tap = ((Z % k) * k + (Y % k)) * k + (X % k);
-      const long m = ((b * v + Z / k) * v + Y / k) * v + X / k;
+      const unsigned t1 = voxl / Vu, X = voxl - t1 * Vu, Z = t1 / Vu, Y = t1 - Z * Vu;
+      const unsigned zq = Z / ku, yq = Y / ku, xq = X / ku;
+      const int tap = (int)(((Z - zq * ku) * ku + (Y - yq * ku)) * ku + (X - xq * ku));
+      const long m = ((b * v + zq) * v + yq) * v + xq;
       Vec8<T>::load(upre + m * ((long)k * k * k * Cout) + (long)tap * Cout + c * 8, a);
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] += bias[c * 8 + j];
@@ -61,28 +61,28 @@ template <typename T> __global__ void up_cat_fwd_kernel(const T* upre, const flo
 template <typename T> __global__ void up_cat_bwd_kernel(const T* dcat, T* dupre, T* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip) {
   extern __shared__ float sdb[];
   const int V = v * k, Cc = has_skip ? 2 * Cout : Cout, nch = Cc >> 3, uch = Cout >> 3;
-  const long total = (long)B * V * V * V * nch;
+  const unsigned total = (unsigned)V * V * V * nch, Vu = (unsigned)V, ku = (unsigned)k;
+  const long b = blockIdx.y, boff = b * ((long)V * V * V);
   for (int i = threadIdx.x; i < Cout; i += blockDim.x) sdb[i] = 0.f;
   __syncthreads();
-  // fixed chunk per thread (stride multiple of nch) so bias partials stay in registers
-  const long stride = ((long)gridDim.x * blockDim.x / nch) * nch;
+  // fixed channel chunk per thread (stride is a multiple of nch) so bias partials stay in registers
+  const unsigned stride = (gridDim.x * blockDim.x / nch) * nch;
   float pb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) pb[j] = 0.f;
-  const long start = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned start = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = (int)(start % nch);
   if (start < stride) {
-    for (long i = start; i < total; i += stride) {
-      const long vox = i / nch;
+    for (unsigned i = start; i < total; i += stride) {
+      const unsigned voxl = i / (unsigned)nch;
+      const long vox = boff + voxl;
       float a[8];
       Vec8<T>::load(dcat + vox * Cc + c * 8, a);
       if (c < uch) {
-        const int X = (int)(vox % V); long t = vox / V;
-        const int Y = (int)(t % V); t /= V;
-        const int Z = (int)(t % V);
-        const long b = t / V;
-        const int tap = ((Z % k) * k + (Y % k)) * k + (X % k);
-        const long m = ((b * v + Z / k) * v + Y / k) * v + X / k;
+        const unsigned t1 = voxl / Vu, X = voxl - t1 * Vu, Z = t1 / Vu, Y = t1 - Z * Vu;
+        const unsigned zq = Z / ku, yq = Y / ku, xq = X / ku;
+        const int tap = (int)(((Z - zq * ku) * ku + (Y - yq * ku)) * ku + (X - xq * ku));
+        const long m = ((b * v + zq) * v + yq) * v + xq;
         Vec8<T>::store(dupre + m * ((long)k * k * k * Cout) + (long)tap * Cout + c * 8, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) pb[j] += a[j];
@@ -100,9 +100,10 @@ template <typename T> __global__ void up_cat_bwd_kernel(const T* dcat, T* dupre,
 int k_up_cat_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, hipStream_t st) {
   if (Cout % 8) return -2;
   long V = (long)v * k;
-  long total = (long)B * V * V * V * ((skip ? 2 : 1) * Cout / 8);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(up_cat_fwd_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)upre, bias, (const bf16_t*)skip, (bf16_t*)out, B, v, k, Cout);
-  else hipLaunchKernelGGL(up_cat_fwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)upre, bias, (const float*)skip, (float*)out, B, v, k, Cout);
+  long total = V * V * V * ((skip ? 2 : 1) * Cout / 8);
+  dim3 grid(ew_blocks(total, 4096), B);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(up_cat_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)upre, bias, (const bf16_t*)skip, (bf16_t*)out, B, v, k, Cout);
+  else hipLaunchKernelGGL(up_cat_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)upre, bias, (const float*)skip, (float*)out, B, v, k, Cout);
   NMH_CHECK_LAUNCH();
   return 0;
 }
@@ -110,12 +111,13 @@ int k_up_cat_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbia
   if (Cout % 8) return -2;
   long V = (long)v * k;
   int nch = (has_skip ? 2 : 1) * Cout / 8;
-  long total = (long)B * V * V * V * nch;
-  unsigned nb = ew_blocks(total, 2048);
+  long total = V * V * V * nch;
+  unsigned nb = ew_blocks(total, 1024);
   if ((long)nb * 256 < nch) nb = (unsigned)((nch + 255) / 256);
   size_t lds = Cout * sizeof(float);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(up_cat_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, st, (const bf16_t*)dcat, (bf16_t*)dupre, (bf16_t*)dskip, dbias, B, v, k, Cout, has_skip);
-  else hipLaunchKernelGGL(up_cat_bwd_kernel<float>, dim3(nb), dim3(256), lds, st, (const float*)dcat, (float*)dupre, (float*)dskip, dbias, B, v, k, Cout, has_skip);
+  dim3 grid(nb, B);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(up_cat_bwd_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)dcat, (bf16_t*)dupre, (bf16_t*)dskip, dbias, B, v, k, Cout, has_skip);
+  else hipLaunchKernelGGL(up_cat_bwd_kernel<float>, grid, dim3(256), lds, st, (const float*)dcat, (float*)dupre, (float*)dskip, dbias, B, v, k, Cout, has_skip);
   NMH_CHECK_LAUNCH();
   return 0;
 }
@@ -133,15 +135,19 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, T* dpred8
   if (threadIdx.x < 8) sh[threadIdx.x] = 0.f;
   __syncthreads();
   const int R = a.R, Cd = a.Cd, g = R >> 2;
-  const long V = (long)R * R * R, total = (long)a.B * V;
+  const long V = (long)R * R * R;
+  const unsigned Vu = (unsigned)V, Ru = (unsigned)R;
   const T* d0 = (const T*)a.d0;
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
   float inv_occ = 0.f, inv_rm = 0.f;
   if (BWD) { inv_occ = (float)(1.0 / a.sums[1]); inv_rm = (float)(1.0 / a.sums[3]); }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long b = i / V, vox = i - b * V;
-    const int x = (int)(vox % R); const long t = vox / R;
-    const int y = (int)(t % R), z = (int)(t / R);
+  const long b = blockIdx.y;
+  for (unsigned vox = blockIdx.x * blockDim.x + threadIdx.x; vox < Vu; vox += gridDim.x * blockDim.x) {
+    const long i = b * V + vox;
+    const unsigned t = vox / Ru;
+    const int x = (int)(vox - t * Ru);
+    const unsigned zq = t / Ru;
+    const int y = (int)(t - zq * Ru), z = (int)zq;
     float p[4] = {a.bout[0], a.bout[1], a.bout[2], a.bout[3]};
     for (int c = 0; c < Cd; c += 8) {
       float v[8];
@@ -192,9 +198,10 @@ int k_loss_fwd(const LossArgs& a, hipStream_t st) {
   if (a.Cd % 8) return -2;
   hipError_t e = hipMemsetAsync(a.sums, 0, 4 * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
-  long total = (long)a.B * a.R * a.R * a.R;
-  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 0>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, nullptr, nullptr, nullptr);
-  else hipLaunchKernelGGL((loss_kernel<float, 0>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, nullptr, nullptr, nullptr);
+  long total = (long)a.R * a.R * a.R;
+  dim3 grid(ew_blocks(total, 2048), a.B);
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 0>), grid, dim3(256), 0, st, a, nullptr, nullptr, nullptr);
+  else hipLaunchKernelGGL((loss_kernel<float, 0>), grid, dim3(256), 0, st, a, nullptr, nullptr, nullptr);
   NMH_CHECK_LAUNCH();
   return 0;
 }
@@ -208,9 +215,10 @@ int k_loss_finalize(const double* sums, float* losses, hipStream_t st) {
   return 0;
 }
 int k_loss_bwd(const LossArgs& a, void* dd0, void* dpred8, float* dbout, hipStream_t st) {
-  long total = (long)a.B * a.R * a.R * a.R;
-  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 1>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, (bf16_t*)dd0, (bf16_t*)dpred8, dbout);
-  else hipLaunchKernelGGL((loss_kernel<float, 1>), dim3(ew_blocks(total, 4096)), dim3(256), 0, st, a, (float*)dd0, (float*)dpred8, dbout);
+  long total = (long)a.R * a.R * a.R;
+  dim3 grid(ew_blocks(total, 2048), a.B);
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a, (bf16_t*)dd0, (bf16_t*)dpred8, dbout);
+  else hipLaunchKernelGGL((loss_kernel<float, 1>), grid, dim3(256), 0, st, a, (float*)dd0, (float*)dpred8, dbout);
   NMH_CHECK_LAUNCH();
   return 0;
 }

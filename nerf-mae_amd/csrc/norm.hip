@@ -379,19 +379,19 @@ int k_window_gather_scale(int dt, const void* dx, void* dyw, const float* rs, in
 // InstanceNorm over channels-last [B][V][C].  Reductions: each thread owns one 8-channel chunk and
 // strides over voxels; block partials -> LDS atomics -> fp64 global atomics (scratch [B][C][2]).
 // ------------------------------------------------------------------------------------------------
-#define IN_VOX_PER_BLOCK 4096
+#define IN_VOX_PER_BLOCK 4096  /* minimum; the launchers grow it so that <= ~256 blocks per sample contend on the 2*C fp64 atomics */
 
 template <typename T, int BWD>
 __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dout, const T* outp, const float* stats, const T* r, const float* stats_r, int rmode,
-                                                        double* acc, double* acc_r, long V, int C, float slope) {
+                                                        double* acc, double* acc_r, long V, int C, float slope, long vpb) {
   extern __shared__ float sred[];  // [4][C]
   const int CL = C >> 3, NV = 256 / CL;
   const int cl = threadIdx.x % CL, vl = threadIdx.x / CL;
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < 4 * C; i += 256) sred[i] = 0.f;
   __syncthreads();
-  const long v0 = (long)blockIdx.x * IN_VOX_PER_BLOCK;
-  long v1 = v0 + IN_VOX_PER_BLOCK;
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
   if (v1 > V) v1 = V;
   float s1[8], s2[8], t1[8], t2[8];
 #pragma unroll
@@ -471,14 +471,20 @@ __global__ void in_finalize_kernel(const double* acc, float* stats, const T* x, 
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
+static inline long in_vox_per_block(long V) {
+  long vpb = (V + 255) / 256;
+  vpb = (vpb + 63) / 64 * 64;
+  return vpb < IN_VOX_PER_BLOCK ? IN_VOX_PER_BLOCK : vpb;
+}
 int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st) {
   if (C % 8 || C / 8 > 256) return -2;
   hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
-  dim3 grid((unsigned)((V + IN_VOX_PER_BLOCK - 1) / IN_VOX_PER_BLOCK), B);
+  const long vpb = in_vox_per_block(V);
+  dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
   size_t lds = 4 * C * sizeof(float);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 0>), grid, dim3(256), lds, st, (const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f);
-  else hipLaunchKernelGGL((in_reduce_kernel<float, 0>), grid, dim3(256), lds, st, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 0>), grid, dim3(256), lds, st, (const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f, vpb);
+  else hipLaunchKernelGGL((in_reduce_kernel<float, 0>), grid, dim3(256), lds, st, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f, vpb);
   NMH_CHECK_LAUNCH();
   long n = (long)B * C;
   if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_finalize_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, stats, (const bf16_t*)x, n, V, C, 1.0 / (double)V, eps);
@@ -492,85 +498,120 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
   if (rmode == 2) { e = hipMemsetAsync(sums_r, 0, sizeof(double) * 2 * B * C, st); if (e != hipSuccess) return (int)e; }
-  dim3 grid((unsigned)((V + IN_VOX_PER_BLOCK - 1) / IN_VOX_PER_BLOCK), B);
+  const long vpb = in_vox_per_block(V);
+  dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
   size_t lds = 4 * C * sizeof(float);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 1>), grid, dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)out, stats, (const bf16_t*)r, stats_r, rmode, sums, sums_r, V, C, slope);
-  else hipLaunchKernelGGL((in_reduce_kernel<float, 1>), grid, dim3(256), lds, st, (const float*)x, (const float*)dout, (const float*)out, stats, (const float*)r, stats_r, rmode, sums, sums_r, V, C, slope);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 1>), grid, dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)out, stats, (const bf16_t*)r, stats_r, rmode, sums, sums_r, V, C, slope, vpb);
+  else hipLaunchKernelGGL((in_reduce_kernel<float, 1>), grid, dim3(256), lds, st, (const float*)x, (const float*)dout, (const float*)out, stats, (const float*)r, stats_r, rmode, sums, sums_r, V, C, slope, vpb);
   NMH_CHECK_LAUNCH();
   return 0;
 }
 
+#define IN_APPLY_VOX_PER_BLOCK 2048
 template <typename T>
-__global__ void in_apply_kernel(const T* x, const float* stats, const T* r, const float* stats_r, int rmode, T* out, long V, int C, float slope, long total) {
-  const int CL = C >> 3;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long vox = i / CL;
-    const int c0 = (int)(i - vox * CL) * 8;
-    const long b = vox / V;
-    float xv[8], rv[8];
-    Vec8<T>::load(x + vox * C + c0, xv);
-    if (rmode) Vec8<T>::load(r + vox * C + c0, rv);
-    const float* sp = stats + (b * C + c0) * 2;
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* stats, const T* r, const float* stats_r, int rmode, T* out, long V, int C, float slope) {
+  // grid (voxel blocks, B); thread = (8-channel chunk cl, voxel lane vl): no integer division in the loop, statistics in registers
+  const int CL = C >> 3, NV = 256 / CL;
+  const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
+  if (vl >= NV) return;
+  float mu[8], rs[8], mur[8], rsr[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float y = (xv[j] - sp[2 * j]) * sp[2 * j + 1];
-      if (rmode == 1) y += rv[j];
-      else if (rmode == 2) y += (rv[j] - stats_r[(b * C + c0 + j) * 2]) * stats_r[(b * C + c0 + j) * 2 + 1];
-      xv[j] = y > 0.f ? y : slope * y;
+  for (int j = 0; j < 8; ++j) {
+    const long sc = ((long)b * C + cl * 8 + j) * 2;
+    mu[j] = stats[sc]; rs[j] = stats[sc + 1];
+    if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; }
+  }
+  const long v0 = (long)blockIdx.x * IN_APPLY_VOX_PER_BLOCK;
+  long v1 = v0 + IN_APPLY_VOX_PER_BLOCK;
+  if (v1 > V) v1 = V;
+  constexpr int U = 2;
+  for (long vb = v0 + vl; vb < v1; vb += (long)NV * U) {
+    float xv[U][8], rv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long v = vb + (long)u * NV;
+      if (v < v1) {
+        const long o = ((long)b * V + v) * C + cl * 8;
+        Vec8<T>::load(x + o, xv[u]);
+        if (rmode) Vec8<T>::load(r + o, rv[u]);
+      }
     }
-    Vec8<T>::store(out + vox * C + c0, xv);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long v = vb + (long)u * NV;
+      if (v < v1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float y = (xv[u][j] - mu[j]) * rs[j];
+          if (rmode == 1) y += rv[u][j];
+          else if (rmode == 2) y += (rv[u][j] - mur[j]) * rsr[j];
+          xv[u][j] = y > 0.f ? y : slope * y;
+        }
+        Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv[u]);
+      }
+    }
   }
 }
 int k_in_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, long V, int C, float slope, hipStream_t st) {
-  long total = (long)B * V * (C / 8);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope, total);
-  else hipLaunchKernelGGL(in_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)x, stats, (const float*)r, stats_r, rmode, (float*)out, V, C, slope, total);
+  if (C % 8 || C / 8 > 256) return -2;
+  dim3 grid((unsigned)((V + IN_APPLY_VOX_PER_BLOCK - 1) / IN_APPLY_VOX_PER_BLOCK), B);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope);
+  else hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, (const float*)r, stats_r, rmode, (float*)out, V, C, slope);
   NMH_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T>
-__global__ void in_bwd_apply_kernel(const T* dout, const T* outp, const T* x, const float* stats, const double* sums, const T* r, const float* stats_r, const double* sums_r,
-                                    int rmode, T* dx, T* dr, int dr_acc, long V, int C, float slope, long total) {
-  const int CL = C >> 3;
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const T* outp, const T* x, const float* stats, const double* sums, const T* r, const float* stats_r,
+                                                            const double* sums_r, int rmode, T* dx, T* dr, int dr_acc, long V, int C, float slope) {
+  const int CL = C >> 3, NV = 256 / CL;
+  const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
+  if (vl >= NV) return;
   const float invV = 1.0f / (float)V;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long vox = i / CL;
-    const int c0 = (int)(i - vox * CL) * 8;
-    const long b = vox / V;
-    float dv[8], ov[8], xv[8], rv[8], o[8], orr[8];
-    Vec8<T>::load(dout + vox * C + c0, dv);
-    Vec8<T>::load(outp + vox * C + c0, ov);
-    Vec8<T>::load(x + vox * C + c0, xv);
-    if (rmode == 2) Vec8<T>::load(r + vox * C + c0, rv);
-    if (rmode == 1 && dr_acc) Vec8<T>::load(dr + vox * C + c0, orr);
+  float mu[8], rs[8], m1[8], m2[8], mur[8], rsr[8], n1[8], n2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long sc = ((long)b * C + cl * 8 + j) * 2;
+    mu[j] = stats[sc]; rs[j] = stats[sc + 1];
+    m1[j] = (float)sums[sc] * invV; m2[j] = (float)sums[sc + 1] * invV;
+    if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; n1[j] = (float)sums_r[sc] * invV; n2[j] = (float)sums_r[sc + 1] * invV; }
+  }
+  const long v0 = (long)blockIdx.x * IN_APPLY_VOX_PER_BLOCK;
+  long v1 = v0 + IN_APPLY_VOX_PER_BLOCK;
+  if (v1 > V) v1 = V;
+  for (long v = v0 + vl; v < v1; v += NV) {
+    const long o = ((long)b * V + v) * C + cl * 8;
+    float dv[8], ov[8], xv[8], rv[8], od[8], orr[8];
+    Vec8<T>::load(dout + o, dv);
+    Vec8<T>::load(outp + o, ov);
+    Vec8<T>::load(x + o, xv);
+    if (rmode == 2) Vec8<T>::load(r + o, rv);
+    if (rmode == 1 && dr_acc) Vec8<T>::load(dr + o, orr);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const long sc = (b * C + c0 + j) * 2;
       const float g = dv[j] * (ov[j] > 0.f ? 1.0f : slope);
-      const float mu = stats[sc], rs = stats[sc + 1];
-      const float xh = (xv[j] - mu) * rs;
-      o[j] = rs * (g - (float)sums[sc] * invV - xh * (float)sums[sc + 1] * invV);
+      const float xh = (xv[j] - mu[j]) * rs[j];
+      od[j] = rs[j] * (g - m1[j] - xh * m2[j]);
       if (rmode == 1) orr[j] = dr_acc ? orr[j] + g : g;
       else if (rmode == 2) {
-        const float mr = stats_r[sc], rr = stats_r[sc + 1];
-        const float rh = (rv[j] - mr) * rr;
-        orr[j] = rr * (g - (float)sums_r[sc] * invV - rh * (float)sums_r[sc + 1] * invV);
+        const float rh = (rv[j] - mur[j]) * rsr[j];
+        orr[j] = rsr[j] * (g - n1[j] - rh * n2[j]);
       }
     }
-    Vec8<T>::store(dx + vox * C + c0, o);
-    if (rmode) Vec8<T>::store(dr + vox * C + c0, orr);
+    Vec8<T>::store(dx + o, od);
+    if (rmode) Vec8<T>::store(dr + o, orr);
   }
 }
 int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
                    const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st) {
-  long total = (long)B * V * (C / 8);
+  if (C % 8 || C / 8 > 256) return -2;
+  dim3 grid((unsigned)((V + IN_APPLY_VOX_PER_BLOCK - 1) / IN_APPLY_VOX_PER_BLOCK), B);
   if (dt == NMH_DT_BF16)
-    hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
-                       (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope, total);
+    hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
+                       (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope);
   else
-    hipLaunchKernelGGL(in_bwd_apply_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, stats, sums,
-                       (const float*)r, stats_r, sums_r, rmode, (float*)dx, (float*)dr, dr_accumulate, V, C, slope, total);
+    hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, stats, sums,
+                       (const float*)r, stats_r, sums_r, rmode, (float*)dx, (float*)dr, dr_accumulate, V, C, slope);
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -203,27 +203,33 @@ class _BlockFn(torch.autograd.Function):
         tps = T // geom.B
         dx2 = dx2.contiguous()
         # ---- MLP branch
+        # weight/bias gradients are off the critical path: they run on a forked side stream and overlap the dgrad chain
         dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
-        ops.gemm_tn(dx2, h_act, _gradbuf(b.mlp[3].weight), rowscale=sd2, rows_per_scale=tps)
-        ops.bias_grad(dx2, _gradbuf(b.mlp[3].bias), T, C, rowscale=sd2, rows_per_scale=tps)
+        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
+            ops.gemm_tn(dx2, h_act, _gradbuf(b.mlp[3].weight), rowscale=sd2, rows_per_scale=tps)
+            ops.bias_grad(dx2, _gradbuf(b.mlp[3].bias), T, C, rowscale=sd2, rows_per_scale=tps)
         dx1n = ops.gemm_nt(dh, pk[key + "fc1.wT"].view(C, 4 * C))
-        ops.gemm_tn(dh, x1n, _gradbuf(b.mlp[0].weight))
-        ops.bias_grad(dh, _gradbuf(b.mlp[0].bias), T, 4 * C)
+        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
+            ops.gemm_tn(dh, x1n, _gradbuf(b.mlp[0].weight))
+            ops.bias_grad(dh, _gradbuf(b.mlp[0].bias), T, 4 * C)
         dx1 = torch.empty_like(x)
         ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2)
         # ---- attention branch
         dyw = torch.empty_like(xnw)
         ops.window_gather_scale(dx1, dyw, sd1, C, geom)
         do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
-        ops.gemm_tn(dyw, o, _gradbuf(b.attn.proj.weight))
-        ops.bias_grad(dyw, _gradbuf(b.attn.proj.bias), geom.rows, C)
+        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
+            ops.gemm_tn(dyw, o, _gradbuf(b.attn.proj.weight))
+            ops.bias_grad(dyw, _gradbuf(b.attn.proj.bias), geom.rows, C)
         dqkv = torch.empty_like(qkv)
         ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
         dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
-        ops.gemm_tn(dqkv, xnw, _gradbuf(b.attn.qkv.weight))
-        ops.bias_grad(dqkv, _gradbuf(b.attn.qkv.bias), geom.rows, 3 * C)
+        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
+            ops.gemm_tn(dqkv, xnw, _gradbuf(b.attn.qkv.weight))
+            ops.bias_grad(dqkv, _gradbuf(b.attn.qkv.bias), geom.rows, 3 * C)
         dx = torch.empty_like(x)
         ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
+        ops.join_side()  # before any temporary of this block is released
         return dx, None, None, None, None
 
 
@@ -326,21 +332,27 @@ class _UpBlockFn(torch.autograd.Function):
         conv = ctx.conv
         da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
         wgrad = ops.conv3d_k3_c48_wgrad if ctx.c48 else ops.conv3d_k3_wgrad
-        wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
-        sums1 = sums2
+        # (the persistent 160^3 kernels own every CU: overlapping two of them only adds contention -> main stream when c48)
+        with ops.side_stream(enable=not ctx.c48):
+            wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
+        sums1 = torch.empty_like(sums2)
         ops.instnorm_bwd_reduce(da1, a1, y1, st1, sums1, B, V, Cout, rmode=0)
-        dy1 = dy2  # reuse
+        dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, a1, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
-        wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
+        with ops.side_stream(enable=not ctx.c48):
+            wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
         if m.has_proj:
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
-            ops.gemm_tn(dy3, cat, _gradbuf(m.conv_block.conv3.weight))
+            with ops.side_stream():
+                ops.gemm_tn(dy3, cat, _gradbuf(m.conv_block.conv3.weight))
         dupre = torch.empty((B * v ** 3, k3 * Cout), dtype=dtype, device=dev)
         dskip = torch.empty((B * V, Cout), dtype=dtype, device=dev) if has_skip else None
         ops.upconv_shuffle_bwd(dcat, dupre, dskip, _gradbuf(m.transp_conv.bias), B, v, k, Cout, has_skip)
         dx = ops.gemm_nt(dupre, pk[key + "t.wd"].view(Cin, k3 * Cout))
-        ops.gemm_tn(dupre, x, _gradbuf(m.transp_conv.weight), omode=2, p0=Cout, p1=k3)
+        with ops.side_stream():
+            ops.gemm_tn(dupre, x, _gradbuf(m.transp_conv.weight), omode=2, p0=Cout, p1=k3)
+        ops.join_side()
         return dx, dskip, None, None, None
 
 

@@ -24,6 +24,43 @@ def _prof(key):
     return b
 
 
+class side_stream:
+    """`with ops.side_stream():` forks a side HIP stream from the current one (also under graph capture) for kernels that are off
+    the critical path (weight/bias gradients); `ops.join_side()` makes the current stream wait for it.  The fork/join pair keeps
+    allocator lifetimes trivial: every tensor touched on the side stream outlives the join."""
+    _streams = {}
+    enabled = True
+    min_rows = int(__import__("os").environ.get("NMH_SIDE_MIN_ROWS", "0"))  # blocks with fewer token rows stay single-stream
+
+    def __init__(self, enable: bool = True):
+        self.enable = enable
+
+    def __enter__(self):
+        if not (side_stream.enabled and self.enable):
+            self.ctx = None
+            return self
+        dev = torch.cuda.current_device()
+        if dev not in side_stream._streams:
+            side_stream._streams[dev] = torch.cuda.Stream(device=dev)
+        self.s = side_stream._streams[dev]
+        self.s.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.s)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+
+def join_side():
+    if side_stream.enabled:
+        s = side_stream._streams.get(torch.cuda.current_device())
+        if s is not None:
+            torch.cuda.current_stream().wait_stream(s)
+
+
 def dt_of(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
