@@ -23,6 +23,7 @@ constexpr int NSTEP = 41, CSTEPS = 9, WCHUNK = CSTEPS * 3 * 1024;
 constexpr int LDS_BYTES = HALO + 2 * WCHUNK;
 constexpr int HCH = (TZ + 2) * HY * HX * 6;  // 16-B chunks in the halo (6480)
 constexpr int HREG = (HCH + 511) / 512;      // 13
+static_assert(HREG == 13, "the counted vmcnt(13) in the chunk barrier assumes 13 halo loads per thread");
 constexpr int PF_CHUNK = 0;                  // weight chunk at whose start the next tile's halo is requested
 static_assert(LINE % 32 == 16 && PLANE % 32 == 16, "bank-half alternation");
 static_assert(LDS_BYTES <= 163840, "LDS budget");
@@ -39,8 +40,13 @@ __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b
   int xt = (int)(t % a.tx); long r = t / a.tx;
   int yt = (int)(r % a.ty); r /= a.ty;
   int zt = (int)(r % a.tz);
-  b = (int)(r / a.tz);
-  z0 = zt * c48::TZ; y0 = yt * c48::TY; x0 = xt * c48::TX;
+  // the tile index is wave-uniform, but the 64-bit divisions above run on the VALU: hand the results back to SGPRs so that the
+  // buffer descriptor built from b is provably uniform (otherwise every buffer_load is wrapped in a waterfall loop: measured
+  // 270 cycles per load, 3.5k cycles per tile)
+  b = __builtin_amdgcn_readfirstlane((int)(r / a.tz));
+  z0 = __builtin_amdgcn_readfirstlane(zt * c48::TZ);
+  y0 = __builtin_amdgcn_readfirstlane(yt * c48::TY);
+  x0 = __builtin_amdgcn_readfirstlane(xt * c48::TX);
 }
 
 __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
@@ -66,29 +72,33 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     asm volatile("" : "+v"(tv));  // opaque: keep the index math below inside the tile loop (no LICM -> no long-lived VGPRs)
     // buffer resource over sample b: offsets are 32-bit, and an offset >= num_records reads as zero (the conv's zero padding)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * (sample_bytes / 2)), 0, (int)sample_bytes, 0x00020000);
+    // chunk id cid = tv + 512*i -> (line, within); 512 = 4*108 + 80, so the pair is advanced incrementally (no divisions)
+    int line = tv / (HX * 6), within = tv - line * (HX * 6);
 #pragma unroll
     for (int i = 0; i < HREG; ++i) {
-      if (i < i0 || i >= i1) continue;
-      const int cid = tv + 512 * i;
-      const int line = cid / (HX * 6), within = cid - line * (HX * 6);
-      const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
-      const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-      const bool ok = cid < HCH && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-      const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * 96 + c6 * 16) : 0xFFFFFFF0u;
-      hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+      if (i >= i0 && i < i1) {
+        const int hz = (line * 205) >> 11, hy = line - hz * HY, hx = (within * 43) >> 8, c6 = within - hx * 6;  // /10 and /6 by multiply-shift
+        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = line < (TZ + 2) * HY && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * 96 + c6 * 16) : 0xFFFFFFF0u;
+        hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+      }
+      within += 80; line += 4;
+      if (within >= HX * 6) { within -= HX * 6; line += 1; }
     }
   };
   auto halo_sstore = [&]() {
     int tv = tid;
     asm volatile("" : "+v"(tv));
+    int line = tv / (HX * 6), within = tv - line * (HX * 6);
 #pragma unroll
     for (int i = 0; i < HREG; ++i) {
-      const int cid = tv + 512 * i;
-      if (cid < HCH) {
-        const int line = cid / (HX * 6), within = cid - line * (HX * 6);
-        const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
-        *reinterpret_cast<uint4*>(halo + hz * PLANE + hy * LINE + hx * 96 + c6 * 16) = hreg[i];
+      if (line < (TZ + 2) * HY) {
+        const int hz = (line * 205) >> 11, hy = line - hz * HY;
+        *reinterpret_cast<uint4*>(halo + hz * PLANE + hy * LINE + within * 16) = hreg[i];  // within*16 = hx*96 + c6*16
       }
+      within += 80; line += 4;
+      if (within >= HX * 6) { within -= HX * 6; line += 1; }
     }
   };
   // weight chunk ck (steps [9ck, min(9ck+9,41))) -> LDS ring slot `buf` by LDS-DMA: the image is lane-linear
@@ -157,8 +167,11 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       const int nxt = (ck < 4) ? ck + 1 : 0;
       // the next tile's halo (13 x 16 B per thread) is requested only now, so its registers are live across the last 5 k-steps
       // and the epilogue instead of the whole tile (the k-loop of chunks 0-3 keeps its fragment double-buffering)
-      if (ck == PF_CHUNK && has_next) halo_gload(tn, 0, HREG);  // (spreading the 13 loads over chunks 0-3 measured 4 % slower)
+      // order matters: DMA first, then the 13 halo loads, so that "vmcnt(13)" at the end of chunk 0 means "older stores and this
+      // chunk's DMA have landed" while the halo prefetch stays in flight (vmcnt retires in order; __syncthreads would drain it)
       if (ck < 4 || has_next) w_dma(nxt, (wb + ck + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ck == PF_CHUNK && has_next) halo_gload(tn, 0, HREG);
       const char* wsrc = wbuf + ((wb + ck) & 1) * WCHUNK;
       constexpr int NST4 = NSTEP - 4 * CSTEPS;
       const int nst = (ck < 4) ? CSTEPS : NST4;
@@ -173,7 +186,9 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
             for (int n = 0; n < 3; ++n) mma(acc[i][n], bf[sl & 1][n], af[sl & 1][i]);  // acc = (W . X^T) tile: rows co, cols voxel
         }
       }
-      __syncthreads();
+      if (ck == PF_CHUNK && has_next) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
     }
     wb ^= 1;  // 5 chunks: chunk 0 of the next tile landed in the other buffer
 
@@ -263,8 +278,10 @@ __device__ __forceinline__ void w48_tile_origin(const W48Args& a, long t, int& b
   int xt = (int)(t % a.tx); long r = t / a.tx;
   int yt = (int)(r % a.ty); r /= a.ty;
   int zt = (int)(r % a.tz);
-  b = (int)(r / a.tz);
-  z0 = zt * w48::TZ; y0 = yt * w48::TY; x0 = xt * w48::TX;
+  b = __builtin_amdgcn_readfirstlane((int)(r / a.tz));
+  z0 = __builtin_amdgcn_readfirstlane(zt * w48::TZ);
+  y0 = __builtin_amdgcn_readfirstlane(yt * w48::TY);
+  x0 = __builtin_amdgcn_readfirstlane(xt * w48::TX);
 }
 
 __global__ __launch_bounds__(1024) void conv48_wgrad_kernel(W48Args a) {
