@@ -62,6 +62,7 @@ class _Lib:
             fn.restype = _ctype(ret)
             fn.argtypes = [_ctype(t) for t, _ in args]
         self.cdll.nmh_error_string.restype = ctypes.c_char_p
+        self.profile = None  # dict -> every int-returning call is bracketed by HIP events on the launch stream (tools/op_breakdown.py)
 
     def call(self, name: str, *args):
         """Call an int-returning entry; tensors -> device pointers, None -> NULL; raises NmhError on failure."""
@@ -83,7 +84,17 @@ class _Lib:
                 conv.append(float(a))
             else:
                 conv.append(int(a))
-        rc = getattr(self.cdll, name)(*conv)
+        prof = self.profile
+        if prof is not None and ret == "int":
+            import torch as _t
+            key = (name,) + tuple(a for a, (t, n) in zip(args, sig) if not t.endswith("*") and isinstance(a, int))
+            e0, e1 = _t.cuda.Event(enable_timing=True), _t.cuda.Event(enable_timing=True)
+            e0.record(_t.cuda.current_stream())
+            rc = getattr(self.cdll, name)(*conv)
+            e1.record(_t.cuda.current_stream())
+            prof.setdefault(key, []).append((e0, e1))
+        else:
+            rc = getattr(self.cdll, name)(*conv)
         if ret == "int" and name != "nmh_version" and rc != 0:  # int64_t/char* returns are values, not status codes
             raise NmhError(f"{name} failed with code {rc}: {self.cdll.nmh_error_string(rc).decode()}")
         return rc

@@ -315,7 +315,7 @@ int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, co
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   const int nw = dt == NMH_DT_BF16 ? 2 : 1;
-  long gx = (nwin + nw - 1) / nw;
+  long gx = (nwin + nw * 4 - 1) / (nw * 4);
   long cap = 2048 / heads;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;

@@ -128,11 +128,8 @@ int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bou
                      int Cd, const double* sums, void* dd0, void* dpred8, float* dWout, float* dbout, void* stream) {
   CLR();
   LossArgs a{dt, d0, Wout, bout, target, extents, tokmask, B, R, Cd, const_cast<double*>(sums), nullptr};
-  int rc = k_loss_bwd(a, dd0, dpred8, dbout, ST);
-  if (rc) return rc;
-  TnGeom gm{};
-  gm.omode = 0; gm.ldo = Cd;
-  return k_gemm_tn(dt, dpred8, 8, d0, Cd, dWout, (long)B * R * R * R, 4, Cd, nullptr, 1, gm, ST);
+  (void)dpred8;  // kept in the ABI for layout stability; the head weight gradient is now fused into the kernel
+  return k_loss_bwd(a, dd0, dWout, dbout, ST);
 }
 int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream) {
   CLR();

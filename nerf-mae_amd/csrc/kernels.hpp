@@ -92,7 +92,7 @@ struct LossArgs {
 };
 int k_loss_fwd(const LossArgs& a, hipStream_t st);
 int k_loss_finalize(const double* sums, float* losses, hipStream_t st);
-int k_loss_bwd(const LossArgs& a, void* dd0, void* dpred8, float* dbout, hipStream_t st);
+int k_loss_bwd(const LossArgs& a, void* dd0, float* dWout, float* dbout, hipStream_t st);
 int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rowscale, int rows_per_scale, hipStream_t st);
 int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st);
 int k_fill_f32(float* p, float v, long n, hipStream_t st);

@@ -129,79 +129,127 @@ __device__ __forceinline__ float block_sum_to(float v, float* sh, int slot) {
   if ((threadIdx.x & 63) == 0) atomicAdd(&sh[slot], v);
   return v;
 }
+// One 256-thread block walks 256-voxel tiles of one sample:
+//   1. the d0 tile (256 x Cd) is copied to LDS with coalesced 16-B loads;
+//   2. thread-per-voxel: 1x1 head from the LDS row, target/mask lookups (coalesced plane reads), loss terms or d(pred);
+//   3. (backward) thread = (8-channel chunk, voxel lane): d(d0) chunk written with coalesced 16-B stores and the head weight
+//      gradient dW[o][c] += d(pred)[o] * d0[c] accumulated in 32 registers -> LDS -> one set of fp32 atomics per block.
 template <typename T, int BWD>
-__global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, T* dpred8, float* dbout) {
-  __shared__ float sh[8];
-  if (threadIdx.x < 8) sh[threadIdx.x] = 0.f;
-  __syncthreads();
-  const int R = a.R, Cd = a.Cd, g = R >> 2;
-  const long V = (long)R * R * R;
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, float* dWout, float* dbout) {
+  extern __shared__ __attribute__((aligned(16))) char lsm[];
+  const int R = a.R, Cd = a.Cd, g = R >> 2, CL = Cd >> 3, NV = 256 / CL;
+  const int rowb = Cd * (int)sizeof(T);
+  char* tile = lsm;                                               // [256][Cd] T
+  float* dps = reinterpret_cast<float*>(lsm + 256 * rowb);        // [256][4]
+  float* sacc = dps + 256 * 4;                                    // [4*Cd + 8]
+  const int tid = threadIdx.x;
+  const long V = (long)R * R * R, b = blockIdx.y;
   const unsigned Vu = (unsigned)V, Ru = (unsigned)R;
-  const T* d0 = (const T*)a.d0;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
+  const T* d0 = (const T*)a.d0 + b * V * Cd;
+  for (int i = tid; i < 4 * Cd + 8; i += 256) sacc[i] = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   float inv_occ = 0.f, inv_rm = 0.f;
   if (BWD) { inv_occ = (float)(1.0 / a.sums[1]); inv_rm = (float)(1.0 / a.sums[3]); }
-  const long b = blockIdx.y;
-  for (unsigned vox = blockIdx.x * blockDim.x + threadIdx.x; vox < Vu; vox += gridDim.x * blockDim.x) {
-    const long i = b * V + vox;
-    const unsigned t = vox / Ru;
-    const int x = (int)(vox - t * Ru);
-    const unsigned zq = t / Ru;
-    const int y = (int)(t - zq * Ru), z = (int)zq;
-    float p[4] = {a.bout[0], a.bout[1], a.bout[2], a.bout[3]};
-    for (int c = 0; c < Cd; c += 8) {
-      float v[8];
-      Vec8<T>::load(d0 + i * Cd + c, v);
+  const int cl = tid % CL, vl = tid / CL;  // phase-3 role
+  float wreg[4][8], wacc[4][8];
+  if (BWD) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        p[0] += v[j] * a.Wout[c + j]; p[1] += v[j] * a.Wout[Cd + c + j];
-        p[2] += v[j] * a.Wout[2 * Cd + c + j]; p[3] += v[j] * a.Wout[3 * Cd + c + j];
-      }
-    }
-    const float* tg = a.target + b * 4 * V + vox;
-    const float t0 = tg[0], t1 = tg[V], t2 = tg[2 * V], t3 = tg[3 * V];
-    const bool occ = t3 > 0.01f;
-    const bool valid = z < a.extents[b * 3] && y < a.extents[b * 3 + 1] && x < a.extents[b * 3 + 2];
-    const bool rm = valid && a.tokmask[((z >> 2) * g + (y >> 2)) * g + (x >> 2)] != 0;
-    const float sg = 1.0f / (1.0f + __expf(-p[3]));
-    if (!BWD) {
-      if (occ) { acc[0] += (p[0] - t0) * (p[0] - t0) + (p[1] - t1) * (p[1] - t1) + (p[2] - t2) * (p[2] - t2); acc[1] += 1.f; }
-      if (rm) { acc[2] += (sg - t3) * (sg - t3); acc[3] += 1.f; }
-      if (a.pred) { float* pr = a.pred + b * 4 * V + vox; pr[0] = p[0]; pr[V] = p[1]; pr[2 * V] = p[2]; pr[3 * V] = p[3]; }
-    } else {
-      float dp[4];
-      dp[0] = occ ? 2.f * (p[0] - t0) * inv_occ : 0.f;
-      dp[1] = occ ? 2.f * (p[1] - t1) * inv_occ : 0.f;
-      dp[2] = occ ? 2.f * (p[2] - t2) * inv_occ : 0.f;
-      dp[3] = rm ? 2.f * (sg - t3) * sg * (1.f - sg) * inv_rm : 0.f;
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int o = 0; o < 4; ++o) accb[o] += dp[o];
+      for (int j = 0; j < 8; ++j) { wreg[o][j] = a.Wout[o * Cd + cl * 8 + j]; wacc[o][j] = 0.f; }
+  }
+  const int cpr = rowb / 16;  // 16-B chunks per row
+  const unsigned ntile = (Vu + 255) / 256;
+  for (unsigned vt = blockIdx.x; vt < ntile; vt += gridDim.x) {
+    const unsigned v0 = vt * 256;
+    const int nvox = (Vu - v0) < 256u ? (int)(Vu - v0) : 256;
+    __syncthreads();
+    const char* src = reinterpret_cast<const char*>(d0 + (long)v0 * Cd);
+    for (int c = tid; c < nvox * cpr; c += 256) *reinterpret_cast<uint4*>(tile + c * 16) = *reinterpret_cast<const uint4*>(src + (long)c * 16);
+    __syncthreads();
+    if (tid < nvox) {
+      const unsigned vox = v0 + tid;
+      const unsigned t = vox / Ru;
+      const int x = (int)(vox - t * Ru);
+      const unsigned zq = t / Ru;
+      const int y = (int)(t - zq * Ru), z = (int)zq;
+      float p[4] = {a.bout[0], a.bout[1], a.bout[2], a.bout[3]};
+      const T* row = reinterpret_cast<const T*>(tile + tid * rowb);
       for (int c = 0; c < Cd; c += 8) {
         float v[8];
+        Vec8<T>::load(row + c, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = dp[0] * a.Wout[c + j] + dp[1] * a.Wout[Cd + c + j] + dp[2] * a.Wout[2 * Cd + c + j] + dp[3] * a.Wout[3 * Cd + c + j];
-        Vec8<T>::store(dd0 + i * Cd + c, v);
+        for (int j = 0; j < 8; ++j) {
+          p[0] += v[j] * a.Wout[c + j]; p[1] += v[j] * a.Wout[Cd + c + j];
+          p[2] += v[j] * a.Wout[2 * Cd + c + j]; p[3] += v[j] * a.Wout[3 * Cd + c + j];
+        }
       }
-      float d8[8] = {dp[0], dp[1], dp[2], dp[3], 0.f, 0.f, 0.f, 0.f};
-      Vec8<T>::store(dpred8 + i * 8, d8);
+      const float* tg = a.target + b * 4 * V + vox;
+      const float t0 = tg[0], t1 = tg[V], t2 = tg[2 * V], t3 = tg[3 * V];
+      const bool occ = t3 > 0.01f;
+      const bool valid = z < a.extents[b * 3] && y < a.extents[b * 3 + 1] && x < a.extents[b * 3 + 2];
+      const bool rm = valid && a.tokmask[((z >> 2) * g + (y >> 2)) * g + (x >> 2)] != 0;
+      const float sg = 1.0f / (1.0f + __expf(-p[3]));
+      if (!BWD) {
+        if (occ) { acc[0] += (p[0] - t0) * (p[0] - t0) + (p[1] - t1) * (p[1] - t1) + (p[2] - t2) * (p[2] - t2); acc[1] += 1.f; }
+        if (rm) { acc[2] += (sg - t3) * (sg - t3); acc[3] += 1.f; }
+        if (a.pred) { float* pr = a.pred + b * 4 * V + vox; pr[0] = p[0]; pr[V] = p[1]; pr[2 * V] = p[2]; pr[3 * V] = p[3]; }
+      } else {
+        float dp[4];
+        dp[0] = occ ? 2.f * (p[0] - t0) * inv_occ : 0.f;
+        dp[1] = occ ? 2.f * (p[1] - t1) * inv_occ : 0.f;
+        dp[2] = occ ? 2.f * (p[2] - t2) * inv_occ : 0.f;
+        dp[3] = rm ? 2.f * (sg - t3) * sg * (1.f - sg) * inv_rm : 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { acc[o] += dp[o]; dps[tid * 4 + o] = dp[o]; }
+      }
+    }
+    if (BWD) {
+      __syncthreads();
+      if (vl < NV) {
+        for (int vv = vl; vv < nvox; vv += NV) {
+          const float4 dp = *reinterpret_cast<const float4*>(dps + vv * 4);
+          float o8[8], d8[8];
+          Vec8<T>::load(reinterpret_cast<const T*>(tile + vv * rowb) + cl * 8, o8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            d8[j] = dp.x * wreg[0][j] + dp.y * wreg[1][j] + dp.z * wreg[2][j] + dp.w * wreg[3][j];
+            wacc[0][j] += dp.x * o8[j]; wacc[1][j] += dp.y * o8[j]; wacc[2][j] += dp.z * o8[j]; wacc[3][j] += dp.w * o8[j];
+          }
+          Vec8<T>::store(dd0 + (b * V + v0 + vv) * Cd + cl * 8, d8);
+        }
+      }
     }
   }
-#pragma unroll
-  for (int o = 0; o < 4; ++o) block_sum_to(BWD ? accb[o] : acc[o], sh, o);
   __syncthreads();
-  if (threadIdx.x < 4) {
-    if (!BWD) atomicAdd(&a.sums[threadIdx.x], (double)sh[threadIdx.x]);
-    else atomicAdd(&dbout[threadIdx.x], sh[threadIdx.x]);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) block_sum_to(acc[o], sacc, 4 * Cd + o);
+  if (BWD && vl < NV) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&sacc[o * Cd + cl * 8 + j], wacc[o][j]);
   }
+  __syncthreads();
+  if (tid < 4) {
+    if (!BWD) atomicAdd(&a.sums[tid], (double)sacc[4 * Cd + tid]);
+    else atomicAdd(&dbout[tid], sacc[4 * Cd + tid]);
+  }
+  if (BWD)
+    for (int i = tid; i < 4 * Cd; i += 256) atomicAdd(&dWout[i], sacc[i]);
+}
+static inline size_t loss_lds(const LossArgs& a) {
+  size_t es = a.dt == NMH_DT_BF16 ? 2 : 4;
+  return 256 * a.Cd * es + 256 * 4 * sizeof(float) + (4 * a.Cd + 8) * sizeof(float);
 }
 int k_loss_fwd(const LossArgs& a, hipStream_t st) {
-  if (a.Cd % 8) return -2;
+  if (a.Cd % 8 || a.Cd > 64) return -2;
   hipError_t e = hipMemsetAsync(a.sums, 0, 4 * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
-  long total = (long)a.R * a.R * a.R;
-  dim3 grid(ew_blocks(total, 2048), a.B);
-  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 0>), grid, dim3(256), 0, st, a, nullptr, nullptr, nullptr);
-  else hipLaunchKernelGGL((loss_kernel<float, 0>), grid, dim3(256), 0, st, a, nullptr, nullptr, nullptr);
+  long ntile = ((long)a.R * a.R * a.R + 255) / 256;
+  dim3 grid((unsigned)(ntile < 2048 ? ntile : 2048), a.B);
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 0>), grid, dim3(256), loss_lds(a), st, a, nullptr, nullptr, nullptr);
+  else hipLaunchKernelGGL((loss_kernel<float, 0>), grid, dim3(256), loss_lds(a), st, a, nullptr, nullptr, nullptr);
   NMH_CHECK_LAUNCH();
   return 0;
 }
@@ -214,11 +262,12 @@ int k_loss_finalize(const double* sums, float* losses, hipStream_t st) {
   NMH_CHECK_LAUNCH();
   return 0;
 }
-int k_loss_bwd(const LossArgs& a, void* dd0, void* dpred8, float* dbout, hipStream_t st) {
-  long total = (long)a.R * a.R * a.R;
-  dim3 grid(ew_blocks(total, 2048), a.B);
-  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a, (bf16_t*)dd0, (bf16_t*)dpred8, dbout);
-  else hipLaunchKernelGGL((loss_kernel<float, 1>), grid, dim3(256), 0, st, a, (float*)dd0, (float*)dpred8, dbout);
+int k_loss_bwd(const LossArgs& a, void* dd0, float* dWout, float* dbout, hipStream_t st) {
+  if (a.Cd % 8 || a.Cd > 64) return -2;
+  long ntile = ((long)a.R * a.R * a.R + 255) / 256;
+  dim3 grid((unsigned)(ntile < 1024 ? ntile : 1024), a.B);
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((loss_kernel<bf16_t, 1>), grid, dim3(256), loss_lds(a), st, a, (bf16_t*)dd0, dWout, dbout);
+  else hipLaunchKernelGGL((loss_kernel<float, 1>), grid, dim3(256), loss_lds(a), st, a, (float*)dd0, dWout, dbout);
   NMH_CHECK_LAUNCH();
   return 0;
 }
@@ -269,7 +318,7 @@ int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* r
   if (N / 8 <= 256) {
     int NV = 256 / (N / 8);
     long nb = (M + (long)NV * 32 - 1) / ((long)NV * 32);  // >= 32 rows per thread before the block touches its N atomics
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     if (dt == NMH_DT_BF16) hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), N * sizeof(float), st, (const bf16_t*)dY, db, M, N, rs, rps);
     else hipLaunchKernelGGL(bias_grad_kernel<float>, dim3((unsigned)nb), dim3(256), N * sizeof(float), st, (const float*)dY, db, M, N, rs, rps);

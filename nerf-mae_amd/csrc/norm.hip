@@ -472,9 +472,11 @@ __global__ void in_finalize_kernel(const double* acc, float* stats, const T* x, 
   }
 }
 static inline long in_vox_per_block(long V) {
+  // <= 256 blocks per sample (their fp64 atomics hit the same 2*C addresses) but >= 512 voxels per block so small volumes still
+  // spread over the chip
   long vpb = (V + 255) / 256;
   vpb = (vpb + 63) / 64 * 64;
-  return vpb < IN_VOX_PER_BLOCK ? IN_VOX_PER_BLOCK : vpb;
+  return vpb < 512 ? 512 : vpb;
 }
 int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st) {
   if (C % 8 || C / 8 > 256) return -2;
