@@ -12,6 +12,7 @@
 // v_mfma_f32_16x16x4_f32) share all indexing, so the f32 build is the 1e-3-parity mode of the same code.
 #include "common.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // fast unsigned division by a runtime constant (n < 2^31), host-built
@@ -240,21 +241,31 @@ template <typename T, class AL>
 static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st) {
   if (N % 8 != 0 || K % 8 != 0) return -2;
   const int t16 = (N + 15) / 16;
-  // small problems (stage 2/3 tokens, 10^3..20^3 decoder volumes): 64-row tiles so that more than a few dozen CUs get work
-  if ((long)M * batch <= 4096 && t16 >= 4) {
-    if (t16 % 4 == 0) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  if (const char* ov = getenv("NMH_GEMM_CFG")) {  // tuning override "MT,NT"
+    int mt = ov[0] - '0', nt = atoi(ov + 2);
+    if (mt == 1 && nt == 4) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (mt == 1 && nt == 6) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (mt == 2 && nt == 6) return launch_nt<T, 2, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (mt == 2 && nt == 8) return launch_nt<T, 2, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (mt == 4 && nt == 6) return launch_nt<T, 4, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (mt == 4 && nt == 8) return launch_nt<T, 4, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  }
+  // 64-row tiles (32-45 KB of LDS -> 3-5 workgroups per CU) for (a) small problems (stage 2/3 tokens, 10^3..20^3 decoder volumes), so
+  // that more than a few dozen CUs get work, and (b) short contractions (every Linear of the encoder, the transpose convs): those
+  // are HBM-bound with a latency-bound prologue/epilogue per workgroup, and co-resident workgroups are what hides it
+  // (measured on 256000x288x96: 145 us with 256x128 tiles, 67 us with 64x96)
+  if (((long)M * batch <= 4096 || K <= 1024) && t16 >= 4) {
     if (t16 % 6 == 0) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (t16 % 4 == 0) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 3 == 0) return launch_nt<T, 1, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
   }
   if (t16 <= 3) return launch_nt<T, 4, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
   if (t16 == 4) return launch_nt<T, 4, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
-  if (t16 % 8 == 0 || t16 > 12) {
-    if (M >= 4096) return launch_nt<T, 4, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
-    return launch_nt<T, 2, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
-  }
-  if (M >= 4096) return launch_nt<T, 4, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
-  return launch_nt<T, 2, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  // long contractions on big M (implicit-GEMM convs at 20^3..40^3, transpose-conv dgrad): 128-row tiles (2 workgroups per CU)
+  // measured 10-30 % faster than 256-row tiles (1 per CU) on every decoder shape
+  if (t16 % 6 == 0) return launch_nt<T, 2, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+  return launch_nt<T, 2, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
 }
 
 int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st) {
