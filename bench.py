@@ -186,7 +186,21 @@ def main():
             ach = fl / (avg * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "%s, conv3d 3x3x3 %d->%d @%d^3, fwd+dgrad launches)" % (kname, E2, E2, R),
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                               "avg_launch_ms": round(avg, 4), "launches_timed": len(ms), "traffic": None}
+                               "avg_launch_ms": round(avg, 4), "launches_timed": len(ms), "traffic": None,
+                               "algorithmic_flop_per_launch": fl}
+            # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes (counters cannot be read in-process); the
+            # committed summary is used when it was taken at the same shape
+            try:
+                import glob
+                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*conv48_pmc.json")))[::-1]:
+                    pm = json.load(open(f))
+                    if pm.get("batch_per_gpu") == Bg and pm.get("resolution") == R and "c48" in kname.replace("conv48", "c48"):
+                        out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = os.path.basename(f) + " (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes)"
+                        out["roofline"]["algorithmic_bytes_per_launch"] = 2.0 * Bg * R ** 3 * E2 * 2
+                        break
+            except Exception:
+                pass
         tot = {}
         for k, evs in prof.items():
             tot[k[0] + ":" + "x".join(str(v) for v in k[1:])] = round(sum(a.elapsed_time(b) for a, b in evs) / ksteps, 3)
