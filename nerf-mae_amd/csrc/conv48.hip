@@ -35,6 +35,7 @@ struct C48Args {
   int B, D, H, W, tz, ty, tx;  // tiles per axis
   long total;                  // B*tz*ty*tx
   int accumulate;
+  double* stats_acc;           // optional [B][48][2] fp64 accumulators: per-channel sum / sum of squares of the (bf16-rounded) outputs
 };
 
 __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
@@ -134,6 +135,31 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   for (int q = 0; q < 2; ++q) { const int r = 4 * q + g; rowoff[q] = (r / 3) * PLANE + (r % 3) * LINE; }
   const int row8 = 2 * PLANE + 2 * LINE;
 
+  // fused InstanceNorm statistics: lane (li, g) owns channels 16n + 4g + r of voxel column li; partial sums live in registers
+  // across all tiles of one sample and are folded (16-lane shuffle reduce -> fp64 atomics) when the sample index changes
+  float st1[3][4], st2[3][4];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st1[n][r] = 0.f; st2[n][r] = 0.f; }
+  int st_b = -1;
+  auto stats_flush = [&]() {
+    if (st_b < 0) return;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a1 = st1[n][r], a2 = st2[n][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        if (li == 0) {
+          double* dst = a.stats_acc + ((long)st_b * 48 + 16 * n + 4 * g + r) * 2;
+          atomicAdd(dst, (double)a1);
+          atomicAdd(dst + 1, (double)a2);
+        }
+        st1[n][r] = 0.f; st2[n][r] = 0.f;
+      }
+  };
   for (; t < tend; t += jstride) {
     const long tn = t + jstride;
     const bool has_next = tn < tend;
@@ -199,6 +225,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       int b, z0, y0, x0;
       c48_tile_origin(a, t, b, z0, y0, x0);
       const int z = z0 + z_l, x = x0 + li;
+      if (a.stats_acc && b != st_b) { stats_flush(); st_b = b; }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = y0 + y_l + i;
@@ -212,10 +239,16 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
               v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xffff0000u);
               v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xffff0000u);
             }
+            const bf16_t h0 = f2bf(v0), h1 = f2bf(v1), h2 = f2bf(v2), h3 = f2bf(v3);
             uint2 w2;
-            w2.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-            w2.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+            w2.x = (unsigned)h0 | ((unsigned)h1 << 16);
+            w2.y = (unsigned)h2 | ((unsigned)h3 << 16);
             *reinterpret_cast<uint2*>(dst + 16 * n) = w2;
+            if (a.stats_acc) {  // statistics of exactly what the normalisation pass will read back
+              const float q0 = bf2f(h0), q1 = bf2f(h1), q2 = bf2f(h2), q3 = bf2f(h3);
+              st1[n][0] += q0; st1[n][1] += q1; st1[n][2] += q2; st1[n][3] += q3;
+              st2[n][0] += q0 * q0; st2[n][1] += q1 * q1; st2[n][2] += q2 * q2; st2[n][3] += q3 * q3;
+            }
           }
         }
       }
@@ -224,9 +257,10 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     if (has_next) halo_sstore();
     __syncthreads();
   }
+  if (a.stats_acc) stats_flush();
 }
 
-int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, hipStream_t st) {
+int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st) {
   using namespace c48;
   C48Args a;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
@@ -234,6 +268,11 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
   a.total = (long)B * a.tz * a.ty * a.tx;
   a.accumulate = accumulate;
+  a.stats_acc = stats_acc;
+  if (stats_acc) {
+    hipError_t e = hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * 48 * B, st);
+    if (e != hipSuccess) return (int)e;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

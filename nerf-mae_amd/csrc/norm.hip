@@ -466,7 +466,7 @@ __global__ void in_finalize_kernel(const double* acc, float* stats, const T* x, 
     const long b = i / C, c = i - b * C;
     double m = acc[2 * i] * invV, var = acc[2 * i + 1] * invV - m * m;
     if (var < 0) var = 0;
-    m += (double)to_f<T>(x[b * V * C + c]);
+    if (x) m += (double)to_f<T>(x[b * V * C + c]);  // shift used by the standalone reduction (none for epilogue-fused sums)
     stats[2 * i] = (float)m;
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
@@ -491,6 +491,13 @@ int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long
   long n = (long)B * C;
   if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_finalize_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, stats, (const bf16_t*)x, n, V, C, 1.0 / (double)V, eps);
   else hipLaunchKernelGGL(in_finalize_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scratch, stats, (const float*)x, n, V, C, 1.0 / (double)V, eps);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_in_finalize(int dt, const double* acc, float* stats, int B, long V, int C, float eps, hipStream_t st) {
+  (void)dt;
+  long n = (long)B * C;
+  hipLaunchKernelGGL(in_finalize_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, acc, stats, (const float*)nullptr, n, V, C, 1.0 / (double)V, eps);
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -285,14 +285,22 @@ class _UpBlockFn(torch.autograd.Function):
             conv = lambda X, nm, co, **kw: ops.conv3d_k3_c48(X, pk[key + nm.replace(".w", ".wk")], **kw)  # noqa: E731
         else:
             conv = lambda X, nm, co, **kw: ops.conv3d_k3(X, pk[key + nm], co, **kw)  # noqa: E731
-        y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout).view(B * V, Cout)
         st1 = torch.empty((B, Cout, 2), device=dev)
-        ops.instnorm_stats(y1, st1, scratch, B, V, Cout)
+        if c48:   # InstanceNorm statistics come out of the conv epilogue (no extra pass over the 160^3 tensor)
+            y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout, stats_acc=scratch).view(B * V, Cout)
+            ops.instnorm_finalize(scratch, st1, B, V, Cout)
+        else:
+            y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout).view(B * V, Cout)
+            ops.instnorm_stats(y1, st1, scratch, B, V, Cout)
         a1 = torch.empty_like(y1)
         ops.instnorm_apply(y1, st1, a1, B, V, Cout)
-        y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout).view(B * V, Cout)
         st2 = torch.empty((B, Cout, 2), device=dev)
-        ops.instnorm_stats(y2, st2, scratch, B, V, Cout)
+        if c48:
+            y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout, stats_acc=scratch).view(B * V, Cout)
+            ops.instnorm_finalize(scratch, st2, B, V, Cout)
+        else:
+            y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout).view(B * V, Cout)
+            ops.instnorm_stats(y2, st2, scratch, B, V, Cout)
         out = torch.empty_like(y2)
         y3 = st3 = None
         if m.has_proj:

@@ -133,16 +133,17 @@ def conv3d_k3(X, Wp, Cout, out=None, accumulate=False):
     return out
 
 
-def conv3d_k3_c48(X, Wk, out=None, accumulate=False):
-    """specialised Cin=Cout=48 bf16 conv (fragment-ordered weights Wk, pack modes 6/7)"""
-    _chk(X, Wk, out)
+def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None):
+    """specialised Cin=Cout=48 bf16 conv (fragment-ordered weights Wk, pack modes 6/7); stats_acc: optional fp64 [B,48,2] buffer that
+    receives the per-(sample,channel) sum / sum-of-squares of the outputs (fused InstanceNorm statistics)"""
+    _chk(X, Wk, out, stats_acc)
     B, D, H, W, Cin = X.shape
     if Cin != 48 or X.dtype != torch.bfloat16:
         raise RuntimeError("conv3d_k3_c48 needs bf16 activations with 48 channels")
     if out is None:
         out = torch.empty((B, D, H, W, 48), dtype=X.dtype, device=X.device)
     ev = _prof(("conv3d_k3_c48", B, D, 48, 48))
-    lib().call("nmh_conv3d_k3_c48", X, Wk, out, B, D, H, W, int(accumulate), _st())
+    lib().call("nmh_conv3d_k3_c48", X, Wk, out, B, D, H, W, int(accumulate), stats_acc, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return out
@@ -218,6 +219,12 @@ def window_attn_bwd(qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, geo
 def instnorm_stats(x, stats, scratch, B, V, C, eps=1e-5):
     _chk(x, stats, scratch)
     lib().call("nmh_instnorm_stats", dt_of(x), x, stats, scratch, B, V, C, eps, _st())
+    return stats
+
+
+def instnorm_finalize(acc, stats, B, V, C, eps=1e-5):
+    _chk(acc, stats)
+    lib().call("nmh_instnorm_finalize", acc, stats, B, V, C, eps, _st())
     return stats
 
 

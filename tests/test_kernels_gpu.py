@@ -470,8 +470,15 @@ def test_conv48_specialised_matches_reference_conv(B, D, H, W):
     n = 41 * 3 * 64 * 8
     wk_f, wk_d = _pack_via_kernel(w, 6, dt, n), _pack_via_kernel(w, 7, dt, n)
     xcl = dev(x.permute(0, 2, 3, 4, 1), dt)
-    yk = ops.conv3d_k3_c48(xcl, wk_f)
+    acc = torch.empty(B, 48, 2, dtype=torch.float64, device="cuda")
+    yk = ops.conv3d_k3_c48(xcl, wk_f, stats_acc=acc)
     check(yk.permute(0, 4, 1, 2, 3), y, dt, "conv48 fwd")
+    # fused InstanceNorm statistics == statistics of the stored (bf16) output
+    st = torch.empty(B, 48, 2, device="cuda")
+    ops.instnorm_finalize(acc, st, B, D * H * W, 48)
+    yf = yk.float().reshape(B, -1, 48)
+    check(st[..., 0], yf.mean(1), torch.float32, "fused IN mean", 5)
+    check(st[..., 1], (yf.var(1, unbiased=False) + 1e-5).rsqrt(), torch.float32, "fused IN rstd", 5)
     base = q(rnd(B, D, H, W, 48, seed=3), dt)
     out = dev(base, dt)
     dycl = dev(dy.permute(0, 2, 3, 4, 1), dt)
