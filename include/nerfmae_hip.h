@@ -77,9 +77,15 @@ NMH_API int nmh_upconv_shuffle_fwd(int dt, const void* upre, const float* bias, 
 NMH_API int nmh_upconv_shuffle_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip, void* stream);
 /* UnetOutBlock 1x1 conv (Cd->4) fused with forward_loss (swin_mae3d.py:1513-1549).  target fp32 (B,4,R,R,R); extents [B][3]
  * valid voxels per axis (replaces the pad_tensor ones-mask, torch_utils.py:56-90); tokmask [g^3] 1 = removed token.
- * sums fp64[4] = {sum_rgb, n_occ, sum_alpha, n_removed}; losses fp32[3] = {loss, loss_rgb, loss_alpha}; pred optional (B,4,R,R,R). */
-NMH_API int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, double* sums, float* losses, float* pred, void* stream);
+ * sums fp64[4] = {sum_rgb, n_occ, sum_alpha, n_removed}; losses fp32[3] = {loss, loss_rgb, loss_alpha}; pred optional (B,4,R,R,R).
+ * dpred optional fp32 [B*R^3][4]: un-normalised d(loss)/d(pred) per voxel for nmh_mae_tail_bwd; sums is then fp64[8] (+ sum_v dpred). */
+NMH_API int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, double* sums, float* losses, float* pred, float* dpred, void* stream);
 NMH_API int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, const double* sums, void* dd0, void* dpred8, float* dWout, float* dbout, void* stream);
+/* Backward of the decoder tail d0 = lrelu(IN(y) + r) -> 1x1 head -> loss in two elementwise passes that never materialise d(d0)
+ * (swin_mae3d.py:1496-1549 + unetr_block.py:62-71 backward): d(d0) = Wout^T dpred is recomputed per element from dpred/loss_sums
+ * (both from nmh_mae_loss_fwd).  in_sums[b][c] = {sum g, sum g*yhat}, dy = IN-backward, dr = g; dWout/dbout accumulate the head
+ * gradients.  stats = {mean, rstd} of y. */
+NMH_API int nmh_mae_tail_bwd(int dt, const void* d0, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums, void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, void* stream);
 NMH_API int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream);
 NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream);
 NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);

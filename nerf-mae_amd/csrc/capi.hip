@@ -121,9 +121,9 @@ int nmh_upconv_shuffle_bwd(int dt, const void* dcat, void* dupre, void* dskip, f
   return k_up_cat_bwd(dt, dcat, dupre, dskip, dbias, B, v, k, Cout, has_skip, ST);
 }
 int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R,
-                     int Cd, double* sums, float* losses, float* pred, void* stream) {
+                     int Cd, double* sums, float* losses, float* pred, float* dpred, void* stream) {
   CLR();
-  LossArgs a{dt, d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, pred};
+  LossArgs a{dt, d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, pred, dpred};
   int rc = k_loss_fwd(a, ST);
   if (rc) return rc;
   return k_loss_finalize(sums, losses, ST);
@@ -131,9 +131,14 @@ int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bou
 int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R,
                      int Cd, const double* sums, void* dd0, void* dpred8, float* dWout, float* dbout, void* stream) {
   CLR();
-  LossArgs a{dt, d0, Wout, bout, target, extents, tokmask, B, R, Cd, const_cast<double*>(sums), nullptr};
+  LossArgs a{dt, d0, Wout, bout, target, extents, tokmask, B, R, Cd, const_cast<double*>(sums), nullptr, nullptr};
   (void)dpred8;  // kept in the ABI for layout stability; the head weight gradient is now fused into the kernel
   return k_loss_bwd(a, dd0, dWout, dbout, ST);
+}
+int nmh_mae_tail_bwd(int dt, const void* d0, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums,
+                     void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, void* stream) {
+  CLR();
+  return k_tail_bwd(dt, d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, (long)V, C, ST);
 }
 int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream) {
   CLR();

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, float* dW
   const unsigned Vu = (unsigned)V, Ru = (unsigned)R;
   const T* d0 = (const T*)a.d0 + b * V * Cd;
   for (int i = tid; i < 4 * Cd + 8; i += 256) sacc[i] = 0.f;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, dpa[4] = {0.f, 0.f, 0.f, 0.f};
   float inv_occ = 0.f, inv_rm = 0.f;
   if (BWD) { inv_occ = (float)(1.0 / a.sums[1]); inv_rm = (float)(1.0 / a.sums[3]); }
   const int cl = tid % CL, vl = tid / CL;  // phase-3 role
@@ -194,6 +194,13 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, float* dW
         if (occ) { acc[0] += (p[0] - t0) * (p[0] - t0) + (p[1] - t1) * (p[1] - t1) + (p[2] - t2) * (p[2] - t2); acc[1] += 1.f; }
         if (rm) { acc[2] += (sg - t3) * (sg - t3); acc[3] += 1.f; }
         if (a.pred) { float* pr = a.pred + b * 4 * V + vox; pr[0] = p[0]; pr[V] = p[1]; pr[2 * V] = p[2]; pr[3 * V] = p[3]; }
+        if (a.dp) {  // un-normalised d(loss)/d(pred): the 1/n_occ, 1/n_removed factors are only known once this kernel has finished
+          float4 d;
+          d.x = occ ? 2.f * (p[0] - t0) : 0.f; d.y = occ ? 2.f * (p[1] - t1) : 0.f; d.z = occ ? 2.f * (p[2] - t2) : 0.f;
+          d.w = rm ? 2.f * (sg - t3) * sg * (1.f - sg) : 0.f;
+          *reinterpret_cast<float4*>(a.dp + (b * V + vox) * 4) = d;
+          dpa[0] += d.x; dpa[1] += d.y; dpa[2] += d.z; dpa[3] += d.w;
+        }
       } else {
         float dp[4];
         dp[0] = occ ? 2.f * (p[0] - t0) * inv_occ : 0.f;
@@ -224,6 +231,10 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, float* dW
   __syncthreads();
 #pragma unroll
   for (int o = 0; o < 4; ++o) block_sum_to(acc[o], sacc, 4 * Cd + o);
+  if (!BWD && a.dp) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) block_sum_to(dpa[o], sacc, 4 * Cd + 4 + o);
+  }
   if (BWD && vl < NV) {
 #pragma unroll
     for (int o = 0; o < 4; ++o)
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a, T* dd0, float* dW
   }
   __syncthreads();
   if (tid < 4) {
-    if (!BWD) atomicAdd(&a.sums[tid], (double)sacc[4 * Cd + tid]);
+    if (!BWD) { atomicAdd(&a.sums[tid], (double)sacc[4 * Cd + tid]); if (a.dp) atomicAdd(&a.sums[4 + tid], (double)sacc[4 * Cd + 4 + tid]); }
     else atomicAdd(&dbout[tid], sacc[4 * Cd + tid]);
   }
   if (BWD)
@@ -244,7 +255,7 @@ static inline size_t loss_lds(const LossArgs& a) {
 }
 int k_loss_fwd(const LossArgs& a, hipStream_t st) {
   if (a.Cd % 8 || a.Cd > 64) return -2;
-  hipError_t e = hipMemsetAsync(a.sums, 0, 4 * sizeof(double), st);
+  hipError_t e = hipMemsetAsync(a.sums, 0, (a.dp ? 8 : 4) * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   long ntile = ((long)a.R * a.R * a.R + 255) / 256;
   dim3 grid((unsigned)(ntile < 2048 ? ntile : 2048), a.B);

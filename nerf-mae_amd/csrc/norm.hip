@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dou
           Vec8<T>::load(x + o, xv[u]);
           if (BWD) {
             Vec8<T>::load(dout + o, dv[u]);
-            Vec8<T>::load(outp + o, ov[u]);
+            if (outp) Vec8<T>::load(outp + o, ov[u]);
             if (rmode == 2) Vec8<T>::load(r + o, rv[u]);
           }
         }
@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dou
           } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float g = dv[u][j] * (ov[u][j] > 0.f ? 1.0f : slope);
+              // without a residual sign(out) == sign(x - mean): `out` need not be read at all
+              const float g = dv[u][j] * ((outp ? ov[u][j] : xv[u][j] - mu[j]) > 0.f ? 1.0f : slope);
               s1[j] += g;
               s2[j] += g * (xv[u][j] - mu[j]) * rs_[j];
               if (rmode == 2) { t1[j] += g; t2[j] += g * (rv[u][j] - mur[j]) * rsr[j]; }
@@ -503,7 +504,7 @@ int k_in_finalize(int dt, const double* acc, float* stats, int B, long V, int C,
 }
 int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, const float* stats, const void* r, const float* stats_r, int rmode,
                     double* sums, double* sums_r, int B, long V, int C, float slope, hipStream_t st) {
-  if (C % 8 || C / 8 > 256) return -2;
+  if (C % 8 || C / 8 > 256 || (!out && rmode != 0)) return -2;
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
   if (rmode == 2) { e = hipMemsetAsync(sums_r, 0, sizeof(double) * 2 * B * C, st); if (e != hipSuccess) return (int)e; }
@@ -592,13 +593,13 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const 
     const long o = ((long)b * V + v) * C + cl * 8;
     float dv[8], ov[8], xv[8], rv[8], od[8], orr[8];
     Vec8<T>::load(dout + o, dv);
-    Vec8<T>::load(outp + o, ov);
+    if (outp) Vec8<T>::load(outp + o, ov);
     Vec8<T>::load(x + o, xv);
     if (rmode == 2) Vec8<T>::load(r + o, rv);
     if (rmode == 1 && dr_acc) Vec8<T>::load(dr + o, orr);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float g = dv[j] * (ov[j] > 0.f ? 1.0f : slope);
+      const float g = dv[j] * ((outp ? ov[j] : xv[j] - mu[j]) > 0.f ? 1.0f : slope);
       const float xh = (xv[j] - mu[j]) * rs[j];
       od[j] = rs[j] * (g - m1[j] - xh * m2[j]);
       if (rmode == 1) orr[j] = dr_acc ? orr[j] + g : g;
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const 
 }
 int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
                    const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st) {
-  if (C % 8 || C / 8 > 256) return -2;
+  if (C % 8 || C / 8 > 256 || (!out && rmode != 0)) return -2;
   dim3 grid((unsigned)((V + IN_APPLY_VOX_PER_BLOCK - 1) / IN_APPLY_VOX_PER_BLOCK), B);
   if (dt == NMH_DT_BF16)
     hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
@@ -621,6 +622,119 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
   else
     hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, stats, sums,
                        (const float*)r, stats_r, sums_r, rmode, (float*)dx, (float*)dr, dr_accumulate, V, C, slope);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- decoder tail backward: d0 = lrelu(IN(x) + r) -> 1x1 head -> loss ----------------------------------------------------------
+// d(d0)[v][c] = sum_o dp[v][o] Wout[o][c] is a 4-term dot per element, so it is recomputed from the per-voxel d(pred) (16 B per voxel,
+// written by the loss forward) instead of being written by one kernel and re-read by two.  Pass 0 (APPLY=0): IN-backward sums
+// {sum g, sum g*xhat} with g = d(d0) * lrelu'(d0), plus the head weight gradient dW[o][c] = sum_v dp[v][o] d0[v][c];
+// pass 1 (APPLY=1): dx = rstd (g - S1/V - xhat S2/V), dr = g.  Same thread mapping as the InstanceNorm kernels above.
+template <typename T, int APPLY>
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dp,
+                                                       const double* __restrict__ lsums, const float* __restrict__ Wout, double* in_sums, T* __restrict__ dx,
+                                                       T* __restrict__ dr, float slope, float* dWout, float* dbout, long V, int C, long vpb) {
+  extern __shared__ float sred[];  // [6][C]
+  const int CL = C >> 3, NV = 256 / CL;
+  const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
+  if (!APPLY) {
+    for (int i = threadIdx.x; i < 6 * C; i += 256) sred[i] = 0.f;
+    __syncthreads();
+  }
+  const float inv_occ = (float)(1.0 / lsums[1]), inv_rm = (float)(1.0 / lsums[3]);
+  float w[4][8], mu[8], rs[8], u1[8], u2[8], wacc[APPLY ? 1 : 4][8];
+  if (vl < NV) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long sc = ((long)b * C + cl * 8 + j) * 2;
+      mu[j] = stats[sc]; rs[j] = stats[sc + 1];
+      u1[j] = u2[j] = 0.f;
+      if (APPLY) { const float invV = 1.0f / (float)V; u1[j] = (float)in_sums[sc] * invV; u2[j] = (float)in_sums[sc + 1] * invV; }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) { w[o][j] = Wout[o * C + cl * 8 + j] * (o < 3 ? inv_occ : inv_rm); if (!APPLY) wacc[o][j] = 0.f; }
+    }
+    const long v0 = (long)blockIdx.x * vpb;
+    long v1 = v0 + vpb;
+    if (v1 > V) v1 = V;
+    constexpr int U = 2;
+    for (long vb = v0 + vl; vb < v1; vb += (long)NV * U) {
+      float ov[U][8], xv[U][8];
+      float4 dq[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long v = vb + (long)u * NV;
+        if (v < v1) {
+          const long o = ((long)b * V + v) * C + cl * 8;
+          Vec8<T>::load(d0 + o, ov[u]);
+          Vec8<T>::load(x + o, xv[u]);
+          dq[u] = *reinterpret_cast<const float4*>(dp + ((long)b * V + v) * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long v = vb + (long)u * NV;
+        if (v < v1) {
+          float gq[8], od[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = dq[u].x * w[0][j] + dq[u].y * w[1][j] + dq[u].z * w[2][j] + dq[u].w * w[3][j];
+            const float g = d * (ov[u][j] > 0.f ? 1.0f : slope);
+            const float xh = (xv[u][j] - mu[j]) * rs[j];
+            if (!APPLY) {
+              u1[j] += g; u2[j] += g * xh;
+              wacc[0][j] += dq[u].x * ov[u][j]; wacc[1][j] += dq[u].y * ov[u][j]; wacc[2][j] += dq[u].z * ov[u][j]; wacc[3][j] += dq[u].w * ov[u][j];
+            } else {
+              gq[j] = g;
+              od[j] = rs[j] * (g - u1[j] - xh * u2[j]);
+            }
+          }
+          if (APPLY) {
+            const long o = ((long)b * V + v) * C + cl * 8;
+            Vec8<T>::store(dx + o, od);
+            Vec8<T>::store(dr + o, gq);
+          }
+        }
+      }
+    }
+    if (!APPLY) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&sred[cl * 8 + j], u1[j]);
+        atomicAdd(&sred[C + cl * 8 + j], u2[j]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) atomicAdd(&sred[(2 + o) * C + cl * 8 + j], wacc[o][j]);
+      }
+    }
+  }
+  if (APPLY) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    atomicAdd(&in_sums[((long)b * C + i) * 2], (double)sred[i]);
+    atomicAdd(&in_sums[((long)b * C + i) * 2 + 1], (double)sred[C + i]);
+  }
+  for (int i = threadIdx.x; i < 4 * C; i += 256) atomicAdd(&dWout[i], sred[2 * C + i] * (i / C < 3 ? inv_occ : inv_rm));
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x < 4) atomicAdd(&dbout[threadIdx.x], (float)(lsums[4 + threadIdx.x] * (threadIdx.x < 3 ? 1.0 / lsums[1] : 1.0 / lsums[3])));
+}
+int k_tail_bwd(int dt, const void* d0, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
+               void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, hipStream_t st) {
+  if (C % 8 || C / 8 > 256) return -2;
+  hipError_t e = hipMemsetAsync(in_sums, 0, sizeof(double) * 2 * B * C, st);
+  if (e != hipSuccess) return (int)e;
+  const long vpb = in_vox_per_block(V);
+  dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + IN_APPLY_VOX_PER_BLOCK - 1) / IN_APPLY_VOX_PER_BLOCK), B);
+  const size_t lds = 6 * C * sizeof(float);
+  if (dt == NMH_DT_BF16) {
+    hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 0>), g0, dim3(256), lds, st, (const bf16_t*)d0, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)nullptr,
+                       (bf16_t*)nullptr, slope, dWout, dbout, V, C, vpb);
+    hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
+                       (bf16_t*)dr, slope, dWout, dbout, V, C, (long)IN_APPLY_VOX_PER_BLOCK);
+  } else {
+    hipLaunchKernelGGL((tail_bwd_kernel<float, 0>), g0, dim3(256), lds, st, (const float*)d0, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)nullptr,
+                       (float*)nullptr, slope, dWout, dbout, V, C, vpb);
+    hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), g1, dim3(256), 0, st, (const float*)d0, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)dx,
+                       (float*)dr, slope, dWout, dbout, V, C, (long)IN_APPLY_VOX_PER_BLOCK);
+  }
   NMH_CHECK_LAUNCH();
   return 0;
 }

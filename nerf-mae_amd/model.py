@@ -266,7 +266,10 @@ class _UpBlockFn(torch.autograd.Function):
     """ConvTranspose3d(k=s) -> cat(skip) -> UnetResBlock (unetr_block.py:57-71,193-200), channels-last."""
 
     @staticmethod
-    def forward(ctx, x, skip, mod, B, v):
+    def forward(ctx, x, skip, mod, B, v, tail=None):
+        """tail = (model, xb, extents, tokmask, pred_out): the block is the last decoder level and the 1x1 head + loss are
+        evaluated here, so that backward can fuse the loss gradient with the backward of the last InstanceNorm; returns the
+        loss triple instead of the feature map."""
         m: "UpBlock3D" = mod
         pk, key = m._pk, m._key
         k, Cin, Cout = m.k, m.cin, m.cout
@@ -312,6 +315,16 @@ class _UpBlockFn(torch.autograd.Function):
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=cat, rmode=1)
         ctx.m, ctx.dims, ctx.conv, ctx.c48 = m, (B, v, has_skip), conv, c48
         ctx.saved = (x, cat, y1, st1, a1, y2, st2, y3, st3, out)
+        ctx.tail = None
+        if tail is not None:
+            assert not m.has_proj
+            model, xb, extents, tokmask, pred_out = tail
+            lsums = torch.empty(8, dtype=torch.float64, device=dev)
+            losses = torch.empty(3, device=dev)
+            dpred = torch.empty((B * V, 4), device=dev) if ctx.needs_input_grad[0] else None
+            ops.mae_loss_fwd(out, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask, B, S, Cout, lsums, losses, pred_out, dpred)
+            ctx.tail = (model, lsums, dpred)
+            return losses
         return out
 
     @staticmethod
@@ -325,16 +338,21 @@ class _UpBlockFn(torch.autograd.Function):
         V = S ** 3
         Cc = cat.shape[1]
         dev, dtype = x.device, x.dtype
-        dout = dout.contiguous()
         sums2 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
         dy2 = torch.empty_like(y2)
         dcat = torch.empty_like(cat)
-        if m.has_proj:
+        if ctx.tail is not None:   # d(loss)/d(losses[0]) == 1 (the reference calls loss.backward()); d(d0) is never materialised
+            model, lsums, dpred = ctx.tail
+            ops.mae_tail_bwd(out, y2, st2, dpred, lsums, model.out.conv.weight, sums2, dy2, dcat,
+                             _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout)
+        elif m.has_proj:
+            dout = dout.contiguous()
             sums3 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
             dy3 = torch.empty_like(y3)
             ops.instnorm_bwd_reduce(dout, out, y2, st2, sums2, B, V, Cout, r=y3, stats_r=st3, sums_r=sums3, rmode=2)
             ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, r=y3, stats_r=st3, sums_r=sums3, rmode=2, dr=dy3)
         else:
+            dout = dout.contiguous()
             ops.instnorm_bwd_reduce(dout, out, y2, st2, sums2, B, V, Cout, rmode=1)
             ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, rmode=1, dr=dcat)  # dcat <- g (plain residual)
         conv = ctx.conv
@@ -346,9 +364,9 @@ class _UpBlockFn(torch.autograd.Function):
         with ops.side_stream(enable=not ctx.c48):
             wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
         sums1 = torch.empty_like(sums2)
-        ops.instnorm_bwd_reduce(da1, a1, y1, st1, sums1, B, V, Cout, rmode=0)
+        ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
-        ops.instnorm_bwd_apply(da1, a1, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
+        ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
         with ops.side_stream(enable=not ctx.c48):
             wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
@@ -363,7 +381,7 @@ class _UpBlockFn(torch.autograd.Function):
         with ops.side_stream():
             ops.gemm_tn(dupre, x, _gradbuf(m.transp_conv.weight), omode=2, p0=Cout, p1=k3)
         ops.join_side()
-        return dx, dskip, None, None, None
+        return dx, dskip, None, None, None, None
 
 
 class _LossFn(torch.autograd.Function):
@@ -495,12 +513,12 @@ class UpBlock3D(nn.Module):
         self.conv_block = ResBlock3D(2 * cout if use_skip else cout, cout)
         self.has_proj = use_skip
 
-    def forward(self, x, skip=None):
-        """channels-last (B,v,v,v,Cin) [+ skip (B,kv,kv,kv,Cout)] -> (B,kv,kv,kv,Cout)"""
+    def forward(self, x, skip=None, tail=None):
+        """channels-last (B,v,v,v,Cin) [+ skip (B,kv,kv,kv,Cout)] -> (B,kv,kv,kv,Cout), or the loss triple when `tail` is given"""
         B, v = x.shape[0], x.shape[1]
         S = v * self.k
-        out = _UpBlockFn.apply(x.reshape(-1, self.cin), skip.reshape(-1, self.cout) if self.use_skip else None, self, B, v)
-        return out.view(B, S, S, S, self.cout)
+        out = _UpBlockFn.apply(x.reshape(-1, self.cin), skip.reshape(-1, self.cout) if self.use_skip else None, self, B, v, tail)
+        return out if tail is not None else out.view(B, S, S, S, self.cout)
 
 
 class OutBlock3D(nn.Module):
@@ -680,14 +698,22 @@ class SwinTransformer_MAE3D_New(nn.Module):
             feats.append(x)
         return feats
 
-    def forward_decoder(self, feats: List[Tensor]) -> Tensor:
+    def forward_decoder(self, feats: List[Tensor], tail=None) -> Tensor:
         f3 = feats[3]
         if self._reducer is not None:
             f3 = self._reducer.trigger(f3, len(self.stages) + 1)  # decoder4 is the last decoder op in backward order
         d = self.decoder4(f3, feats[2])
         d = self.decoder3(d, feats[1])
         d = self.decoder2(d, feats[0])
-        return self.decoder1(d)
+        return self.decoder1(d, tail=tail)
+
+    fuse_tail = True   # loss backward fused with the last decoder level's InstanceNorm backward (False: separate kernels)
+
+    def _decode_and_loss(self, feats, xb, ext, mask_dev, pred):
+        if self.fuse_tail:
+            return self.forward_decoder(feats, tail=(self, xb, ext, mask_dev, pred))
+        d0 = self.forward_decoder(feats)
+        return _LossFn.apply(d0.reshape(-1, d0.shape[-1]), self, xb, ext, mask_dev, pred)
 
     def forward(self, x: List[Tensor], is_eval: bool = False, block_mask: Optional[Tensor] = None, sd_noise=None, return_pred: bool = False):
         device = self.mask_token.device
@@ -700,10 +726,9 @@ class SwinTransformer_MAE3D_New(nn.Module):
         mask_dev = block_mask.to(torch.uint8).contiguous().view(-1).to(device, non_blocking=True)
         tok = _EmbedFn.apply(self._anchor, self, xb, mask_dev).view(B, g, g, g, self.embed_dim)
         feats = self.forward_encoder(tok, sd_noise)
-        d0 = self.forward_decoder(feats)
         want_pred = is_eval or return_pred
         pred = torch.empty((B, 4, R, R, R), device=device) if want_pred else None
-        losses = _LossFn.apply(d0.reshape(-1, d0.shape[-1]), self, xb, ext, mask_dev, pred)
+        losses = self._decode_and_loss(feats, xb, ext, mask_dev, pred)
         loss, loss_rgb, loss_alpha = losses[0], losses[1], losses[2]
         if return_pred:
             return loss, loss_rgb, loss_alpha, pred
@@ -720,8 +745,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
         g = R // 4
         self._packer.run()
         tok = _EmbedFn.apply(self._anchor, self, xb, mask_dev).view(B, g, g, g, self.embed_dim)
-        d0 = self.forward_decoder(self.forward_encoder(tok))
-        losses = _LossFn.apply(d0.reshape(-1, d0.shape[-1]), self, xb, ext, mask_dev, None)
+        losses = self._decode_and_loss(self.forward_encoder(tok), xb, ext, mask_dev, None)
         return losses[0], losses[1], losses[2]
 
     def encoder_features(self, xb: Tensor) -> List[Tensor]:

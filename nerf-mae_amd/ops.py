@@ -263,15 +263,23 @@ def upconv_shuffle_bwd(dcat, dupre, dskip, dbias, B, v, k, Cout, has_skip):
     lib().call("nmh_upconv_shuffle_bwd", dt_of(dcat), dcat, dupre, dskip, dbias, B, v, k, Cout, int(has_skip), _st())
 
 
-def mae_loss_fwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, losses, pred=None):
-    _chk(d0, Wout, bout, target, extents, tokmask, sums, losses, pred)
-    lib().call("nmh_mae_loss_fwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, losses, pred, _st())
+def mae_loss_fwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, losses, pred=None, dpred=None):
+    """sums: fp64[4] (fp64[8] when dpred [B*R^3, 4] fp32 is requested for mae_tail_bwd)"""
+    _chk(d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred)
+    if dpred is not None and sums.numel() < 8:
+        raise ValueError("mae_loss_fwd: sums needs 8 entries when dpred is requested")
+    lib().call("nmh_mae_loss_fwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, losses, pred, dpred, _st())
     return losses
 
 
 def mae_loss_bwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, dpred8, dWout, dbout):
     _chk(d0, Wout, bout, target, extents, tokmask, sums, dd0, dpred8, dWout, dbout)
     lib().call("nmh_mae_loss_bwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, dpred8, dWout, dbout, _st())
+
+
+def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01):
+    _chk(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout)
+    lib().call("nmh_mae_tail_bwd", dt_of(d0), d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, _st())
 
 
 def bias_grad(dY, db, M, N, rowscale=None, rows_per_scale=1):

@@ -384,6 +384,79 @@ def test_loss_head(dt):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_tail_backward_fused(dt):
+    """d0 = lrelu(IN(y) + r) -> 1x1 head -> loss: the two-pass fused backward (d(d0) never stored) against autograd."""
+    from oracle import mae3d_oracle as O
+    ops = _ops()
+    B, R, Cd = 2, 32, 48
+    V = R ** 3
+    x = torch.stack([O.synthetic_grid((R, R, R), 3), O.synthetic_grid((R, R, R), 4)])
+    valid = torch.ones_like(x)
+    valid[1, :, 28:] = 0
+    x = x * valid
+    ext = torch.tensor([[R, R, R], [28, R, R]], dtype=torch.int32)
+    y, r = q(rnd(B, V, Cd) * 1.3 + 0.2, dt), q(rnd(B, V, Cd, seed=7), dt)
+    Wo, bo = rnd(4, Cd, seed=1, scale=0.2), rnd(4, seed=2, scale=0.1)
+    tm = O.draw_block_mask((R // 4,) * 3, 0.6, rng=__import__("random").Random(5))
+    yr, rr, Wr, br_ = (t.clone().requires_grad_(True) for t in (y, r, Wo, bo))
+    inorm = lambda t: F.instance_norm(t.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+    d0_ref = F.leaky_relu(inorm(yr) + rr, 0.01)
+    d0q = q(d0_ref.detach(), dt)                       # the kernels see the stored (rounded) forward output
+    d0s = d0_ref + (d0q - d0_ref).detach()
+    pred = (d0s.reshape(B, R, R, R, Cd) @ Wr.T + br_).permute(0, 4, 1, 2, 3)
+    l, *_ = O.mae_loss(x, pred, valid, tm[None, ..., None].expand(B, -1, -1, -1, 1))
+    l.backward()
+    yd = dev(y, dt)
+    stats, scratch = torch.empty(B, Cd, 2, device="cuda"), torch.empty(B, Cd, 2, dtype=torch.float64, device="cuda")
+    ops.instnorm_stats(yd, stats, scratch, B, V, Cd)
+    lsums, losses = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda")
+    args = (dev(d0q.reshape(-1, Cd), dt), dev(Wo), dev(bo), dev(x), dev(ext), dev(tm.to(torch.uint8)), B, R, Cd, lsums)
+    dpred = torch.empty(B * V, 4, device="cuda")
+    ops.mae_loss_fwd(*args, losses, None, dpred)
+    np.testing.assert_allclose(losses[0].item(), l.item(), rtol=TOL[dt])
+    dy, dr = torch.empty(B * V, Cd, dtype=dt, device="cuda"), torch.empty(B * V, Cd, dtype=dt, device="cuda")
+    dW, db = torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda")
+    in_sums = torch.empty(B, Cd, 2, dtype=torch.float64, device="cuda")
+    ops.mae_tail_bwd(args[0], yd.view(-1, Cd), stats, dpred, lsums, args[1], in_sums, dy, dr, dW, db, B, V, Cd)
+    check(dr, rr.grad.reshape(-1, Cd), dt, "tail dr", 3)
+    check(dy, yr.grad.reshape(-1, Cd), dt, "tail dy", 3)
+    check(dW, Wr.grad, dt, "tail dWout", 2)
+    check(db, br_.grad, dt, "tail dbout", 2)
+    # and the unfused kernels give the same thing
+    dd0 = torch.empty(B * V, Cd, dtype=dt, device="cuda")
+    dW2, db2 = torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda")
+    ops.mae_loss_bwd(*args, dd0, torch.empty(B * V, 8, dtype=dt, device="cuda"), dW2, db2)
+    sums2 = torch.empty_like(in_sums)
+    rd = dev(r, dt)
+    ops.instnorm_bwd_reduce(dd0, args[0], yd, stats, sums2, B, V, Cd, r=rd, rmode=1)
+    dy2, dr2 = torch.empty_like(dy), torch.empty_like(dr)
+    ops.instnorm_bwd_apply(dd0, args[0], yd, stats, sums2, dy2, B, V, Cd, r=rd, rmode=1, dr=dr2)
+    check(dy, dy2.float().cpu(), dt, "fused vs unfused dy", 3)
+    check(dW, dW2.cpu(), dt, "fused vs unfused dW", 2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_instnorm_bwd_without_out(dt):
+    """rmode 0: sign(out) == sign(x - mean), so `out` may be omitted."""
+    ops = _ops()
+    B, V, C = 2, 1500, 48
+    x, dout = q(rnd(B, V, C) * 1.5 + 0.3, dt), q(rnd(B, V, C, seed=2), dt)
+    xd, dd = dev(x, dt), dev(dout, dt)
+    stats, scratch = torch.empty(B, C, 2, device="cuda"), torch.empty(B, C, 2, dtype=torch.float64, device="cuda")
+    ops.instnorm_stats(xd, stats, scratch, B, V, C)
+    out = torch.empty(B, V, C, dtype=dt, device="cuda")
+    ops.instnorm_apply(xd, stats, out, B, V, C)
+    res = []
+    for o in (out, None):
+        sums = torch.empty(B, C, 2, dtype=torch.float64, device="cuda")
+        ops.instnorm_bwd_reduce(dd, o, xd, stats, sums, B, V, C)
+        dx = torch.empty(B, V, C, dtype=dt, device="cuda")
+        ops.instnorm_bwd_apply(dd, o, xd, stats, sums, dx, B, V, C)
+        res.append(dx.float().cpu())
+    check(res[1], res[0], dt, "dx without out", 1)
+
+
+@pytest.mark.parametrize("dt", DTS)
 def test_patch_embed_gather_and_bias_grad(dt):
     ops = _ops()
     B, R, C = 2, 16, 96

@@ -109,6 +109,24 @@ def test_fp32_forward_backward_matches_oracle(cfg, name, res):
         assert cos > 0.9999, (n, cos)
 
 
+def test_fused_and_unfused_decoder_tail_agree():
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(TINY, torch.float32, res=32, init="default")
+    xs = [O.synthetic_grid((32, 32, 32), 11).cuda(), O.synthetic_grid((30, 28, 32), 12).cuda()]
+    bm = O.draw_block_mask((8, 8, 8), ora.masking_prob, rng=random.Random(3))
+    grads = []
+    for fuse in (True, False):
+        hip.fuse_tail = fuse
+        hip.zero_grad()
+        out = hip(xs, block_mask=bm)
+        out[0].backward()
+        grads.append((out[0].item(), hip._flat_grad.clone()))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-6 * abs(grads[1][0])   # (fp64 atomics: not bit-reproducible run to run)
+    assert relerr(grads[0][1], grads[1][1]) < 5e-3   # same conditioning caveat as above: 1e-7 differences are amplified
+    a, b = grads[0][1].double(), grads[1][1].double()
+    assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.99999
+
+
 def test_bf16_close_to_oracle_and_eval_contract():
     from oracle import mae3d_oracle as O
     res = 96

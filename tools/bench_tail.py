@@ -1,0 +1,48 @@
+"""Micro-benchmark of the decoder-tail backward kernels at the bench shape (B grids of 160^3 x 48)."""
+import sys
+import time
+import torch
+sys.path.insert(0, ".")
+from nerf_mae_amd import ops
+
+B, R, Cd = int(sys.argv[1]) if len(sys.argv) > 1 else 4, 160, 48
+V = R ** 3
+dev = "cuda"
+dt = torch.bfloat16
+d0 = torch.randn(B * V, Cd, device=dev, dtype=dt)
+y = torch.randn(B * V, Cd, device=dev, dtype=dt)
+x = torch.rand(B, 4, R, R, R, device=dev)
+ext = torch.tensor([[R, R, R]] * B, dtype=torch.int32, device=dev)
+tm = (torch.rand(40 ** 3, device=dev) < 0.75).to(torch.uint8)
+Wo, bo = torch.randn(4, Cd, device=dev) * 0.1, torch.zeros(4, device=dev)
+stats = torch.empty(B, Cd, 2, device=dev)
+scr = torch.empty(B, Cd, 2, dtype=torch.float64, device=dev)
+ops.instnorm_stats(y, stats, scr, B, V, Cd)
+lsums, losses = torch.empty(8, dtype=torch.float64, device=dev), torch.empty(3, device=dev)
+dpred = torch.empty(B * V, 4, device=dev)
+ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)
+dy, dr, dd0 = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+dW, db = torch.zeros(4, Cd, device=dev), torch.zeros(4, device=dev)
+sums = torch.empty(B, Cd, 2, dtype=torch.float64, device=dev)
+
+
+def timeit(f, n=10):
+    f(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n * 1e3
+
+
+def fused():
+    ops.mae_tail_bwd(d0, y, stats, dpred, lsums, Wo, sums, dy, dr, dW, db, B, V, Cd)
+
+
+def unfused():
+    ops.mae_loss_bwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, dd0, torch.empty(1, 8, device=dev, dtype=dt), dW, db)
+    ops.instnorm_bwd_reduce(dd0, d0, y, stats, sums, B, V, Cd, r=d0, rmode=1)
+    ops.instnorm_bwd_apply(dd0, d0, y, stats, sums, dy, B, V, Cd, r=d0, rmode=1, dr=dr)
+
+
+print(f"fused tail bwd  {timeit(fused):.3f} ms   unfused {timeit(unfused):.3f} ms   loss fwd {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None)):.3f} / with dpred {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)):.3f} ms")
