@@ -473,11 +473,11 @@ __global__ void in_finalize_kernel(const double* acc, float* stats, const T* x, 
   }
 }
 static inline long in_vox_per_block(long V) {
-  // <= 256 blocks per sample (their fp64 atomics hit the same 2*C addresses) but >= 512 voxels per block so small volumes still
+  // <= 256 blocks per sample (their fp64 atomics hit the same 2*C addresses) but >= 128 voxels per block so small volumes still
   // spread over the chip
   long vpb = (V + 255) / 256;
   vpb = (vpb + 63) / 64 * 64;
-  return vpb < 512 ? 512 : vpb;
+  return vpb < 128 ? 128 : vpb;
 }
 int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st) {
   if (C % 8 || C / 8 > 256) return -2;
@@ -518,8 +518,15 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
 }
 
 #define IN_APPLY_VOX_PER_BLOCK 2048
+// voxels per block of the apply passes: 2048 on the big volumes, fewer on the coarse decoder levels so that >= ~1024 blocks exist
+static inline long in_apply_vpb(long V, int B, int C) {
+  const int NV = 256 / (C >> 3);
+  long vpb = (V * B + 1023) / 1024;
+  if (vpb < 4L * NV) vpb = 4L * NV;
+  return vpb > IN_APPLY_VOX_PER_BLOCK ? IN_APPLY_VOX_PER_BLOCK : vpb;
+}
 template <typename T>
-__global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* stats, const T* r, const float* stats_r, int rmode, T* out, long V, int C, float slope) {
+__global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* stats, const T* r, const float* stats_r, int rmode, T* out, long V, int C, float slope, long vpb) {
   // grid (voxel blocks, B); thread = (8-channel chunk cl, voxel lane vl): no integer division in the loop, statistics in registers
   const int CL = C >> 3, NV = 256 / CL;
   const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
@@ -531,8 +538,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* 
     mu[j] = stats[sc]; rs[j] = stats[sc + 1];
     if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; }
   }
-  const long v0 = (long)blockIdx.x * IN_APPLY_VOX_PER_BLOCK;
-  long v1 = v0 + IN_APPLY_VOX_PER_BLOCK;
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
   if (v1 > V) v1 = V;
   constexpr int U = 2;
   for (long vb = v0 + vl; vb < v1; vb += (long)NV * U) {
@@ -564,16 +571,17 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* 
 }
 int k_in_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, long V, int C, float slope, hipStream_t st) {
   if (C % 8 || C / 8 > 256) return -2;
-  dim3 grid((unsigned)((V + IN_APPLY_VOX_PER_BLOCK - 1) / IN_APPLY_VOX_PER_BLOCK), B);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope);
-  else hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, (const float*)r, stats_r, rmode, (float*)out, V, C, slope);
+  const long vpb = in_apply_vpb(V, B, C);
+  dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope, vpb);
+  else hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, (const float*)r, stats_r, rmode, (float*)out, V, C, slope, vpb);
   NMH_CHECK_LAUNCH();
   return 0;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const T* outp, const T* x, const float* stats, const double* sums, const T* r, const float* stats_r,
-                                                            const double* sums_r, int rmode, T* dx, T* dr, int dr_acc, long V, int C, float slope) {
+                                                            const double* sums_r, int rmode, T* dx, T* dr, int dr_acc, long V, int C, float slope, long vpb) {
   const int CL = C >> 3, NV = 256 / CL;
   const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
   if (vl >= NV) return;
@@ -586,8 +594,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const 
     m1[j] = (float)sums[sc] * invV; m2[j] = (float)sums[sc + 1] * invV;
     if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; n1[j] = (float)sums_r[sc] * invV; n2[j] = (float)sums_r[sc + 1] * invV; }
   }
-  const long v0 = (long)blockIdx.x * IN_APPLY_VOX_PER_BLOCK;
-  long v1 = v0 + IN_APPLY_VOX_PER_BLOCK;
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
   if (v1 > V) v1 = V;
   for (long v = v0 + vl; v < v1; v += NV) {
     const long o = ((long)b * V + v) * C + cl * 8;
@@ -615,13 +623,14 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const 
 int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
                    const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st) {
   if (C % 8 || C / 8 > 256 || (!out && rmode != 0)) return -2;
-  dim3 grid((unsigned)((V + IN_APPLY_VOX_PER_BLOCK - 1) / IN_APPLY_VOX_PER_BLOCK), B);
+  const long vpb = in_apply_vpb(V, B, C);
+  dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
   if (dt == NMH_DT_BF16)
     hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
-                       (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope);
+                       (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope, vpb);
   else
     hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, stats, sums,
-                       (const float*)r, stats_r, sums_r, rmode, (float*)dx, (float*)dr, dr_accumulate, V, C, slope);
+                       (const float*)r, stats_r, sums_r, rmode, (float*)dx, (float*)dr, dr_accumulate, V, C, slope, vpb);
   NMH_CHECK_LAUNCH();
   return 0;
 }
@@ -722,18 +731,19 @@ int k_tail_bwd(int dt, const void* d0, const void* xin, const float* in_stats, c
   hipError_t e = hipMemsetAsync(in_sums, 0, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
   const long vpb = in_vox_per_block(V);
-  dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + IN_APPLY_VOX_PER_BLOCK - 1) / IN_APPLY_VOX_PER_BLOCK), B);
+  const long vpa = in_apply_vpb(V, B, C);
+  dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + vpa - 1) / vpa), B);
   const size_t lds = 6 * C * sizeof(float);
   if (dt == NMH_DT_BF16) {
     hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 0>), g0, dim3(256), lds, st, (const bf16_t*)d0, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)nullptr,
                        (bf16_t*)nullptr, slope, dWout, dbout, V, C, vpb);
     hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
-                       (bf16_t*)dr, slope, dWout, dbout, V, C, (long)IN_APPLY_VOX_PER_BLOCK);
+                       (bf16_t*)dr, slope, dWout, dbout, V, C, vpa);
   } else {
     hipLaunchKernelGGL((tail_bwd_kernel<float, 0>), g0, dim3(256), lds, st, (const float*)d0, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)nullptr,
                        (float*)nullptr, slope, dWout, dbout, V, C, vpb);
     hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), g1, dim3(256), 0, st, (const float*)d0, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)dx,
-                       (float*)dr, slope, dWout, dbout, V, C, (long)IN_APPLY_VOX_PER_BLOCK);
+                       (float*)dr, slope, dWout, dbout, V, C, vpa);
   }
   NMH_CHECK_LAUNCH();
   return 0;
