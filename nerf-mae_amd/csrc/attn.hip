@@ -153,27 +153,71 @@ int k_attn_fwd(int dt, const void* qkv, const float* table, void* out, float* ls
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of the window attention core, one wave per (window, head), NW waves per block sharing the head's bias table.
+//   phase A (S^T layout, lane <-> query): P, dP -> D_i = sum_j P dP, dS, d(bias), dQ = dS K
+//   phase B (S layout,   lane <-> key)  : P, dS recomputed -> dV = P^T dO, dK = dS^T Q
+// Register/LDS budget is what bounds this kernel (everything is latency-chained inside a wave, so occupancy is the lever):
+//   * only one query tile (phase A) / key tile (phase B) of P and dP is live at a time (32 accumulators, was 256);
+//   * the K and Q tiles share one LDS buffer (K is only needed transposed in phase A, Q only in phase B) and both LDS tiles
+//     are written from the fragment registers (no second global read); dO row fragments are re-read from its LDS tile;
+//   * d(bias): within a lane the bin depends only on (it - jt, r), so 28 register accumulators replace the 64x64 LDS tile;
+//   * products are formed transposed (mma(acc, B, A)) so that every lane owns 4 consecutive head-dim elements -> 8-byte stores.
+template <typename T> __device__ __forceinline__ void frag_to_lds(char* tile, int RS, int row, int g, const Frag<T>& f);
+template <> __device__ __forceinline__ void frag_to_lds<bf16_t>(char* tile, int RS, int row, int g, const Frag<bf16_t>& f) {
+  *reinterpret_cast<bf16x8*>(tile + row * RS + 16 * g) = f.v;
+}
+template <> __device__ __forceinline__ void frag_to_lds<float>(char* tile, int RS, int row, int g, const Frag<float>& f) {
+  float4* d = reinterpret_cast<float4*>(tile + row * RS + 32 * g);
+  d[0] = float4{f.v[0], f.v[1], f.v[2], f.v[3]};
+  d[1] = float4{f.v[4], f.v[5], f.v[6], f.v[7]};
+}
+template <typename T> __device__ __forceinline__ Frag<T> lds_row_frag(const char* tile, int RS, int row, int g);
+template <> __device__ __forceinline__ Frag<bf16_t> lds_row_frag<bf16_t>(const char* tile, int RS, int row, int g) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(tile + row * RS + 16 * g);
+  return f;
+}
+template <> __device__ __forceinline__ Frag<float> lds_row_frag<float>(const char* tile, int RS, int row, int g) {
+  const float4* d = reinterpret_cast<const float4*>(tile + row * RS + 32 * g);
+  const float4 a = d[0], b = d[1];
+  Frag<float> f;
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w; f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4& v, float s) {
+  uint2 u;
+  u.x = (unsigned)f2bf(v[0] * s) | ((unsigned)f2bf(v[1] * s) << 16);
+  u.y = (unsigned)f2bf(v[2] * s) | ((unsigned)f2bf(v[3] * s) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void store4(float* p, const f32x4& v, float s) { *reinterpret_cast<float4*>(p) = float4{v[0] * s, v[1] * s, v[2] * s, v[3] * s}; }
+
 template <typename T, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table, const T* __restrict__ dout, const float* __restrict__ lse,
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table, const T* __restrict__ dout, const float* __restrict__ lse,
                                                         T* __restrict__ dqkv, float* __restrict__ dtable, int heads, int C, WinMap wm, long nwin) {
   constexpr int RS = OddRS32<32 * (int)sizeof(T)>::v;
-  __shared__ __attribute__((aligned(16))) char sQ[NW][64 * RS];
-  __shared__ __attribute__((aligned(16))) char sK[NW][64 * RS];
-  __shared__ __attribute__((aligned(16))) char sO[NW][64 * RS];
-  __shared__ float sB[NW][344], sDB[NW][344], sD[NW][64], sL[NW][64];
-  // d(bias) of one (query,key) pair always comes from the same lane/register, so it is accumulated over all windows of this
-  // wave in a private 64x64 LDS tile (conflict-free adds) and folded into the 343 bins once at the end (was: 4096 colliding
-  // LDS atomics per window)
-  __shared__ float sDS[NW][64 * 64];
-  __shared__ int sR[NW][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+  __shared__ __attribute__((aligned(16))) char sA[NW][64 * RS];   // K tile (phase A), then Q tile (phase B)
+  __shared__ __attribute__((aligned(16))) char sO[NW][64 * RS];   // dO tile
+  __shared__ float sB[344], sDB[344];
+  __shared__ __attribute__((aligned(16))) float sD[NW][64];
+  __shared__ __attribute__((aligned(16))) float sL[NW][64];
+  __shared__ unsigned sR[NW][16];                                  // region id of the 64 tokens, one byte each
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.y;
   const int nW = (wm.PH >> 2) * (wm.PW >> 2) * (wm.PD >> 2);
   const bool shifted = (wm.s0 + wm.s1 + wm.s2) > 0;
   const long ld = 3L * C;
   const float scale = 0.17677669529663689f;
-  for (int t = lane; t < 344; t += 64) { sB[wave][t] = t < 343 ? table[t * heads + h] : 0.f; sDB[wave][t] = 0.f; }
-  for (int t = lane; t < 64 * 64; t += 64) sDS[wave][t] = 0.f;
+  for (int t = threadIdx.x; t < 344; t += 64 * NW) { sB[t] = t < 343 ? table[t * heads + h] : 0.f; sDB[t] = 0.f; }
+  __syncthreads();
+  float dsacc[7][4];
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dsacc[q][r] = 0.f;
+  char* tA = sA[wave];
+  char* tO = sO[wave];
+  const unsigned char* sRb = reinterpret_cast<const unsigned char*>(sR[wave]);
 
   for (long win = (long)blockIdx.x * NW + wave; win < nwin; win += (long)gridDim.x * NW) {
     const T* qb = qkv + win * 64 * ld + h * 32;
@@ -181,147 +225,162 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const T* __restrict__
     const T* vb = qb + 2 * C;
     const T* dob = dout + win * 64 * C + h * 32;
     T* dqb = dqkv + win * 64 * ld + h * 32;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    stage_tile<T, RS>(sQ[wave], qb, ld, lane);
-    stage_tile<T, RS>(sK[wave], kb, ld, lane);
-    stage_tile<T, RS>(sO[wave], dob, (long)C, lane);
-    sR[wave][lane] = shifted ? token_region(wm, (int)(win % nW), lane) : 0;
-    sL[wave][lane] = lse[(win * heads + h) * 64 + lane];
-    Frag<T> kf[4], qf[4], vf[4], df[4];
+    // opaque lane id: everything derived from it (24 store offsets, 16 load offsets, LDS addresses, the 56 bias values a lane
+    // uses) is loop-invariant and would otherwise be hoisted into ~200 registers that stay live across the whole loop
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int g = lane >> 4, li = lane & 15;
+    // relative-position bin of (query i, key j), i = 16 i0 + 4 i1 + i2: (i0-j0+3)*49 + (i1-j1+3)*7 + (i2-j2+3)
+    const int c1 = (li >> 2) - g, c2 = li & 3;
+    const int binA = (c1 + 3) * 7 + c2 + 3;  // phase A (i = 16it+li, j = 16jt+4g+r): binA + (it-jt+3)*49 - r
+    const int binB = (3 - c1) * 7 + 3 - c2;  // phase B (i = 16it+4g+r, j = 16jt+li): binB + (it-jt+3)*49 + r
+    Frag<T> kf[4], qf[4], vf[4];
+    {
+      Frag<T> df[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      kf[t] = gfrag<T>(kb, ld, t * 16 + li, g); qf[t] = gfrag<T>(qb, ld, t * 16 + li, g);
-      vf[t] = gfrag<T>(vb, ld, t * 16 + li, g); df[t] = gfrag<T>(dob, (long)C, t * 16 + li, g);
+      for (int t = 0; t < 4; ++t) {
+        kf[t] = gfrag<T>(kb, ld, t * 16 + li, g); qf[t] = gfrag<T>(qb, ld, t * 16 + li, g);
+        vf[t] = gfrag<T>(vb, ld, t * 16 + li, g); df[t] = gfrag<T>(dob, (long)C, t * 16 + li, g);
+      }
+      sL[wave][lane] = lse[(win * heads + h) * 64 + lane];
+      if (shifted) reinterpret_cast<unsigned char*>(sR[wave])[lane] = (unsigned char)token_region(wm, (int)(win % nW), lane);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { frag_to_lds<T>(tA, RS, t * 16 + li, g, kf[t]); frag_to_lds<T>(tO, RS, t * 16 + li, g, df[t]); }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---------------- phase A: S^T layout (lane <-> query) : D_i, d(bias), dQ ----------------
-    {
-      f32x4 p[4][4], dp[4][4];
+    // ---------------- phase A ----------------
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      f32x4 p[4], dp[4];
+      {
+        const Frag<T> dfi = lds_row_frag<T>(tO, RS, it * 16 + li, g);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          p[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[jt], kf[jt], qf[it]);
+          dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[jt], vf[jt], dfi);
+        }
+      }
+      const int i = 16 * it + li;
+      const unsigned ri = shifted ? sRb[i] : 0u;
+      const float L = sL[wave][i];
+      float dsum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const unsigned rw = shifted ? sR[wave][4 * jt + g] : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = p[jt][r] * scale + sB[binA + (it - jt + 3) * 49 - r];
+          if (shifted && ((rw >> (8 * r)) & 255u) != ri) v += -100.0f;
+          const float e = __expf(v - L);
+          p[jt][r] = e;
+          dsum += e * dp[jt][r];
+        }
+      }
+      dsum += __shfl_xor(dsum, 16, 64);
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (g == 0) sD[wave][i] = dsum;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          p[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[jt][it], kf[jt], qf[it]);
-          dp[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[jt][it], vf[jt], df[it]);
+        for (int r = 0; r < 4; ++r) {
+          const float ds = p[jt][r] * (dp[jt][r] - dsum);
+          dp[jt][r] = ds;
+          dsacc[it - jt + 3][r] += ds;
         }
+      // dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]
+      f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int i = 16 * it + li;
-        const int ri = sR[wave][i];
-        const float L = sL[wave][i];
-        float dsum = 0.f;
+      for (int ks = 0; ks < 2; ++ks) {
+        const Frag<T> a = pack_frag(dp[2 * ks], dp[2 * ks + 1], (T*)nullptr);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * jt + 4 * g + r;
-            float v = p[jt][it][r] * scale + sB[wave][relidx(i, j)];
-            if (shifted && sR[wave][j] != ri) v += -100.0f;
-            const float e = __expf(v - L);
-            p[jt][it][r] = e;
-            dsum += e * dp[jt][it][r];
-          }
-        dsum += __shfl_xor(dsum, 16, 64);
-        dsum += __shfl_xor(dsum, 32, 64);
-        if (g == 0) sD[wave][i] = dsum;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * jt + 4 * g + r;
-            const float ds = p[jt][it][r] * (dp[jt][it][r] - dsum);
-            dp[jt][it][r] = ds;
-            sDS[wave][j * 64 + i] += ds;  // lanes li = consecutive i: conflict-free
-          }
-        // dQ rows of this query tile: sum_j dS[i][j] K[j][d]
-        f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          Frag<T> a = pack_frag(dp[2 * ks][it], dp[2 * ks + 1][it], (T*)nullptr);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            Frag<T> b = lds_frag_t(sK[wave], RS, ks * 32, dt * 16, lane, (T*)nullptr);
-            mma(o[dt], a, b);
-          }
+        for (int dt = 0; dt < 2; ++dt) {
+          const Frag<T> b = lds_frag_t(tA, RS, ks * 32, dt * 16, lane, (T*)nullptr);
+          mma(o[dt], b, a);
         }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dqb[(16 * it + 4 * g + r) * ld + 16 * dt + li] = from_f<T>(o[dt][r] * scale);
       }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) store4(dqb + (long)i * ld + 16 * dt + 4 * g, o[dt], scale);
+      __builtin_amdgcn_sched_barrier(0);   // keeps the query tiles sequential (interleaved, they need 4x the registers)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---------------- phase B: S layout (lane <-> key) : dV, dK ----------------
-    {
-      f32x4 p[4][4], dp[4][4];  // [it][jt]: query i = 16it+4g+r, key j = 16jt+li
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
+    for (int t = 0; t < 4; ++t) frag_to_lds<T>(tA, RS, t * 16 + li, g, qf[t]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- phase B ----------------
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-          p[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[it][jt], qf[it], kf[jt]);
-          dp[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[it][jt], df[it], vf[jt]);
-        }
+    for (int jt = 0; jt < 4; ++jt) {
+      f32x4 p[4], dp[4];  // [it]: query i = 16it+4g+r, key j = 16jt+li
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const int j = 16 * jt + li;
-        const int rj = sR[wave][j];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * it + 4 * g + r;
-            float v = p[it][jt][r] * scale + sB[wave][relidx(i, j)];
-            if (shifted && sR[wave][i] != rj) v += -100.0f;
-            const float e = __expf(v - sL[wave][i]);
-            p[it][jt][r] = e;
-            dp[it][jt][r] = e * (dp[it][jt][r] - sD[wave][i]);
-          }
-        f32x4 ov[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, ok[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          Frag<T> ap = pack_frag(p[2 * ks][jt], p[2 * ks + 1][jt], (T*)nullptr);
-          Frag<T> ad = pack_frag(dp[2 * ks][jt], dp[2 * ks + 1][jt], (T*)nullptr);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            Frag<T> bo = lds_frag_t(sO[wave], RS, ks * 32, dt * 16, lane, (T*)nullptr);
-            mma(ov[dt], ap, bo);
-            Frag<T> bq = lds_frag_t(sQ[wave], RS, ks * 32, dt * 16, lane, (T*)nullptr);
-            mma(ok[dt], ad, bq);
-          }
-        }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const long ro = (long)(16 * jt + 4 * g + r) * ld + 16 * dt + li;
-            dqb[ro + 2 * C] = from_f<T>(ov[dt][r]);
-            dqb[ro + C] = from_f<T>(ok[dt][r] * scale);
-          }
+      for (int it = 0; it < 4; ++it) {
+        const Frag<T> dfi = lds_row_frag<T>(tO, RS, it * 16 + li, g);
+        p[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[it], qf[it], kf[jt]);
+        dp[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[it], dfi, vf[jt]);
       }
+      const int j = 16 * jt + li;
+      const unsigned rj = shifted ? sRb[j] : 0u;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const unsigned rw = shifted ? sR[wave][4 * it + g] : 0u;
+        const float4 L4 = *reinterpret_cast<const float4*>(&sL[wave][16 * it + 4 * g]);
+        const float4 D4 = *reinterpret_cast<const float4*>(&sD[wave][16 * it + 4 * g]);
+        const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = p[it][r] * scale + sB[binB + (it - jt + 3) * 49 + r];
+          if (shifted && ((rw >> (8 * r)) & 255u) != rj) v += -100.0f;
+          const float e = __expf(v - Lr[r]);
+          p[it][r] = e;
+          dp[it][r] = e * (dp[it][r] - Dr[r]);
+        }
+      }
+      // dV^T[d][j] = sum_i dO[i][d] P[i][j];  dK^T[d][j] = sum_i Q[i][d] dS[i][j]
+      f32x4 ov[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, ok[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const Frag<T> ap = pack_frag(p[2 * ks], p[2 * ks + 1], (T*)nullptr);
+        const Frag<T> ad = pack_frag(dp[2 * ks], dp[2 * ks + 1], (T*)nullptr);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const Frag<T> bo = lds_frag_t(tO, RS, ks * 32, dt * 16, lane, (T*)nullptr);
+          mma(ov[dt], bo, ap);
+          const Frag<T> bq = lds_frag_t(tA, RS, ks * 32, dt * 16, lane, (T*)nullptr);
+          mma(ok[dt], bq, ad);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        store4(dqb + (long)j * ld + 2 * C + 16 * dt + 4 * g, ov[dt], 1.0f);
+        store4(dqb + (long)j * ld + C + 16 * dt + 4 * g, ok[dt], scale);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (int t = lane; t < 64 * 64; t += 64) atomicAdd(&sDB[wave][relidx(t & 63, t >> 6)], sDS[wave][t]);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (int t = lane; t < 343; t += 64) atomicAdd(dtable + t * heads + h, sDB[wave][t]);
+  const int binA0 = ((((lane0 & 15) >> 2) - (lane0 >> 4)) + 3) * 7 + (lane0 & 3) + 3;
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&sDB[binA0 + q * 49 - r], dsacc[q][r]);
+  __syncthreads();
+  for (int t = threadIdx.x; t < 343; t += 64 * NW) atomicAdd(dtable + t * heads + h, sDB[t]);
 }
 
 int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, const float* lse, void* dqkv, float* dtable, int heads, int C, const WinMap& wm, hipStream_t st) {
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
-  const int nw = dt == NMH_DT_BF16 ? 2 : 1;
-  long gx = (nwin + nw * 4 - 1) / (nw * 4);
-  long cap = 2048 / heads;
+  constexpr int NW = 2;
+  // one wave per (window, head); a wave loops over several windows only when there are more than ~12 waves per CU worth of them
+  long gx = (nwin + NW - 1) / NW;
+  long cap = (256L * 12 / NW) / heads;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   dim3 grid((unsigned)gx, heads);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin);
-  else hipLaunchKernelGGL((attn_bwd_kernel<float, 1>), grid, dim3(64), 0, st, (const float*)qkv, table, (const float*)dout, lse, (float*)dqkv, dtable, heads, C, wm, nwin);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin);
+  else hipLaunchKernelGGL((attn_bwd_kernel<float, NW>), grid, dim3(64 * NW), 0, st, (const float*)qkv, table, (const float*)dout, lse, (float*)dqkv, dtable, heads, C, wm, nwin);
   NMH_CHECK_LAUNCH();
   return 0;
 }
