@@ -354,6 +354,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
   for (int a = 0; a < NTW; ++a)
 #pragma unroll
     for (int b = 0; b < KTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fused bias gradient: the first k-tile's wk==0 waves also multiply their A fragments with an all-ones B fragment, which
+  // leaves the column sums of A (identical in all 16 columns) in NTW extra accumulators -- one more MFMA per A fragment
+  // instead of a separate pass over A
+  const bool want_bias = gm.dbias != nullptr && blockIdx.y == 0 && wk == 0;
+  f32x4 bacc[NTW];
+  Frag<T> ones;
+#pragma unroll
+  for (int a = 0; a < NTW; ++a) bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if constexpr (sizeof(T) == 2) ones.v[j] = (short)0x3F80; else ones.v[j] = 1.0f;
+  }
 
   uint4 ra[IA], rb[IB];
   auto gload = [&](long mc) {
@@ -420,6 +432,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
         Frag<T> af = lds_frag_t(sA, RSA, s * 32, (wn * NTW + a) * 16, lane, (T*)nullptr);
 #pragma unroll
         for (int b = 0; b < KTW; ++b) mma(acc[a][b], af, bf[b]);
+        if (want_bias) mma(bacc[a], af, ones);
       }
     }
   }
@@ -437,6 +450,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
           else atomicAdd(o, acc[a][b][r]);
         }
       }
+  if (want_bias && li == 0) {
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wn * NTW + a) * 16 + 4 * g + r;
+        if (n < N) {
+          if (gridDim.z == 1) gm.dbias[n] += bacc[a][r];
+          else atomicAdd(gm.dbias + n, bacc[a][r]);
+        }
+      }
+  }
 }
 
 template <typename T, int NTW, int KTW, class BL>
@@ -449,7 +474,10 @@ static int launch_tn(const void* A, long lda, const void* Bm, const BL& bl, floa
   if (want < 1) want = 1;
   long mps = (Mtot + want - 1) / want;
   mps = (mps + 63) / 64 * 64;
-  if (mps < 1024) mps = 1024;          // every split ends in BNW*BKW atomics: give it >= 16 chunks of MFMA work first
+  long mps_min = 1024;                 // every split ends in BNW*BKW atomics: give it >= 16 chunks of MFMA work first
+  if (const char* e = getenv("NMH_TN_MPS")) mps_min = atol(e);
+  if (const char* e = getenv("NMH_TN_WANT")) { want = atol(e) / ((long)gx * gy); if (want < 1) want = 1; mps = ((Mtot + want - 1) / want + 63) / 64 * 64; }
+  if (mps < mps_min) mps = mps_min;
   int gz = (int)((Mtot + mps - 1) / mps);
   hipLaunchKernelGGL((gemm_tn_kernel<T, NTW, KTW, BL>), dim3(gx, gy, gz), dim3(256), 0, st, (const T*)A, lda, (const T*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
   NMH_CHECK_LAUNCH();

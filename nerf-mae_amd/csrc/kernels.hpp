@@ -23,6 +23,7 @@ struct TnGeom {
   long ldo;
   int Cin, D, H, W; unsigned V;
   FDiv dC, dW, dH, dV;
+  float* dbias;         // optional: dbias[n] += sum_m A[m][n]*rs(m) (column sums of the A operand, e.g. a Linear's bias gradient)
 };
 
 // window partition geometry (3-D shifted windows, window edge 4): real dims, padded dims, effective shifts

@@ -159,8 +159,7 @@ class _EmbedFn(torch.autograd.Function):
         dy0 = torch.empty_like(y0)
         ops.layernorm_bwd(dtok.contiguous(), y0, ln.weight, mean, rstd, dy0, _gradbuf(ln.weight), _gradbuf(ln.bias), T, C,
                           mask=mask_dev, dmask_token=_gradbuf(m.mask_token) if mask_dev is not None else None, tokens_per_sample=g ** 3)
-        ops.gemm_tn(dy0, A, _gradbuf(conv.weight))
-        ops.bias_grad(dy0, _gradbuf(conv.bias), T, C)
+        ops.gemm_tn(dy0, A, _gradbuf(conv.weight), dbias=_gradbuf(conv.bias))
         return None, None, None, None
 
 
@@ -206,12 +205,10 @@ class _BlockFn(torch.autograd.Function):
         # weight/bias gradients are off the critical path: they run on a forked side stream and overlap the dgrad chain
         dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
         with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dx2, h_act, _gradbuf(b.mlp[3].weight), rowscale=sd2, rows_per_scale=tps)
-            ops.bias_grad(dx2, _gradbuf(b.mlp[3].bias), T, C, rowscale=sd2, rows_per_scale=tps)
+            ops.gemm_tn(dx2, h_act, _gradbuf(b.mlp[3].weight), rowscale=sd2, rows_per_scale=tps, dbias=_gradbuf(b.mlp[3].bias))
         dx1n = ops.gemm_nt(dh, pk[key + "fc1.wT"].view(C, 4 * C))
         with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dh, x1n, _gradbuf(b.mlp[0].weight))
-            ops.bias_grad(dh, _gradbuf(b.mlp[0].bias), T, 4 * C)
+            ops.gemm_tn(dh, x1n, _gradbuf(b.mlp[0].weight), dbias=_gradbuf(b.mlp[0].bias))
         dx1 = torch.empty_like(x)
         ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2)
         # ---- attention branch
@@ -219,14 +216,12 @@ class _BlockFn(torch.autograd.Function):
         ops.window_gather_scale(dx1, dyw, sd1, C, geom)
         do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
         with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dyw, o, _gradbuf(b.attn.proj.weight))
-            ops.bias_grad(dyw, _gradbuf(b.attn.proj.bias), geom.rows, C)
+            ops.gemm_tn(dyw, o, _gradbuf(b.attn.proj.weight), dbias=_gradbuf(b.attn.proj.bias))
         dqkv = torch.empty_like(qkv)
         ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
         dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
         with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dqkv, xnw, _gradbuf(b.attn.qkv.weight))
-            ops.bias_grad(dqkv, _gradbuf(b.attn.qkv.bias), geom.rows, 3 * C)
+            ops.gemm_tn(dqkv, xnw, _gradbuf(b.attn.qkv.weight), dbias=_gradbuf(b.attn.qkv.bias))
         dx = torch.empty_like(x)
         ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
         ops.join_side()  # before any temporary of this block is released
@@ -683,9 +678,24 @@ class SwinTransformer_MAE3D_New(nn.Module):
             ext.append([a0, a1, a2])
         return xb, torch.tensor(ext, dtype=torch.int32).to(device, non_blocking=True)
 
+    def _draw_sd_noise(self, B: int, device):
+        """row-mode stochastic-depth factors of every block (attention and MLP branch) in TWO launches instead of four per block
+        (torchvision StochasticDepth(p, "row"): bernoulli(1-p)/(1-p) per sample, swin_mae3d.py:390-414)"""
+        blocks = [m for st in self.stages for m in st if isinstance(m, SwinBlock3D)]
+        if not self.training or all(b.sd_prob == 0.0 for b in blocks):
+            return None
+        keep = getattr(self, "_sd_keep", None)
+        if keep is None or keep.device != device or keep.shape[1] != B:
+            k = torch.tensor([1.0 - b.sd_prob for b in blocks for _ in (0, 1)], device=device)
+            keep = self._sd_keep = k[:, None].expand(-1, B).contiguous()
+        noise = torch.bernoulli(keep).div_(keep)
+        return [(noise[2 * i], noise[2 * i + 1]) for i in range(len(blocks))]
+
     def forward_encoder(self, tok: Tensor, sd_noise=None):
         feats, x, bi = [], tok, 0
         red = self._reducer
+        if sd_noise is None:
+            sd_noise = self._draw_sd_noise(tok.shape[0], tok.device)
         for si, st in enumerate(self.stages):
             if red is not None:
                 x = red.trigger(x, si + 1)  # backward reaching here => stage si gradients are complete

@@ -29,7 +29,7 @@ class side_stream:
     the critical path (weight/bias gradients); `ops.join_side()` makes the current stream wait for it.  The fork/join pair keeps
     allocator lifetimes trivial: every tensor touched on the side stream outlives the join."""
     _streams = {}
-    enabled = True
+    enabled = __import__("os").environ.get("NMH_NO_SIDE", "0") != "1"
     min_rows = int(__import__("os").environ.get("NMH_SIDE_MIN_ROWS", "0"))  # blocks with fewer token rows stay single-stream
 
     def __init__(self, enable: bool = True):
@@ -109,14 +109,14 @@ def gemm_nt(A, W, bias=None, act=0, C2=None, resid=None, rowscale=None, rows_per
     return out
 
 
-def gemm_tn(A, B, dW, rowscale=None, rows_per_scale=1, omode=0, ldo=None, p0=0, p1=0, N=None, K=None, M=None):
-    """dW[N,K] += A[M,N]^T @ B[M,K] (fp32 atomics into dW)."""
-    _chk(A, B, dW, rowscale)
+def gemm_tn(A, B, dW, rowscale=None, rows_per_scale=1, omode=0, ldo=None, p0=0, p1=0, N=None, K=None, M=None, dbias=None):
+    """dW[N,K] += A[M,N]^T @ B[M,K] (fp32 atomics into dW); dbias[N] += column sums of A (optional, same pass)."""
+    _chk(A, B, dW, rowscale, dbias)
     M = A.shape[0] if M is None else M
     N = A.shape[1] if N is None else N
     K = B.shape[1] if K is None else K
     lib().call("nmh_gemm_tn", dt_of(A), A, A.stride(0), B, B.stride(0), dW, M, N, K, rowscale, rows_per_scale, omode,
-               K if ldo is None else ldo, p0, p1, _st())
+               K if ldo is None else ldo, p0, p1, dbias, _st())
     return dW
 
 

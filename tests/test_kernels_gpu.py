@@ -94,10 +94,13 @@ def test_gemm_tn(dt, M, N, K):
     rs = torch.tensor([0.5, 2.0, 1.0, 0.0, 1.5])
     rps = (M + 4) // 5
     dW = torch.full((N, K), 0.25, device="cuda")
-    ops.gemm_tn(dev(A, dt), dev(B, dt), dW, rowscale=dev(rs), rows_per_scale=rps, N=N)
+    db = torch.full((N,), -0.5, device="cuda")
+    ops.gemm_tn(dev(A, dt), dev(B, dt), dW, rowscale=dev(rs), rows_per_scale=rps, N=N, dbias=db)
     sc = rs.repeat_interleave(rps)[:M, None]
-    ref = 0.25 + (q(A[:, :N] * sc, dt) if dt == torch.bfloat16 else A[:, :N] * sc).T @ B
+    As = q(A[:, :N] * sc, dt) if dt == torch.bfloat16 else A[:, :N] * sc
+    ref = 0.25 + As.T @ B
     check(dW, ref, dt, "gemm_tn", mult=1.0 if dt == torch.float32 else 1.0)
+    check(db, -0.5 + As.sum(0), dt, "gemm_tn fused bias grad")   # column sums of A from the same pass
 
 
 @pytest.mark.parametrize("dt", DTS)

@@ -22,4 +22,4 @@ byname = collections.defaultdict(lambda: [0.0, 0])
 for t, n, k in rows: byname[k[0]][0] += t; byname[k[0]][1] += n
 for k, (t, n) in sorted(byname.items(), key=lambda kv: -kv[1][0]): print(f"  {k:34s} {t:7.2f} ms {n:5d} calls")
 print("top shapes:")
-for t, n, k in rows[:45]: print(f"  {t:7.3f} ms {n:3d}x {k[0][4:]:28s} {k[1:]}")
+for t, n, k in rows[:70]: print(f"  {t:7.3f} ms {n:3d}x {k[0][4:]:28s} {k[1:]}")
