@@ -13,6 +13,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
+#include <type_traits>
+static inline bool lda_ok(long lda, long ldb) { return lda % 8 == 0 && ldb % 8 == 0; }
 
 // ------------------------------------------------------------------------------------------------
 // fast unsigned division by a runtime constant (n < 2^31), host-built
@@ -119,6 +121,37 @@ template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams&
   Vec8<T>::store((T*)ep.C + o, v);
 }
 
+// epilogue shared by the NT kernels: per wave, one 16-row m-tile at a time through a private LDS slab (16-byte row stores)
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, const EpiParams& ep, int m0, int n0, int M, int N, int wave, int lane) {
+  constexpr int BN = 16 * NT, SLD = BN + 4;
+  const int g = lane >> 4, li = lane & 15;
+  float* stg = reinterpret_cast<float*>(smem) + wave * 16 * SLD;
+  const long zrow = (long)blockIdx.z * M;
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stg[(4 * g + r) * SLD + b * 16 + li] = acc[a][b][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int it = lane; it < 16 * (BN / 8); it += 64) {
+      const int row = it / (BN / 8), cc = it - row * (BN / 8);
+      const int grow = m0 + wave * 16 * MT + a * 16 + row, gcol = n0 + cc * 8;
+      if (grow < M && gcol < N) {
+        float v[8];
+        float4 x0 = *reinterpret_cast<const float4*>(stg + row * SLD + cc * 8);
+        float4 x1 = *reinterpret_cast<const float4*>(stg + row * SLD + cc * 8 + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        epilogue8<T>(ep, zrow + grow, gcol, v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // gemm_nt kernel: 256 threads = 4 waves stacked along M, each wave (16*MT) x (16*NT); WG tile (64*MT) x (16*NT)
 // LDS: two stages of swizzled 128-byte rows (A: 64*MT rows, B: 16*NT rows); register prefetch of tile t+1
@@ -192,32 +225,126 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
     __syncthreads();
   }
 
-  // ---- epilogue: per wave, one 16-row m-tile at a time through a private LDS slab ----
-  constexpr int SLD = BN + 4;
-  float* stg = reinterpret_cast<float*>(smem) + wave * 16 * SLD;
-  const long zrow = (long)blockIdx.z * M;
+  nt_epilogue<T, MT, NT>(acc, smem, ep, m0, n0, M, N, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_nt, LDS-DMA pipelined variant (bf16, plain row-major A): same tiles / swizzle / fragments / epilogue as gemm_nt_kernel, but
+// the operand tiles go global -> LDS by `global_load_lds_dwordx4` into a ring of ST stages with ST-1 K-tiles in flight (counted
+// vmcnt + one raw s_barrier per K-tile).  The register-prefetch kernel has ONE tile in flight per workgroup, so a short-M GEMM
+// (encoder stage 2/3: 252..1008 workgroups) pays a full global-load latency per K-tile; here it pays it once.
+// The DMA image is lane-linear (lane l -> 16 bytes at dst + 16 l = row l/8, chunk position l%8), so the XOR swizzle is applied on
+// the source side: the lane at chunk position c' fetches logical chunk c' ^ ((row>>1)&7).
+// ------------------------------------------------------------------------------------------------
+__device__ uint4 g_zero16_nt[1];   // zero source for K-tail lanes
+
+template <int MT, int NT, int ST>
+__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, long lda, long rows_per_z, const bf16_t* __restrict__ Bw, long ldb, int M, int N, int K,
+                                                          EpiParams ep) {
+  using T = bf16_t;
+  constexpr int BM = 64 * MT, BN = 16 * NT, BNP = (BN + 31) / 32 * 32, KT = 64;
+  constexpr int AR = BM / 32, BR = BNP / 32, PCS = AR + BR, STAGE = (BM + BNP) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int lrow = lane >> 3, row8 = 8 * wave + lrow;
+  const int kc = ((lane & 7) ^ ((row8 >> 1) & 7)) * 8;   // logical k offset (elements) this lane fetches in every piece
+  const T* asrc[AR];
+  const T* bsrc[BR];
 #pragma unroll
-  for (int a = 0; a < MT; ++a) {
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + 32 * i + row8;
+    if (m > M - 1) m = M - 1;                              // clamped rows are computed but never stored
+    asrc[i] = A + ((long)blockIdx.z * rows_per_z + m) * lda + kc;
+  }
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
+  for (int i = 0; i < BR; ++i) {
+    int n = n0 + 32 * i + row8;
+    if (n > N - 1) n = N - 1;
+    bsrc[i] = Bw + (long)n * ldb + kc;
+  }
+  const int nk = (K + KT - 1) / KT;
+  // the zero page lives in a VGPR pair so that the K-tail select is a v_cndmask, not a divergent branch around two load forms
+  unsigned long long zpage = (unsigned long long)(const void*)g_zero16_nt;
+  asm volatile("" : "+v"(zpage));
+  auto issue = [&](int kt) {
+    char* slot = smem + (kt % ST) * STAGE + wave * 1024;
+    const bool ok = kt * KT + kc < K;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) stg[(4 * g + r) * SLD + b * 16 + li] = acc[a][b][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int it = lane; it < 16 * (BN / 8); it += 64) {
-      const int row = it / (BN / 8), cc = it - row * (BN / 8);
-      const int grow = m0 + wave * 16 * MT + a * 16 + row, gcol = n0 + cc * 8;
-      if (grow < M && gcol < N) {
-        float v[8];
-        float4 x0 = *reinterpret_cast<const float4*>(stg + row * SLD + cc * 8);
-        float4 x1 = *reinterpret_cast<const float4*>(stg + row * SLD + cc * 8 + 4);
-        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        epilogue8<T>(ep, zrow + grow, gcol, v);
+    for (int i = 0; i < AR; ++i) {
+      const void* src = (const void*)(ok ? (unsigned long long)(asrc[i] + kt * KT) : zpage);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + i * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const void* src = (const void*)(ok ? (unsigned long long)(bsrc[i] + kt * KT) : zpage);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + BM * 128 + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (s < nk) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed once at most the pieces of the ST-2 younger stages are outstanding (vmcnt retires in order)
+    if (nk - 1 - kt >= ST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PCS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's pieces of stage kt are visible; everyone is done reading stage kt-1
+    if (kt + ST - 1 < nk) issue(kt + ST - 1);   // refills the slot of stage kt-1
+    const char* As = smem + (kt % ST) * STAGE;
+    const char* Bs = As + BM * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> bf[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bf[b] = lds_frag(Bs, b * 16 + li, s, g, (T*)nullptr);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        Frag<T> af = lds_frag(As, wave * 16 * MT + a * 16 + li, s, g, (T*)nullptr);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) mma(acc[a][b], af, bf[b]);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
+  __syncthreads();   // the epilogue reuses the ring as staging space
+  nt_epilogue<T, MT, NT>(acc, smem, ep, m0, n0, M, N, wave, lane);
+}
+
+template <int MT, int NT, int ST>
+static int launch_nt_dma(const ADirect<bf16_t>& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st) {
+  constexpr int BM = 64 * MT, BN = 16 * NT, BNP = (BN + 31) / 32 * 32;
+  constexpr int lds_main = ST * (BM + BNP) * 128, lds_epi = 4 * 16 * (BN + 4) * 4;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MT, NT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_dma_kernel<MT, NT, ST>), grid, dim3(256), lds, st, al.A, al.lda, al.rows_per_z, (const bf16_t*)Bw, ldb, M, N, K, ep);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+// The pipelined kernel pays off where one workgroup's K loop is long and few workgroups exist to hide it (measured, M <= 8192:
+// fc2 4000x384x1536 21.9 -> 15.2 us, 500x768x3072 34.6 -> 24.5 us); with K <= 384 or >= 1000 workgroups the register-prefetch
+// kernel's smaller LDS footprint (more co-resident workgroups) wins.  NMH_GEMM_DMA=0 disables, =3/4 forces it (ring depth).
+template <typename T, int MT, int NT, class AL>
+static bool try_dma(const AL& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st, int* rc) {
+  if constexpr (std::is_same<AL, ADirect<bf16_t>>::value && MT == 1) {
+    static const int dma_st = [] { const char* e = getenv("NMH_GEMM_DMA"); return e ? atoi(e) : -1; }();
+    if (dma_st == 0 || !lda_ok(al.lda, ldb)) return false;
+    const bool auto_on = dma_st < 0 && K >= 1024 && (long)M * batch <= 8192;
+    if (dma_st == 3) { *rc = launch_nt_dma<MT, NT, 3>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
+    if (dma_st == 4 || auto_on) { *rc = launch_nt_dma<MT, NT, 4>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
+  }
+  return false;
 }
 
 template <typename T, int MT, int NT, class AL>
@@ -225,6 +352,10 @@ static int launch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K
   constexpr int BM = 64 * MT, BN = 16 * NT;
   constexpr int lds_main = 2 * (BM + BN) * 128, lds_epi = 4 * 16 * (BN + 4) * 4;
   constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  {
+    int rc = 0;
+    if (try_dma<T, MT, NT, AL>(al, Bw, ldb, M, N, K, batch, ep, st, &rc)) return rc;
+  }
   dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch);
   static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
   if (!attr_set) {
@@ -254,7 +385,7 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
   // that more than a few dozen CUs get work, and (b) short contractions (every Linear of the encoder, the transpose convs): those
   // are HBM-bound with a latency-bound prologue/epilogue per workgroup, and co-resident workgroups are what hides it
   // (measured on 256000x288x96: 145 us with 256x128 tiles, 67 us with 64x96)
-  if (((long)M * batch <= 4096 || K <= 1024) && t16 >= 4) {
+  if (((long)M * batch <= 8192 || K <= 1024) && t16 >= 4) {
     if (t16 % 6 == 0) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 4 == 0) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 3 == 0) return launch_nt<T, 1, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);

@@ -26,3 +26,9 @@ t("fc1 stage1", 32000, 768, 192, act=1)
 t("qkv stage2", 6912, 1152, 384)
 t("fc1 stage2", 4000, 1536, 384, act=1)
 t("fc2 stage2", 4000, 384, 1536)
+t("proj stage2", 6912, 384, 384)
+t("qkv dgrad stage2", 6912, 384, 1152)
+t("fc1 stage3", 500, 3072, 768, act=1)
+t("fc2 stage3", 500, 768, 3072)
+t("fc2 stage1", 32000, 192, 768)
+t("convT dgrad dec1", 256000, 96, 3072)
