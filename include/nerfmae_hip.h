@@ -82,6 +82,9 @@ NMH_API int nmh_upconv_shuffle_bwd(int dt, const void* dcat, void* dupre, void* 
  * dpred optional fp32 [B*R^3][4]: un-normalised d(loss)/d(pred) per voxel for nmh_mae_tail_bwd; sums is then fp64[8] (+ sum_v dpred). */
 NMH_API int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, double* sums, float* losses, float* pred, float* dpred, void* stream);
 NMH_API int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, const double* sums, void* dd0, void* dpred8, float* dWout, float* dbout, void* stream);
+/* Forward of the decoder tail in one pass: d0 = lrelu(IN(y) + r) (unetr_block.py:62-71) -> 1x1 head -> loss terms
+ * (swin_mae3d.py:1496-1549); arguments as nmh_instnorm_apply (rmode 1) + nmh_mae_loss_fwd. */
+NMH_API int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, void* stream);
 /* Backward of the decoder tail d0 = lrelu(IN(y) + r) -> 1x1 head -> loss in two elementwise passes that never materialise d(d0)
  * (swin_mae3d.py:1496-1549 + unetr_block.py:62-71 backward): d(d0) = Wout^T dpred is recomputed per element from dpred/loss_sums
  * (both from nmh_mae_loss_fwd).  in_sums[b][c] = {sum g, sum g*yhat}, dy = IN-backward, dr = g; dWout/dbout accumulate the head

@@ -135,6 +135,14 @@ int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bou
   (void)dpred8;  // kept in the ABI for layout stability; the head weight gradient is now fused into the kernel
   return k_loss_bwd(a, dd0, dWout, dbout, ST);
 }
+int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, void* d0, const float* Wout, const float* bout, const float* target, const int* extents,
+                     const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, void* stream) {
+  CLR();
+  LossArgs a{dt, nullptr, Wout, bout, target, extents, tokmask, B, R, C, sums, pred, dpred};
+  int rc = k_tail_fwd(a, y, stats, r, d0, slope, ST);
+  if (rc) return rc;
+  return k_loss_finalize(sums, losses, ST);
+}
 int nmh_mae_tail_bwd(int dt, const void* d0, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums,
                      void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, void* stream) {
   CLR();

@@ -748,3 +748,112 @@ int k_tail_bwd(int dt, const void* d0, const void* xin, const float* in_stats, c
   NMH_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- decoder tail forward: d0 = lrelu(IN(x) + r) -> 1x1 head -> loss terms, one pass ------------------------------------------
+// The normalisation pass already holds every d0 chunk in registers, so the 1x1 head (C -> 4) is evaluated there: each lane forms the
+// partial dot of its 8 channels, the C/8 lanes of a voxel are summed with ds_bpermute (a wave holds floor(64/(C/8)) whole voxels, the
+// rest of its lanes idle), and the voxel's leader lane evaluates the loss terms / writes d(pred) -- the separate loss kernel (one more
+// read of d0) disappears.  Same math as loss_kernel<T,0> (misc.hip); the head sees the stored (rounded) d0, as the backward does.
+template <typename T>
+__global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ r, T* __restrict__ out, LossArgs a,
+                                                       long V, int C, float slope, long vpb) {
+  __shared__ float sacc[8];
+  const int CL = C >> 3, VPW = 64 / CL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int vl = lane / CL, cl = lane - vl * CL;
+  const bool active = vl < VPW;
+  const bool leader = active && cl == 0;
+  if (threadIdx.x < 8) sacc[threadIdx.x] = 0.f;
+  __syncthreads();
+  float mu[8], rs[8], w[4][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = (active ? cl : 0) * 8 + j;
+    mu[j] = stats[((long)b * C + c) * 2]; rs[j] = stats[((long)b * C + c) * 2 + 1];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) w[o][j] = a.Wout[o * C + c];
+  }
+  const float b0 = a.bout[0], b1 = a.bout[1], b2 = a.bout[2], b3 = a.bout[3];
+  const int e0 = a.extents[b * 3], e1 = a.extents[b * 3 + 1], e2 = a.extents[b * 3 + 2];
+  const unsigned Ru = (unsigned)a.R;
+  const int g = a.R >> 2;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
+  if (v1 > V) v1 = V;
+  for (long base = v0 + wave * VPW; base < v1; base += 4 * VPW) {   // wave-uniform trip count: the shuffles below need every lane
+    const long v = base + vl;
+    const bool ok = active && v < v1;
+    float xv[8], rv[8], t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    unsigned char tmk = 0;
+    int zz = 0, yy = 0, xx = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xv[j] = 0.f; rv[j] = 0.f; }
+    if (ok) {
+      const long o = ((long)b * V + v) * C + cl * 8;
+      Vec8<T>::load(x + o, xv);
+      Vec8<T>::load(r + o, rv);
+      if (cl == 0) {
+        const unsigned vox = (unsigned)v, tq = vox / Ru, zq = tq / Ru;
+        xx = (int)(vox - tq * Ru); yy = (int)(tq - zq * Ru); zz = (int)zq;
+        const float* tg = a.target + (long)b * 4 * V + v;
+        t0 = tg[0]; t1 = tg[V]; t2 = tg[2 * V]; t3 = tg[3 * V];
+        tmk = a.tokmask[((zz >> 2) * g + (yy >> 2)) * g + (xx >> 2)];
+      }
+    }
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = (xv[j] - mu[j]) * rs[j] + rv[j];
+      y = y > 0.f ? y : slope * y;
+      xv[j] = y;
+      const float yr = to_f<T>(from_f<T>(y));   // the value the backward (and the reference's next op) sees
+      p[0] += yr * w[0][j]; p[1] += yr * w[1][j]; p[2] += yr * w[2][j]; p[3] += yr * w[3][j];
+    }
+    if (ok) Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv);
+    float tot[4] = {0.f, 0.f, 0.f, 0.f};
+    const int src0 = vl * CL;
+    for (int c = 0; c < CL; ++c) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) tot[o] += __shfl(p[o], src0 + c, 64);
+    }
+    if (ok && cl == 0) {
+      const float p0 = tot[0] + b0, p1 = tot[1] + b1, p2 = tot[2] + b2, p3 = tot[3] + b3;
+      const bool occ = t3 > 0.01f;
+      const bool rm = zz < e0 && yy < e1 && xx < e2 && tmk != 0;
+      const float sg = 1.0f / (1.0f + __expf(-p3));
+      if (occ) { acc[0] += (p0 - t0) * (p0 - t0) + (p1 - t1) * (p1 - t1) + (p2 - t2) * (p2 - t2); acc[1] += 1.f; }
+      if (rm) { acc[2] += (sg - t3) * (sg - t3); acc[3] += 1.f; }
+      if (a.pred) { float* pr = a.pred + (long)b * 4 * V + v; pr[0] = p0; pr[V] = p1; pr[2 * V] = p2; pr[3 * V] = p3; }
+      if (a.dp) {
+        float4 d;
+        d.x = occ ? 2.f * (p0 - t0) : 0.f; d.y = occ ? 2.f * (p1 - t1) : 0.f; d.z = occ ? 2.f * (p2 - t2) : 0.f;
+        d.w = rm ? 2.f * (sg - t3) * sg * (1.f - sg) : 0.f;
+        *reinterpret_cast<float4*>(a.dp + ((long)b * V + v) * 4) = d;
+        acc[4] += d.x; acc[5] += d.y; acc[6] += d.z; acc[7] += d.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const float s = wave_sum(leader ? acc[o] : 0.f);
+    if (lane == 0) atomicAdd(&sacc[o], s);
+  }
+  __syncthreads();
+  if (threadIdx.x < (a.dp ? 8 : 4)) atomicAdd(&a.sums[threadIdx.x], (double)sacc[threadIdx.x]);
+}
+int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void* r, void* out, float slope, hipStream_t st) {
+  const int C = a.Cd;
+  if (C % 8 || C > 512) return -2;
+  const long V = (long)a.R * a.R * a.R;
+  hipError_t e = hipMemsetAsync(a.sums, 0, (a.dp ? 8 : 4) * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  long vpb = (V * a.B + 2047) / 2048;
+  if (vpb < 160) vpb = 160;
+  if (vpb > 2048) vpb = 2048;
+  dim3 grid((unsigned)((V + vpb - 1) / vpb), a.B);
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL(tail_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, (bf16_t*)out, a, V, C, slope, vpb);
+  else hipLaunchKernelGGL(tail_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, (const float*)r, (float*)out, a, V, C, slope, vpb);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

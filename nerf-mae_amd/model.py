@@ -301,12 +301,13 @@ class _UpBlockFn(torch.autograd.Function):
             ops.instnorm_stats(y2, st2, scratch, B, V, Cout)
         out = torch.empty_like(y2)
         y3 = st3 = None
+        fused_tail = tail is not None and not m.has_proj
         if m.has_proj:
             y3 = ops.gemm_nt(cat, pk[key + "c3.w"].view(Cout, Cc))
             st3 = torch.empty((B, Cout, 2), device=dev)
             ops.instnorm_stats(y3, st3, scratch, B, V, Cout)
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=y3, stats_r=st3, rmode=2)
-        else:
+        elif not fused_tail:
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=cat, rmode=1)
         ctx.m, ctx.dims, ctx.conv, ctx.c48 = m, (B, v, has_skip), conv, c48
         ctx.saved = (x, cat, y1, st1, a1, y2, st2, y3, st3, out)
@@ -317,7 +318,9 @@ class _UpBlockFn(torch.autograd.Function):
             lsums = torch.empty(8, dtype=torch.float64, device=dev)
             losses = torch.empty(3, device=dev)
             dpred = torch.empty((B * V, 4), device=dev) if ctx.needs_input_grad[0] else None
-            ops.mae_loss_fwd(out, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask, B, S, Cout, lsums, losses, pred_out, dpred)
+            # last InstanceNorm + residual + LeakyReLU, the 1x1 head and the loss terms in one pass over (y2, cat)
+            ops.mae_tail_fwd(y2, st2, cat, out, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask, B, S, Cout, lsums, losses,
+                             pred_out, dpred)
             ctx.tail = (model, lsums, dpred)
             return losses
         return out

@@ -277,6 +277,15 @@ def mae_loss_bwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, 
     lib().call("nmh_mae_loss_bwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, dpred8, dWout, dbout, _st())
 
 
+def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred=None, dpred=None, slope=0.01):
+    """d0 = lrelu(IN(y) + r), 1x1 head and loss terms in one pass (instnorm_apply rmode 1 + mae_loss_fwd)"""
+    _chk(y, stats, r, d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred)
+    if dpred is not None and sums.numel() < 8:
+        raise ValueError("mae_tail_fwd: sums needs 8 entries when dpred is requested")
+    lib().call("nmh_mae_tail_fwd", dt_of(y), y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope, _st())
+    return losses
+
+
 def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01):
     _chk(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout)
     lib().call("nmh_mae_tail_bwd", dt_of(d0), d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, _st())

@@ -417,6 +417,17 @@ def test_tail_backward_fused(dt):
     dpred = torch.empty(B * V, 4, device="cuda")
     ops.mae_loss_fwd(*args, losses, None, dpred)
     np.testing.assert_allclose(losses[0].item(), l.item(), rtol=TOL[dt])
+    # one-pass forward tail (normalise + residual + LeakyReLU + head + loss terms) against the two separate kernels
+    lsums2, losses2 = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda")
+    d0k = torch.empty(B * V, Cd, dtype=dt, device="cuda")
+    dpred2, predk = torch.empty(B * V, 4, device="cuda"), torch.empty(B, 4, R, R, R, device="cuda")
+    ops.mae_tail_fwd(yd.view(-1, Cd), stats, dev(r, dt).view(-1, Cd), d0k, args[1], args[2], args[3], args[4], args[5], B, R, Cd, lsums2, losses2,
+                     predk, dpred2)
+    check(d0k, d0_ref.detach().reshape(-1, Cd), dt, "tail fwd d0")
+    check(predk, pred.detach(), dt, "tail fwd pred", 2)
+    np.testing.assert_allclose(losses2.cpu().numpy(), losses.cpu().numpy(), rtol=TOL[dt])
+    check(dpred2, dpred.cpu(), dt, "tail fwd dpred", 3)
+    np.testing.assert_allclose(lsums2.cpu().numpy(), lsums.cpu().numpy(), rtol=50 * TOL[dt], atol=1e-3)
     dy, dr = torch.empty(B * V, Cd, dtype=dt, device="cuda"), torch.empty(B * V, Cd, dtype=dt, device="cuda")
     dW, db = torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda")
     in_sums = torch.empty(B, Cd, 2, dtype=torch.float64, device="cuda")

@@ -46,3 +46,8 @@ def unfused():
 
 
 print(f"fused tail bwd  {timeit(fused):.3f} ms   unfused {timeit(unfused):.3f} ms   loss fwd {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None)):.3f} / with dpred {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)):.3f} ms")
+out = torch.empty_like(y)
+r = torch.randn_like(y)
+t_f = timeit(lambda: ops.mae_tail_fwd(y, stats, r, out, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred))
+t_u = timeit(lambda: (ops.instnorm_apply(y, stats, out, B, V, Cd, r=r, rmode=1), ops.mae_loss_fwd(out, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)))
+print(f"fused tail fwd {t_f:.3f} ms   unfused (in_apply + loss fwd) {t_u:.3f} ms")
