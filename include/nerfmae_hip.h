@@ -73,7 +73,13 @@ NMH_API int nmh_instnorm_bwd_apply(int dt, const void* dout, const void* out, co
 
 /* im2row of the 4x4x4 stride-4 patch conv input: x fp32 (B,4,R,R,R) -> A[(b,z,y,x)][256] (swin_mae3d.py:1120-1126) */
 NMH_API int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream);
-/* ConvTranspose3d(k=stride) pixel shuffle + bias + channel concat with the skip (unetr_block.py:193-198) and its adjoint */
+/* ConvTranspose3d(kernel = stride = k) (unetr_block.py:151-158,193-198) as GEMMs with the pixel shuffle folded into the addressing,
+ * channels-last.  x [B*v^3][Cin] coarse grid; cat/dcat [B*(v*k)^3][ldc] fine grid, the transpose conv occupies columns [0,Cout)
+ * (the skip connection, if any, the rest).  Wt packed [(tap,co)][ci], Wd packed [ci][(tap,co)], dW fp32 [Cin][Cout][k^3]. */
+NMH_API int nmh_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, int64_t ldc, int B, int v, int k, int Cin, int Cout, void* stream);
+NMH_API int nmh_upconv_dgrad(int dt, const void* dcat, int64_t ldc, const void* Wd, void* dx, int B, int v, int k, int Cin, int Cout, void* stream);
+NMH_API int nmh_upconv_wgrad(int dt, const void* dcat, int64_t ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, void* stream);
+/* (unfused pieces) ConvTranspose3d(k=stride) pixel shuffle + bias + channel concat with the skip (unetr_block.py:193-198) and its adjoint */
 NMH_API int nmh_upconv_shuffle_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, void* stream);
 NMH_API int nmh_upconv_shuffle_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip, void* stream);
 /* UnetOutBlock 1x1 conv (Cd->4) fused with forward_loss (swin_mae3d.py:1513-1549).  target fp32 (B,4,R,R,R); extents [B][3]

@@ -39,6 +39,18 @@ int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, 
   if (omode == 2) { gm.Cin = p0; gm.V = (unsigned)p1; gm.dC = make_fdiv(p0); }
   return k_gemm_tn(dt, A, lda, B, ldb, dW, M, N, K, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, gm, ST);
 }
+int nmh_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, int64_t ldc, int B, int v, int k, int Cin, int Cout, void* stream) {
+  CLR();
+  return k_upconv_fwd(dt, x, Wt, bias, cat, (long)ldc, B, v, k, Cin, Cout, ST);
+}
+int nmh_upconv_dgrad(int dt, const void* dcat, int64_t ldc, const void* Wd, void* dx, int B, int v, int k, int Cin, int Cout, void* stream) {
+  CLR();
+  return k_upconv_dgrad(dt, dcat, (long)ldc, Wd, dx, B, v, k, Cin, Cout, ST);
+}
+int nmh_upconv_wgrad(int dt, const void* dcat, int64_t ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, void* stream) {
+  CLR();
+  return k_upconv_wgrad(dt, dcat, (long)ldc, x, dW, dbias, B, v, k, Cin, Cout, ST);
+}
 int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
   CLR();
   EpiParams ep{Y, Cout, nullptr, 0, nullptr, nullptr, nullptr, 1, accumulate};

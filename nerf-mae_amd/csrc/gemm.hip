@@ -49,6 +49,35 @@ template <typename T> struct ADirect {
   }
 };
 
+// pixel-shuffled view of a fine-grid tensor: A[m][tap*Cout + co] = X[fine(m, tap)][co] (ConvTranspose3d k = stride, input gradient)
+template <typename T> struct AUp {
+  const T* X; long ldc; int v, k, Cout; FDiv dv, dk, dc;
+  struct Row { long fine0; bool ok; };
+  struct Kst { long off; bool ok; };
+  __device__ __forceinline__ void init_row(Row& r, int m, int M) const {
+    r.ok = m < M;
+    unsigned q = fdiv((unsigned)m, dv), x = m - q * v;
+    unsigned q2 = fdiv(q, dv), y = q - q2 * v;
+    unsigned b = fdiv(q2, dv), z = q2 - b * v;
+    const long V = (long)v * k;
+    r.fine0 = (((long)b * V + z * k) * V + y * k) * V + x * k;
+  }
+  __device__ __forceinline__ Kst init_k(int kk, int K) const {
+    Kst s;
+    s.ok = kk < K;
+    unsigned tap = fdiv((unsigned)kk, dc);
+    int co = kk - (int)tap * Cout;
+    unsigned tq = fdiv(tap, dk), tx = tap - tq * k, tz = fdiv(tq, dk), ty = tq - tz * k;
+    const long V = (long)v * k;
+    s.off = (((long)tz * V + ty) * V + tx) * ldc + co;
+    return s;
+  }
+  __device__ __forceinline__ uint4 load(const Row& r, const Kst& s) const {
+    if (!(r.ok && s.ok)) return make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(X + r.fine0 * ldc + s.off);
+  }
+};
+
 // implicit-GEMM view of conv3d k=3 pad=1 over channels-last X[(b*D+z)*H+y)*W+x][Cin]; k = tap*Cin + ci,
 // tap = (dz+1)*9 + (dy+1)*3 + (dx+1)
 template <typename T> struct AConv3 {
@@ -86,6 +115,21 @@ template <typename T> struct AConv3 {
 // epilogue (runtime-flagged, wave-uniform branches); operates on 8 consecutive columns
 // ------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams& ep, long grow, int gcol, float (&v)[8]) {
+  if (ep.up_k) {   // ConvTranspose3d pixel shuffle: (coarse voxel, tap, co) -> fine voxel row, channel co
+    const unsigned m = (unsigned)grow, k = (unsigned)ep.up_k, vv = (unsigned)ep.up_v;
+    const unsigned q = fdiv(m, ep.up_dv), x = m - q * vv, q2 = fdiv(q, ep.up_dv), y = q - q2 * vv, b = fdiv(q2, ep.up_dv), z = q2 - b * vv;
+    const unsigned tap = fdiv((unsigned)gcol, ep.up_dc);
+    const int co = gcol - (int)tap * ep.up_cout;
+    const unsigned tq = fdiv(tap, ep.up_dk), tx = tap - tq * k, tz = fdiv(tq, ep.up_dk), ty = tq - tz * k;
+    const long V = (long)vv * k;
+    const long fine = (((long)b * V + z * k + tz) * V + y * k + ty) * V + x * k + tx;
+    if (ep.bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += ep.bias[co + j];
+    }
+    Vec8<T>::store((T*)ep.C + fine * ep.ldc + co, v);
+    return;
+  }
   if (ep.bias) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += ep.bias[gcol + j];
@@ -507,6 +551,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
       int n = n0 + c * CE;
       ra[i] = make_uint4(0, 0, 0, 0);
       if (it < CH * CPA && m < mend && n < N) {
+        if (gm.up_k) {   // pixel-shuffled view of the fine-grid gradient (ConvTranspose3d backward)
+          const unsigned mu = (unsigned)m, k = (unsigned)gm.up_k, vv = (unsigned)gm.up_v;
+          const unsigned q = fdiv(mu, gm.up_dv), x = mu - q * vv, q2 = fdiv(q, gm.up_dv), y = q - q2 * vv, b = fdiv(q2, gm.up_dv), z = q2 - b * vv;
+          const unsigned tap = fdiv((unsigned)n, gm.dC);
+          const int co = n - (int)tap * gm.Cin;
+          const unsigned tq = fdiv(tap, gm.up_dk), tx = tap - tq * k, tz = fdiv(tq, gm.up_dk), ty = tq - tz * k;
+          const long V = (long)vv * k;
+          const long fine = (((long)b * V + z * k + tz) * V + y * k + ty) * V + x * k + tx;
+          ra[i] = *reinterpret_cast<const uint4*>(A + fine * gm.up_ldc + co);
+        } else
         ra[i] = *reinterpret_cast<const uint4*>(A + m * lda + n);
         if (rowscale) {
           float s = rowscale[m / rows_per_scale];
@@ -588,8 +642,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + (wn * NTW + a) * 16 + 4 * g + r;
         if (n < N) {
-          if (gridDim.z == 1) gm.dbias[n] += bacc[a][r];
-          else atomicAdd(gm.dbias + n, bacc[a][r]);
+          // (the shuffled view repeats each bias channel once per tap: always atomics there)
+          const int nb = gm.up_k ? n - (int)fdiv((unsigned)n, gm.dC) * gm.Cin : n;
+          if (gridDim.z == 1 && !gm.up_k) gm.dbias[nb] += bacc[a][r];
+          else atomicAdd(gm.dbias + nb, bacc[a][r]);
         }
       }
   }
@@ -636,4 +692,37 @@ int k_conv3_tn(int dt, const void* dY, const void* X, float* dW, int B, int D, i
   long M = (long)B * D * H * W;
   if (dt == NMH_DT_BF16) return dispatch_tn<bf16_t>(dY, Cout, X, bl, dW, M, Cout, 27 * Cin, nullptr, 1, gm, st);
   return dispatch_tn<float>(dY, Cout, X, bl, dW, M, Cout, 27 * Cin, nullptr, 1, gm, st);
+}
+
+// ---- ConvTranspose3d (kernel = stride) ------------------------------------------------------------------------------------------
+static void up_epi(EpiParams& ep, int k, int v, int Cout) {
+  ep.up_k = k; ep.up_v = v; ep.up_cout = Cout;
+  ep.up_dv = make_fdiv(v); ep.up_dk = make_fdiv(k); ep.up_dc = make_fdiv(Cout);
+}
+int k_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, long ldc, int B, int v, int k, int Cin, int Cout, hipStream_t st) {
+  if (Cout % 8 || Cin % 8) return -2;
+  const int M = B * v * v * v, N = k * k * k * Cout;
+  EpiParams ep{cat, ldc, bias, 0, nullptr, nullptr, nullptr, 1, 0};
+  up_epi(ep, k, v, Cout);
+  return k_gemm_nt(dt, x, Cin, Wt, Cin, M, N, Cin, ep, st);
+}
+int k_upconv_dgrad(int dt, const void* dcat, long ldc, const void* Wd, void* dx, int B, int v, int k, int Cin, int Cout, hipStream_t st) {
+  if (Cout % 8 || Cin % 8) return -2;
+  const int M = B * v * v * v, K = k * k * k * Cout;
+  EpiParams ep{dx, Cin, nullptr, 0, nullptr, nullptr, nullptr, 1, 0};
+  if (dt == NMH_DT_BF16) {
+    AUp<bf16_t> al{(const bf16_t*)dcat, ldc, v, k, Cout, make_fdiv(v), make_fdiv(k), make_fdiv(Cout)};
+    return dispatch_nt<bf16_t>(al, Wd, K, M, Cin, K, 1, ep, st);
+  }
+  AUp<float> al{(const float*)dcat, ldc, v, k, Cout, make_fdiv(v), make_fdiv(k), make_fdiv(Cout)};
+  return dispatch_nt<float>(al, Wd, K, M, Cin, K, 1, ep, st);
+}
+int k_upconv_wgrad(int dt, const void* dcat, long ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, hipStream_t st) {
+  if (Cout % 8 || Cin % 8) return -2;
+  const long M = (long)B * v * v * v;
+  const int k3 = k * k * k;
+  TnGeom gm{};
+  gm.omode = 2; gm.Cin = Cout; gm.V = (unsigned)k3; gm.dC = make_fdiv(Cout); gm.dbias = dbias;
+  gm.up_k = k; gm.up_v = v; gm.up_ldc = ldc; gm.up_dv = make_fdiv(v); gm.up_dk = make_fdiv(k);
+  return k_gemm_tn(dt, dcat, (long)k3 * Cout, x, Cin, dW, M, k3 * Cout, Cin, nullptr, 1, gm, st);
 }

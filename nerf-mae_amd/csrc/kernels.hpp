@@ -15,6 +15,10 @@ struct EpiParams {
   const void* resid;
   const float* rowscale; int rows_per_scale;
   int accumulate;
+  // ConvTranspose3d(kernel = stride = up_k) pixel shuffle folded into the store (up_k > 0): GEMM row m = coarse voxel (b,z,y,x) of a
+  // up_v^3 grid, column = tap*up_cout + co  ->  C[fine voxel (b, z*k+tz, y*k+ty, x*k+tx)][co], row stride ldc; bias indexed by co
+  int up_k, up_v, up_cout;
+  FDiv up_dv, up_dk, up_dc;
 };
 
 // geometry for gemm_tn gather / output remap
@@ -24,12 +28,22 @@ struct TnGeom {
   int Cin, D, H, W; unsigned V;
   FDiv dC, dW, dH, dV;
   float* dbias;         // optional: dbias[n] += sum_m A[m][n]*rs(m) (column sums of the A operand, e.g. a Linear's bias gradient)
+  // up_k > 0: the A operand is the pixel-shuffled view of a fine-grid tensor (ConvTranspose3d k = stride backward):
+  // A[m][n = tap*Cout + co] = X[fine voxel (m, tap)][co], X row stride up_ldc, Cout = Cin field; dbias is then indexed by co
+  int up_k, up_v; long up_ldc; FDiv up_dv, up_dk;
 };
 
 // window partition geometry (3-D shifted windows, window edge 4): real dims, padded dims, effective shifts
 struct WinMap { int B, H, W, D, PH, PW, PD, s0, s1, s2; };
 
 int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st);
+// ConvTranspose3d (kernel = stride = k) as GEMMs with the pixel shuffle folded into addressing (unetr_block.py:151-158):
+//   fwd:   cat[fine][0:Cout] = x[coarse] . Wt^T + bias   (Wt packed [(tap,co)][ci])
+//   dgrad: dx[coarse][ci] = sum_(tap,co) dcat[fine][co] Wd[ci][(tap,co)]
+//   wgrad: dW[ci][co][tap] += sum_coarse x[coarse][ci] dcat[fine][co];  dbias[co] += sum dcat
+int k_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, long ldc, int B, int v, int k, int Cin, int Cout, hipStream_t st);
+int k_upconv_dgrad(int dt, const void* dcat, long ldc, const void* Wd, void* dx, int B, int v, int k, int Cin, int Cout, hipStream_t st);
+int k_upconv_wgrad(int dt, const void* dcat, long ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, hipStream_t st);
 int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st);
 int k_gemm_tn(int dt, const void* A, long lda, const void* Bm, long ldb, float* Out, long M, int N, int K, const float* rowscale, int rows_per_scale, const TnGeom& gm, hipStream_t st);
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st);

@@ -272,10 +272,10 @@ class _UpBlockFn(torch.autograd.Function):
         dev, dtype = x.device, x.dtype
         has_skip = skip is not None
         Cc = 2 * Cout if has_skip else Cout
-        upre = ops.gemm_nt(x, pk[key + "t.w"].view(k3 * Cout, Cin))
         cat = torch.empty((B * V, Cc), dtype=dtype, device=dev)
-        ops.upconv_shuffle_fwd(upre, m.transp_conv.bias, skip, cat, B, v, k, Cout)
-        del upre
+        ops.upconv_fwd(x, pk[key + "t.w"].view(k3 * Cout, Cin), m.transp_conv.bias, cat, B, v, k, Cin, Cout)   # pixel shuffle in the epilogue
+        if has_skip:
+            cat[:, Cout:].copy_(skip)
         S = v * k
         scratch = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
         c48 = (key + "c1.wk") in pk.views and (key + "c2.wk") in pk.views
@@ -372,12 +372,11 @@ class _UpBlockFn(torch.autograd.Function):
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
             with ops.side_stream():
                 ops.gemm_tn(dy3, cat, _gradbuf(m.conv_block.conv3.weight))
-        dupre = torch.empty((B * v ** 3, k3 * Cout), dtype=dtype, device=dev)
-        dskip = torch.empty((B * V, Cout), dtype=dtype, device=dev) if has_skip else None
-        ops.upconv_shuffle_bwd(dcat, dupre, dskip, _gradbuf(m.transp_conv.bias), B, v, k, Cout, has_skip)
-        dx = ops.gemm_nt(dupre, pk[key + "t.wd"].view(Cin, k3 * Cout))
+        dskip = dcat[:, Cout:].contiguous() if has_skip else None
+        dx = torch.empty((B * v ** 3, Cin), dtype=dtype, device=dev)
+        ops.upconv_dgrad(dcat, pk[key + "t.wd"].view(Cin, k3 * Cout), dx, B, v, k, Cin, Cout)   # reads dcat through the pixel shuffle
         with ops.side_stream():
-            ops.gemm_tn(dupre, x, _gradbuf(m.transp_conv.weight), omode=2, p0=Cout, p1=k3)
+            ops.upconv_wgrad(dcat, x, _gradbuf(m.transp_conv.weight), _gradbuf(m.transp_conv.bias), B, v, k, Cin, Cout)
         ops.join_side()
         return dx, dskip, None, None, None, None
 

@@ -252,6 +252,24 @@ def patch_embed_gather(x, A, B, R):
     return A
 
 
+def upconv_fwd(x, Wt, bias, cat, B, v, k, Cin, Cout):
+    """ConvTranspose3d(k=stride): cat[fine voxel][0:Cout] = x[coarse] @ Wt^T + bias (pixel shuffle in the GEMM epilogue)"""
+    _chk(x, Wt, bias, cat)
+    lib().call("nmh_upconv_fwd", dt_of(x), x, Wt, bias, cat, cat.stride(0), B, v, k, Cin, Cout, _st())
+    return cat
+
+
+def upconv_dgrad(dcat, Wd, dx, B, v, k, Cin, Cout):
+    _chk(dcat, Wd, dx)
+    lib().call("nmh_upconv_dgrad", dt_of(dcat), dcat, dcat.stride(0), Wd, dx, B, v, k, Cin, Cout, _st())
+    return dx
+
+
+def upconv_wgrad(dcat, x, dW, dbias, B, v, k, Cin, Cout):
+    _chk(dcat, x, dW, dbias)
+    lib().call("nmh_upconv_wgrad", dt_of(dcat), dcat, dcat.stride(0), x, dW, dbias, B, v, k, Cin, Cout, _st())
+
+
 def upconv_shuffle_fwd(upre, bias, skip, out, B, v, k, Cout):
     _chk(upre, bias, skip, out)
     lib().call("nmh_upconv_shuffle_fwd", dt_of(upre), upre, bias, skip, out, B, v, k, Cout, _st())

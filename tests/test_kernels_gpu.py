@@ -349,6 +349,19 @@ def test_upconv_block_pieces(dt, k, Cin, Cout, v, skip):
     dW = torch.zeros(Cin, Cout, k, k, k, device="cuda")
     ops.gemm_tn(dupre, xcl, dW, omode=2, p0=Cout, p1=k3)
     check(dW, wr.grad, dt, "upconv dW", 2)
+    # the product path: pixel shuffle folded into the GEMM epilogue / operand loaders
+    out2 = torch.zeros(B * V ** 3, Cc, dtype=dt, device="cuda")
+    ops.upconv_fwd(xcl, wf, dev(b), out2, B, v, k, Cin, Cout)
+    check(out2[:, :Cout].float().cpu().view(B, V, V, V, Cout).permute(0, 4, 1, 2, 3), y.detach(), dt, "fused upconv fwd")
+    if skip:
+        assert out2[:, Cout:].abs().max().item() == 0.0   # the skip half is left to the caller
+    dx2 = torch.empty(B * v ** 3, Cin, dtype=dt, device="cuda")
+    ops.upconv_dgrad(dc, wd, dx2, B, v, k, Cin, Cout)
+    check(dx2.view(B, v, v, v, Cin).permute(0, 4, 1, 2, 3), xr.grad, dt, "fused upconv dx", 2)
+    dW2, db2 = torch.zeros(Cin, Cout, k, k, k, device="cuda"), torch.zeros(Cout, device="cuda")
+    ops.upconv_wgrad(dc, xcl, dW2, db2, B, v, k, Cin, Cout)
+    check(dW2, wr.grad, dt, "fused upconv dW", 2)
+    check(db2, br.grad, dt, "fused upconv dbias", 2)
 
 
 @pytest.mark.parametrize("dt", DTS)
