@@ -472,6 +472,7 @@ struct BDirectTN {
   template <typename T> __device__ __forceinline__ uint4 load(const T* B, long mglob, int k, int /*K*/, const TnGeom&) const {
     return *reinterpret_cast<const uint4*>(B + mglob * ldb + k);
   }
+  template <typename T> __device__ __forceinline__ const T* addr(const T* B, long mglob, int k, const TnGeom&) const { return B + mglob * ldb + k; }
 };
 struct BConv3TN {
   // B[m][k] = X[voxel(m)+tap(k)][ci(k)] with zero padding; m is a global voxel index over (b,z,y,x)
@@ -488,6 +489,21 @@ struct BConv3TN {
     int y = q - q2 * gm.H + dy, z = (int)q2 + dz;
     if ((unsigned)z >= (unsigned)gm.D || (unsigned)y >= (unsigned)gm.H || (unsigned)x >= (unsigned)gm.W) return make_uint4(0, 0, 0, 0);
     return *reinterpret_cast<const uint4*>(X + (mglob + ((long)dz * gm.H + dy) * gm.W + dx) * gm.Cin + ci);
+  }
+  // same element as load(), as an address (nullptr = zero padding)
+  template <typename T> __device__ __forceinline__ const T* addr(const T* X, long mglob, int k, const TnGeom& gm) const {
+    unsigned tap = fdiv((unsigned)k, gm.dC);
+    int ci = k - (int)tap * gm.Cin;
+    int t9 = tap / 9, r9 = tap - t9 * 9, t3 = r9 / 3;
+    int dz = t9 - 1, dy = t3 - 1, dx = r9 - t3 * 3 - 1;
+    unsigned b = fdiv((unsigned)mglob, gm.dV);
+    unsigned ml = (unsigned)mglob - b * gm.V;
+    unsigned q = fdiv(ml, gm.dW);
+    int x = ml - q * gm.W + dx;
+    unsigned q2 = fdiv(q, gm.dH);
+    int y = q - q2 * gm.H + dy, z = (int)q2 + dz;
+    if ((unsigned)z >= (unsigned)gm.D || (unsigned)y >= (unsigned)gm.H || (unsigned)x >= (unsigned)gm.W) return nullptr;
+    return X + (mglob + ((long)dz * gm.H + dy) * gm.W + dx) * gm.Cin + ci;
   }
 };
 
@@ -651,6 +667,171 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn, LDS-DMA pipelined variant (bf16): same 96x96 workgroup tile, wave layout, slot map and epilogue as gemm_tn_kernel, but
+// the 64-row operand chunks go global -> LDS by `global_load_lds_dwordx4` into a ring of ST stages (ST-1 chunks in flight, counted
+// vmcnt + one raw s_barrier per chunk) instead of one register-staged chunk: the contraction loop of a weight gradient is long
+// (M = tokens or voxels) and its chunks are small (24 KB), so the single-stage kernel is bound by one global-load latency per chunk.
+// LDS tiles are dense (192-byte rows; the DMA image is lane-linear) with the 8-byte column chunks of rows 4..7 (mod 8) XORed by 4,
+// which keeps the transpose reads conflict-free; the swizzle is applied on the source address of each DMA lane.
+// Stochastic-depth row scales are applied to the accumulators: the launcher aligns the M splits to the samples.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Frag<bf16_t> lds_frag_t_sw(const char* tile, int m0, int col0, int lane) {
+  constexpr int RS = 192;
+  const int g = lane >> 4, p = lane & 15;
+  const int row = m0 + 4 * g + (p >> 2);
+  const int ch = ((col0 >> 2) + (p & 3)) ^ (((row >> 2) & 1) << 2);
+  const char* a = tile + row * RS + ch * 8;
+  bf16x4 lo = ds_read_tr16(a);
+  bf16x4 hi = ds_read_tr16(a + 16 * RS);
+  Frag<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+
+template <class BL, int ST>
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bm, BL bl, float* __restrict__ Out, long Mtot, int N,
+                                                          int K, int m_per_split, const float* __restrict__ rowscale, int rows_per_scale, TnGeom gm) {
+  using T = bf16_t;
+  constexpr int NTW = 3, KTW = 3, BNW = 96, BKW = 96, CH = 64, RS = 192, TILE = CH * RS, STAGE = 2 * TILE, PCS = STAGE / 1024 / 4;  // 6 pieces per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave >> 1, wk = wave & 1, g = lane >> 4, li = lane & 15;
+  const int n0 = blockIdx.x * BNW, k0 = blockIdx.y * BKW;
+  const long mbeg = (long)blockIdx.z * m_per_split;
+  long mend = mbeg + m_per_split;
+  if (mend > Mtot) mend = Mtot;
+
+  // this lane's position in each of its 6 pieces: piece i (< 3: A tile, >= 3: B tile) covers tile bytes [1024 (wave + 4 (i%3)) + 16 lane, +16)
+  int prow[3], pcol[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int off = 1024 * (wave + 4 * i) + 16 * lane;
+    const int row = off / RS, u = (off - row * RS) >> 4;
+    prow[i] = row;
+    pcol[i] = (u ^ (((row >> 2) & 1) << 1)) * 8;   // logical column (elements) stored at this LDS position
+  }
+  unsigned long long zpage = (unsigned long long)(const void*)g_zero16_nt;
+  asm volatile("" : "+v"(zpage));
+  auto issue = [&](int c) {   // chunk c of this split -> ring slot c % ST
+    const long mc = mbeg + (long)c * CH;
+    char* slot = smem + (c % ST) * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const long m = mc + prow[i];
+      const int n = n0 + pcol[i];
+      unsigned long long src = zpage;
+      if (m < mend && n < N) {
+        if (gm.up_k) {
+          const unsigned mu = (unsigned)m, k = (unsigned)gm.up_k, vv = (unsigned)gm.up_v;
+          const unsigned q = fdiv(mu, gm.up_dv), x = mu - q * vv, q2 = fdiv(q, gm.up_dv), y = q - q2 * vv, b = fdiv(q2, gm.up_dv), z = q2 - b * vv;
+          const unsigned tap = fdiv((unsigned)n, gm.dC);
+          const int co = n - (int)tap * gm.Cin;
+          const unsigned tq = fdiv(tap, gm.up_dk), tx = tap - tq * k, tz = fdiv(tq, gm.up_dk), ty = tq - tz * k;
+          const long V = (long)vv * k;
+          const long fine = (((long)b * V + z * k + tz) * V + y * k + ty) * V + x * k + tx;
+          src = (unsigned long long)(A + fine * gm.up_ldc + co);
+        } else {
+          src = (unsigned long long)(A + m * lda + n);
+        }
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + i * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const long m = mc + prow[i];
+      const int k = k0 + pcol[i];
+      unsigned long long src = zpage;
+      if (m < mend && k < K) {
+        const T* p = bl.template addr<T>(Bm, m, k, gm);
+        if (p) src = (unsigned long long)p;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + TILE + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[NTW][KTW];
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < KTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool want_bias = gm.dbias != nullptr && blockIdx.y == 0 && wk == 0;
+  f32x4 bacc[NTW];
+  Frag<T> ones;
+#pragma unroll
+  for (int a = 0; a < NTW; ++a) bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones.v[j] = (short)0x3F80;
+
+  const int nc = mbeg < mend ? (int)((mend - mbeg + CH - 1) / CH) : 0;
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (s < nc) issue(s);
+  for (int c = 0; c < nc; ++c) {
+    if (nc - 1 - c >= ST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PCS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c + ST - 1 < nc) issue(c + ST - 1);
+    const char* sA = smem + (c % ST) * STAGE;
+    const char* sB = sA + TILE;
+#pragma unroll
+    for (int s = 0; s < CH / 32; ++s) {
+      Frag<T> bf[KTW];
+#pragma unroll
+      for (int b = 0; b < KTW; ++b) bf[b] = lds_frag_t_sw(sB, s * 32, (wk * KTW + b) * 16, lane);
+#pragma unroll
+      for (int a = 0; a < NTW; ++a) {
+        Frag<T> af = lds_frag_t_sw(sA, s * 32, (wn * NTW + a) * 16, lane);
+#pragma unroll
+        for (int b = 0; b < KTW; ++b) mma(acc[a][b], af, bf[b]);
+        if (want_bias) mma(bacc[a], af, ones);
+      }
+    }
+  }
+  const float sc = (rowscale && mbeg < Mtot) ? rowscale[mbeg / rows_per_scale] : 1.0f;   // split lies inside one sample (launcher)
+#pragma unroll
+  for (int a = 0; a < NTW; ++a)
+#pragma unroll
+    for (int b = 0; b < KTW; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n = n0 + (wn * NTW + a) * 16 + 4 * g + r, k = k0 + (wk * KTW + b) * 16 + li;
+        if (n < N && k < K) {
+          float* o = Out + omap_index(gm, n, k);
+          if (gridDim.z == 1) *o += acc[a][b][r] * sc;
+          else atomicAdd(o, acc[a][b][r] * sc);
+        }
+      }
+  if (want_bias && li == 0) {
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wn * NTW + a) * 16 + 4 * g + r;
+        if (n < N) {
+          const int nb = gm.up_k ? n - (int)fdiv((unsigned)n, gm.dC) * gm.Cin : n;
+          if (gridDim.z == 1 && !gm.up_k) gm.dbias[nb] += bacc[a][r] * sc;
+          else atomicAdd(gm.dbias + nb, bacc[a][r] * sc);
+        }
+      }
+  }
+}
+
+template <class BL, int ST>
+static int launch_tn_dma(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, long mps, const float* rs, int rps, const TnGeom& gm, hipStream_t st) {
+  constexpr int lds = ST * 2 * 64 * 192;
+  int gx = (N + 95) / 96, gy = (K + 95) / 96, gz = (int)((Mtot + mps - 1) / mps);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<BL, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_dma_kernel<BL, ST>), dim3(gx, gy, gz), dim3(256), lds, st, (const bf16_t*)A, lda, (const bf16_t*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
 template <typename T, int NTW, int KTW, class BL>
 static int launch_tn(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, const float* rs, int rps, const TnGeom& gm, hipStream_t st) {
   constexpr int BNW = 32 * NTW, BKW = 32 * KTW;
@@ -665,6 +846,22 @@ static int launch_tn(const void* A, long lda, const void* Bm, const BL& bl, floa
   if (const char* e = getenv("NMH_TN_MPS")) mps_min = atol(e);
   if (const char* e = getenv("NMH_TN_WANT")) { want = atol(e) / ((long)gx * gy); if (want < 1) want = 1; mps = ((Mtot + want - 1) / want + 63) / 64 * 64; }
   if (mps < mps_min) mps = mps_min;
+  if constexpr (std::is_same<T, bf16_t>::value && NTW == 3 && KTW == 3) {
+    // measured: 8-12 % on the implicit-GEMM conv weight gradients (their gather loader is the longer dependency chain), within
+    // noise on the plain ones (which are bound by L2 -> LDS bandwidth of the 96x96 tiles, not by latency): default on for convs only
+    static const int dma_st = [] { const char* e = getenv("NMH_TN_DMA"); return e ? atoi(e) : (std::is_same<BL, BConv3TN>::value ? 3 : 0); }();
+    if (dma_st && lda % 8 == 0) {
+      long m2 = mps;
+      if (rs) {   // row scales are applied per split: every split must lie inside one sample
+        long j = (rps + m2 - 1) / m2;
+        while (j > 1 && rps % j) --j;
+        m2 = rps / j;
+      }
+      if (dma_st == 2) return launch_tn_dma<BL, 2>(A, lda, Bm, bl, Out, Mtot, N, K, m2, rs, rps, gm, st);
+      if (dma_st == 4) return launch_tn_dma<BL, 4>(A, lda, Bm, bl, Out, Mtot, N, K, m2, rs, rps, gm, st);
+      return launch_tn_dma<BL, 3>(A, lda, Bm, bl, Out, Mtot, N, K, m2, rs, rps, gm, st);
+    }
+  }
   int gz = (int)((Mtot + mps - 1) / mps);
   hipLaunchKernelGGL((gemm_tn_kernel<T, NTW, KTW, BL>), dim3(gx, gy, gz), dim3(256), 0, st, (const T*)A, lda, (const T*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
   NMH_CHECK_LAUNCH();

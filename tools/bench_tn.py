@@ -23,3 +23,4 @@ t("qkv wgrad s2", 6912, 1152, 384)
 t("fc1 wgrad s2", 4000, 1536, 384)
 t("fc2 wgrad s2", 4000, 384, 1536)
 t("proj wgrad s2", 6912, 384, 384)
+t("fc1 wgrad s3", 500, 3072, 768)
