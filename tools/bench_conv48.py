@@ -1,6 +1,6 @@
 """micro-benchmark of the specialised decoder1 conv kernels (forward/dgrad and wgrad) at 160^3 x 48, bf16"""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from nerf_mae_amd import ops
 from tests.test_kernels_gpu import _pack_via_kernel
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
