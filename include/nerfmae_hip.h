@@ -45,6 +45,9 @@ NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int
 NMH_API int nmh_instnorm_finalize(const double* acc, float* stats, int B, int64_t V, int C, float eps, void* stream);
 /* weight gradient of the specialised layer; ws = fp32 scratch of nmh_conv3d_k3_c48_wgrad_ws_floats() elements (per-workgroup partials) */
 NMH_API int nmh_conv3d_k3_c48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, void* stream);
+/* the same LDS-halo weight-gradient kernel for any Cin, Cout that are multiples of 48 (bf16): (Cin/48)*(Cout/48) independent 48x48
+ * blocks on strided channel slices, every activation row read once per block instead of once per tap; ws as above. */
+NMH_API int nmh_conv3d_k3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, void* stream);
 NMH_API int64_t nmh_conv3d_k3_c48_wgrad_ws_floats(void);
 /* dW[Cout][Cin][3][3][3] (PyTorch layout, fp32) += conv weight gradient */
 NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, void* stream);

@@ -68,6 +68,10 @@ int nmh_conv3d_k3_c48_wgrad(const void* dY, const void* X, float* dW, float* ws,
   CLR();
   return k_conv48_wgrad(dY, X, dW, ws, B, D, H, W, ST);
 }
+int nmh_conv3d_k3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
+  CLR();
+  return k_conv3_wgrad_halo(dY, X, dW, ws, B, D, H, W, Cin, Cout, ST);
+}
 int64_t nmh_conv3d_k3_c48_wgrad_ws_floats(void) { return (int64_t)k_conv48_wgrad_ws_floats(); }
 int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
   CLR();

@@ -312,6 +312,9 @@ struct W48Args {
   const bf16_t* X; const bf16_t* dY; float* ws;
   int B, D, H, W, tz, ty, tx;
   long total;
+  // channel sub-problems: a Cin x Cout convolution is (Cin/48) x (Cout/48) independent 48 x 48 weight-gradient blocks on strided
+  // channel slices of X / dY; blockIdx.y = sub-problem (ci slice fastest).  ldx/ldy = channel counts (row strides in elements)
+  int ldx, ldy, nci;
 };
 
 __device__ __forceinline__ void w48_tile_origin(const W48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
@@ -334,9 +337,15 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, p = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  const int nx = 8, xcd = blockIdx.x % nx, jb = blockIdx.x / nx, jstride = gridDim.x / nx;
+  // one problem (decoder1): the tile range is cut into 8 XCD-contiguous parts; channel sub-problems: plain striding inside the slice
+  const bool multi = gridDim.y > 1;
+  const int nx = multi ? 1 : 8, xcd = blockIdx.x % nx, jb = blockIdx.x / nx, jstride = gridDim.x / nx;
   const long per = (a.total + nx - 1) / nx;
   const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
+  const int sub = blockIdx.y, cs = sub % a.nci, os = sub / a.nci;
+  const bf16_t* Xs = a.X + cs * 48;
+  const bf16_t* dYs = a.dY + os * 48;
+  const long ldx = a.ldx, ldy = a.ldy;
 
   uint4 hreg[HREG];
   auto halo_gload = [&](long t) {
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
         const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
         const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
         if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-          hreg[i] = *reinterpret_cast<const uint4*>(a.X + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8);
+          hreg[i] = *reinterpret_cast<const uint4*>(Xs + ((((long)b * a.D + z) * a.H + y) * a.W + x) * ldx + c6 * 8);
       }
     }
   };
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
       const int u = u0 + lane, v = u / 6, c6 = u - v * 6;
       const int line = v >> 4, x = x0 + (v & 15), z = z0 + (line >> 2), y = y0 + (line & 3);
       const void* src = (z < a.D && y < a.H && x < a.W)
-                            ? (const void*)(a.dY + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8)
+                            ? (const void*)(dYs + ((((long)b * a.D + z) * a.H + y) * a.W + x) * ldy + c6 * 8)
                             : (const void*)g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(dyb + buf * DYT + u0 * 16), 16, 0, 0);
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
     cur ^= 1;
   }
   // flush: ws[block][u][ct][row 16][col 16]
-  float* wsb = a.ws + (long)blockIdx.x * PARTIAL;
+  float* wsb = a.ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * PARTIAL;
 #pragma unroll
   for (int i = 0; i < UPW; ++i) {
     const int u = wave + NW * i;
@@ -456,25 +465,28 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   }
 }
 
-// dW[(co*48+ci)*27+tap] += sum_blocks ws[block][u = tap*3+cit][ct][row][col], co = ct*16+row, ci = cit*16+col
-__global__ void conv48_wgrad_reduce_kernel(const float* ws, float* dW, int nblocks) {
+// dW[(co*Cin+ci)*27+tap] += sum_blocks ws[sub][block][u = tap*3+cit][ct][row][col], co = os*48+ct*16+row, ci = cs*48+cit*16+col
+__global__ void conv48_wgrad_reduce_kernel(const float* ws, float* dW, int nblocks, int nci, int Cin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w48::PARTIAL) return;
+  const int sub = blockIdx.y, cs = sub % nci, os = sub / nci;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += ws[(long)b * w48::PARTIAL + i];
+  for (int b = 0; b < nblocks; ++b) s += ws[((long)sub * nblocks + b) * w48::PARTIAL + i];
   const int col = i & 15, row = (i >> 4) & 15, uc = i >> 8, ct = uc % 3, u = uc / 3, tap = u / 3, cit = u - tap * 3;
-  dW[((ct * 16 + row) * 48 + cit * 16 + col) * 27 + tap] += s;
+  dW[((long)(os * 48 + ct * 16 + row) * Cin + cs * 48 + cit * 16 + col) * 27 + tap] += s;
 }
 
 long k_conv48_wgrad_ws_floats() { return 256L * w48::PARTIAL; }
 
-int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st) {
+static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st) {
   using namespace w48;
   W48Args a;
   a.X = (const bf16_t*)X; a.dY = (const bf16_t*)dY; a.ws = ws;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
   a.total = (long)B * a.tz * a.ty * a.tx;
+  a.ldx = Cin; a.ldy = Cout; a.nci = Cin / 48;
+  const int nsub = (Cin / 48) * (Cout / 48);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv48_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -482,12 +494,26 @@ int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, i
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  int nb = a.total < 256 ? (int)((a.total + 7) / 8 * 8) : 256;
+  int nb;
+  if (nsub == 1) nb = a.total < 256 ? (int)((a.total + 7) / 8 * 8) : 256;   // 8 XCD-contiguous tile ranges
+  else {
+    nb = 256 / nsub;
+    if (nb < 1) nb = 1;
+    if (nb > a.total) nb = (int)a.total;
+  }
   static const int nw = getenv("NMH_W48_WAVES") ? atoi(getenv("NMH_W48_WAVES")) : 8;  // 8 waves x 10 blocks measured 5 % faster than 16 x 5
-  if (nw == 8) hipLaunchKernelGGL(conv48_wgrad_kernel<8>, dim3(nb), dim3(512), LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(conv48_wgrad_kernel<16>, dim3(nb), dim3(1024), LDS_BYTES, st, a);
+  if (nw == 8) hipLaunchKernelGGL(conv48_wgrad_kernel<8>, dim3(nb, nsub), dim3(512), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(conv48_wgrad_kernel<16>, dim3(nb, nsub), dim3(1024), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv48_wgrad_reduce_kernel, dim3((PARTIAL + 255) / 256), dim3(256), 0, st, ws, dW, nb);
+  hipLaunchKernelGGL(conv48_wgrad_reduce_kernel, dim3((PARTIAL + 255) / 256, nsub), dim3(256), 0, st, ws, dW, nb, a.nci, Cin);
   NMH_CHECK_LAUNCH();
   return 0;
+}
+int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st) {
+  return launch_wgrad_halo(dY, X, dW, ws, B, D, H, W, 48, 48, st);
+}
+// any Cin, Cout that are multiples of 48 (the decoder levels 96..768): (Cin/48)*(Cout/48) sub-problems, <= 256 workgroups in total
+int k_conv3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st) {
+  if (Cin % 48 || Cout % 48 || (Cin / 48) * (Cout / 48) > 256) return -2;
+  return launch_wgrad_halo(dY, X, dW, ws, B, D, H, W, Cin, Cout, st);
 }

@@ -50,6 +50,7 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
 int k_in_finalize(int dt, const double* acc, float* stats, int B, long V, int C, float eps, hipStream_t st);
 int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st);
 long k_conv48_wgrad_ws_floats();
+int k_conv3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st);
 int k_conv3_tn(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st);
 
 // ---- norm.hip ----

@@ -166,11 +166,27 @@ def conv3d_k3_c48_wgrad(dY, X, dW):
     return dW
 
 
+_HALO_WS = {}
+HALO_WGRAD = __import__("os").environ.get("NMH_HALO_WGRAD", "1") != "0"
+
+
 def conv3d_k3_wgrad(dY, X, dW):
+    """dW[Cout][Cin][3][3][3] += weight gradient.  bf16 with Cin, Cout multiples of 48: LDS-halo kernel on 48x48 channel blocks
+    (own workspace: these launches run on the side stream); otherwise the implicit-GEMM kernel."""
     _chk(dY, X, dW)
     B, D, H, W, Cin = X.shape
-    ev = _prof(("conv3d_k3_wgrad", B, D, Cin, dY.shape[-1]))
-    lib().call("nmh_conv3d_k3_wgrad", dt_of(X), dY, X, dW, B, D, H, W, Cin, dY.shape[-1], _st())
+    Cout = dY.shape[-1]
+    ev = _prof(("conv3d_k3_wgrad", B, D, Cin, Cout))
+    # (measured at 4 grids: 40^3 192->96 842 -> 354 us, 20^3 384->192 515 -> 243 us; at 10^3 the 4x4x16 tiles are mostly padding
+    # and the implicit GEMM wins: 229 vs 267 us)
+    if (HALO_WGRAD and X.dtype == torch.bfloat16 and Cin % 48 == 0 and Cout % 48 == 0 and (Cin // 48) * (Cout // 48) <= 256
+            and D * H * W >= 4096):
+        key = X.device.index
+        if key not in _HALO_WS:
+            _HALO_WS[key] = torch.empty(lib().call("nmh_conv3d_k3_c48_wgrad_ws_floats"), dtype=torch.float32, device=X.device)
+        lib().call("nmh_conv3d_k3_wgrad_halo", dY, X, dW, _HALO_WS[key], B, D, H, W, Cin, Cout, _st())
+    else:
+        lib().call("nmh_conv3d_k3_wgrad", dt_of(X), dY, X, dW, B, D, H, W, Cin, Cout, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return dW

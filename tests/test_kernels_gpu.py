@@ -104,7 +104,7 @@ def test_gemm_tn(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 5, 6, 7, 16, 24), (1, 8, 8, 8, 48, 48), (1, 4, 9, 5, 96, 48), (1, 10, 10, 10, 24, 96)])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 5, 6, 7, 16, 24), (1, 8, 8, 8, 48, 48), (1, 4, 9, 5, 96, 48), (1, 10, 10, 10, 24, 96), (2, 10, 10, 10, 192, 96), (1, 5, 6, 20, 96, 192)])
 def test_conv3d_fwd_dgrad_wgrad(dt, B, D, H, W, Cin, Cout):
     ops = _ops()
     x = q(rnd(B, Cin, D, H, W), dt)
