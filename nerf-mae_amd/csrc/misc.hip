@@ -378,16 +378,18 @@ int k_fill_f32(float* p, float v, long n, hipStream_t st) {
 //  mode 6/7 conv48 fragment order (conv48.hip): dst [step 41][ntile 3][lane 64][8] from the mode-2 (fwd) / mode-3 (dgrad) view
 //           W'[n][tap][k]: lane (li = n%16, g), slot j; steps < 36: tap-row r = 4*(s/18)+g, vector c = s%18; steps >= 36: row 8,
 //           c = 4*(s-36)+g (c >= 18 -> zero padding)
-__device__ __forceinline__ long pack_src_index(const PackDesc& d, long i) {
+// (32-bit index math: every packed tensor has < 2^31 elements; 64-bit div/mod is ~10x the instructions)
+__device__ __forceinline__ long pack_src_index(const PackDesc& d, long il) {
+  const unsigned i = (unsigned)il, d0 = (unsigned)d.d0, d1 = (unsigned)d.d1, d2 = (unsigned)d.d2;
   switch (d.mode) {
-    case 1: { long c = i / d.d0, r = i - c * d.d0; return r * d.d1 + c; }
-    case 2: { long ci = i % d.d1; long t2 = i / d.d1; long t = t2 % 27, co = t2 / 27; return (co * d.d1 + ci) * 27 + t; }
-    case 3: { long co = i % d.d0; long t2 = i / d.d0; long t = t2 % 27, ci = t2 / 27; return (co * d.d1 + ci) * 27 + (26 - t); }
-    case 4: { long ci = i % d.d0; long t2 = i / d.d0; long co = t2 % d.d1, t = t2 / d.d1; return (ci * d.d1 + co) * d.d2 + t; }
-    case 5: { long n = (long)d.d1 * d.d2; long ci = i / n, r = i - ci * n; long t = r / d.d1, co = r - t * d.d1; return (ci * d.d1 + co) * d.d2 + t; }
+    case 1: { unsigned c = i / d0, r = i - c * d0; return (long)(r * d1 + c); }
+    case 2: { unsigned t2 = i / d1, ci = i - t2 * d1, co = t2 / 27u, t = t2 - co * 27u; return (long)((co * d1 + ci) * 27u + t); }
+    case 3: { unsigned t2 = i / d0, co = i - t2 * d0, ci = t2 / 27u, t = t2 - ci * 27u; return (long)((co * d1 + ci) * 27u + (26u - t)); }
+    case 4: { unsigned t2 = i / d0, ci = i - t2 * d0, t = t2 / d1, co = t2 - t * d1; return (long)((ci * d1 + co) * d2 + t); }
+    case 5: { unsigned n = d1 * d2, ci = i / n, r = i - ci * n, t = r / d1, co = r - t * d1; return (long)((ci * d1 + co) * d2 + t); }
     case 6: case 7: {
       const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-      const long sn = i >> 9;
+      const unsigned sn = i >> 9;
       const int nt = (int)(sn % 3), st = (int)(sn / 3), g = lane >> 4, n = nt * 16 + (lane & 15);
       int r, c;
       if (st < 36) { r = 4 * (st / 18) + g; c = st % 18; } else { r = 8; c = 4 * (st - 36) + g; }
@@ -396,7 +398,7 @@ __device__ __forceinline__ long pack_src_index(const PackDesc& d, long i) {
       // W'[n][tap][k]: fwd  = W[co=n][ci=k][tap];  dgrad = W[co=k][ci=n][26-tap]
       return d.mode == 6 ? ((long)n * 48 + k) * 27 + tap : ((long)k * 48 + n) * 27 + (26 - tap);
     }
-    default: return i;
+    default: return il;
   }
 }
 template <typename T> __global__ void pack_kernel(const PackDesc* descs, const int* blk2desc, const long* blkstart) {
