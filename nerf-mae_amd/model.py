@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import math
 import random
+import os
 import struct
 from functools import partial
 from typing import Callable, List, Optional, Sequence
@@ -101,7 +102,10 @@ class _Packer:
         esz = self.buf.element_size()
         descs, blk2desc, blkstart = b"", [], []
         off = 0
+        self.split = None   # first block of the decoder packs (they can be produced while the encoder runs)
         for i, (key, p, mode, dims, n) in enumerate(self.items):
+            if self.split is None and key.startswith("decoder"):
+                self.split = len(blk2desc)
             self.views[key] = self.buf[off:off + n]
             descs += struct.pack("<QQiiiiq", p.data_ptr(), self.buf.data_ptr() + off * esz, mode, dims[0], dims[1], dims[2], n)
             for s in range(0, n, 1024):
@@ -114,7 +118,19 @@ class _Packer:
         self.dt = ops.BF16 if dtype == torch.bfloat16 else ops.F32
 
     def run(self):
-        ops.pack_weights(self.dt, self.descs, self.blk2desc, self.blkstart, self.blk2desc.numel())
+        """encoder layouts on the current stream; the decoder layouts (60 % of the elements, the stride-27 conv gathers) on the
+        forked side stream, where they overlap the latency-bound encoder -- `join()` before the decoder reads them"""
+        n = self.blk2desc.numel()
+        sp = self.split if (self.split and ops.side_stream.enabled and os.environ.get("NMH_PACK_SPLIT", "1") != "0") else n
+        if sp > 0:
+            ops.pack_weights(self.dt, self.descs, self.blk2desc[:sp], self.blkstart[:sp], sp)
+        if sp < n:
+            with ops.side_stream():
+                ops.pack_weights(self.dt, self.descs, self.blk2desc[sp:], self.blkstart[sp:], n - sp)
+
+    @staticmethod
+    def join():
+        ops.join_side()
 
     def __getitem__(self, key):
         return self.views[key]
@@ -711,6 +727,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
         return feats
 
     def forward_decoder(self, feats: List[Tensor], tail=None) -> Tensor:
+        self._packer.join()   # decoder weight layouts are packed on the side stream while the encoder runs
         f3 = feats[3]
         if self._reducer is not None:
             f3 = self._reducer.trigger(f3, len(self.stages) + 1)  # decoder4 is the last decoder op in backward order

@@ -2,7 +2,7 @@
 import sys
 import time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from nerf_mae_amd import ops
 
 dt = torch.bfloat16
