@@ -361,10 +361,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
     __builtin_amdgcn_wave_barrier();
   }
   const int binA0 = ((((lane0 & 15) >> 2) - (lane0 >> 4)) + 3) * 7 + (lane0 & 3) + 3;
+  // lanes of one 16-lane group hit 16 distinct bins, lanes of different groups may share one: one group at a time keeps every
+  // ds_add_f32 conflict-free (same-address LDS float atomics inside an instruction cost ~300 ns each on this part)
 #pragma unroll
-  for (int q = 0; q < 7; ++q)
+  for (int ph = 0; ph < 4; ++ph) {
+    if ((lane0 >> 4) == ph) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(&sDB[binA0 + q * 49 - r], dsacc[q][r]);
+      for (int q = 0; q < 7; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&sDB[binA0 + q * 49 - r], dsacc[q][r]);
+    }
+  }
   __syncthreads();
   for (int t = threadIdx.x; t < 343; t += 64 * NW) atomicAdd(dtable + t * heads + h, sDB[t]);
 }

@@ -5,6 +5,7 @@
 // unetr_block.py:57-71 (IN eps=1e-5, no affine; LeakyReLU 0.01).
 #include "common.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // window maps.  Window-ordered row m = ((b*nwz+wz)*nwy+wy)*nwx+wx)*64 + tz*16+ty*4+tx.
@@ -175,10 +176,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   const T* dy = (const T*)a.dy;
   T* dx = (T*)a.dx;
   const float invC = 1.0f / (float)C;
-  for (int i = threadIdx.x; i < 3 * C; i += 256) sacc[i] = 0.f;
-  __syncthreads();
   // small rows keep dgamma/dbeta partials in registers; wide rows (NCH >= 4) flush per row to LDS
   constexpr bool FLUSH = NCH >= 4;
+  for (int i = threadIdx.x; i < (FLUSH ? 3 : 12) * C; i += 256) sacc[i] = 0.f;   // [4 waves][3][C] (one slab when flushing per row)
+  __syncthreads();
   constexpr int PN = FLUSH ? 1 : NCH, PMN = (MODE == 0 && !FLUSH) ? NCH : 1;
   float pg[PN][8], pb[PN][8], pm[PMN][8];
 #pragma unroll
@@ -262,32 +263,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     }
   }
   if (!FLUSH) {
+    // the 64/LPR rows of a wave hold partials for the SAME columns: sum them with shuffles first, then one row-lane group issues
+    // conflict-free LDS adds (64/LPR-way same-address ds_add_f32 measured ~300 ns per instruction: 15 of this kernel's 27 us)
+    const bool lead = (threadIdx.x & 63) < LPR;
 #pragma unroll
     for (int i = 0; i < PN; ++i) {
       const int c = sub + i * LPR;
-      if (c < nch)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          atomicAdd(&sacc[c * 8 + j], pg[i][j]);
-          atomicAdd(&sacc[C + c * 8 + j], pb[i][j]);
-          if (MODE == 0 && a.mask) atomicAdd(&sacc[2 * C + c * 8 + j], pm[MODE == 0 ? i : 0][j]);
+      for (int j = 0; j < 8; ++j) {
+        float vg = pg[i][j], vb = pb[i][j], vm = (MODE == 0 && a.mask) ? pm[MODE == 0 ? i : 0][j] : 0.f;
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+          vg += __shfl_xor(vg, o, 64);
+          vb += __shfl_xor(vb, o, 64);
+          if (MODE == 0 && a.mask) vm += __shfl_xor(vm, o, 64);
         }
+        if (lead && c < nch) {   // per-wave slab: plain stores, summed over the 4 waves below
+          float* sw = sacc + (threadIdx.x >> 6) * 3 * C;
+          sw[c * 8 + j] = vg;
+          sw[C + c * 8 + j] = vb;
+          if (MODE == 0 && a.mask) sw[2 * C + c * 8 + j] = vm;
+        }
+      }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(a.dgamma + i, sacc[i]);
-    atomicAdd(a.dbeta + i, sacc[C + i]);
-    if (MODE == 0 && a.mask) atomicAdd(a.dmask_token + i, sacc[2 * C + i]);
+    float g = sacc[i], b = sacc[C + i], m = sacc[2 * C + i];
+    if (!FLUSH) {
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { g += sacc[w * 3 * C + i]; b += sacc[w * 3 * C + C + i]; m += sacc[w * 3 * C + 2 * C + i]; }
+    }
+    atomicAdd(a.dgamma + i, g);
+    atomicAdd(a.dbeta + i, b);
+    if (MODE == 0 && a.mask) atomicAdd(a.dmask_token + i, m);
   }
 }
 
 template <typename T, int MODE> static int ln_bwd_dispatch(const LnBwdArgs& a, hipStream_t st) {
   const int nch = a.C / 8;
   if (a.C % 8) return -2;
-  const size_t lds = 3 * (size_t)a.C * sizeof(float);
 #define LNB_LAUNCH(LPR, NCH)                                                                        \
   {                                                                                                 \
+    const size_t lds = ((NCH) >= 4 ? 3 : 12) * (size_t)a.C * sizeof(float);                         \
     long nb = (a.rows + (256 / LPR) - 1) / (256 / LPR);                                             \
     if (nb > 1024) nb = 1024;                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NCH, MODE>), dim3((unsigned)nb), dim3(256), lds, st, a); \
