@@ -32,8 +32,10 @@ NMH_API const char* nmh_error_string(int code);
 NMH_API int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* C, int64_t ldc, const float* bias, int act, void* C2, const void* resid, const float* rowscale, int rows_per_scale, int accumulate, void* stream);
 /* dW[N,K] += sum_m A[m,N]*rowscale . B[m,K]  (fp32 atomics): weight gradients of the ops above.
  * omode 0: dW[n*ldo+k]; omode 2: ConvTranspose3d weight [Cin=K][Cout=p0][k3=p1] with n = tap*Cout+co.
- * dbias (optional): dbias[n] += sum_m A[m,n]*rowscale -- the layer's bias gradient from the same pass over A. */
-NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale, int omode, int64_t ldo, int p0, int p1, float* dbias, void* stream);
+ * dbias (optional): dbias[n] += sum_m A[m,n]*rowscale -- the layer's bias gradient from the same pass over A.
+ * ws (optional, ws_floats fp32): scratch for the partial tiles of a split contraction; with it the splits are summed by a second
+ * launch instead of fp32 global atomics (one scratch per stream: concurrent calls must not share it). */
+NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale, int omode, int64_t ldo, int p0, int p1, float* dbias, float* ws, int64_t ws_floats, void* stream);
 /* Y[(b,z,y,x)][Cout] (+)= conv3d(k=3,pad=1) of channels-last X with packed weights [Cout][27][Cin] (nn.Conv3d in
  * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout]. */
 NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);

@@ -31,11 +31,11 @@ int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, 
   return k_gemm_nt(dt, A, lda, W, ldw, M, N, K, ep, ST);
 }
 int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale,
-                int omode, int64_t ldo, int p0, int p1, float* dbias, void* stream) {
+                int omode, int64_t ldo, int p0, int p1, float* dbias, float* ws, int64_t ws_floats, void* stream) {
   CLR();
   if (M <= 0) return 0;
   TnGeom gm{};
-  gm.omode = omode; gm.ldo = ldo; gm.dbias = dbias;
+  gm.omode = omode; gm.ldo = ldo; gm.dbias = dbias; gm.ws = ws; gm.ws_floats = ws ? (long)ws_floats : 0;
   if (omode == 2) { gm.Cin = p0; gm.V = (unsigned)p1; gm.dC = make_fdiv(p0); }
   return k_gemm_tn(dt, A, lda, B, ldb, dW, M, N, K, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, gm, ST);
 }

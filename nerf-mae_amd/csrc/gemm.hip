@@ -646,6 +646,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
       for (int r = 0; r < 4; ++r) {
         int n = n0 + (wn * NTW + a) * 16 + 4 * g + r, k = k0 + (wk * KTW + b) * 16 + li;
         if (n < N && k < K) {
+          if (gm.part) { gm.part[((long)blockIdx.z * N + n) * K + k] = acc[a][b][r]; continue; }  // summed by tn_reduce_kernel
           float* o = Out + omap_index(gm, n, k);
           if (gridDim.z == 1) *o += acc[a][b][r];  // sole owner of this output element: plain read-modify-write
           else atomicAdd(o, acc[a][b][r]);
@@ -658,6 +659,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + (wn * NTW + a) * 16 + 4 * g + r;
         if (n < N) {
+          if (gm.part) { gm.part[(long)gridDim.z * N * K + (long)blockIdx.z * N + n] = bacc[a][r]; continue; }
           // (the shuffled view repeats each bias channel once per tap: always atomics there)
           const int nb = gm.up_k ? n - (int)fdiv((unsigned)n, gm.dC) * gm.Cin : n;
           if (gridDim.z == 1 && !gm.up_k) gm.dbias[nb] += bacc[a][r];
@@ -797,6 +799,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
       for (int r = 0; r < 4; ++r) {
         int n = n0 + (wn * NTW + a) * 16 + 4 * g + r, k = k0 + (wk * KTW + b) * 16 + li;
         if (n < N && k < K) {
+          if (gm.part) { gm.part[((long)blockIdx.z * N + n) * K + k] = acc[a][b][r] * sc; continue; }
           float* o = Out + omap_index(gm, n, k);
           if (gridDim.z == 1) *o += acc[a][b][r] * sc;
           else atomicAdd(o, acc[a][b][r] * sc);
@@ -809,6 +812,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + (wn * NTW + a) * 16 + 4 * g + r;
         if (n < N) {
+          if (gm.part) { gm.part[(long)gridDim.z * N * K + (long)blockIdx.z * N + n] = bacc[a][r] * sc; continue; }
           const int nb = gm.up_k ? n - (int)fdiv((unsigned)n, gm.dC) * gm.Cin : n;
           if (gridDim.z == 1 && !gm.up_k) gm.dbias[nb] += bacc[a][r] * sc;
           else atomicAdd(gm.dbias + nb, bacc[a][r] * sc);
@@ -817,10 +821,39 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
   }
 }
 
+
+// sums the split partials [gz][N][K] (+ [gz][N] bias sums) into Out / dbias: one thread per output element, coalesced over k
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int gz, int N, int K, float* __restrict__ Out, TnGeom gm) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x, NK = (long)N * K;
+  if (i < NK) {
+    float s = 0.f;
+    for (int z = 0; z < gz; ++z) s += part[(long)z * NK + i];
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    Out[omap_index(gm, n, k)] += s;
+  } else if (gm.dbias && i < NK + N) {
+    const int n = (int)(i - NK);
+    float s = 0.f;
+    for (int z = 0; z < gz; ++z) s += part[(long)gz * NK + (long)z * N + n];
+    if (gm.up_k) atomicAdd(gm.dbias + (n - (int)fdiv((unsigned)n, gm.dC) * gm.Cin), s);
+    else gm.dbias[n] += s;
+  }
+}
+// many splits of a small output (the 256000-row stage-0 gradients: 125-250 splits) would write more partial bytes than the operands
+// hold; those keep the atomics
+static int tn_ws_max_splits() { static const int v = getenv("NMH_TN_WS_SPLITS") ? atoi(getenv("NMH_TN_WS_SPLITS")) : 16; return v; }
+static int launch_tn_reduce(const TnGeom& gm, int gz, int N, int K, float* Out, hipStream_t st) {
+  const long tot = (long)N * K + (gm.dbias ? N : 0);
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gm.part, gz, N, K, Out, gm);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
 template <class BL, int ST>
-static int launch_tn_dma(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, long mps, const float* rs, int rps, const TnGeom& gm, hipStream_t st) {
+static int launch_tn_dma(const void* A, long lda, const void* Bm, const BL& bl, float* Out, long Mtot, int N, int K, long mps, const float* rs, int rps, const TnGeom& gm0, hipStream_t st) {
   constexpr int lds = ST * 2 * 64 * 192;
   int gx = (N + 95) / 96, gy = (K + 95) / 96, gz = (int)((Mtot + mps - 1) / mps);
+  TnGeom gm = gm0;
+  gm.part = (gm.ws && gz > 1 && gz <= tn_ws_max_splits() && (long)gz * N * (K + 1) <= gm.ws_floats) ? gm.ws : nullptr;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<BL, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -829,6 +862,7 @@ static int launch_tn_dma(const void* A, long lda, const void* Bm, const BL& bl, 
   }
   hipLaunchKernelGGL((gemm_tn_dma_kernel<BL, ST>), dim3(gx, gy, gz), dim3(256), lds, st, (const bf16_t*)A, lda, (const bf16_t*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
   NMH_CHECK_LAUNCH();
+  if (gm.part) return launch_tn_reduce(gm, gz, N, K, Out, st);
   return 0;
 }
 
@@ -863,8 +897,11 @@ static int launch_tn(const void* A, long lda, const void* Bm, const BL& bl, floa
     }
   }
   int gz = (int)((Mtot + mps - 1) / mps);
-  hipLaunchKernelGGL((gemm_tn_kernel<T, NTW, KTW, BL>), dim3(gx, gy, gz), dim3(256), 0, st, (const T*)A, lda, (const T*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
+  TnGeom gp = gm;
+  gp.part = (gp.ws && gz > 1 && gz <= tn_ws_max_splits() && (long)gz * N * (K + 1) <= gp.ws_floats) ? gp.ws : nullptr;
+  hipLaunchKernelGGL((gemm_tn_kernel<T, NTW, KTW, BL>), dim3(gx, gy, gz), dim3(256), 0, st, (const T*)A, lda, (const T*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gp);
   NMH_CHECK_LAUNCH();
+  if (gp.part) return launch_tn_reduce(gp, gz, N, K, Out, st);
   return 0;
 }
 

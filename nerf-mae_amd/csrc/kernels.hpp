@@ -31,6 +31,10 @@ struct TnGeom {
   // up_k > 0: the A operand is the pixel-shuffled view of a fine-grid tensor (ConvTranspose3d k = stride backward):
   // A[m][n = tap*Cout + co] = X[fine voxel (m, tap)][co], X row stride up_ldc, Cout = Cin field; dbias is then indexed by co
   int up_k, up_v; long up_ldc; FDiv up_dv, up_dk;
+  // split-contraction partials: with a workspace the M splits store plain fp32 partial tiles [split][N][K] (+ [split][N] bias sums)
+  // and a second kernel sums them into Out -- instead of gz fp32 global atomics per output element (measured: the atomics are
+  // most of the time of the small-M weight gradients)
+  float* ws; long ws_floats; float* part;
 };
 
 // window partition geometry (3-D shifted windows, window edge 4): real dims, padded dims, effective shifts

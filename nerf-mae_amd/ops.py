@@ -109,14 +109,30 @@ def gemm_nt(A, W, bias=None, act=0, C2=None, resid=None, rowscale=None, rows_per
     return out
 
 
+_TN_WS = {}
+TN_WS_FLOATS = int(__import__("os").environ.get("NMH_TN_WS_MB", "48")) * (1 << 18)   # 0 disables (fp32 atomics instead)
+
+
+def _tn_workspace(device):
+    """scratch for split-contraction partials, one per (device, stream): weight-gradient GEMMs of the main and the side stream overlap"""
+    if TN_WS_FLOATS <= 0:
+        return None
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _TN_WS.get(key)
+    if ws is None:
+        ws = _TN_WS[key] = torch.empty(TN_WS_FLOATS, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm_tn(A, B, dW, rowscale=None, rows_per_scale=1, omode=0, ldo=None, p0=0, p1=0, N=None, K=None, M=None, dbias=None):
     """dW[N,K] += A[M,N]^T @ B[M,K] (fp32 atomics into dW); dbias[N] += column sums of A (optional, same pass)."""
     _chk(A, B, dW, rowscale, dbias)
     M = A.shape[0] if M is None else M
     N = A.shape[1] if N is None else N
     K = B.shape[1] if K is None else K
+    ws = _tn_workspace(A.device)
     lib().call("nmh_gemm_tn", dt_of(A), A, A.stride(0), B, B.stride(0), dW, M, N, K, rowscale, rows_per_scale, omode,
-               K if ldo is None else ldo, p0, p1, dbias, _st())
+               K if ldo is None else ldo, p0, p1, dbias, ws, 0 if ws is None else ws.numel(), _st())
     return dW
 
 
