@@ -461,21 +461,27 @@ __global__ __launch_bounds__(256) void in_reduce_kernel(const T* x, const T* dou
         }
       }
     }
+  }
+  // block reduction without LDS atomics (the NV voxel lanes of a channel all hit the same address: same-address ds_add_f32 costs
+  // ~300 ns per instruction, which dominated the short blocks of the coarse decoder levels): every thread parks its partials in a
+  // private column of sp[value][thread]; thread (k, c) then sums the NV entries of its channel
+  float* sp = sred + 4 * C;   // [32][256]
+  const int nk = (BWD && rmode == 2) ? 4 : 2;
+  if (vl < NV) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      atomicAdd(&sred[cl * 8 + j], s1[j]);
-      atomicAdd(&sred[C + cl * 8 + j], s2[j]);
-      if (BWD && rmode == 2) { atomicAdd(&sred[2 * C + cl * 8 + j], t1[j]); atomicAdd(&sred[3 * C + cl * 8 + j], t2[j]); }
+      sp[(0 * 8 + j) * 256 + threadIdx.x] = s1[j];
+      sp[(1 * 8 + j) * 256 + threadIdx.x] = s2[j];
+      if (BWD && rmode == 2) { sp[(2 * 8 + j) * 256 + threadIdx.x] = t1[j]; sp[(3 * 8 + j) * 256 + threadIdx.x] = t2[j]; }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) {
-    atomicAdd(&acc[((long)b * C + i) * 2], (double)sred[i]);
-    atomicAdd(&acc[((long)b * C + i) * 2 + 1], (double)sred[C + i]);
-    if (BWD && rmode == 2) {
-      atomicAdd(&acc_r[((long)b * C + i) * 2], (double)sred[2 * C + i]);
-      atomicAdd(&acc_r[((long)b * C + i) * 2 + 1], (double)sred[3 * C + i]);
-    }
+  for (int i = threadIdx.x; i < nk * C; i += 256) {
+    const int k = i / C, c = i - k * C, ccl = c >> 3, j = c & 7;
+    float t = 0.f;
+    for (int q = 0; q < NV; ++q) t += sp[(k * 8 + j) * 256 + ccl + CL * q];
+    double* dst = (k < 2 ? acc : acc_r) + ((long)b * C + c) * 2 + (k & 1);
+    atomicAdd(dst, (double)t);
   }
 }
 template <typename T>
@@ -503,7 +509,7 @@ int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long
   if (e != hipSuccess) return (int)e;
   const long vpb = in_vox_per_block(V);
   dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
-  size_t lds = 4 * C * sizeof(float);
+  size_t lds = (4 * C + 32 * 256) * sizeof(float);
   if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 0>), grid, dim3(256), lds, st, (const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f, vpb);
   else hipLaunchKernelGGL((in_reduce_kernel<float, 0>), grid, dim3(256), lds, st, (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, scratch, nullptr, V, C, 0.f, vpb);
   NMH_CHECK_LAUNCH();
@@ -528,7 +534,7 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
   if (rmode == 2) { e = hipMemsetAsync(sums_r, 0, sizeof(double) * 2 * B * C, st); if (e != hipSuccess) return (int)e; }
   const long vpb = in_vox_per_block(V);
   dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
-  size_t lds = 4 * C * sizeof(float);
+  size_t lds = (4 * C + 32 * 256) * sizeof(float);
   if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 1>), grid, dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)out, stats, (const bf16_t*)r, stats_r, rmode, sums, sums_r, V, C, slope, vpb);
   else hipLaunchKernelGGL((in_reduce_kernel<float, 1>), grid, dim3(256), lds, st, (const float*)x, (const float*)dout, (const float*)out, stats, (const float*)r, stats_r, rmode, sums, sums_r, V, C, slope, vpb);
   NMH_CHECK_LAUNCH();
