@@ -40,11 +40,8 @@ NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64
  * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout]. */
 NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 /* The same convolution specialised for Cin = Cout = 48, bf16 (decoder1.conv_block at 160^3 -- 75 % of the model's FLOPs): persistent
- * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad).
- * stats_acc (optional fp64 [B][48][2]): per-channel {sum, sum of squares} of the outputs (InstanceNorm statistics, see
- * nmh_instnorm_finalize); with bwd_y / bwd_stats ({mean, rstd} of bwd_y) the launch is an input-gradient conv followed by the
- * backward of lrelu(IN(bwd_y)) and stats_acc receives that backward's {sum g, sum g*yhat} (unetr_block.py:57-61 backward). */
-NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, const void* bwd_y, const float* bwd_stats, float slope, void* stream);
+ * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad). */
+NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, void* stream);
 /* stats_acc (optional, fp64 [B][48][2], zeroed by the call): the conv epilogue also accumulates per-(sample,channel) sum and sum of squares of
  * its outputs, i.e. the InstanceNorm3d statistics of the following norm layer; nmh_instnorm_finalize turns them into {mean, rstd}. */
 NMH_API int nmh_instnorm_finalize(const double* acc, float* stats, int B, int64_t V, int C, float eps, void* stream);

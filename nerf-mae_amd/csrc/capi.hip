@@ -56,10 +56,9 @@ int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, 
   EpiParams ep{Y, Cout, nullptr, 0, nullptr, nullptr, nullptr, 1, accumulate};
   return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
 }
-int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, const void* bwd_y,
-                      const float* bwd_stats, float slope, void* stream) {
+int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, void* stream) {
   CLR();
-  return k_conv48(X, Wk, Y, B, D, H, W, accumulate, stats_acc, bwd_y, bwd_stats, slope, ST);
+  return k_conv48(X, Wk, Y, B, D, H, W, accumulate, stats_acc, ST);
 }
 int nmh_instnorm_finalize(const double* acc, float* stats, int B, int64_t V, int C, float eps, void* stream) {
   CLR();

@@ -21,8 +21,7 @@ namespace c48 {
 constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
 constexpr int LINE = HX * 96 + 16, PLANE = HY * LINE + 16, HALO = (TZ + 2) * PLANE;
 constexpr int NSTEP = 41, CSTEPS = 9, WCHUNK = CSTEPS * 3 * 1024;
-constexpr int STAT_OFF = HALO + 2 * WCHUNK;   // [48][2] floats: {mean, rstd} of the sample being processed (backward-sum epilogue)
-constexpr int LDS_BYTES = STAT_OFF + 48 * 2 * 4;
+constexpr int LDS_BYTES = HALO + 2 * WCHUNK;
 constexpr int HCH = (TZ + 2) * HY * HX * 6;  // 16-B chunks in the halo (6480)
 constexpr int HREG = (HCH + 511) / 512;      // 13
 static_assert(HREG == 13, "the counted vmcnt(13) in the chunk barrier assumes 13 halo loads per thread");
@@ -37,10 +36,6 @@ struct C48Args {
   long total;                  // B*tz*ty*tx
   int accumulate;
   double* stats_acc;           // optional [B][48][2] fp64 accumulators: per-channel sum / sum of squares of the (bf16-rounded) outputs
-  // backward-sum epilogue (the launch computes dA = conv-dgrad and the next op is the backward of lrelu(IN(y))): with bwd_y/bwd_stats
-  // the accumulators receive {sum g, sum g*yhat}, g = dA * lrelu'(yhat), i.e. exactly what the InstanceNorm-backward reduction pass
-  // would compute from a second read of dA and y
-  const bf16_t* bwd_y; const float* bwd_stats; float slope;
 };
 
 __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
@@ -230,14 +225,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       int b, z0, y0, x0;
       c48_tile_origin(a, t, b, z0, y0, x0);
       const int z = z0 + z_l, x = x0 + li;
-      if (a.stats_acc && b != st_b) {
-        stats_flush(); st_b = b;
-        if (a.bwd_y) {   // (b is uniform over the workgroup: every wave takes this branch together)
-          __syncthreads();
-          if (tid < 96) reinterpret_cast<float*>(smem + STAT_OFF)[tid] = a.bwd_stats[(long)b * 96 + tid];
-          __syncthreads();
-        }
-      }
+      if (a.stats_acc && b != st_b) { stats_flush(); st_b = b; }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = y0 + y_l + i;
@@ -258,20 +246,8 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
             *reinterpret_cast<uint2*>(dst + 16 * n) = w2;
             if (a.stats_acc) {  // statistics of exactly what the normalisation pass will read back
               const float q0 = bf2f(h0), q1 = bf2f(h1), q2 = bf2f(h2), q3 = bf2f(h3);
-              if (!a.bwd_y) {
-                st1[n][0] += q0; st1[n][1] += q1; st1[n][2] += q2; st1[n][3] += q3;
-                st2[n][0] += q0 * q0; st2[n][1] += q1 * q1; st2[n][2] += q2 * q2; st2[n][3] += q3 * q3;
-              } else {
-                const uint2 yv = *reinterpret_cast<const uint2*>(a.bwd_y + (dst - a.Y) + 16 * n);
-                const float* sst = reinterpret_cast<const float*>(smem + STAT_OFF) + (16 * n + 4 * g) * 2;   // {mean, rstd} x 4 channels
-                const float4 ma = *reinterpret_cast<const float4*>(sst), mb = *reinterpret_cast<const float4*>(sst + 4);
-                const float x0h = (__uint_as_float(yv.x << 16) - ma.x) * ma.y, x1h = (__uint_as_float(yv.x & 0xffff0000u) - ma.z) * ma.w;
-                const float x2h = (__uint_as_float(yv.y << 16) - mb.x) * mb.y, x3h = (__uint_as_float(yv.y & 0xffff0000u) - mb.z) * mb.w;
-                const float g0 = q0 * (x0h > 0.f ? 1.f : a.slope), g1 = q1 * (x1h > 0.f ? 1.f : a.slope);
-                const float g2 = q2 * (x2h > 0.f ? 1.f : a.slope), g3 = q3 * (x3h > 0.f ? 1.f : a.slope);
-                st1[n][0] += g0; st1[n][1] += g1; st1[n][2] += g2; st1[n][3] += g3;
-                st2[n][0] += g0 * x0h; st2[n][1] += g1 * x1h; st2[n][2] += g2 * x2h; st2[n][3] += g3 * x3h;
-              }
+              st1[n][0] += q0; st1[n][1] += q1; st1[n][2] += q2; st1[n][3] += q3;
+              st2[n][0] += q0 * q0; st2[n][1] += q1 * q1; st2[n][2] += q2 * q2; st2[n][3] += q3 * q3;
             }
           }
         }
@@ -284,8 +260,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   if (a.stats_acc) stats_flush();
 }
 
-int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, const void* bwd_y, const float* bwd_stats,
-             float slope, hipStream_t st) {
+int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st) {
   using namespace c48;
   C48Args a;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
@@ -294,8 +269,6 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   a.total = (long)B * a.tz * a.ty * a.tx;
   a.accumulate = accumulate;
   a.stats_acc = stats_acc;
-  a.bwd_y = stats_acc ? (const bf16_t*)bwd_y : nullptr; a.bwd_stats = bwd_stats; a.slope = slope;
-  if (bwd_y && (!stats_acc || !bwd_stats || accumulate)) return -2;
   if (stats_acc) {
     hipError_t e = hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * 48 * B, st);
     if (e != hipSuccess) return (int)e;

@@ -50,8 +50,7 @@ int k_upconv_dgrad(int dt, const void* dcat, long ldc, const void* Wd, void* dx,
 int k_upconv_wgrad(int dt, const void* dcat, long ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, hipStream_t st);
 int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st);
 int k_gemm_tn(int dt, const void* A, long lda, const void* Bm, long ldb, float* Out, long M, int N, int K, const float* rowscale, int rows_per_scale, const TnGeom& gm, hipStream_t st);
-int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, const void* bwd_y, const float* bwd_stats,
-             float slope, hipStream_t st);
+int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st);
 int k_in_finalize(int dt, const double* acc, float* stats, int B, long V, int C, float eps, hipStream_t st);
 int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st);
 long k_conv48_wgrad_ws_floats();

@@ -371,19 +371,14 @@ class _UpBlockFn(torch.autograd.Function):
             ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, rmode=1, dr=dcat)  # dcat <- g (plain residual)
         conv = ctx.conv
         wgrad = ops.conv3d_k3_c48_wgrad if ctx.c48 else ops.conv3d_k3_wgrad
-        sums1 = torch.empty_like(sums2)
-        fuse_red = ctx.c48 and os.environ.get("NMH_C48_BWDSUM", "1") != "0"
-        if fuse_red:   # the IN-backward reduction over (da1, y1) happens in the epilogue of the conv that produces da1
-            da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout, stats_acc=sums1, bwd_y=y1, bwd_stats=st1).view(B * V, Cout)
-        else:
-            da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
+        da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
         # Weight gradients run on the forked side stream -- except the persistent 160^3 kernels, which own every CU: overlapping
         # them with the next MFMA kernel OR with the HBM-bound InstanceNorm passes measured slower (51.2 vs 50.4 ms at 4 grids,
         # 34.8 vs 30.8 ms at 1), so they stay on the main stream.
         with ops.side_stream(enable=not ctx.c48):
             wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
-        if not fuse_red:
-            ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
+        sums1 = torch.empty_like(sums2)
+        ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)

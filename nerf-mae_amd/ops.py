@@ -149,18 +149,17 @@ def conv3d_k3(X, Wp, Cout, out=None, accumulate=False):
     return out
 
 
-def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None, bwd_y=None, bwd_stats=None, slope=0.01):
+def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None):
     """specialised Cin=Cout=48 bf16 conv (fragment-ordered weights Wk, pack modes 6/7); stats_acc: optional fp64 [B,48,2] buffer that
-    receives the per-(sample,channel) sum / sum-of-squares of the outputs (fused InstanceNorm statistics) -- or, with bwd_y /
-    bwd_stats, the sums {sum g, sum g*yhat} of the backward of lrelu(IN(bwd_y)) applied to the output (an input gradient)"""
-    _chk(X, Wk, out, stats_acc, bwd_y, bwd_stats)
+    receives the per-(sample,channel) sum / sum-of-squares of the outputs (fused InstanceNorm statistics)"""
+    _chk(X, Wk, out, stats_acc)
     B, D, H, W, Cin = X.shape
     if Cin != 48 or X.dtype != torch.bfloat16:
         raise RuntimeError("conv3d_k3_c48 needs bf16 activations with 48 channels")
     if out is None:
         out = torch.empty((B, D, H, W, 48), dtype=X.dtype, device=X.device)
     ev = _prof(("conv3d_k3_c48", B, D, 48, 48))
-    lib().call("nmh_conv3d_k3_c48", X, Wk, out, B, D, H, W, int(accumulate), stats_acc, bwd_y, bwd_stats, slope, _st())
+    lib().call("nmh_conv3d_k3_c48", X, Wk, out, B, D, H, W, int(accumulate), stats_acc, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return out

@@ -584,16 +584,6 @@ def test_conv48_specialised_matches_reference_conv(B, D, H, W):
     dycl = dev(dy.permute(0, 2, 3, 4, 1), dt)
     ops.conv3d_k3_c48(dycl, wk_d, out=out, accumulate=True)
     check(out.permute(0, 4, 1, 2, 3), xr.grad + base.permute(0, 4, 1, 2, 3), dt, "conv48 dgrad+accumulate")
-    # backward-sum epilogue: dA = conv-dgrad(dy), sums of the backward of lrelu(IN(yref)) over (dA, yref) == the separate reduction pass
-    V = D * H * W
-    yref = dev(q(rnd(B, V, 48, seed=5) * 1.2 + 0.1, dt), dt)
-    st_y, scr = torch.empty(B, 48, 2, device="cuda"), torch.empty(B, 48, 2, dtype=torch.float64, device="cuda")
-    ops.instnorm_stats(yref, st_y, scr, B, V, 48)
-    sums_f = torch.empty(B, 48, 2, dtype=torch.float64, device="cuda")
-    dA = ops.conv3d_k3_c48(dycl, wk_d, stats_acc=sums_f, bwd_y=yref, bwd_stats=st_y)
-    sums_r = torch.empty_like(sums_f)
-    ops.instnorm_bwd_reduce(dA.view(B, V, 48), None, yref, st_y, sums_r, B, V, 48, rmode=0)
-    np.testing.assert_allclose(sums_f.cpu().numpy(), sums_r.cpu().numpy(), rtol=1e-4, atol=1e-3)
     wr = w.clone().requires_grad_(True)
     F.conv3d(x, wr, padding=1).backward(dy)
     dW = torch.full((48, 48, 3, 3, 3), 0.5, device="cuda")
