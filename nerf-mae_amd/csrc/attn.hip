@@ -28,8 +28,10 @@ template <> __device__ __forceinline__ Frag<float> gfrag<float>(const float* bas
 // pack two C-layout accumulators (4 regs each) into an A-operand fragment following the tr slot map
 __device__ __forceinline__ Frag<bf16_t> pack_frag(const f32x4& lo, const f32x4& hi, bf16_t*) {
   Frag<bf16_t> f;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { f.v[j] = (short)f2bf(lo[j]); f.v[4 + j] = (short)f2bf(hi[j]); }
+  const unsigned w0 = pk_bf16(lo[0], lo[1]), w1 = pk_bf16(lo[2], lo[3]), w2 = pk_bf16(hi[0], hi[1]), w3 = pk_bf16(hi[2], hi[3]);
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  u4v u = {w0, w1, w2, w3};
+  f.v = __builtin_bit_cast(bf16x8, u);
   return f;
 }
 __device__ __forceinline__ Frag<float> pack_frag(const f32x4& lo, const f32x4& hi, float*) {
@@ -186,8 +188,8 @@ template <> __device__ __forceinline__ Frag<float> lds_row_frag<float>(const cha
 }
 __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v, float s) {
   uint2 u;
-  u.x = (unsigned)f2bf(v[0] * s) | ((unsigned)f2bf(v[1] * s) << 16);
-  u.y = (unsigned)f2bf(v[2] * s) | ((unsigned)f2bf(v[3] * s) << 16);
+  u.x = pk_bf16(v[0] * s, v[1] * s);
+  u.y = pk_bf16(v[2] * s, v[3] * s);
   *reinterpret_cast<uint2*>(p) = u;
 }
 __device__ __forceinline__ void store4(float* p, const f32x4& v, float s) { *reinterpret_cast<float4*>(p) = float4{v[0] * s, v[1] * s, v[2] * s, v[3] * s}; }

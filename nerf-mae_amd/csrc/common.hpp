@@ -14,11 +14,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define NMH_DT_F32 0
 #define NMH_DT_BF16 1
 
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);  // round-to-nearest-even
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even: gfx950 has v_cvt_pk_bf16_f32 (two values per instruction; the integer emulation is 4-5 VALU
+// instructions per value, which showed up in every epilogue)
+typedef float nmh_f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 nmh_b2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {   // {lo, hi} -> one dword, lo in bits 0-15
+  nmh_f2v v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, nmh_b2v));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -50,7 +54,7 @@ template <> struct Vec8<bf16_t> {
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
     unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

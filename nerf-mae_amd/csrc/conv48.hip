@@ -239,13 +239,12 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
               v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xffff0000u);
               v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xffff0000u);
             }
-            const bf16_t h0 = f2bf(v0), h1 = f2bf(v1), h2 = f2bf(v2), h3 = f2bf(v3);
             uint2 w2;
-            w2.x = (unsigned)h0 | ((unsigned)h1 << 16);
-            w2.y = (unsigned)h2 | ((unsigned)h3 << 16);
+            w2.x = pk_bf16(v0, v1);
+            w2.y = pk_bf16(v2, v3);
             *reinterpret_cast<uint2*>(dst + 16 * n) = w2;
             if (a.stats_acc) {  // statistics of exactly what the normalisation pass will read back
-              const float q0 = bf2f(h0), q1 = bf2f(h1), q2 = bf2f(h2), q3 = bf2f(h3);
+              const float q0 = __uint_as_float(w2.x << 16), q1 = __uint_as_float(w2.x & 0xffff0000u), q2 = __uint_as_float(w2.y << 16), q3 = __uint_as_float(w2.y & 0xffff0000u);
               st1[n][0] += q0; st1[n][1] += q1; st1[n][2] += q2; st1[n][3] += q3;
               st2[n][0] += q0 * q0; st2[n][1] += q1 * q1; st2[n][2] += q2 * q2; st2[n][3] += q3 * q3;
             }

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const T* __restrict__ A, l
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               v[0] = __uint_as_float(w[q] << 16) * s; v[1] = __uint_as_float(w[q] & 0xffff0000u) * s;
-              w[q] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+              w[q] = pk_bf16(v[0], v[1]);
             }
             ra[i] = make_uint4(w[0], w[1], w[2], w[3]);
           } else {
