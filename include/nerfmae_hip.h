@@ -101,6 +101,12 @@ NMH_API int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const vo
  * (both from nmh_mae_loss_fwd).  in_sums[b][c] = {sum g, sum g*yhat}, dy = IN-backward, dr = g; dWout/dbout accumulate the head
  * gradients.  stats = {mean, rstd} of y. */
 NMH_API int nmh_mae_tail_bwd(int dt, const void* d0, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums, void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, void* stream);
+/* Input pipeline in one pass (nerf_rpn/datasets.py:88-101,198-233,247-248 + torch_utils.py:56-90): one stored scene
+ * rgbsigma (W,L,H,4), fp32 or uint8, already in device memory -> the (4,R,R,R) fp32 slot of the padded batch: uint8/255, optional
+ * density->alpha = clip(1-exp(-exp(sigma)/100),0,1) (fp32 scenes), (W,L,H,C)->(C,W,L,H), the z-up augmentations (flags: 1 = 90-degree
+ * rotation [transpose axes 0,1 then flip axis 0], 2 = flip axis 0, 4 = flip axis 1, applied in that order), zero padding at the high
+ * end of each axis.  The valid extents of the result are (rot ? L : W, rot ? W : L, H). */
+NMH_API int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst, int R, int flags, void* stream);
 NMH_API int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream);
 NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream);
 NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);

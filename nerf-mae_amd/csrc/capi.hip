@@ -164,6 +164,10 @@ int nmh_mae_tail_bwd(int dt, const void* d0, const void* y, const float* stats, 
   CLR();
   return k_tail_bwd(dt, d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, (long)V, C, ST);
 }
+int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst, int R, int flags, void* stream) {
+  CLR();
+  return k_grid_prepare(src_u8, src, W, L, H, dst, R, flags, ST);
+}
 int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream) {
   CLR();
   if (M <= 0) return 0;

@@ -469,3 +469,49 @@ int k_adamw(float* p, const float* g, float* m, float* v, long n, const float* h
   NMH_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- input pipeline: raw radiance grid -> padded network input, one pass -------------------------------------------------------
+// src: one scene as stored on disk, (W, L, H, 4) channels-last, fp32 or uint8 (nerf_rpn/datasets.py:88-101).  In one pass:
+//   uint8 -> /255; density -> alpha = clip(1 - exp(-exp(sigma)/100), 0, 1) on channel 3 (:247-248, fp32 grids, optional);
+//   (W,L,H,C) -> (C,W,L,H); z-up 90-degree rotation = transpose axes 0,1 then flip axis 0, and flips of axes 0 / 1 (:198-233);
+//   zero padding at the high end of every axis up to R^3 (torch_utils.py:56-90).  dst: (4, R, R, R) fp32 slot of the batch tensor.
+// Output voxel (i, j, k) of the (A0, A1, A2 = H) result reads source voxel (w, l, h = k): the last axis is never permuted, so both
+// the 16-byte (4-byte for uint8) source reads and the four plane writes are coalesced along k.
+template <typename S>
+__global__ __launch_bounds__(256) void grid_prepare_kernel(const S* __restrict__ src, int W, int L, int H, float* __restrict__ dst, int R, int flags) {
+  const bool rot = flags & 1, f0 = flags & 2, f1 = flags & 4, dens = flags & 8;
+  const int A0 = rot ? L : W, A1 = rot ? W : L;
+  const long R3 = (long)R * R * R;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < R3; o += (long)gridDim.x * 256) {
+    const int k = (int)(o % R);
+    const long t = o / R;
+    const int j = (int)(t % R), i = (int)(t / R);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (i < A0 && j < A1 && k < H) {
+      // undo the flips (applied last), then the rotation: rotated[i][j] = x[j][A0-1-i]
+      int ii = f0 ? A0 - 1 - i : i, jj = f1 ? A1 - 1 - j : j;
+      int w, l;
+      if (rot) { w = jj; l = A0 - 1 - ii; } else { w = ii; l = jj; }
+      const long si = (((long)w * L + l) * H + k) * 4;
+      if constexpr (sizeof(S) == 1) {
+        const uchar4 u = *reinterpret_cast<const uchar4*>(src + si);
+        v0 = u.x * (1.0f / 255.0f); v1 = u.y * (1.0f / 255.0f); v2 = u.z * (1.0f / 255.0f); v3 = u.w * (1.0f / 255.0f);
+      } else {
+        const float4 u = *reinterpret_cast<const float4*>(src + si);
+        v0 = u.x; v1 = u.y; v2 = u.z; v3 = u.w;
+        if (dens) v3 = fminf(fmaxf(1.0f - expf(-expf(v3) / 100.0f), 0.0f), 1.0f);
+      }
+    }
+    dst[o] = v0; dst[R3 + o] = v1; dst[2 * R3 + o] = v2; dst[3 * R3 + o] = v3;
+  }
+}
+int k_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst, int R, int flags, hipStream_t st) {
+  const bool rot = flags & 1;
+  if ((rot ? L : W) > R || (rot ? W : L) > R || H > R || W <= 0 || L <= 0 || H <= 0) return -2;
+  const long R3 = (long)R * R * R;
+  const unsigned nb = (unsigned)((R3 + 255) / 256 < 8192 ? (R3 + 255) / 256 : 8192);
+  if (src_u8) hipLaunchKernelGGL(grid_prepare_kernel<unsigned char>, dim3(nb), dim3(256), 0, st, (const unsigned char*)src, W, L, H, dst, R, flags);
+  else hipLaunchKernelGGL(grid_prepare_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)src, W, L, H, dst, R, flags);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

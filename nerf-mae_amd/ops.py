@@ -341,6 +341,19 @@ def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, d
     lib().call("nmh_mae_tail_bwd", dt_of(d0), d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, _st())
 
 
+GRID_ROT, GRID_FLIP0, GRID_FLIP1, GRID_DENSITY = 1, 2, 4, 8
+
+
+def grid_prepare(src, dst, R, flags=0):
+    """src: one stored scene (W,L,H,4) fp32|uint8 on the device; dst: (4,R,R,R) fp32 slot; returns the valid extents"""
+    _chk(src, dst)
+    if src.dim() != 4 or src.shape[3] != 4 or src.dtype not in (torch.float32, torch.uint8):
+        raise ValueError("grid_prepare: src must be (W,L,H,4) float32 or uint8")
+    W, L, H, _ = src.shape
+    lib().call("nmh_grid_prepare", int(src.dtype == torch.uint8), src, W, L, H, dst, R, flags, _st())
+    return (L, W, H) if flags & GRID_ROT else (W, L, H)
+
+
 def bias_grad(dY, db, M, N, rowscale=None, rows_per_scale=1):
     _chk(dY, db, rowscale)
     lib().call("nmh_bias_grad", dt_of(dY), dY, db, M, N, rowscale, rows_per_scale, _st())

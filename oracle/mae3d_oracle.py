@@ -439,3 +439,49 @@ def synthetic_grid(shape=(160, 160, 160), seed: int = 0) -> Tensor:
     sigma[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = box
     alpha = torch.clamp(1.0 - torch.exp(-torch.exp(sigma) / 100.0), 0.0, 1.0)
     return torch.cat([rgb, alpha[None]], 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# input pipeline restatement; pinned by tests/golden/g11_input_pipeline.npz (oracle/gen_golden_input.py)
+# ---------------------------------------------------------------------------------------------------------------------
+GRID_ROT, GRID_FLIP0, GRID_FLIP1, GRID_DENSITY = 1, 2, 4, 8
+
+
+def density_to_alpha(density):
+    """nerf_rpn/datasets.py:247-248"""
+    import numpy as np
+    return np.clip(1.0 - np.exp(-np.exp(density) / 100.0), 0.0, 1.0)
+
+
+def draw_augmentation(flip_prob: float, rotate_prob: float, rng=random) -> int:
+    """order of the random draws in augment_rpn_inputs with boxes=None, z_up=True (datasets.py:198-233)"""
+    flags = 0
+    if rng.random() < rotate_prob:
+        flags |= GRID_ROT
+    for bit in (GRID_FLIP0, GRID_FLIP1):
+        if rng.random() < flip_prob:
+            flags |= bit
+    return flags
+
+
+def prepare_grid(scene, R: int, flags: int = 0):
+    """stored scene (W,L,H,4) float32|uint8 numpy -> ((4,R,R,R) float32 tensor, extents): datasets.py:88-101 (density->alpha when
+    GRID_DENSITY is set and the scene is float, uint8 -> /255, channels first), :198-233 (rotation = transpose(1,2) + flip(1), flips),
+    torch_utils.py:56-90 (zero padding at the high end)."""
+    import numpy as np
+    g = np.array(scene, copy=True)
+    if g.dtype != np.uint8 and flags & GRID_DENSITY:
+        g[..., -1] = density_to_alpha(g[..., -1])
+    t = torch.from_numpy(np.ascontiguousarray(np.transpose(g, (3, 0, 1, 2))))
+    if t.dtype == torch.uint8:
+        t = t.float() / 255.0
+    if flags & GRID_ROT:
+        t = torch.flip(torch.transpose(t, 1, 2), [1])
+    if flags & GRID_FLIP0:
+        t = t.flip(dims=[1])
+    if flags & GRID_FLIP1:
+        t = t.flip(dims=[2])
+    out = torch.zeros((4, R, R, R), dtype=torch.float32)
+    a0, a1, a2 = t.shape[1:]
+    out[:, :a0, :a1, :a2] = t
+    return out, (a0, a1, a2)

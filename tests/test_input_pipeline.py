@@ -1,0 +1,78 @@
+"""Input pipeline: oracle restatement vs the reference's own functions (golden g11), host logic, and the
+HIP kernel vs the oracle."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mae3d_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "g11_input_pipeline.npz")
+R = 12
+
+
+def _scene(seed, shape, u8=False):   # same generator as oracle/gen_golden_input.py
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal(tuple(shape) + (4,)).astype(np.float32) * 2.0
+    if u8:
+        return rng.integers(0, 256, tuple(shape) + (4,), dtype=np.uint8)
+    return g
+
+
+def _cases():
+    g = np.load(GOLD)
+    for s, w, l, h, u8 in g["cases"]:
+        for aug in range(6):
+            yield g, int(s), (int(w), int(l), int(h)), bool(u8), aug
+
+
+def test_oracle_matches_reference_golden():
+    n = 0
+    for g, s, sh, u8, aug in _cases():
+        random.seed(100 * s + aug)
+        flags = O.draw_augmentation(0.5, 0.5, random) | (0 if u8 else O.GRID_DENSITY)
+        out, ext = O.prepare_grid(_scene(s, sh, u8), R, flags)
+        np.testing.assert_array_equal(np.array(ext), g[f"c{s}_a{aug}_ext"])
+        np.testing.assert_allclose(out.numpy(), g[f"c{s}_a{aug}"], rtol=1e-6, atol=1e-7)
+        assert abs(float(ext[0] * ext[1] * ext[2] * 4) - float(g[f"c{s}_a{aug}_masksum"][0])) < 0.5   # the ones-mask == the extents
+        n += 1
+    assert n == 24
+
+
+def test_host_draw_order_matches_oracle():
+    from nerf_mae_amd import data, ops
+    assert (ops.GRID_ROT, ops.GRID_FLIP0, ops.GRID_FLIP1, ops.GRID_DENSITY) == (O.GRID_ROT, O.GRID_FLIP0, O.GRID_FLIP1, O.GRID_DENSITY)
+    for seed in range(50):
+        a, b = random.Random(seed), random.Random(seed)
+        assert data.draw_augmentation(0.5, 0.3, a) == O.draw_augmentation(0.5, 0.3, b)
+    with pytest.raises(ValueError):
+        data.draw_augmentation(1.5, 0.0)
+    sc = data.synthetic_scene((10, 8, 6), 3)
+    assert sc.shape == (10, 8, 6, 4) and sc.dtype == np.float32
+    assert data.synthetic_scene((10, 8, 6), 3, dtype=np.uint8).dtype == np.uint8
+
+
+@pytest.mark.gpu
+def test_grid_prepare_kernel_matches_golden_and_oracle():
+    from nerf_mae_amd import data, ops
+    for g, s, sh, u8, aug in _cases():
+        random.seed(100 * s + aug)
+        flags = O.draw_augmentation(0.5, 0.5, random) | (0 if u8 else O.GRID_DENSITY)
+        src = torch.from_numpy(_scene(s, sh, u8)).cuda()
+        dst = torch.full((4, R, R, R), 7.0, device="cuda")
+        ext = ops.grid_prepare(src, dst, R, flags)
+        assert tuple(ext) == tuple(int(v) for v in g[f"c{s}_a{aug}_ext"])
+        np.testing.assert_allclose(dst.cpu().numpy(), g[f"c{s}_a{aug}"], rtol=2e-6, atol=2e-7)
+    # the batcher: staging through pinned memory, per-sample flags, extents tensor; full-size scene incl. uint8
+    bt = data.GridBatcher(160, "cuda", normalize_density=True)
+    scenes = [data.synthetic_scene((160, 132, 96), 1), data.synthetic_scene((120, 160, 144), 2, dtype=np.uint8)]
+    flags = [ops.GRID_ROT | ops.GRID_FLIP1, ops.GRID_FLIP0]
+    xb, ext = bt(scenes, flags=flags)
+    assert ext.cpu().tolist() == [[132, 160, 96], [120, 160, 144]]
+    for i, sc in enumerate(scenes):
+        ref, _ = O.prepare_grid(sc, 160, flags[i] | (O.GRID_DENSITY if sc.dtype != np.uint8 else 0))
+        np.testing.assert_allclose(xb[i].cpu().numpy(), ref.numpy(), rtol=2e-6, atol=2e-7)
+    with pytest.raises(Exception):
+        ops.grid_prepare(torch.zeros(200, 4, 4, 4, device="cuda"), xb[0], 160, 0)   # does not fit the resolution
