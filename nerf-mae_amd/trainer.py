@@ -143,3 +143,132 @@ class GraphedTrainStep:
             dist.all_reduce(self.model._flat_grad, op=dist.ReduceOp.AVG, group=self.reducer.group)
             self._g2.replay()
         return self.losses
+
+
+# --------------------------------------------------------------------------------------------------
+# Trainer parity extras: metrics, checkpoints, epoch loop
+# --------------------------------------------------------------------------------------------------
+def mse(pred_rgb: torch.Tensor, target_rgb: torch.Tensor, valid_mask: torch.Tensor) -> torch.Tensor:
+    """mean squared error over the RGB entries of the voxels selected by valid_mask (nerf_rpn/model/metrics.py:69-75);
+    evaluation-only bookkeeping on the eval tuple (stock tensor ops, not part of the training step)"""
+    err = (pred_rgb - target_rgb) ** 2
+    return err[valid_mask.expand_as(err)].mean()
+
+
+def psnr(pred_rgb: torch.Tensor, target_rgb: torch.Tensor, valid_mask: torch.Tensor) -> torch.Tensor:
+    """-10 log10(mse) (metrics.py:78-79)"""
+    return -10.0 * torch.log10(mse(pred_rgb, target_rgb, valid_mask))
+
+
+def eval_metrics(eval_out) -> tuple:
+    """(psnr, mse) of one `model(x, is_eval=True)` 6-tuple exactly as the reference's eval loop computes them
+    (run_swin_mae3d.py:747-760).  Both also follow from the fused loss: mse == loss_rgb / 3, because loss_rgb divides the same
+    masked sum by the voxel count instead of the entry count (swin_mae3d.py:1535)."""
+    _, _, _, pred, mask, target = eval_out
+    m = mask.bool()
+    return psnr(pred[..., :3], target[..., :3], m), mse(pred[..., :3], target[..., :3], m)
+
+
+def save_checkpoint(path: str, model, epoch: int, train_args: dict, opt: "FusedAdamW" = None, step: int = None):
+    """the reference's checkpoint (run_swin_mae3d.py:471-489): {"epoch", "state_dict", "train_args"}; state_dict keys/shapes are the
+    reference's, so nerf_rpn loads it unchanged.  With `opt` the file additionally carries what a TRUE resume needs (the reference
+    cannot resume its optimizer): AdamW moments over the flat buffer, step count, beta powers, schedule position."""
+    ck = {"epoch": epoch, "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "train_args": dict(train_args)}
+    if opt is not None:
+        ck["resume"] = {"m": opt.m.detach().cpu(), "v": opt.v.detach().cpu(), "t": opt.t, "b1_pow": opt.b1_pow, "b2_pow": opt.b2_pow,
+                        "lr": opt.lr, "betas": opt.betas, "step": step}
+    torch.save(ck, path)
+
+
+def load_checkpoint(path: str, model, opt: "FusedAdamW" = None, strict: bool = True) -> dict:
+    """loads a reference-format checkpoint (also one written by the reference itself); returns the checkpoint dict.  With `opt` and
+    a "resume" section the optimizer continues where it stopped."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model.load_state_dict(ck["state_dict"], strict=strict)
+    if opt is not None and "resume" in ck:
+        r = ck["resume"]
+        if model._flat is None or not model._flat.is_cuda:
+            raise RuntimeError("load_checkpoint: move the model to the HIP device before restoring the optimizer")
+        opt.m.copy_(r["m"]); opt.v.copy_(r["v"])
+        opt.t, opt.b1_pow, opt.b2_pow, opt.lr, opt.betas = r["t"], r["b1_pow"], r["b2_pow"], r["lr"], tuple(r["betas"])
+    return ck
+
+
+class Trainer:
+    """Epoch loop of run_swin_mae3d.py:600-709 without wandb: OneCycle schedule stepped every iteration, HIP-graph train step,
+    evaluation every `eval_interval` epochs, `model_best.pt` by validation PSNR (:620-629) and `epoch_{k}.pt`; rank 0 writes.
+    `train_scenes` / `val_scenes`: sequences of stored scenes ((W,L,H,4) arrays or paths); sharded across ranks with
+    DistributedSampler semantics (dist.shard_indices)."""
+
+    def __init__(self, model, train_scenes, val_scenes=None, batch_size: int = 4, num_epochs: int = 1, lr: float = 1e-4, weight_decay: float = 1e-3,
+                 clip_grad_norm: float = 0.1, eval_interval: int = 1, save_path: str = None, normalize_density: bool = True, flip_prob: float = 0.0,
+                 rotate_prob: float = 0.0, rank: int = 0, world: int = 1, reducer=None, log=print, train_args: dict = None, seed: int = 0):
+        from . import data, dist as _dist
+        self.model, self.train_scenes, self.val_scenes = model, train_scenes, val_scenes
+        self.batch, self.epochs, self.eval_interval, self.save_path = batch_size, num_epochs, eval_interval, save_path
+        self.rank, self.world, self.log, self.seed = rank, world, log, seed
+        self.args = dict(train_args or {}, lr=lr, weight_decay=weight_decay, clip_grad_norm=clip_grad_norm, batch_size=batch_size * world,
+                         num_epochs=num_epochs, normalize_density=normalize_density, flip_prob=flip_prob, rotate_prob=rotate_prob)
+        self._shard = _dist.shard_indices
+        dev = model.mask_token.device
+        self.batcher = data.GridBatcher(model.resolution, dev, normalize_density, flip_prob, rotate_prob)
+        self.val_batcher = data.GridBatcher(model.resolution, dev, normalize_density)
+        self.opt = FusedAdamW(model, lr=lr, weight_decay=weight_decay, max_grad_norm=clip_grad_norm)
+        self.steps_per_epoch = max(1, len(self._shard(len(train_scenes), rank, world, 0)) // batch_size)
+        self.sched = OneCycle(lr, num_epochs * self.steps_per_epoch)
+        self.step_fn = GraphedTrainStep(model, self.opt, batch_size, reducer=reducer)
+        self.global_step, self.best_metric, self.history = 0, None, []
+
+    def _scene(self, s):
+        from . import data
+        return data.load_scene(s) if isinstance(s, str) else s
+
+    def train_epoch(self, epoch: int):
+        import random
+        from .model import draw_block_mask
+        self.model.train()
+        idx = self._shard(len(self.train_scenes), self.rank, self.world, epoch, seed=self.seed)
+        g = self.model.resolution // 4
+        tot = 0.0
+        for b in range(self.steps_per_epoch):
+            scenes = [self._scene(self.train_scenes[i]) for i in idx[b * self.batch:(b + 1) * self.batch]]
+            xb, ext = self.batcher(scenes, out=self.step_fn.x)           # straight into the graph's static input
+            self.step_fn.ext.copy_(ext)
+            lr, b1 = self.sched.at(self.global_step)
+            self.opt.set_hyper(lr=lr, beta1=b1)
+            losses = self.step_fn(None, draw_block_mask((g, g, g), self.model.masking_prob, rng=random))
+            self.global_step += 1
+            tot += float(losses[0])
+        return tot / self.steps_per_epoch
+
+    @torch.no_grad()
+    def evaluate(self):
+        self.model.eval()
+        ps, ms = [], []
+        for s in self.val_scenes:
+            xb, ext = self.val_batcher([self._scene(s)], flags=[0])
+            a0, a1, a2 = ext[0].tolist()
+            out = self.model([xb[0, :, :a0, :a1, :a2]], is_eval=True)
+            p, m = eval_metrics(out)
+            ps.append(float(p)); ms.append(float(m))
+        self.model.train()
+        return sum(ps) / len(ps), sum(ms) / len(ms)
+
+    def fit(self):
+        import os
+        if self.save_path and self.rank == 0:
+            os.makedirs(self.save_path, exist_ok=True)
+        for epoch in range(1, self.epochs + 1):
+            loss = self.train_epoch(epoch)
+            rec = {"epoch": epoch, "train_loss": loss}
+            if self.rank == 0 and self.val_scenes and (epoch % self.eval_interval == 0 or epoch == self.epochs):
+                rec["psnr"], rec["mse"] = self.evaluate()
+                if self.save_path:
+                    if self.best_metric is None or rec["psnr"] > self.best_metric:
+                        self.best_metric = rec["psnr"]
+                        save_checkpoint(os.path.join(self.save_path, "model_best.pt"), self.model, epoch, self.args, self.opt, self.global_step)
+                    save_checkpoint(os.path.join(self.save_path, f"epoch_{epoch}.pt"), self.model, epoch, self.args, self.opt, self.global_step)
+            self.history.append(rec)
+            if self.rank == 0:
+                self.log(" ".join(f"{k}={v:.5g}" if isinstance(v, float) else f"{k}={v}" for k, v in rec.items()))
+        return self.history
