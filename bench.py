@@ -73,7 +73,7 @@ def main():
     from nerf_mae_amd.dist import GradReducer, broadcast_parameters
     from nerf_mae_amd.model import SWIN_CONFIGS, build_model
     from nerf_mae_amd.trainer import FusedAdamW, GraphedTrainStep, OneCycle
-    from oracle import mae3d_oracle as O  # only for the synthetic-grid generator and the cpu_baseline leg
+    from nerf_mae_amd import data
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +101,10 @@ def main():
 
     # synthetic inputs: valid extents cycle through {160^3, 160x132x96, 120x160x144}, resident in HBM
     exts = [(R, R, R), (R, int(R * 0.825), int(R * 0.6)), (int(R * 0.75), R, int(R * 0.9))]
-    grids = [O.synthetic_grid(exts[(rank * Bg + i) % 3], seed=rank * 131 + i).to(dev) for i in range(Bg)]
+    # stored-format scenes (W,L,H,4 with raw density) go through the product input pipeline (density->alpha, layout, padding on the GPU)
+    scenes = [data.synthetic_scene(exts[(rank * Bg + i) % 3], seed=rank * 131 + i) for i in range(Bg)]
+    xb0, ext0 = data.GridBatcher(R, dev, normalize_density=True)(scenes, flags=[0] * Bg)
+    grids = [xb0[i, :, :e[0], :e[1], :e[2]].contiguous() for i, e in enumerate(ext0.tolist())]
     mask_rng = random.Random(1000 + rank)
     g = R // 4
 
@@ -208,6 +211,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (a port of the reference's PyTorch path) on the host cores, bounded sample: ONE grid fwd+bwd
+        from oracle import mae3d_oracle as O   # the only use of oracle/ in this file
         ncores = os.cpu_count() or 1
         try:
             import psutil
