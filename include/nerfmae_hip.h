@@ -30,6 +30,10 @@ NMH_API const char* nmh_error_string(int code);
  * epilogue order: +bias[N]; act 1: C2=pre-activation, exact-erf GELU; act 2: *= gelu'(C2); *= rowscale[row/rows_per_scale]
  * (stochastic depth, :367-368); += resid; accumulate: += C.  C, C2, resid share ldc. */
 NMH_API int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* C, int64_t ldc, const float* bias, int act, void* C2, const void* resid, const float* rowscale, int rows_per_scale, int accumulate, void* stream);
+/* Attention output projection with the window reverse folded into the store (swin_mae3d.py:176-197 + the residual of :367):
+ * out[tok] = resid[tok] + rowscale[tok / tokens_per_sample] * (A[m] . W^T + bias) for every window-ordered row m that maps to a token
+ * (pad rows are dropped); wm as in nmh_window_scatter_residual, which this replaces. */
+NMH_API int nmh_gemm_nt_window_scatter(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* out, const void* resid, const float* bias, const float* rowscale, int tokens_per_sample, const int* wm, void* stream);
 /* dW[N,K] += sum_m A[m,N]*rowscale . B[m,K]  (fp32 atomics): weight gradients of the ops above.
  * omode 0: dW[n*ldo+k]; omode 2: ConvTranspose3d weight [Cin=K][Cout=p0][k3=p1] with n = tap*Cout+co.
  * dbias (optional): dbias[n] += sum_m A[m,n]*rowscale -- the layer's bias gradient from the same pass over A.
@@ -57,9 +61,11 @@ NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW
 /* LayerNorm eps over the last dim (swin_mae3d.py:341,351,388,1128) with the surrounding data movement folded in:
  * src_mode 0 rows as-is (+ optional patch-embed post-ops: + pos[tok], masked tokens <- mask_token; :1459-1463,1375-1380),
  * src_mode 1 output in window order (pad -> roll -> partition, :62-101; pad rows are zeros),
- * src_mode 2 patch-merge gather of 8 tokens -> 8C row (:390-402).  mean/rstd are saved per token (modes 0,1) / row (2). */
+ * src_mode 2 patch-merge gather of 8 tokens -> 8C row (:390-402).  mean/rstd are saved per token (modes 0,1) / row (2).
+ * backward, mode 0: dyw (optional, with wm) receives the same gradient in window order scaled by dyw_scale[tok / tokens_per_sample]
+ * (the adjoint of the attention branch's window reverse; replaces nmh_window_gather_scale). */
 NMH_API int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C, const int* wm, const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, void* stream);
-NMH_API int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* stream);
+NMH_API int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* dyw, const float* dyw_scale, void* stream);
 /* out[tok] = x[tok] + rowscale[b]*yw[window_row(tok)]: window reverse + un-roll + un-pad (:176-196) + residual + stochastic depth */
 NMH_API int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream);
 /* dyw[window_row] = rowscale[b]*dx[tok] (0 for pad rows): adjoint of the above */

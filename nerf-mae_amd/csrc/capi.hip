@@ -30,6 +30,14 @@ int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, 
   EpiParams ep{C, ldc, bias, act, C2, resid, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, accumulate};
   return k_gemm_nt(dt, A, lda, W, ldw, M, N, K, ep, ST);
 }
+int nmh_gemm_nt_window_scatter(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* out, const void* resid, const float* bias,
+                               const float* rowscale, int tokens_per_sample, const int* wm, void* stream) {
+  CLR();
+  if (M <= 0) return 0;
+  EpiParams ep{out, N, bias, 0, nullptr, resid, rowscale, tokens_per_sample > 0 ? tokens_per_sample : 1, 0};
+  ep.win_on = 1; ep.wm = to_wm(wm);
+  return k_gemm_nt(dt, A, lda, W, ldw, M, N, K, ep, ST);
+}
 int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale,
                 int omode, int64_t ldo, int p0, int p1, float* dbias, float* ws, int64_t ws_floats, void* stream) {
   CLR();
@@ -85,10 +93,12 @@ int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const floa
   return k_ln_fwd(a, ST);
 }
 int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx,
-                      float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* stream) {
+                      float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample,
+                      void* dyw, const float* dyw_scale, void* stream) {
   CLR();
   if (rows <= 0) return 0;
-  LnBwdArgs a{dt, src_mode, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, C, to_wm(wm), mask, dmask_token, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1)};
+  LnBwdArgs a{dt, src_mode, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, C, to_wm(wm), mask, dmask_token, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1),
+              dyw, dyw_scale};
   return k_ln_bwd(a, ST);
 }
 int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream) {

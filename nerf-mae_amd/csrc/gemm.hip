@@ -134,6 +134,10 @@ template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams&
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] += ep.bias[gcol + j];
   }
+  if (ep.win_on) {   // window-ordered GEMM row -> token row; pad rows have no token
+    grow = win_to_tok(ep.wm, grow);
+    if (grow < 0) return;
+  }
   const long o = grow * ep.ldc + gcol;
   if (ep.act == 1) {
     Vec8<T>::store((T*)ep.C2 + o, v);

@@ -5,6 +5,9 @@
 struct FDiv { unsigned M; int sh; unsigned d; };
 FDiv make_fdiv(unsigned d);
 
+// window partition geometry (3-D shifted windows, window edge 4): real dims, padded dims, effective shifts
+struct WinMap { int B, H, W, D, PH, PW, PD, s0, s1, s2; };
+
 // GEMM epilogue description (all optional, evaluated in this order):
 //   v = acc (+ bias[col]);  act==1: C2 = v, v = gelu(v);  act==2: v *= gelu'(C2);  v *= rowscale[row/rows_per_scale];
 //   v += resid;  accumulate: v += C;  C = v.         C, C2, resid share leading dimension ldc.
@@ -19,6 +22,9 @@ struct EpiParams {
   // up_v^3 grid, column = tap*up_cout + co  ->  C[fine voxel (b, z*k+tz, y*k+ty, x*k+tx)][co], row stride ldc; bias indexed by co
   int up_k, up_v, up_cout;
   FDiv up_dv, up_dk, up_dc;
+  // window reverse folded into the store (win_on): GEMM row = window-ordered row -> token row (pad rows dropped); bias, rowscale
+  // (indexed by token / rows_per_scale) and resid (token order) as usual: x1[tok] = x[tok] + s_b * (o . Wproj^T + b)
+  int win_on; WinMap wm;
 };
 
 // geometry for gemm_tn gather / output remap
@@ -37,9 +43,38 @@ struct TnGeom {
   float* ws; long ws_floats; float* part;
 };
 
-// window partition geometry (3-D shifted windows, window edge 4): real dims, padded dims, effective shifts
-struct WinMap { int B, H, W, D, PH, PW, PD, s0, s1, s2; };
 
+#ifdef __HIPCC__
+// window order <-> token order of the 4x4x4 shifted-window partition (pad -> roll(-shift) -> partition; swin_mae3d.py:62-101)
+__device__ __forceinline__ long win_to_tok(const WinMap& w, long m) {
+  const int t = (int)(m & 63);
+  long win = m >> 6;
+  const int nwy = w.PW >> 2, nwx = w.PD >> 2, nwz = w.PH >> 2;
+  int wx = (int)(win % nwx); win /= nwx;
+  int wy = (int)(win % nwy); win /= nwy;
+  int wz = (int)(win % nwz);
+  long b = win / nwz;
+  int sz = wz * 4 + (t >> 4) + w.s0, sy = wy * 4 + ((t >> 2) & 3) + w.s1, sx = wx * 4 + (t & 3) + w.s2;
+  if (sz >= w.PH) sz -= w.PH;
+  if (sy >= w.PW) sy -= w.PW;
+  if (sx >= w.PD) sx -= w.PD;
+  if (sz >= w.H || sy >= w.W || sx >= w.D) return -1;
+  return ((b * w.H + sz) * w.W + sy) * w.D + sx;
+}
+__device__ __forceinline__ long tok_to_win(const WinMap& w, long tok) {
+  int x = (int)(tok % w.D); tok /= w.D;
+  int y = (int)(tok % w.W); tok /= w.W;
+  int z = (int)(tok % w.H);
+  long b = tok / w.H;
+  int pz = z - w.s0, py = y - w.s1, px = x - w.s2;
+  if (pz < 0) pz += w.PH;
+  if (py < 0) py += w.PW;
+  if (px < 0) px += w.PD;
+  long win = ((b * (w.PH >> 2) + (pz >> 2)) * (w.PW >> 2) + (py >> 2)) * (w.PD >> 2) + (px >> 2);
+  return win * 64 + ((pz & 3) << 4) + ((py & 3) << 2) + (px & 3);
+}
+
+#endif
 int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st);
 // ConvTranspose3d (kernel = stride = k) as GEMMs with the pixel shuffle folded into addressing (unetr_block.py:151-158):
 //   fwd:   cat[fine][0:Cout] = x[coarse] . Wt^T + bias   (Wt packed [(tap,co)][ci])
@@ -78,6 +113,7 @@ struct LnBwdArgs {
   float* dgamma; float* dbeta;          // fp32 accumulators (atomicAdd)
   long rows; int C; WinMap wm;
   const unsigned char* mask; float* dmask_token; long tokens_per_sample;
+  void* dyw; const float* dyw_scale;    // MODE 0 only: second output in window order (wm), scaled per sample (fused window gather)
 };
 int k_ln_bwd(const LnBwdArgs& a, hipStream_t st);
 

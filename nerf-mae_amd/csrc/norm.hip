@@ -11,34 +11,6 @@
 // window maps.  Window-ordered row m = ((b*nwz+wz)*nwy+wy)*nwx+wx)*64 + tz*16+ty*4+tx.
 // rolled[p] = padded[(p + shift) mod P]  (torch.roll(x, -shift)), padded rows beyond the real dims are zero.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ long win_to_tok(const WinMap& w, long m) {
-  const int t = (int)(m & 63);
-  long win = m >> 6;
-  const int nwy = w.PW >> 2, nwx = w.PD >> 2, nwz = w.PH >> 2;
-  int wx = (int)(win % nwx); win /= nwx;
-  int wy = (int)(win % nwy); win /= nwy;
-  int wz = (int)(win % nwz);
-  long b = win / nwz;
-  int sz = wz * 4 + (t >> 4) + w.s0, sy = wy * 4 + ((t >> 2) & 3) + w.s1, sx = wx * 4 + (t & 3) + w.s2;
-  if (sz >= w.PH) sz -= w.PH;
-  if (sy >= w.PW) sy -= w.PW;
-  if (sx >= w.PD) sx -= w.PD;
-  if (sz >= w.H || sy >= w.W || sx >= w.D) return -1;
-  return ((b * w.H + sz) * w.W + sy) * w.D + sx;
-}
-__device__ __forceinline__ long tok_to_win(const WinMap& w, long tok) {
-  int x = (int)(tok % w.D); tok /= w.D;
-  int y = (int)(tok % w.W); tok /= w.W;
-  int z = (int)(tok % w.H);
-  long b = tok / w.H;
-  int pz = z - w.s0, py = y - w.s1, px = x - w.s2;
-  if (pz < 0) pz += w.PH;
-  if (py < 0) py += w.PW;
-  if (px < 0) px += w.PD;
-  long win = ((b * (w.PH >> 2) + (pz >> 2)) * (w.PW >> 2) + (py >> 2)) * (w.PD >> 2) + (px >> 2);
-  return win * 64 + ((pz & 3) << 4) + ((py & 3) << 2) + (px & 3);
-}
-
 template <int LPR> __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -258,6 +230,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
             for (int j = 0; j < 8; ++j) o[j] += r[j];
           }
           Vec8<T>::store(dx + row * C + c * 8, o);
+          if (MODE == 0 && a.dyw) {   // adjoint of the window scatter fused here: dyw[win(row)] = s_b * dx[row] (pad rows pre-zeroed)
+            const float sc = a.dyw_scale ? a.dyw_scale[row / a.tokens_per_sample] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= sc;
+            Vec8<T>::store((T*)a.dyw + tok_to_win(a.wm, row) * C + c * 8, o);
+          }
         }
       }
     }
@@ -322,6 +300,15 @@ template <typename T, int MODE> static int ln_bwd_dispatch(const LnBwdArgs& a, h
   return 0;
 }
 int k_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
+  if (a.dyw) {
+    if (a.src_mode != 0) return -2;
+    const WinMap& w = a.wm;
+    if ((long)w.PH * w.PW * w.PD != (long)w.H * w.W * w.D) {   // pad rows of the window-ordered tensor receive no token
+      const size_t es = a.dt == NMH_DT_BF16 ? 2 : 4;
+      hipError_t e = hipMemsetAsync(a.dyw, 0, (size_t)w.B * w.PH * w.PW * w.PD * a.C * es, st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
   if (a.dt == NMH_DT_BF16) {
     if (a.src_mode == 0) return ln_bwd_dispatch<bf16_t, 0>(a, st);
     if (a.src_mode == 1) return ln_bwd_dispatch<bf16_t, 1>(a, st);

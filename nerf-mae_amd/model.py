@@ -196,9 +196,8 @@ class _BlockFn(torch.autograd.Function):
         o = torch.empty((geom.rows, C), dtype=dtype, device=dev)
         lse = torch.empty(geom.rows * heads, device=dev)
         ops.window_attn_fwd(qkv, b.attn.relative_position_bias_table, o, lse, heads, C, geom)
-        yw = ops.gemm_nt(o, pk[key + "proj.w"].view(C, C), bias=b.attn.proj.bias)
-        x1 = torch.empty_like(x)
-        ops.window_scatter_residual(yw, x, x1, sd1, C, geom)
+        x1 = torch.empty_like(x)   # x1 = x + sd1 * window_reverse(proj(o)): the reverse + residual are the GEMM's store
+        ops.gemm_nt_window_scatter(o, pk[key + "proj.w"].view(C, C), x1, x, b.attn.proj.bias, sd1, tps, geom)
         x1n = torch.empty_like(x)
         mean2, rstd2 = torch.empty(T, device=dev), torch.empty(T, device=dev)
         ops.layernorm_fwd(x1, b.norm2.weight, b.norm2.bias, x1n, mean2, rstd2, T, C)
@@ -226,10 +225,10 @@ class _BlockFn(torch.autograd.Function):
         with ops.side_stream(enable=T >= ops.side_stream.min_rows):
             ops.gemm_tn(dh, x1n, _gradbuf(b.mlp[0].weight), dbias=_gradbuf(b.mlp[0].bias))
         dx1 = torch.empty_like(x)
-        ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2)
+        dyw = torch.empty_like(xnw)   # = sd1 * dx1 in window order (adjoint of the window reverse), second output of the LN backward
+        ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
+                          geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1)
         # ---- attention branch
-        dyw = torch.empty_like(xnw)
-        ops.window_gather_scale(dx1, dyw, sd1, C, geom)
         do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
         with ops.side_stream(enable=T >= ops.side_stream.min_rows):
             ops.gemm_tn(dyw, o, _gradbuf(b.attn.proj.weight), dbias=_gradbuf(b.attn.proj.bias))

@@ -217,11 +217,22 @@ def layernorm_fwd(x, gamma, beta, out, mean, rstd, rows, C, src_mode=0, geom: Op
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, src_mode=0, geom: Optional[WinGeom] = None, dres=None,
-                  mask=None, dmask_token=None, tokens_per_sample=1):
-    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dres, mask, dmask_token)
+                  mask=None, dmask_token=None, tokens_per_sample=1, dyw=None, dyw_scale=None):
+    """dyw (mode 0, with geom): second output = dx in window order times dyw_scale[sample] (fused window gather)"""
+    _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dres, mask, dmask_token, dyw, dyw_scale)
     lib().call("nmh_layernorm_bwd", dt_of(x), src_mode, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C,
-               geom.carr if geom is not None else None, mask, dmask_token, tokens_per_sample, _st())
+               geom.carr if geom is not None else None, mask, dmask_token, tokens_per_sample, dyw, dyw_scale, _st())
     return dx
+
+
+def gemm_nt_window_scatter(A, W, out, resid, bias, rowscale, tokens_per_sample, geom: WinGeom):
+    """out[tok] = resid[tok] + rowscale[sample] * (A[m] @ W^T + bias) for window-ordered rows m (proj + window reverse + residual)"""
+    _chk(A, W, out, resid, bias, rowscale)
+    M, K = A.shape
+    N = W.shape[0]
+    lib().call("nmh_gemm_nt_window_scatter", dt_of(A), A, A.stride(0), W, W.stride(0), M, N, K, out, resid, bias, rowscale, tokens_per_sample,
+               geom.carr, _st())
+    return out
 
 
 def window_scatter_residual(yw, x, out, rowscale, C, geom: WinGeom):

@@ -181,6 +181,28 @@ def test_layernorm_window_modes(dt, shape, shift):
     if sum(geom.shift) > 0:
         xp = torch.roll(xp, shifts=[-s for s in geom.shift], dims=(1, 2, 3))
     check(g2, O.window_partition(xp).reshape(-1, C), dt, "window gather")
+    # the product path: the window reverse is the store of the proj GEMM, the window gather a second output of the LN backward
+    Wp, bp = q(rnd(C, C, seed=6, scale=C ** -0.5), dt), rnd(C, seed=7, scale=0.1)
+    o3 = torch.empty(T, C, dtype=dt, device="cuda")
+    ops.gemm_nt_window_scatter(dev(yw, dt), dev(Wp, dt), o3, dev(x.reshape(T, C), dt), dev(bp), dev(rs), T // B, geom)
+    pv = O.window_reverse((yw @ Wp.T + bp).view(-1, 64, C), B, *geom.P)
+    if sum(geom.shift) > 0:
+        pv = torch.roll(pv, shifts=list(geom.shift), dims=(1, 2, 3))
+    check(o3, (x + rs.view(B, 1, 1, 1, 1) * pv[:, :H, :W, :D]).reshape(T, C), dt, "proj + window scatter + residual", 2)
+    dy0 = q(rnd(T, C, seed=8), dt)
+    dx0, dx1 = torch.empty(T, C, dtype=dt, device="cuda"), torch.empty(T, C, dtype=dt, device="cuda")
+    dgs = [torch.zeros(C, device="cuda") for _ in range(4)]
+    mean0, rstd0 = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    ln0 = torch.empty(T, C, dtype=dt, device="cuda")
+    ops.layernorm_fwd(dev(x.reshape(T, C), dt), dev(gam), dev(bet), ln0, mean0, rstd0, T, C)
+    ops.layernorm_bwd(dev(dy0, dt), dev(x.reshape(T, C), dt), dev(gam), mean0, rstd0, dx0, dgs[0], dgs[1], T, C, dres=dev(dres, dt))
+    g_ref = torch.empty(geom.rows, C, dtype=dt, device="cuda")
+    ops.window_gather_scale(dx0, g_ref, dev(rs), C, geom)
+    g_fused = torch.full((geom.rows, C), 3.0, dtype=dt, device="cuda")
+    ops.layernorm_bwd(dev(dy0, dt), dev(x.reshape(T, C), dt), dev(gam), mean0, rstd0, dx1, dgs[2], dgs[3], T, C, dres=dev(dres, dt),
+                      geom=geom, tokens_per_sample=T // B, dyw=g_fused, dyw_scale=dev(rs))
+    check(dx1, dx0.float().cpu(), dt, "ln bwd dx unchanged by the fused gather")
+    check(g_fused, g_ref.float().cpu(), dt, "ln bwd fused window gather", 2)
 
 
 @pytest.mark.parametrize("dt", DTS)
