@@ -120,11 +120,12 @@ NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
 /* fp32 master weights -> compute-dtype GEMM operand layouts, one launch for the whole model.  descs: device array of
  * {const float* src; void* dst; int mode; int d0,d1,d2; int64 n} (40 bytes, see kernels.hpp PackDesc), one block per 1024 dst elements. */
 NMH_API int nmh_pack_weights(int dt, const void* descs_dev, const int* blk2desc_dev, const int64_t* blkstart_dev, int nblocks, void* stream);
-/* clip_grad_norm_ + AdamW (run_swin_mae3d.py:588-592,665-668) over the flat fp32 parameter buffer; hyper (device fp32[7]) =
- * {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t}; coef (device) = min(1, max_norm/(norm+1e-6)). */
+/* clip_grad_norm_ + AdamW (run_swin_mae3d.py:588-592,665-668) over the flat fp32 parameter buffer; hyper (device fp32[8]) =
+ * {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, zero_g}; coef (device) = min(1, max_norm/(norm+1e-6)); zero_g != 0:
+ * the step also clears g (the next step's zero_grad for free). */
 NMH_API int nmh_grad_sqnorm(const float* g, int64_t n, double* acc, void* stream);
 NMH_API int nmh_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, void* stream);
-NMH_API int nmh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* coef, void* stream);
+NMH_API int nmh_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper, const float* coef, void* stream);
 
 #ifdef __cplusplus
 }

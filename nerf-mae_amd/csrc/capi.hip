@@ -197,6 +197,6 @@ int nmh_grad_sqnorm(const float* g, int64_t n, double* acc, void* stream) {
   CLR(); return k_sqnorm(g, (long)n, acc, ST); }
 int nmh_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, void* stream) {
   CLR(); return k_clip_coef(acc, max_norm, coef, norm_out, ST); }
-int nmh_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* coef, void* stream) {
+int nmh_adamw_step(float* p, float* g, float* m, float* v, int64_t n, const float* hyper, const float* coef, void* stream) {
   CLR(); return k_adamw(p, g, m, v, (long)n, hyper, coef, ST); }
 }

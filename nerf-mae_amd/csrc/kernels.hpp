@@ -164,7 +164,7 @@ struct PackDesc { const float* src; void* dst; int mode; int d0, d1, d2; long n;
 int k_pack_weights(int dt, const PackDesc* descs_dev, const int* blk2desc_dev, const long* blkstart_dev, int nblocks, hipStream_t st);
 int k_sqnorm(const float* g, long n, double* acc, hipStream_t st);
 int k_clip_coef(const double* acc, float max_norm, float* coef, float* norm_out, hipStream_t st);
-int k_adamw(float* p, const float* g, float* m, float* v, long n, const float* hyper /*lr,b1,b2,eps,wd,bc1,bc2*/, const float* coef, hipStream_t st);
+int k_adamw(float* p, float* g, float* m, float* v, long n, const float* hyper /*lr,b1,b2,eps,wd,bc1,bc2,zero_g*/, const float* coef, hipStream_t st);
 
 // raw scene (W,L,H,4) fp32|uint8 -> padded (4,R,R,R) fp32 network input; flags: 1 rotate (z-up 90 deg), 2 flip axis 0, 4 flip axis 1, 8 density->alpha
 int k_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst, int R, int flags, hipStream_t st);

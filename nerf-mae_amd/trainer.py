@@ -47,6 +47,7 @@ class FusedAdamW:
         self.hyper = torch.tensor([0.0, betas[0], betas[1], eps, 0.0, 1.0, 1.0, 0.0], device=flat.device)
         self.t = 0
         self.b1_pow = self.b2_pow = 1.0
+        self.zero_grads_after_step = False   # the AdamW kernel also clears the flat gradient buffer (GraphedTrainStep turns it on)
 
     def set_hyper(self, lr=None, beta1=None):
         if lr is not None:
@@ -60,7 +61,8 @@ class FusedAdamW:
         b1, b2 = self.betas
         self.b1_pow *= b1
         self.b2_pow *= b2
-        h = torch.tensor([self.lr, b1, b2, self.eps, self.wd, 1.0 - self.b1_pow, 1.0 - self.b2_pow, 0.0], dtype=torch.float32)
+        h = torch.tensor([self.lr, b1, b2, self.eps, self.wd, 1.0 - self.b1_pow, 1.0 - self.b2_pow, 1.0 if self.zero_grads_after_step else 0.0],
+                         dtype=torch.float32)
         self.hyper.copy_(h, non_blocking=True)
 
     def launch(self):
@@ -97,8 +99,9 @@ class GraphedTrainStep:
         self._g1 = self._g2 = None
         self._warm = warmup
 
-    def _fwd_bwd(self):
-        self.model.zero_grad()
+    def _fwd_bwd(self, zero=True):
+        if zero:
+            self.model.zero_grad()
         out = self.model.forward_static(self.x, self.ext, self.mask)
         out[0].backward()
         return out
@@ -110,10 +113,14 @@ class GraphedTrainStep:
             for _ in range(self._warm):
                 self._fwd_bwd()     # warm-up touches no optimizer state (lazy kernel attributes / allocator pools only)
         torch.cuda.current_stream().wait_stream(s)
+        # inside the replayed step the gradient buffer is cleared by the optimizer kernel of the previous step (hyper[7]); only the
+        # first replay needs it cleared here
+        self.opt.zero_grads_after_step = True
+        self.model.zero_grad()
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):
-            out = self._fwd_bwd()
+            out = self._fwd_bwd(zero=False)
             self.losses = torch.stack([o.detach() for o in out[:3]])
             if self.reducer is None or self.reducer.world == 1:
                 self.opt.launch()
