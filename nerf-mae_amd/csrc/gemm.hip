@@ -388,7 +388,8 @@ static bool try_dma(const AL& al, const void* Bw, long ldb, int M, int N, int K,
   if constexpr (std::is_same<AL, ADirect<bf16_t>>::value && MT == 1) {
     static const int dma_st = [] { const char* e = getenv("NMH_GEMM_DMA"); return e ? atoi(e) : -1; }();
     if (dma_st == 0 || !lda_ok(al.lda, ldb)) return false;
-    const bool auto_on = dma_st < 0 && K >= 1024 && (long)M * batch <= 8192;
+    static const int min_k = [] { const char* e = getenv("NMH_GEMM_DMA_MINK"); return e ? atoi(e) : 1024; }();
+    const bool auto_on = dma_st < 0 && K >= min_k && (long)M * batch <= 8192;
     if (dma_st == 3) { *rc = launch_nt_dma<MT, NT, 3>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
     if (dma_st == 4 || auto_on) { *rc = launch_nt_dma<MT, NT, 4>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
   }
