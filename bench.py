@@ -143,17 +143,24 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # per-kernel durations with HIP events on the launch stream: a few extra eager steps on the same model/data right after
-    # the timed region (graph replays cannot carry per-launch events; the kernels, shapes and data are identical)
+    # the timed region (graph replays cannot carry per-launch events; the kernels, shapes and data are identical).  The side stream
+    # is off for these steps so that an event pair brackets exactly one kernel (in the replayed step the decoder weight pack and the
+    # weight-gradient GEMMs overlap other kernels; rocprofv3 of the replay shows the same per-launch time, profiles/)
     prof = None
     if not args.no_kernel_timing and rank == 0:
+        side_was, ops.side_stream.enabled = ops.side_stream.enabled, False
         ops.PROFILE = {}
         ksteps = min(3, args.steps)
-        for i in range(ksteps):
+        for i in range(ksteps + 1):
+            if i == 1:
+                torch.cuda.synchronize()
+                ops.PROFILE = {}       # first eager step after the replays: lazy allocations, not timed
             model.zero_grad()
             l3 = model(grids, block_mask=draw_block_mask((g, g, g), 0.75, rng=mask_rng))
             l3[0].backward()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        ops.side_stream.enabled = side_was
     barrier()
     if world > 1:
         t = torch.tensor([dt], device=dev)
