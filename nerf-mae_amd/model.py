@@ -60,14 +60,16 @@ def relative_position_index(ws: int = WS) -> Tensor:
 
 
 def draw_block_mask(g: Sequence[int], p_remove: float, block: int = 4, rng=random) -> Tensor:
-    """swin_mae3d.py:1366-1373: one python-`random` draw per 4x4x4-token block in raster order -> uint8 (g0,g1,g2), 1 = removed."""
-    m = torch.zeros(tuple(g), dtype=torch.uint8)
-    for h in range(0, g[0] - block + 1, block):
-        for w in range(0, g[1] - block + 1, block):
-            for d in range(0, g[2] - block + 1, block):
-                if rng.random() < p_remove:
-                    m[h:h + block, w:w + block, d:d + block] = 1
-    return m
+    """swin_mae3d.py:1366-1373: one python-`random` draw per 4x4x4-token block in raster order -> uint8 (g0,g1,g2), 1 = removed.
+    The draws keep the reference's order (same RNG stream, same pattern); only the block fill is vectorised (the per-block tensor
+    slicing of a literal restatement costs 20-60 ms of host time per step and caps small-batch throughput)."""
+    nb = [max(0, (gi - block) // block + 1) for gi in g]
+    bits = np.fromiter((rng.random() < p_remove for _ in range(nb[0] * nb[1] * nb[2])), dtype=np.uint8, count=nb[0] * nb[1] * nb[2])
+    m = np.zeros(tuple(g), dtype=np.uint8)
+    if bits.size:
+        blk = bits.reshape(nb).repeat(block, 0).repeat(block, 1).repeat(block, 2)
+        m[:blk.shape[0], :blk.shape[1], :blk.shape[2]] = blk
+    return torch.from_numpy(m)
 
 
 # --------------------------------------------------------------------------------------------------

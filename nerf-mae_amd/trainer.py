@@ -61,9 +61,14 @@ class FusedAdamW:
         b1, b2 = self.betas
         self.b1_pow *= b1
         self.b2_pow *= b2
-        h = torch.tensor([self.lr, b1, b2, self.eps, self.wd, 1.0 - self.b1_pow, 1.0 - self.b2_pow, 1.0 if self.zero_grads_after_step else 0.0],
-                         dtype=torch.float32)
-        self.hyper.copy_(h, non_blocking=True)
+        # through a ring of pinned slots: a pageable source would make the copy (stream-ordered behind the running step) block the
+        # host, serialising the launch of step i+1 with the execution of step i
+        if getattr(self, "_pin", None) is None:
+            self._pin = torch.empty((8, 8), dtype=torch.float32).pin_memory() if self.hyper.is_cuda else torch.empty((8, 8))
+        slot = self._pin[self.t % 8]
+        slot.copy_(torch.tensor([self.lr, b1, b2, self.eps, self.wd, 1.0 - self.b1_pow, 1.0 - self.b2_pow,
+                                 1.0 if self.zero_grads_after_step else 0.0], dtype=torch.float32))
+        self.hyper.copy_(slot, non_blocking=True)
 
     def launch(self):
         """the three device-side launches (graph-capturable): grad norm, clip coefficient, AdamW update"""
@@ -138,9 +143,14 @@ class GraphedTrainStep:
                 a0, a1, a2 = t.shape[1:]
                 self.x[i, :, :a0, :a1, :a2].copy_(t, non_blocking=True)
                 ext.append([a0, a1, a2])
-            self.ext.copy_(torch.tensor(ext, dtype=torch.int32), non_blocking=True)
-        if block_mask is not None:
-            self.mask.copy_(block_mask.to(torch.uint8).reshape(-1), non_blocking=True)
+            self.ext.copy_(torch.tensor(ext, dtype=torch.int32).pin_memory(), non_blocking=True)
+        if block_mask is not None:   # pinned ring, see FusedAdamW.update_hyper
+            if getattr(self, "_pin_mask", None) is None:
+                self._pin_mask, self._pin_i = torch.empty((8, self.mask.numel()), dtype=torch.uint8).pin_memory(), 0
+            slot = self._pin_mask[self._pin_i % 8]
+            self._pin_i += 1
+            slot.copy_(block_mask.to(torch.uint8).reshape(-1))
+            self.mask.copy_(slot, non_blocking=True)
         if self._g1 is None:
             self._capture()
         self.opt.update_hyper()
