@@ -112,6 +112,7 @@ class GraphedTrainStep:
         return out
 
     def _capture(self):
+        ops.side_stream.auto(self.x.shape[0])
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
