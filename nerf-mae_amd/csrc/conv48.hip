@@ -21,11 +21,10 @@ namespace c48 {
 constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
 constexpr int LINE = HX * 96 + 16, PLANE = HY * LINE + 16, HALO = (TZ + 2) * PLANE;
 constexpr int NSTEP = 41, CSTEPS = 9, WCHUNK = CSTEPS * 3 * 1024;
-constexpr int LDS_BYTES = HALO + 2 * WCHUNK;
+constexpr int LDS_BYTES = HALO + 2 * WCHUNK + 2 * 96 * 4;  // halo, weight ring, statistics accumulators
 constexpr int HCH = (TZ + 2) * HY * HX * 6;  // 16-B chunks in the halo (6480)
 constexpr int HREG = (HCH + 511) / 512;      // 13
-static_assert(HREG == 13, "the counted vmcnt(13) in the chunk barrier assumes 13 halo loads per thread");
-constexpr int PF_CHUNK = 0;                  // weight chunk at whose start the next tile's halo is requested
+static_assert(HREG == 13, "the halo request schedule (4+3+3+3 over weight chunks 0-3) assumes 13 loads per thread");
 static_assert(LINE % 32 == 16 && PLANE % 32 == 16, "bank-half alternation");
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 }  // namespace c48
@@ -51,6 +50,9 @@ __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b
   x0 = __builtin_amdgcn_readfirstlane(xt * c48::TX);
 }
 
+// DBG (diagnostic builds only, NMH_C48_DBG): 1 = no output stores, 2 = no halo prefetch / LDS refill, 4 = no weight DMA and no
+// chunk barriers, 8 = no MFMAs (operand traffic only), 16 = no operand reads in the k-loop (MFMAs only).  DBG = 0 is the product.
+template <int DBG>
 __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   using namespace c48;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,29 +67,24 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 
   uint4 hreg[HREG];
   const unsigned sample_bytes = (unsigned)a.D * a.H * a.W * 96u;  // one sample of X (< 4 GiB)
-  // loads hreg[i0 .. i1) of tile t.  __syncthreads() drains vmcnt(0), so the prefetch is spread over the weight chunks:
-  // each barrier then only waits for loads that had a whole chunk of MFMAs (~1.6 us) to land.
-  auto halo_gload = [&](long t, int i0, int i1) {
-    int b, z0, y0, x0;
-    c48_tile_origin(a, t, b, z0, y0, x0);
+  // halo request i (of 13) of the tile at origin (b, z0, y0, x0): chunk id cid = tid + 512 i -> (line, within).  The requests of the
+  // NEXT tile are dealt one at a time over the k-steps of the current tile (see the chunk loop): a burst of 13 x 8 wave-loads backs
+  // up the CU's vector-memory path (measured ~40-75 cycles per 1-KB wave-load, latency-bound misses) and every wave then sits at
+  // issue in front of its MFMAs; one request every few k-steps never queues.
+  // `bytes` = sample_bytes, or 0 when there is no next tile: the request is still issued (no branch inside the k-loop) but every lane
+  // is out of range and reads zero without touching memory
+  auto halo_gload_one = [&](int i, int b, int z0, int y0, int x0, unsigned bytes) {
     int tv = tid;
     asm volatile("" : "+v"(tv));  // opaque: keep the index math below inside the tile loop (no LICM -> no long-lived VGPRs)
     // buffer resource over sample b: offsets are 32-bit, and an offset >= num_records reads as zero (the conv's zero padding)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * (sample_bytes / 2)), 0, (int)sample_bytes, 0x00020000);
-    // chunk id cid = tv + 512*i -> (line, within); 512 = 4*108 + 80, so the pair is advanced incrementally (no divisions)
-    int line = tv / (HX * 6), within = tv - line * (HX * 6);
-#pragma unroll
-    for (int i = 0; i < HREG; ++i) {
-      if (i >= i0 && i < i1) {
-        const int hz = (line * 205) >> 11, hy = line - hz * HY, hx = (within * 43) >> 8, c6 = within - hx * 6;  // /10 and /6 by multiply-shift
-        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-        const bool ok = line < (TZ + 2) * HY && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * 96 + c6 * 16) : 0xFFFFFFF0u;
-        hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
-      }
-      within += 80; line += 4;
-      if (within >= HX * 6) { within -= HX * 6; line += 1; }
-    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * (sample_bytes / 2)), 0, (int)bytes, 0x00020000);
+    const int cid = tv + 512 * i;
+    const int line = (cid * 4855) >> 19, within = cid - line * (HX * 6);                                      // /108 by multiply-shift
+    const int hz = (line * 205) >> 11, hy = line - hz * HY, hx = (within * 43) >> 8, c6 = within - hx * 6;  // /10 and /6
+    const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+    const bool ok = line < (TZ + 2) * HY && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * 96 + c6 * 16) : 0xFFFFFFF0u;
+    hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };
   auto halo_sstore = [&]() {
     int tv = tid;
@@ -115,14 +112,29 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     }
   };
 
+  auto w_dma_one = [&](int ck, int buf, int j) {  // j-th (of <= 4) DMA instruction of this wave for chunk ck
+    const int nunits = ((ck < 4) ? CSTEPS : (NSTEP - 4 * CSTEPS)) * 192;
+    const int u0 = wave * 64 + 512 * j;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));  // opaque: the (tile-invariant) 64-bit source addresses would otherwise be hoisted out of the tile loop: 40 VGPRs
+    if (u0 < nunits)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.Wk) + (long)ck * CSTEPS * 3072 + (long)(u0 + lv) * 16),
+                                       (__attribute__((address_space(3))) void*)(wbuf + buf * WCHUNK + u0 * 16), 16, 0, 0);
+  };
+
   // zero the 16-B pads once (they are only ever multiplied by zero weights, but must not hold NaN patterns)
   for (int i = tid; i < HALO / 16; i += 512) reinterpret_cast<uint4*>(halo)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 192) reinterpret_cast<float*>(smem + HALO + 2 * WCHUNK)[tid] = 0.f;  // statistics accumulators
   __syncthreads();
 
   long t = tbeg + jb;
   if (t >= tend) return;
-  halo_gload(t, 0, HREG);
+  int cb, cz0, cy0, cx0;  // origin of the current tile; the next tile's origin is computed once (64-bit divisions) and carried over
+  c48_tile_origin(a, t, cb, cz0, cy0, cx0);
+#pragma unroll
+  for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, cx0, sample_bytes);
   w_dma(0, 0);
+  if (DBG & 4) w_dma(1, 1);
   halo_sstore();
   __syncthreads();
   int wb = 0;  // LDS buffer holding chunk 0 of the current tile
@@ -135,34 +147,48 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   for (int q = 0; q < 2; ++q) { const int r = 4 * q + g; rowoff[q] = (r / 3) * PLANE + (r % 3) * LINE; }
   const int row8 = 2 * PLANE + 2 * LINE;
 
-  // fused InstanceNorm statistics: lane (li, g) owns channels 16n + 4g + r of voxel column li; partial sums live in registers
-  // across all tiles of one sample and are folded (16-lane shuffle reduce -> fp64 atomics) when the sample index changes
-  float st1[3][4], st2[3][4];
-#pragma unroll
-  for (int n = 0; n < 3; ++n)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { st1[n][r] = 0.f; st2[n][r] = 0.f; }
-  int st_b = -1;
+  // fused InstanceNorm statistics: lane (li, g) owns channels 16n + 4g + r of voxel column li.  Per tile the wave's partial sums are
+  // folded over its 16 voxel columns (DPP row scan) and added to a workgroup accumulator in LDS (ds_add_f32, [2][48][2] floats: the
+  // registers they used to occupy across tiles are what lets the k-loop keep its prefetch depth); the accumulator is flushed with fp64
+  // atomics when the workgroup moves to another sample.  Two accumulators alternate, so the flush (threads 0-95, during the first
+  // epilogue of the new sample) cannot race with that tile's additions.
+  float* const sacc = reinterpret_cast<float*>(smem + HALO + 2 * WCHUNK);
+  int st_b = -1, scur = 0;
   auto stats_flush = [&]() {
-    if (st_b < 0) return;
-#pragma unroll
-    for (int n = 0; n < 3; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a1 = st1[n][r], a2 = st2[n][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
-        if (li == 0) {
-          double* dst = a.stats_acc + ((long)st_b * 48 + 16 * n + 4 * g + r) * 2;
-          atomicAdd(dst, (double)a1);
-          atomicAdd(dst + 1, (double)a2);
-        }
-        st1[n][r] = 0.f; st2[n][r] = 0.f;
-      }
+    if (st_b >= 0 && tid < 96) {
+      const float v = sacc[scur * 96 + tid];
+      sacc[scur * 96 + tid] = 0.f;
+      atomicAdd(a.stats_acc + (long)st_b * 96 + tid, (double)v);
+    }
   };
+  auto row_sum = [](float v) -> float {  // inclusive scan over the 16-lane row: lane 15 ends up with the row total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+  };
+  // DBG & 32: per-wave cycle accounting (s_memtime) of the tile phases, written to stats_acc reinterpreted as int64 [block][wave][12]
+  long long ph[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) ph[i] = 0;
+  long long tlast = 0;
+  auto stamp = [&](int slot) {
+    if (DBG & 32) {
+      const long long now = (long long)__builtin_amdgcn_s_memtime();
+      ph[slot] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (DBG & 32) tlast = (long long)__builtin_amdgcn_s_memtime();
+  const long long tbegin = tlast;
   for (; t < tend; t += jstride) {
     const long tn = t + jstride;
     const bool has_next = tn < tend;
+    const bool pf_next = has_next && !(DBG & 2);
+    int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;
+    if (has_next) c48_tile_origin(a, tn, nb, nz0, ny0, nx0);
+    const unsigned nbytes = pf_next ? sample_bytes : 0u;
     f32x4 acc[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -192,44 +218,72 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 #pragma unroll
     for (int ck = 0; ck < 5; ++ck) {
       const int nxt = (ck < 4) ? ck + 1 : 0;
-      // the next tile's halo (13 x 16 B per thread) is requested only now, so its registers are live across the last 5 k-steps
-      // and the epilogue instead of the whole tile (the k-loop of chunks 0-3 keeps its fragment double-buffering)
-      // order matters: DMA first, then the 13 halo loads, so that "vmcnt(13)" at the end of chunk 0 means "older stores and this
-      // chunk's DMA have landed" while the halo prefetch stays in flight (vmcnt retires in order; __syncthreads would drain it)
-      if (ck < 4 || has_next) w_dma(nxt, (wb + ck + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ck == PF_CHUNK && has_next) halo_gload(tn, 0, HREG);
+      // VMEM issue is dealt over the k-steps: steps 0-3 carry this wave's (<= 4) DMA instructions for the next weight chunk, later steps
+      // the halo requests of the next tile (HSLOT: 4+3+3+3 = 13 over chunks 0-3).  vmcnt retires in order, so "vmcnt(#halo requests of
+      // this chunk)" at the chunk barrier means "the DMA and everything older has landed" while the newest requests stay in flight.
+      const bool do_dma = !(DBG & 4);  // (the chunk-0 image requested during the last tile is simply never read)
       const char* wsrc = wbuf + ((wb + ck) & 1) * WCHUNK;
       constexpr int NST4 = NSTEP - 4 * CSTEPS;
       const int nst = (ck < 4) ? CSTEPS : NST4;
-      ld_frags(0, wsrc, 0, ck * CSTEPS);
+      const int hbase = ck == 0 ? 0 : 4 + 3 * (ck - 1);  // first halo request index of this chunk
+      const int hcnt = ck == 0 ? 4 : (ck < 4 ? 3 : 0);
+      if (!(DBG & 16) || ck == 0) ld_frags(0, wsrc, 0, ck * CSTEPS);
+      if ((DBG & 16) && ck == 0) ld_frags(1, wsrc, 1, 1);
 #pragma unroll
       for (int sl = 0; sl < CSTEPS; ++sl) {
         if (sl < nst) {
-          if (sl + 1 < nst) ld_frags((sl + 1) & 1, wsrc, sl + 1, ck * CSTEPS + sl + 1);
+          if (!(DBG & 16) && sl + 1 < nst) ld_frags((sl + 1) & 1, wsrc, sl + 1, ck * CSTEPS + sl + 1);
+          if (do_dma && sl < 4) w_dma_one(nxt, (wb + ck + 1) & 1, sl);
+          if (sl >= 4) {
+            // chunk 0: steps 4,5,6,8; chunks 1-3: steps 4,6,8
+            const int k = (hcnt == 4) ? (sl == 4 ? 0 : sl == 5 ? 1 : sl == 6 ? 2 : sl == 8 ? 3 : -1) : (hcnt == 3) ? (sl == 4 ? 0 : sl == 6 ? 1 : sl == 8 ? 2 : -1) : -1;
+            if (k >= 0) halo_gload_one(hbase + k, nb, nz0, ny0, nx0, nbytes);
+          }
+          if (DBG & 8) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+            for (int n = 0; n < 3; ++n) asm volatile("" ::"v"(bf[sl & 1][n].v));
 #pragma unroll
-            for (int n = 0; n < 3; ++n) mma(acc[i][n], bf[sl & 1][n], af[sl & 1][i]);  // acc = (W . X^T) tile: rows co, cols voxel
+            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[sl & 1][i].v));
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int n = 0; n < 3; ++n) mma(acc[i][n], bf[sl & 1][n], af[sl & 1][i]);  // acc = (W . X^T) tile: rows co, cols voxel
+          }
         }
       }
-      if (ck == PF_CHUNK && has_next) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      stamp(ck == 0 ? 0 : ck == 1 ? 2 : 4);
+      if (!(DBG & 4)) {
+        if (hcnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (hcnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DBG & 32) stamp(ck == 0 ? 1 : ck == 1 ? 3 : 5);
+        __builtin_amdgcn_s_barrier();
+      }
+      stamp(ck == 0 ? 9 : ck == 1 ? 10 : 11);
     }
     wb ^= 1;  // 5 chunks: chunk 0 of the next tile landed in the other buffer
 
     // ---- epilogue: transposed accumulators (row = co = 16n + 4g + r, col = voxel x = li): every lane owns 4 consecutive
     //      channels of one voxel per (x-line, co-tile) -> 8-byte bf16 stores straight from registers, no LDS restaging ----
     {
-      int b, z0, y0, x0;
-      c48_tile_origin(a, t, b, z0, y0, x0);
+      const int b = cb, z0 = cz0, y0 = cy0, x0 = cx0;
       const int z = z0 + z_l, x = x0 + li;
-      if (a.stats_acc && b != st_b) { stats_flush(); st_b = b; }
+      const bool stats = !(DBG & 32) && a.stats_acc;
+      if (stats && b != st_b) {
+        stats_flush();
+        if (st_b >= 0) scur ^= 1;
+        st_b = b;
+      }
+      float st1[3][4], st2[3][4];
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st1[n][r] = 0.f; st2[n][r] = 0.f; }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int y = y0 + y_l + i;
-        if (z < a.D && y < a.H && x < a.W) {
+        if (z < a.D && y < a.H && x < a.W && (!(DBG & 1) || a.accumulate == 77)) {
           bf16_t* dst = a.Y + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + 4 * g;
 #pragma unroll
           for (int n = 0; n < 3; ++n) {
@@ -243,7 +297,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
             w2.x = pk_bf16(v0, v1);
             w2.y = pk_bf16(v2, v3);
             *reinterpret_cast<uint2*>(dst + 16 * n) = w2;
-            if (a.stats_acc) {  // statistics of exactly what the normalisation pass will read back
+            if (stats) {  // statistics of exactly what the normalisation pass will read back
               const float q0 = __uint_as_float(w2.x << 16), q1 = __uint_as_float(w2.x & 0xffff0000u), q2 = __uint_as_float(w2.y << 16), q3 = __uint_as_float(w2.y & 0xffff0000u);
               st1[n][0] += q0; st1[n][1] += q1; st1[n][2] += q2; st1[n][3] += q3;
               st2[n][0] += q0 * q0; st2[n][1] += q1 * q1; st2[n][2] += q2 * q2; st2[n][3] += q3 * q3;
@@ -251,13 +305,40 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
           }
         }
       }
+      if (stats) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a1 = row_sum(st1[n][r]), a2 = row_sum(st2[n][r]);
+            if (li == 15) {
+              float* dst = sacc + scur * 96 + (16 * n + 4 * g + r) * 2;
+              atomicAdd(dst, a1);
+              atomicAdd(dst + 1, a2);
+            }
+          }
+      }
     }
     // (the barrier closing weight chunk 4 already guarantees every wave is done reading the halo)
-    if (has_next) halo_sstore();
+    stamp(6);
+    cb = nb; cz0 = nz0; cy0 = ny0; cx0 = nx0;
+    if (pf_next) halo_sstore();
+    stamp(7);
     __syncthreads();
+    stamp(8);
+  }
+  if (DBG & 32) {
+    if (lane == 0) {
+      long long* o = reinterpret_cast<long long*>(a.stats_acc) + ((long)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) o[i] = ph[i];
+      o[12] = (long long)__builtin_amdgcn_s_memtime() - tbegin;
+    }
+    return;
   }
   if (a.stats_acc) stats_flush();
 }
+
 
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st) {
   using namespace c48;
@@ -268,18 +349,30 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   a.total = (long)B * a.tz * a.ty * a.tx;
   a.accumulate = accumulate;
   a.stats_acc = stats_acc;
-  if (stats_acc) {
+  static const int dbg = getenv("NMH_C48_DBG") ? atoi(getenv("NMH_C48_DBG")) : 0;
+  if (stats_acc && !(dbg & 32)) {
     hipError_t e = hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * 48 * B, st);
     if (e != hipSuccess) return (int)e;
   }
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   long nb = a.total < 256 ? ((a.total + 7) / 8 * 8) : 256;
-  hipLaunchKernelGGL(conv48_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
+  if (dbg) {  // timing decomposition only: results are wrong by construction
+#define C48_DBG_CASE(D) case D: { hipFuncSetAttribute((const void*)conv48_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+    hipLaunchKernelGGL(conv48_kernel<D>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a); break; }
+    switch (dbg) {
+      C48_DBG_CASE(1) C48_DBG_CASE(2) C48_DBG_CASE(3) C48_DBG_CASE(4) C48_DBG_CASE(7) C48_DBG_CASE(8) C48_DBG_CASE(15) C48_DBG_CASE(16) C48_DBG_CASE(23) C48_DBG_CASE(32)
+      default: return -1;
+    }
+#undef C48_DBG_CASE
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
+  hipLaunchKernelGGL(conv48_kernel<0>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
 }
