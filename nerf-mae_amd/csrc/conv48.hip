@@ -439,22 +439,23 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   const bf16_t* dYs = a.dY + os * 48;
   const long ldx = a.ldx, ldy = a.ldy;
 
+  const unsigned sample_bytes_x = (unsigned)a.D * a.H * a.W * (unsigned)a.ldx * 2u;  // one sample of X, all channels (< 4 GiB: checked at launch)
   uint4 hreg[HREG];
-  auto halo_gload = [&](long t) {
-    int b, z0, y0, x0;
-    w48_tile_origin(a, t, b, z0, y0, x0);
-#pragma unroll
-    for (int i = 0; i < HREG; ++i) {
-      const int cid = tid + NT * i;
-      hreg[i] = make_uint4(0, 0, 0, 0);
-      if (cid < HCH) {
-        const int line = cid / (HX * 6), within = cid - line * (HX * 6);
-        const int hz = line / HY, hy = line - hz * HY, hx = within / 6, c6 = within - hx * 6;
-        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-        if ((unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W)
-          hreg[i] = *reinterpret_cast<const uint4*>(Xs + ((((long)b * a.D + z) * a.H + y) * a.W + x) * ldx + c6 * 8);
-      }
-    }
+  // halo request i / dY DMA instruction j of the tile at origin (b, z0, y0, x0).  `on` = false (no next tile) keeps the instruction in
+  // the stream (no branches inside the k-loop) but touches no memory.  The requests of the NEXT tile are dealt over the k-steps of the
+  // current one: issued as one burst they back up the CU's vector-memory path and every wave waits in front of its MFMAs (see conv48).
+  auto halo_gload_one = [&](int i, int b, int z0, int y0, int x0, bool on) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));  // opaque: no hoisting of the tile-invariant index math out of the tile loop (VGPR budget)
+    const int cid = tv + NT * i;
+    const int line = (cid * 4855) >> 19, within = cid - line * (HX * 6);  // /108
+    const int hz = (line * 43) >> 8, hy = line - hz * HY, hx = (within * 43) >> 8, c6 = within - hx * 6;  // /6, /6
+    const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+    // buffer resource over the channel slice of sample b: 32-bit offsets, and an offset >= num_records reads as zero (the zero padding)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Xs + (long)b * (sample_bytes_x / 2)), 0, on ? (int)sample_bytes_x : 0, 0x00020000);
+    const bool ok = cid < HCH && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+    const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * (a.ldx * 2) + c6 * 16) : 0xFFFFFFF0u;
+    hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };
   auto halo_sstore = [&]() {
 #pragma unroll
@@ -463,13 +464,15 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
       if (cid < HCH) reinterpret_cast<uint4*>(halo)[cid] = hreg[i];  // halo image is dense: chunk id == LDS chunk index
     }
   };
-  auto dy_dma = [&](long t, int buf) {
-    int b, z0, y0, x0;
-    w48_tile_origin(a, t, b, z0, y0, x0);
-    for (int u0 = wave * 64; u0 < DCH; u0 += NT) {
-      const int u = u0 + lane, v = u / 6, c6 = u - v * 6;
+  constexpr int NDMA = (DCH + NT - 1) / NT;  // DMA instructions per wave and tile: 3 (8 waves) or 2 (16 waves, the second one on waves 0-7)
+  auto dy_dma_one = [&](int j, int b, int z0, int y0, int x0, int buf, bool on) {
+    const int u0 = wave * 64 + NT * j;
+    if (u0 < DCH) {
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+      const int u = u0 + lv, v = (u * 10923) >> 16, c6 = u - v * 6;  // /6 (u < 4096)
       const int line = v >> 4, x = x0 + (v & 15), z = z0 + (line >> 2), y = y0 + (line & 3);
-      const void* src = (z < a.D && y < a.H && x < a.W)
+      const void* src = (on && z < a.D && y < a.H && x < a.W)
                             ? (const void*)(dYs + ((((long)b * a.D + z) * a.H + y) * a.W + x) * ldy + c6 * 8)
                             : (const void*)g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -500,23 +503,38 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   long t = tbeg + jb;
   int cur = 0;
   if (t < tend) {
-    dy_dma(t, 0);
-    halo_gload(t);
+    int b, z0, y0, x0;
+    w48_tile_origin(a, t, b, z0, y0, x0);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) dy_dma_one(j, b, z0, y0, x0, 0, true);
+#pragma unroll
+    for (int i = 0; i < HREG; ++i) halo_gload_one(i, b, z0, y0, x0, true);
     halo_sstore();
   }
   __syncthreads();
   for (; t < tend; t += jstride) {
     const long tn = t + jstride;
     const bool has_next = tn < tend;
-    if (has_next) { dy_dma(tn, cur ^ 1); halo_gload(tn); }
+    int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;
+    if (has_next) w48_tile_origin(a, tn, nb, nz0, ny0, nx0);
     const char* dyc = dyb + cur * DYT;
-#pragma unroll (NW == 8 ? 2 : 1)
+#pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       // lines 2ks, 2ks+1 of the tile: (z_l, y_l) = (ks>>1, (ks&1)*2) and y_l+1
       const int lbase = (ks >> 1) * PLANE + ((ks & 1) * 2) * LINE + lane_off;
       Frag<bf16_t> af[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) af[c] = lds_frag_t(dyc, 96, ks * 32, c * 16, lane, (bf16_t*)nullptr);
+      // VMEM schedule of the next tile: DMA instruction ks on the first NDMA steps; halo requests 1,1,1,2,2,1 (8 waves) or 1,1,1,1
+      // (16 waves) on steps 0-5, so the last two steps (~2k cycles) give the newest requests time to land before the tile barrier
+      if (ks < NDMA) dy_dma_one(ks, nb, nz0, ny0, nx0, cur ^ 1, has_next);
+      {
+        constexpr int h8[9] = {0, 1, 2, 3, 5, 7, 8, 8, 8}, h4[9] = {0, 1, 2, 3, 4, 4, 4, 4, 4};
+        const int h0 = HREG == 8 ? h8[ks] : h4[ks], h1 = HREG == 8 ? h8[ks + 1] : h4[ks + 1];
+#pragma unroll
+        for (int i = 0; i < HREG; ++i)
+          if (i >= h0 && i < h1) halo_gload_one(i, nb, nz0, ny0, nx0, has_next);
+      }
 #pragma unroll
       for (int i = 0; i < UPW; ++i) {
         const char* pb = halo + lbase + uoff[i];
@@ -606,6 +624,6 @@ int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, i
 }
 // any Cin, Cout that are multiples of 48 (the decoder levels 96..768): (Cin/48)*(Cout/48) sub-problems, <= 256 workgroups in total
 int k_conv3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st) {
-  if (Cin % 48 || Cout % 48 || (Cin / 48) * (Cout / 48) > 256) return -2;
+  if (Cin % 48 || Cout % 48 || (Cin / 48) * (Cout / 48) > 256 || (double)D * H * W * Cin * 2 >= 4294967296.0) return -2;
   return launch_wgrad_halo(dY, X, dW, ws, B, D, H, W, Cin, Cout, st);
 }
