@@ -43,6 +43,18 @@ NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64
 /* Y[(b,z,y,x)][Cout] (+)= conv3d(k=3,pad=1) of channels-last X with packed weights [Cout][27][Cin] (nn.Conv3d in
  * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout]. */
 NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+/* The same convolution with a per-output-channel bias in the epilogue (nn.Conv3d(C, C, 3, padding=1) of the FPN neck,
+ * nerf_rpn/model/fpn.py:104). */
+NMH_API int nmh_conv3d_k3_bias(int dt, const void* X, const void* Wp, const float* bias, void* Y, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+/* FPN top-down pathway (nerf_rpn/model/fpn.py:150-159): fine[b,zf,yf,xf,:] += coarse[b,src(zf),src(yf),src(xf),:] with
+ * F.interpolate(mode="nearest", size=fine) source indices src(i) = min(floor(i * (float)in/out), in-1); channels-last, C % 8 == 0.
+ * _bwd is its adjoint: dcoarse += sum of dfine over the voxels that read it. */
+NMH_API int nmh_nearest_upsample_add(int dt, const void* coarse, void* fine, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream);
+NMH_API int nmh_nearest_upsample_add_bwd(int dt, const void* dfine, void* dcoarse, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream);
+/* channels-last compute tensor [B][V][C] (dt) <-> fp32 NCDHW feature map [B][C][V], the layout nerf_rpn's heads consume
+ * (torch.permute(x,[0,4,1,2,3]).contiguous(), feature_extractor.py:1183-1185), and back for the incoming gradient. */
+NMH_API int nmh_ndhwc_to_ncdhw(int dt, const void* src, float* dst, int B, int64_t V, int C, void* stream);
+NMH_API int nmh_ncdhw_to_ndhwc(int dt, const float* src, void* dst, int B, int64_t V, int C, void* stream);
 /* The same convolution specialised for Cin = Cout = 48, bf16 (decoder1.conv_block at 160^3 -- 75 % of the model's FLOPs): persistent
  * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad). */
 NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, void* stream);

@@ -64,6 +64,27 @@ int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, 
   EpiParams ep{Y, Cout, nullptr, 0, nullptr, nullptr, nullptr, 1, accumulate};
   return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
 }
+int nmh_conv3d_k3_bias(int dt, const void* X, const void* Wp, const float* bias, void* Y, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
+  CLR();
+  EpiParams ep{Y, Cout, bias, 0, nullptr, nullptr, nullptr, 1, 0};
+  return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
+}
+int nmh_nearest_upsample_add(int dt, const void* coarse, void* fine, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream) {
+  CLR();
+  return k_nearest_up_add(dt, coarse, fine, B, Dc, Hc, Wc, Df, Hf, Wf, C, 0, ST);
+}
+int nmh_nearest_upsample_add_bwd(int dt, const void* dfine, void* dcoarse, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream) {
+  CLR();
+  return k_nearest_up_add(dt, dcoarse, const_cast<void*>(dfine), B, Dc, Hc, Wc, Df, Hf, Wf, C, 1, ST);
+}
+int nmh_ndhwc_to_ncdhw(int dt, const void* src, float* dst, int B, int64_t V, int C, void* stream) {
+  CLR();
+  return k_vc_transpose(dt, src, dst, B, (long)V, C, 0, ST);
+}
+int nmh_ncdhw_to_ndhwc(int dt, const float* src, void* dst, int B, int64_t V, int C, void* stream) {
+  CLR();
+  return k_vc_transpose(dt, src, dst, B, (long)V, C, 1, ST);
+}
 int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, void* stream) {
   CLR();
   return k_conv48(X, Wk, Y, B, D, H, W, accumulate, stats_acc, ST);

@@ -517,3 +517,125 @@ int k_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst,
   NMH_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- FPN neck pieces (nerf_rpn/model/fpn.py:150-166, the rank-1 widening of SURVEY 8(f)) ------------------------------------------
+// top-down pathway: fine[b][zf][yf][xf][:] += coarse[b][src(zf)][src(yf)][src(xf)][:], src = F.interpolate(mode='nearest', size=fine):
+// src(i) = min(int(floorf(i * (float)in / out)), in - 1) exactly as ATen computes it; channels-last, 8 channels per thread.
+struct UpGeom { int Dc, Hc, Wc, Df, Hf, Wf; float sz, sy, sx; };
+__device__ __forceinline__ int nearest_src(int i, float s, int n) { int v = (int)floorf((float)i * s); return v < n - 1 ? v : n - 1; }
+template <typename T>
+__global__ __launch_bounds__(256) void nearest_up_add_kernel(const T* __restrict__ coarse, T* __restrict__ fine, int B, UpGeom g, int C8) {
+  const long total = (long)B * g.Df * g.Hf * g.Wf * C8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C8);
+    long v = i / C8;
+    const int xf = (int)(v % g.Wf); v /= g.Wf;
+    const int yf = (int)(v % g.Hf); v /= g.Hf;
+    const int zf = (int)(v % g.Df);
+    const int b = (int)(v / g.Df);
+    const long cv = (((long)b * g.Dc + nearest_src(zf, g.sz, g.Dc)) * g.Hc + nearest_src(yf, g.sy, g.Hc)) * g.Wc + nearest_src(xf, g.sx, g.Wc);
+    float a[8], s[8];
+    Vec8<T>::load(fine + i * 8, a);
+    Vec8<T>::load(coarse + (cv * C8 + c) * 8, s);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += s[j];
+    Vec8<T>::store(fine + i * 8, a);
+  }
+}
+// adjoint: dcoarse[b][zc][yc][xc][:] += sum over the fine voxels whose nearest source is (zc,yc,xc) (a contiguous box per axis)
+template <typename T>
+__global__ __launch_bounds__(256) void nearest_up_add_bwd_kernel(const T* __restrict__ dfine, T* __restrict__ dcoarse, int B, UpGeom g, int C8) {
+  const long total = (long)B * g.Dc * g.Hc * g.Wc * C8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C8);
+    long v = i / C8;
+    const int xc = (int)(v % g.Wc); v /= g.Wc;
+    const int yc = (int)(v % g.Hc); v /= g.Hc;
+    const int zc = (int)(v % g.Dc);
+    const int b = (int)(v / g.Dc);
+    float a[8];
+    Vec8<T>::load(dcoarse + i * 8, a);
+    // candidate fine range per axis: [floor(c*out/in) - 1, floor((c+1)*out/in) + 1], filtered by the exact source test
+    const int z0 = max(0, (int)((long)zc * g.Df / g.Dc) - 1), z1 = min(g.Df - 1, (int)((long)(zc + 1) * g.Df / g.Dc) + 1);
+    const int y0 = max(0, (int)((long)yc * g.Hf / g.Hc) - 1), y1 = min(g.Hf - 1, (int)((long)(yc + 1) * g.Hf / g.Hc) + 1);
+    const int x0 = max(0, (int)((long)xc * g.Wf / g.Wc) - 1), x1 = min(g.Wf - 1, (int)((long)(xc + 1) * g.Wf / g.Wc) + 1);
+    for (int zf = z0; zf <= z1; ++zf) {
+      if (nearest_src(zf, g.sz, g.Dc) != zc) continue;
+      for (int yf = y0; yf <= y1; ++yf) {
+        if (nearest_src(yf, g.sy, g.Hc) != yc) continue;
+        for (int xf = x0; xf <= x1; ++xf) {
+          if (nearest_src(xf, g.sx, g.Wc) != xc) continue;
+          float s[8];
+          Vec8<T>::load(dfine + (((((long)b * g.Df + zf) * g.Hf + yf) * g.Wf + xf) * C8 + c) * 8, s);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += s[j];
+        }
+      }
+    }
+    Vec8<T>::store(dcoarse + i * 8, a);
+  }
+}
+static UpGeom up_geom(int Dc, int Hc, int Wc, int Df, int Hf, int Wf) {
+  UpGeom g{Dc, Hc, Wc, Df, Hf, Wf, (float)Dc / (float)Df, (float)Hc / (float)Hf, (float)Wc / (float)Wf};
+  return g;
+}
+int k_nearest_up_add(int dt, const void* coarse, void* fine, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, int bwd, hipStream_t st) {
+  if (C % 8 || B <= 0 || Dc <= 0 || Hc <= 0 || Wc <= 0 || Df <= 0 || Hf <= 0 || Wf <= 0) return -2;
+  const UpGeom g = up_geom(Dc, Hc, Wc, Df, Hf, Wf);
+  const int C8 = C / 8;
+  if (!bwd) {
+    const unsigned nb = ew_blocks((long)B * Df * Hf * Wf * C8);
+    if (dt == NMH_DT_BF16) hipLaunchKernelGGL(nearest_up_add_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)coarse, (bf16_t*)fine, B, g, C8);
+    else hipLaunchKernelGGL(nearest_up_add_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)coarse, (float*)fine, B, g, C8);
+  } else {  // (dfine = `fine` is read, dcoarse = `coarse` is accumulated into)
+    const unsigned nb = ew_blocks((long)B * Dc * Hc * Wc * C8);
+    if (dt == NMH_DT_BF16) hipLaunchKernelGGL(nearest_up_add_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)fine, (bf16_t*)const_cast<void*>(coarse), B, g, C8);
+    else hipLaunchKernelGGL(nearest_up_add_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)fine, (float*)const_cast<void*>(coarse), B, g, C8);
+  }
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// channels-last compute tensors <-> the NCDHW fp32 feature maps the detection heads consume (feature_extractor.py:1183-1185):
+// per sample a [V][C] <-> [C][V] transpose through a 32x33 LDS tile, both sides coalesced; dir 0: T [V][C] -> fp32 [C][V], 1: back
+template <typename T, int DIR>
+__global__ __launch_bounds__(256) void vc_transpose_kernel(const void* __restrict__ src_, void* __restrict__ dst_, long V, int C) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const long v0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads
+  if (DIR == 0) {
+    const T* src = (const T*)src_ + (long)b * V * C;
+    float* dst = (float*)dst_ + (long)b * V * C;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+      if (v0 + r < V && c0 + tx < C) tile[r][tx] = to_f(src[(v0 + r) * C + c0 + tx]);
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+      if (c0 + r < C && v0 + tx < V) dst[(long)(c0 + r) * V + v0 + tx] = tile[tx][r];
+  } else {
+    const float* src = (const float*)src_ + (long)b * V * C;
+    T* dst = (T*)dst_ + (long)b * V * C;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+      if (c0 + r < C && v0 + tx < V) tile[tx][r] = src[(long)(c0 + r) * V + v0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+      if (v0 + r < V && c0 + tx < C) dst[(v0 + r) * C + c0 + tx] = from_f<T>(tile[r][tx]);
+  }
+}
+int k_vc_transpose(int dt, const void* src, void* dst, int B, long V, int C, int dir, hipStream_t st) {
+  if (B <= 0 || V <= 0 || C <= 0 || B > 65535 || (C + 31) / 32 > 65535) return -2;
+  dim3 grid((unsigned)((V + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+  if (dt == NMH_DT_BF16) {
+    if (dir == 0) hipLaunchKernelGGL((vc_transpose_kernel<bf16_t, 0>), grid, dim3(256), 0, st, src, dst, V, C);
+    else hipLaunchKernelGGL((vc_transpose_kernel<bf16_t, 1>), grid, dim3(256), 0, st, src, dst, V, C);
+  } else {
+    if (dir == 0) hipLaunchKernelGGL((vc_transpose_kernel<float, 0>), grid, dim3(256), 0, st, src, dst, V, C);
+    else hipLaunchKernelGGL((vc_transpose_kernel<float, 1>), grid, dim3(256), 0, st, src, dst, V, C);
+  }
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

@@ -403,3 +403,51 @@ def clip_coef(acc, max_norm, coef, norm_out=None):
 
 def adamw_step(p, g, m, v, hyper, coef=None):
     lib().call("nmh_adamw_step", p, g, m, v, p.numel(), hyper, coef, _st())
+
+
+# ---- FPN neck (nerf_rpn/model/fpn.py) -----------------------------------------------------------------------
+def conv3d_k3_bias(X, Wp, bias, Cout, out=None):
+    """conv3d_k3 with a per-output-channel fp32 bias in the epilogue: X (B,D,H,W,Cin) channels-last, Wp packed [Cout][27][Cin]."""
+    _chk(X, Wp, bias, out)
+    B, D, H, W, Cin = X.shape
+    if out is None:
+        out = torch.empty((B, D, H, W, Cout), dtype=X.dtype, device=X.device)
+    lib().call("nmh_conv3d_k3_bias", dt_of(X), X, Wp, bias, out, B, D, H, W, Cin, Cout, _st())
+    return out
+
+
+def nearest_upsample_add(coarse, fine):
+    """fine (B,Df,Hf,Wf,C) += F.interpolate(coarse (B,Dc,Hc,Wc,C), size=fine, mode='nearest'), channels-last, in place."""
+    _chk(coarse, fine)
+    B, Dc, Hc, Wc, C = coarse.shape
+    _, Df, Hf, Wf, _ = fine.shape
+    lib().call("nmh_nearest_upsample_add", dt_of(fine), coarse, fine, B, Dc, Hc, Wc, Df, Hf, Wf, C, _st())
+    return fine
+
+
+def nearest_upsample_add_bwd(dfine, dcoarse):
+    """adjoint of nearest_upsample_add: dcoarse += sum of dfine over the fine voxels that read each coarse voxel, in place."""
+    _chk(dfine, dcoarse)
+    B, Dc, Hc, Wc, C = dcoarse.shape
+    _, Df, Hf, Wf, _ = dfine.shape
+    lib().call("nmh_nearest_upsample_add_bwd", dt_of(dfine), dfine, dcoarse, B, Dc, Hc, Wc, Df, Hf, Wf, C, _st())
+    return dcoarse
+
+
+def ndhwc_to_ncdhw(x):
+    """channels-last compute tensor (B,D,H,W,C) -> fp32 NCDHW (B,C,D,H,W)"""
+    _chk(x)
+    B, D, H, W, C = x.shape
+    out = torch.empty((B, C, D, H, W), dtype=torch.float32, device=x.device)
+    lib().call("nmh_ndhwc_to_ncdhw", dt_of(x), x, out, B, D * H * W, C, _st())
+    return out
+
+
+def ncdhw_to_ndhwc(g, dtype):
+    """fp32 NCDHW gradient (B,C,D,H,W) -> channels-last (B,D,H,W,C) in the compute dtype"""
+    g = g.float().contiguous()
+    _chk(g)
+    B, C, D, H, W = g.shape
+    out = torch.empty((B, D, H, W, C), dtype=dtype, device=g.device)
+    lib().call("nmh_ncdhw_to_ndhwc", dt_of(out), g, out, B, D * H * W, C, _st())
+    return out

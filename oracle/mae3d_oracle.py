@@ -381,6 +381,43 @@ class MAE3DOracle(nn.Module):
         return [z.permute(0, 4, 1, 2, 3).contiguous() for z in self.encode(t)]
 
 
+class FPNOracle(nn.Module):
+    """CPU restatement of the FPN neck as SwinTransformer_FPN_Pretrained_Skip configures it (nerf_rpn/model/fpn.py:57-166 with
+    start_level=0, end_level=-1, add_extra_convs=False, num_outs=len(in_channels), upsample nearest): 1x1 lateral convs, top-down
+    `laterals[i-1] += F.interpolate(laterals[i], size=prev_shape, mode="nearest")` (fpn.py:150-159), 3x3x3 output convs."""
+
+    def __init__(self, in_channels: Sequence[int], out_channels: int, num_outs: int):
+        super().__init__()
+        assert num_outs == len(in_channels)
+        self.in_channels, self.out_channels = list(in_channels), out_channels
+        self.lateral_convs = nn.ModuleList([nn.Conv3d(c, out_channels, 1) for c in in_channels])
+        self.fpn_convs = nn.ModuleList([nn.Conv3d(out_channels, out_channels, 3, padding=1) for _ in in_channels])
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        lat = [l(x) for l, x in zip(self.lateral_convs, inputs)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        return tuple(c(x) for c, x in zip(self.fpn_convs, lat))
+
+
+class FPNSkipOracle(nn.Module):
+    """CPU restatement of SwinTransformer_FPN_Pretrained_Skip (nerf_rpn/model/feature_extractor.py:1067-1187): the MAE-pretrained
+    encoder (decoders, head and mask token deleted, :1159-1164) + FPN neck; forward(x (B,4,R,R,R)) -> 4 NCDHW maps (:1176-1187)."""
+
+    def __init__(self, out_channels: int = 256, resolution: int = 160, backbone_type: str = "swin_s", **kw):
+        super().__init__()
+        base = build_oracle(backbone_type, resolution=resolution, stochastic_depth_prob=kw.pop("stochastic_depth_prob", 0.1), **kw)
+        del base.decoder4, base.decoder3, base.decoder2, base.decoder1, base.out, base.mask_token
+        self.base = base
+        E = base.embed_dim
+        self.out_channels = out_channels
+        self.fpn_neck = FPNOracle([E, 2 * E, 4 * E, 8 * E], out_channels, 4)
+
+    def forward(self, x: Tensor):
+        return self.fpn_neck(self.base.encoder_features(x))
+
+
 def build_oracle(name: str = "swin_t", **kw) -> MAE3DOracle:
     cfg = dict(SWIN_CONFIGS[name])
     if name == "swin_b":
