@@ -79,11 +79,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    # dry-run hooks for a 1-GPU box (control flow of the N > 1 path: rank > 0 capture, flat all-reduce, optimizer graph): every rank
+    # on device 0 and gloo instead of RCCL (which refuses two ranks on one GPU).  Never set by the driver.
+    backend = os.environ.get("NMH_BENCH_BACKEND", "nccl")
+    if os.environ.get("NMH_BENCH_SHARE_GPU", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     R, Bg = args.resolution, args.batch_per_gpu
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -131,7 +139,11 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                torch.cuda.synchronize()
+                dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):

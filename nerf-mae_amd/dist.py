@@ -64,6 +64,10 @@ class GradReducer:
             g.div_(self.world)
             self.pending.append(seg)
             return
+        if dist.get_backend(self.group) != "nccl":
+            # device tensors over gloo (single-GPU dry runs): no stream-ordered collectives, and a blocking all-reduce issued from the
+            # autograd thread deadlocks -- nothing to overlap anyway, finish() reduces the whole buffer from the calling thread
+            return
         cur = torch.cuda.current_stream()
         self.comm_stream.wait_stream(cur)
         with torch.cuda.stream(self.comm_stream):
@@ -76,9 +80,25 @@ class GradReducer:
                 dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
         self.pending.append(seg)
 
+    def allreduce_flat(self):
+        """the whole flat gradient buffer in one message on the current stream (graph mode: between the backward graph and the
+        optimizer graph).  RCCL averages in the collective; other backends (gloo: CPU tests and single-GPU dry runs) sum and scale."""
+        if self.world == 1:
+            return
+        g = self.model._flat_grad
+        if self.on_gpu and dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.div_(self.world)
+
     def finish(self):
         """call after backward: reduce any segment whose trigger did not fire, then join the comm stream"""
         if self.world == 1:
+            return
+        if self.on_gpu and dist.get_backend(self.group) != "nccl":
+            self.allreduce_flat()
+            self.pending = []
             return
         for seg in range(self.nseg):
             if seg not in self.pending:

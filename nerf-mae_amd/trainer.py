@@ -157,8 +157,7 @@ class GraphedTrainStep:
         self.opt.update_hyper()
         self._g1.replay()
         if self._g2 is not None:
-            import torch.distributed as dist
-            dist.all_reduce(self.model._flat_grad, op=dist.ReduceOp.AVG, group=self.reducer.group)
+            self.reducer.allreduce_flat()
             self._g2.replay()
         return self.losses
 

@@ -1,0 +1,100 @@
+"""GPU, world_size 2 on ONE device over gloo (RCCL refuses two ranks on one GPU; the 8-GPU run is the driver's): the control flow of
+the data-parallel step -- rank > 0 capture, backward graph -> flat gradient all-reduce -> optimizer graph, and the eager reducer --
+must leave both ranks with identical parameters that equal a single-process step on the averaged gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8])
+
+
+def _build():
+    from nerf_mae_amd.model import SwinTransformer_MAE3D
+    torch.manual_seed(5)
+    m = SwinTransformer_MAE3D(patch_size=[4] * 3, window_size=[4] * 3, resolution=32, masking_prob=0.75, stochastic_depth_prob=0.0,
+                              compute_dtype=torch.float32, **TINY).cuda()
+    m.train()
+    m.flatten_parameters()
+    return m
+
+
+def _data(rank):
+    from oracle import mae3d_oracle as O
+    return [O.synthetic_grid((32, 32, 32), 40 + rank).cuda()], O.draw_block_mask((8, 8, 8), 0.75, rng=__import__("random").Random(9))
+
+
+def _worker(rank, world, port, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_mae_amd.dist import GradReducer, broadcast_parameters
+        from nerf_mae_amd.trainer import FusedAdamW, GraphedTrainStep
+        m = _build()
+        broadcast_parameters(m)
+        red = GradReducer(m)
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1)
+        grids, bm = _data(rank)
+        if mode == "graph":
+            step = GraphedTrainStep(m, opt, 1, reducer=red)
+            for _ in range(2):
+                step(grids, bm)
+        else:
+            m._reducer = red
+            for _ in range(2):
+                m.zero_grad()
+                m(grids, block_mask=bm)[0].backward()
+                red.finish()
+                opt.step()
+        torch.cuda.synchronize()
+        flat = m._flat.detach().cpu()
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), (both[0] - both[1]).abs().max()
+        q.put((rank, "ok", flat if rank == 0 else None))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_two_ranks_one_gpu_match_single_process_average(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000) + (0 if mode == "graph" else 1)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    flat2 = None
+    for rank, msg, flat in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+        if flat is not None:
+            flat2 = flat
+    # single process: average the two ranks' gradients by hand, same optimizer
+    from nerf_mae_amd.trainer import FusedAdamW
+    m = _build()
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1)
+    for _ in range(2):
+        gs = []
+        for r in range(2):
+            grids, bm = _data(r)
+            m.zero_grad()
+            m(grids, block_mask=bm)[0].backward()
+            gs.append(m._flat_grad.clone())
+        m._flat_grad.copy_((gs[0] + gs[1]) / 2)
+        opt.step()
+    torch.cuda.synchronize()
+    ref = m._flat.detach().cpu()
+    assert ((flat2 - ref).abs().max() / ref.abs().max()).item() < 1e-5
