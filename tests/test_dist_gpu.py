@@ -40,7 +40,7 @@ def _worker(rank, world, port, mode, q):
         m = _build()
         broadcast_parameters(m)
         red = GradReducer(m)
-        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1)
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1, eps=1.0)  # eps=1: the update stays linear in tiny gradients, so atomics-order noise is not amplified to +-lr
         grids, bm = _data(rank)
         if mode == "graph":
             step = GraphedTrainStep(m, opt, 1, reducer=red)
@@ -58,7 +58,7 @@ def _worker(rank, world, port, mode, q):
         both = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1]), (both[0] - both[1]).abs().max()
-        q.put((rank, "ok", flat if rank == 0 else None))
+        q.put((rank, "ok", flat.numpy() if rank == 0 else None))   # numpy: pickled by value (a tensor would travel as a shared-memory handle)
     except Exception:  # noqa: BLE001
         import traceback
         q.put((rank, traceback.format_exc(), None))
@@ -81,11 +81,11 @@ def test_two_ranks_one_gpu_match_single_process_average(mode):
     for rank, msg, flat in res:
         assert msg == "ok", f"rank {rank}: {msg}"
         if flat is not None:
-            flat2 = flat
+            flat2 = torch.from_numpy(flat)
     # single process: average the two ranks' gradients by hand, same optimizer
     from nerf_mae_amd.trainer import FusedAdamW
     m = _build()
-    opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1)
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1, eps=1.0)  # eps=1: the update stays linear in tiny gradients, so atomics-order noise is not amplified to +-lr
     for _ in range(2):
         gs = []
         for r in range(2):
