@@ -51,6 +51,9 @@ NMH_API int nmh_conv3d_k3_bias(int dt, const void* X, const void* Wp, const floa
  * _bwd is its adjoint: dcoarse += sum of dfine over the voxels that read it. */
 NMH_API int nmh_nearest_upsample_add(int dt, const void* coarse, void* fine, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream);
 NMH_API int nmh_nearest_upsample_add_bwd(int dt, const void* dfine, void* dcoarse, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream);
+/* dst[m][0..C) = src[m][0..C), row strides lds / ldd in elements: the skip connection entering (and its gradient leaving) the
+ * channel-concatenated decoder tensor -- torch.cat((out, skip), dim=1), unetr_block.py:196-197, in channels-last. */
+NMH_API int nmh_copy_cols(int dt, const void* src, int64_t lds, void* dst, int64_t ldd, int64_t M, int C, void* stream);
 /* channels-last compute tensor [B][V][C] (dt) <-> fp32 NCDHW feature map [B][C][V], the layout nerf_rpn's heads consume
  * (torch.permute(x,[0,4,1,2,3]).contiguous(), feature_extractor.py:1183-1185), and back for the incoming gradient. */
 NMH_API int nmh_ndhwc_to_ncdhw(int dt, const void* src, float* dst, int B, int64_t V, int C, void* stream);

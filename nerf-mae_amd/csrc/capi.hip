@@ -77,6 +77,10 @@ int nmh_nearest_upsample_add_bwd(int dt, const void* dfine, void* dcoarse, int B
   CLR();
   return k_nearest_up_add(dt, dcoarse, const_cast<void*>(dfine), B, Dc, Hc, Wc, Df, Hf, Wf, C, 1, ST);
 }
+int nmh_copy_cols(int dt, const void* src, int64_t lds, void* dst, int64_t ldd, int64_t M, int C, void* stream) {
+  CLR();
+  return k_copy_cols(dt, src, (long)lds, dst, (long)ldd, (long)M, C, ST);
+}
 int nmh_ndhwc_to_ncdhw(int dt, const void* src, float* dst, int B, int64_t V, int C, void* stream) {
   CLR();
   return k_vc_transpose(dt, src, dst, B, (long)V, C, 0, ST);

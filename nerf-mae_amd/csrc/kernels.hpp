@@ -93,6 +93,7 @@ int k_conv3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int 
 int k_conv3_tn(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st);
 int k_nearest_up_add(int dt, const void* coarse, void* fine, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, int bwd, hipStream_t st);
 int k_vc_transpose(int dt, const void* src, void* dst, int B, long V, int C, int dir, hipStream_t st);
+int k_copy_cols(int dt, const void* src, long lds, void* dst, long ldd, long M, int C, hipStream_t st);
 
 // ---- norm.hip ----
 // src_mode: 0 direct rows, 1 window-ordered output rows (gather tokens, pads -> 0), 2 patch-merge gather (8 tokens -> 8C row)

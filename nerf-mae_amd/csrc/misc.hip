@@ -639,3 +639,25 @@ int k_vc_transpose(int dt, const void* src, void* dst, int B, long V, int C, int
   NMH_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- strided 2-D copy: dst[m][0..C) = src[m][0..C) with independent row strides (skip connection into / out of the channel-concatenated
+// decoder tensor, unetr_block.py:196-197: torch.cat((out, skip), dim=1) in channels-last = a column block copy), 16 bytes per thread ----
+template <typename T>
+__global__ __launch_bounds__(256) void copy_cols_kernel(const T* __restrict__ src, long lds, T* __restrict__ dst, long ldd, long M, int Cv) {
+  constexpr int E = 16 / sizeof(T);
+  const long total = M * Cv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / Cv;
+    const int c = (int)(i - m * Cv);
+    *reinterpret_cast<uint4*>(dst + m * ldd + c * E) = *reinterpret_cast<const uint4*>(src + m * lds + c * E);
+  }
+}
+int k_copy_cols(int dt, const void* src, long lds, void* dst, long ldd, long M, int C, hipStream_t st) {
+  const int E = dt == NMH_DT_BF16 ? 8 : 4;
+  if (M <= 0 || C <= 0 || C % E || lds % E || ldd % E || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return -2;
+  const unsigned nb = ew_blocks(M * (C / E));
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(copy_cols_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, M, C / E);
+  else hipLaunchKernelGGL(copy_cols_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)src, lds, (float*)dst, ldd, M, C / E);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

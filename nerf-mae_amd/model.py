@@ -292,7 +292,7 @@ class _UpBlockFn(torch.autograd.Function):
         cat = torch.empty((B * V, Cc), dtype=dtype, device=dev)
         ops.upconv_fwd(x, pk[key + "t.w"].view(k3 * Cout, Cin), m.transp_conv.bias, cat, B, v, k, Cin, Cout)   # pixel shuffle in the epilogue
         if has_skip:
-            cat[:, Cout:].copy_(skip)
+            ops.copy_cols(skip.reshape(B * V, Cout), cat[:, Cout:])
         S = v * k
         scratch = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
         c48 = (key + "c1.wk") in pk.views and (key + "c2.wk") in pk.views
@@ -389,7 +389,10 @@ class _UpBlockFn(torch.autograd.Function):
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
             with ops.side_stream():
                 ops.gemm_tn(dy3, cat, _gradbuf(m.conv_block.conv3.weight))
-        dskip = dcat[:, Cout:].contiguous() if has_skip else None
+        dskip = None
+        if has_skip:
+            dskip = torch.empty((B * V, Cout), dtype=dtype, device=dev)
+            ops.copy_cols(dcat[:, Cout:], dskip)
         dx = torch.empty((B * v ** 3, Cin), dtype=dtype, device=dev)
         ops.upconv_dgrad(dcat, pk[key + "t.wd"].view(Cin, k3 * Cout), dx, B, v, k, Cin, Cout)   # reads dcat through the pixel shuffle
         with ops.side_stream():

@@ -451,3 +451,14 @@ def ncdhw_to_ndhwc(g, dtype):
     out = torch.empty((B, D, H, W, C), dtype=dtype, device=g.device)
     lib().call("nmh_ncdhw_to_ndhwc", dt_of(out), g, out, B, D * H * W, C, _st())
     return out
+
+
+def copy_cols(src, dst):
+    """dst[m, :C] = src[m, :C] for 2-D views with arbitrary row strides (unit column stride): skip connection <-> concatenated tensor"""
+    if src.dim() != 2 or dst.dim() != 2 or src.shape != dst.shape or src.stride(1) != 1 or dst.stride(1) != 1 or src.dtype != dst.dtype:
+        raise RuntimeError("copy_cols needs two 2-D views of equal shape and dtype with unit column stride")
+    if not (src.is_cuda and dst.is_cuda):
+        raise RuntimeError("nerf_mae_amd ops need HIP device tensors (no CPU fallback)")
+    M, C = src.shape
+    lib().call("nmh_copy_cols", dt_of(src), src, src.stride(0), dst, dst.stride(0), M, C, _st())
+    return dst

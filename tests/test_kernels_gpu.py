@@ -611,3 +611,19 @@ def test_conv48_specialised_matches_reference_conv(B, D, H, W):
     dW = torch.full((48, 48, 3, 3, 3), 0.5, device="cuda")
     ops.conv3d_k3_c48_wgrad(dycl, xcl, dW)
     check(dW, wr.grad + 0.5, dt, "conv48 wgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_copy_cols_strided(dtype):
+    """skip connection into / out of the concatenated decoder tensor (torch.cat(dim=1) in channels-last = column block copy)"""
+    from nerf_mae_amd import ops
+    M, C = 1000, 96
+    skip = torch.randn(M, C, device="cuda").to(dtype)
+    cat = torch.zeros(M, 2 * C, device="cuda", dtype=dtype)
+    ops.copy_cols(skip, cat[:, C:])
+    assert torch.equal(cat[:, C:], skip) and (cat[:, :C] == 0).all()
+    back = torch.empty_like(skip)
+    ops.copy_cols(cat[:, C:], back)
+    assert torch.equal(back, skip)
+    with pytest.raises(RuntimeError):
+        ops.copy_cols(skip, cat[:, C:C + 8])
