@@ -194,10 +194,10 @@ int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, v
   if (rc) return rc;
   return k_loss_finalize(sums, losses, ST);
 }
-int nmh_mae_tail_bwd(int dt, const void* d0, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums,
+int nmh_mae_tail_bwd(int dt, const void* d0, const void* r, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums,
                      void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, void* stream) {
   CLR();
-  return k_tail_bwd(dt, d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, (long)V, C, ST);
+  return k_tail_bwd(dt, d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, (long)V, C, ST);
 }
 int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst, int R, int flags, void* stream) {
   CLR();

@@ -157,7 +157,7 @@ int k_loss_bwd(const LossArgs& a, void* dd0, float* dWout, float* dbout, hipStre
 // d0 = lrelu(IN(x)+r) -> out, fused with the 1x1 head and the loss terms (a.d0 unused; sums/pred/dp as in k_loss_fwd)
 int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void* r, void* out, float slope, hipStream_t st);
 // loss backward + backward of d0 = lrelu(IN(x)+r) in two elementwise passes over (d0, x, dp): dx, dr = g; also head weight/bias gradients
-int k_tail_bwd(int dt, const void* d0, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
+int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
                void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, hipStream_t st);
 int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rowscale, int rows_per_scale, hipStream_t st);
 int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st);

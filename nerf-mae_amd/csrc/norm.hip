@@ -652,7 +652,7 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
 // {sum g, sum g*xhat} with g = d(d0) * lrelu'(d0), plus the head weight gradient dW[o][c] = sum_v dp[v][o] d0[v][c];
 // pass 1 (APPLY=1): dx = rstd (g - S1/V - xhat S2/V), dr = g.  Same thread mapping as the InstanceNorm kernels above.
 template <typename T, int APPLY>
-__global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dp,
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0, const T* __restrict__ rres, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dp,
                                                        const double* __restrict__ lsums, const float* __restrict__ Wout, double* in_sums, T* __restrict__ dx,
                                                        T* __restrict__ dr, float slope, float* dWout, float* dbout, long V, int C, long vpb) {
   extern __shared__ float sred[];  // [6][C]
@@ -686,9 +686,17 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
         const long v = vb + (long)u * NV;
         if (v < v1) {
           const long o = ((long)b * V + v) * C + cl * 8;
-          Vec8<T>::load(d0 + o, ov[u]);
+          Vec8<T>::load((d0 ? d0 : rres) + o, ov[u]);
           Vec8<T>::load(x + o, xv[u]);
           dq[u] = *reinterpret_cast<const float4*>(dp + ((long)b * V + v) * 4);
+          if (!d0) {  // d0 was not stored by the forward: rebuild it bit-exactly (same fp32 expression, same rounding) from x and r
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float y = (xv[u][j] - mu[j]) * rs[j] + ov[u][j];
+              y = y > 0.f ? y : slope * y;
+              ov[u][j] = to_f<T>(from_f<T>(y));
+            }
+          }
         }
       }
 #pragma unroll
@@ -736,9 +744,9 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
   for (int i = threadIdx.x; i < 4 * C; i += 256) atomicAdd(&dWout[i], sred[2 * C + i] * (i / C < 3 ? inv_occ : inv_rm));
   if (blockIdx.x == 0 && b == 0 && threadIdx.x < 4) atomicAdd(&dbout[threadIdx.x], (float)(lsums[4 + threadIdx.x] * (threadIdx.x < 3 ? 1.0 / lsums[1] : 1.0 / lsums[3])));
 }
-int k_tail_bwd(int dt, const void* d0, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
+int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
                void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, hipStream_t st) {
-  if (C % 8 || C / 8 > 256) return -2;
+  if (C % 8 || C / 8 > 256 || (!d0 && !r)) return -2;
   hipError_t e = hipMemsetAsync(in_sums, 0, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
   const long vpb = in_vox_per_block(V);
@@ -746,14 +754,14 @@ int k_tail_bwd(int dt, const void* d0, const void* xin, const float* in_stats, c
   dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + vpa - 1) / vpa), B);
   const size_t lds = 6 * C * sizeof(float);
   if (dt == NMH_DT_BF16) {
-    hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 0>), g0, dim3(256), lds, st, (const bf16_t*)d0, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)nullptr,
+    hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 0>), g0, dim3(256), lds, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)nullptr,
                        (bf16_t*)nullptr, slope, dWout, dbout, V, C, vpb);
-    hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
+    hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
                        (bf16_t*)dr, slope, dWout, dbout, V, C, vpa);
   } else {
-    hipLaunchKernelGGL((tail_bwd_kernel<float, 0>), g0, dim3(256), lds, st, (const float*)d0, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)nullptr,
+    hipLaunchKernelGGL((tail_bwd_kernel<float, 0>), g0, dim3(256), lds, st, (const float*)d0, (const float*)r, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)nullptr,
                        (float*)nullptr, slope, dWout, dbout, V, C, vpb);
-    hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), g1, dim3(256), 0, st, (const float*)d0, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)dx,
+    hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), g1, dim3(256), 0, st, (const float*)d0, (const float*)r, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)dx,
                        (float*)dr, slope, dWout, dbout, V, C, vpa);
   }
   NMH_CHECK_LAUNCH();
@@ -821,7 +829,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
       const float yr = to_f<T>(from_f<T>(y));   // the value the backward (and the reference's next op) sees
       p[0] += yr * w[0][j]; p[1] += yr * w[1][j]; p[2] += yr * w[2][j]; p[3] += yr * w[3][j];
     }
-    if (ok) Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv);
+    if (ok && out) Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv);
     float tot[4] = {0.f, 0.f, 0.f, 0.f};
     const int src0 = vl * CL;
     for (int c = 0; c < CL; ++c) {

@@ -316,9 +316,10 @@ class _UpBlockFn(torch.autograd.Function):
         else:
             y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout).view(B * V, Cout)
             ops.instnorm_stats(y2, st2, scratch, B, V, Cout)
-        out = torch.empty_like(y2)
         y3 = st3 = None
         fused_tail = tail is not None and not m.has_proj
+        # fused tail: d0 = lrelu(IN(y2) + cat) is consumed inside the tail kernels and rebuilt from (y2, cat) in the backward -- never stored
+        out = None if fused_tail else torch.empty_like(y2)
         if m.has_proj:
             y3 = ops.gemm_nt(cat, pk[key + "c3.w"].view(Cout, Cc))
             st3 = torch.empty((B, Cout, 2), device=dev)
@@ -358,8 +359,8 @@ class _UpBlockFn(torch.autograd.Function):
         dcat = torch.empty_like(cat)
         if ctx.tail is not None:   # d(loss)/d(losses[0]) == 1 (the reference calls loss.backward()); d(d0) is never materialised
             model, lsums, dpred = ctx.tail
-            ops.mae_tail_bwd(out, y2, st2, dpred, lsums, model.out.conv.weight, sums2, dy2, dcat,
-                             _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout)
+            ops.mae_tail_bwd(None, y2, st2, dpred, lsums, model.out.conv.weight, sums2, dy2, dcat,
+                             _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout, r=cat)
         elif m.has_proj:
             dout = dout.contiguous()
             sums3 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)

@@ -352,7 +352,7 @@ def mae_loss_bwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, 
 
 
 def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred=None, dpred=None, slope=0.01):
-    """d0 = lrelu(IN(y) + r), 1x1 head and loss terms in one pass (instnorm_apply rmode 1 + mae_loss_fwd)"""
+    """d0 = lrelu(IN(y) + r), 1x1 head and loss terms in one pass (instnorm_apply rmode 1 + mae_loss_fwd); d0 = None: not stored"""
     _chk(y, stats, r, d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred)
     if dpred is not None and sums.numel() < 8:
         raise ValueError("mae_tail_fwd: sums needs 8 entries when dpred is requested")
@@ -360,9 +360,12 @@ def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C,
     return losses
 
 
-def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01):
-    _chk(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout)
-    lib().call("nmh_mae_tail_bwd", dt_of(d0), d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, _st())
+def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01, r=None):
+    """d0 may be None when r (the forward's residual input) is given: the kernel rebuilds d0 from y, stats and r"""
+    _chk(d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout)
+    if d0 is None and r is None:
+        raise ValueError("mae_tail_bwd needs d0 or r")
+    lib().call("nmh_mae_tail_bwd", dt_of(y), d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, _st())
 
 
 GRID_ROT, GRID_FLIP0, GRID_FLIP1, GRID_DENSITY = 1, 2, 4, 8

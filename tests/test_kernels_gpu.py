@@ -482,6 +482,20 @@ def test_tail_backward_fused(dt):
     ops.instnorm_bwd_apply(dd0, args[0], yd, stats, sums2, dy2, B, V, Cd, r=rd, rmode=1, dr=dr2)
     check(dy, dy2.float().cpu(), dt, "fused vs unfused dy", 3)
     check(dW, dW2.cpu(), dt, "fused vs unfused dW", 2)
+    # d0 not stored: the forward skips the write, the backward rebuilds d0 from (y, stats, r) -- identical results
+    lsums3, losses3, dpred3 = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda"), torch.empty(B * V, 4, device="cuda")
+    ops.mae_tail_fwd(yd.view(-1, Cd), stats, rd.view(-1, Cd), None, args[1], args[2], args[3], args[4], args[5], B, R, Cd, lsums3, losses3, None, dpred3)
+    assert torch.equal(dpred3, dpred2) and torch.allclose(losses3, losses2, rtol=1e-6)
+    dy3, dr3 = torch.empty_like(dy), torch.empty_like(dr)
+    dW3, db3 = torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda")
+    in_sums3 = torch.empty_like(in_sums)
+    in_sumsk = torch.empty_like(in_sums)
+    dyk, drk, dWk, dbk = torch.empty_like(dy), torch.empty_like(dr), torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda")
+    ops.mae_tail_bwd(d0k, yd.view(-1, Cd), stats, dpred2, lsums2, args[1], in_sumsk, dyk, drk, dWk, dbk, B, V, Cd)          # stored d0 of the fused forward
+    ops.mae_tail_bwd(None, yd.view(-1, Cd), stats, dpred2, lsums2, args[1], in_sums3, dy3, dr3, dW3, db3, B, V, Cd, r=rd.view(-1, Cd))
+    assert torch.equal(dr3, drk)                                                        # elementwise: bit-identical
+    assert torch.allclose(dy3.float(), dyk.float(), rtol=1e-2 if dt == torch.bfloat16 else 1e-4, atol=1e-6)   # goes through the fp64-atomic channel sums
+    assert torch.allclose(dW3, dWk, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("dt", DTS)

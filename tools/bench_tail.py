@@ -36,7 +36,7 @@ def timeit(f, n=10):
 
 
 def fused():
-    ops.mae_tail_bwd(d0, y, stats, dpred, lsums, Wo, sums, dy, dr, dW, db, B, V, Cd)
+    ops.mae_tail_bwd(None, y, stats, dpred, lsums, Wo, sums, dy, dr, dW, db, B, V, Cd, r=r)
 
 
 def unfused():
