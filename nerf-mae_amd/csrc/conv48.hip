@@ -351,7 +351,7 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   a.stats_acc = stats_acc;
   static const int dbg = getenv("NMH_C48_DBG") ? atoi(getenv("NMH_C48_DBG")) : 0;
   if (stats_acc && !(dbg & 32)) {
-    hipError_t e = hipMemsetAsync(stats_acc, 0, sizeof(double) * 2 * 48 * B, st);
+    hipError_t e = nmh_zero_async(stats_acc, sizeof(double) * 2 * 48 * B, st);
     if (e != hipSuccess) return (int)e;
   }
   static bool attr_set = false;
@@ -580,8 +580,16 @@ __global__ void conv48_wgrad_reduce_kernel(const float* ws, float* dW, int nbloc
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w48::PARTIAL) return;
   const int sub = blockIdx.y, cs = sub % nci, os = sub / nci;
-  float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += ws[((long)sub * nblocks + b) * w48::PARTIAL + i];
+  // 8 independent partial sums: the loads of one thread are 249 KB apart, so memory-level parallelism has to come from unrolling
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* src = ws + (long)sub * nblocks * w48::PARTIAL + i;
+  int b = 0;
+  for (; b + 8 <= nblocks; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += src[(long)(b + u) * w48::PARTIAL];
+  }
+  for (; b < nblocks; ++b) s8[0] += src[(long)b * w48::PARTIAL];
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   const int col = i & 15, row = (i >> 4) & 15, uc = i >> 8, ct = uc % 3, u = uc / 3, tap = u / 3, cit = u - tap * 3;
   dW[((long)(os * 48 + ct * 16 + row) * Cin + cs * 48 + cit * 16 + col) * 27 + tap] += s;
 }

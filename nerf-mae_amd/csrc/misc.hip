@@ -255,7 +255,7 @@ static inline size_t loss_lds(const LossArgs& a) {
 }
 int k_loss_fwd(const LossArgs& a, hipStream_t st) {
   if (a.Cd % 8 || a.Cd > 64) return -2;
-  hipError_t e = hipMemsetAsync(a.sums, 0, (a.dp ? 8 : 4) * sizeof(double), st);
+  hipError_t e = nmh_zero_async(a.sums, (a.dp ? 8 : 4) * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   long ntile = ((long)a.R * a.R * a.R + 255) / 256;
   dim3 grid((unsigned)(ntile < 2048 ? ntile : 2048), a.B);
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, dou
   if (threadIdx.x == 0) atomicAdd(acc, (double)(sh[0] + sh[1] + sh[2] + sh[3]));
 }
 int k_sqnorm(const float* g, long n, double* acc, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(acc, 0, sizeof(double), st);
+  hipError_t e = nmh_zero_async(acc, sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(ew_blocks((n + 3) / 4, 2048)), dim3(256), 0, st, g, n, acc);
   NMH_CHECK_LAUNCH();

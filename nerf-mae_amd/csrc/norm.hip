@@ -305,7 +305,7 @@ int k_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
     const WinMap& w = a.wm;
     if ((long)w.PH * w.PW * w.PD != (long)w.H * w.W * w.D) {   // pad rows of the window-ordered tensor receive no token
       const size_t es = a.dt == NMH_DT_BF16 ? 2 : 4;
-      hipError_t e = hipMemsetAsync(a.dyw, 0, (size_t)w.B * w.PH * w.PW * w.PD * a.C * es, st);
+      hipError_t e = nmh_zero_async(a.dyw, (size_t)w.B * w.PH * w.PW * w.PD * a.C * es, st);
       if (e != hipSuccess) return (int)e;
     }
   }
@@ -492,7 +492,7 @@ static inline long in_vox_per_block(long V) {
 }
 int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st) {
   if (C % 8 || C / 8 > 256) return -2;
-  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B * C, st);
+  hipError_t e = nmh_zero_async(scratch, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
   const long vpb = in_vox_per_block(V);
   dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
@@ -516,9 +516,9 @@ int k_in_finalize(int dt, const double* acc, float* stats, int B, long V, int C,
 int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, const float* stats, const void* r, const float* stats_r, int rmode,
                     double* sums, double* sums_r, int B, long V, int C, float slope, hipStream_t st) {
   if (C % 8 || C / 8 > 256 || (!out && rmode != 0)) return -2;
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * C, st);
+  hipError_t e = nmh_zero_async(sums, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
-  if (rmode == 2) { e = hipMemsetAsync(sums_r, 0, sizeof(double) * 2 * B * C, st); if (e != hipSuccess) return (int)e; }
+  if (rmode == 2) { e = nmh_zero_async(sums_r, sizeof(double) * 2 * B * C, st); if (e != hipSuccess) return (int)e; }
   const long vpb = in_vox_per_block(V);
   dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
   size_t lds = (4 * C + 32 * 256) * sizeof(float);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
 int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
                void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, hipStream_t st) {
   if (C % 8 || C / 8 > 256 || (!d0 && !r)) return -2;
-  hipError_t e = hipMemsetAsync(in_sums, 0, sizeof(double) * 2 * B * C, st);
+  hipError_t e = nmh_zero_async(in_sums, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
   const long vpb = in_vox_per_block(V);
   const long vpa = in_apply_vpb(V, B, C);
@@ -865,7 +865,7 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
   const int C = a.Cd;
   if (C % 8 || C > 512) return -2;
   const long V = (long)a.R * a.R * a.R;
-  hipError_t e = hipMemsetAsync(a.sums, 0, (a.dp ? 8 : 4) * sizeof(double), st);
+  hipError_t e = nmh_zero_async(a.sums, (a.dp ? 8 : 4) * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   long vpb = (V * a.B + 2047) / 2048;
   if (vpb < 160) vpb = 160;
