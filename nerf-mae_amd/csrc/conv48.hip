@@ -264,6 +264,12 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     }
     wb ^= 1;  // 5 chunks: chunk 0 of the next tile landed in the other buffer
 
+    // the next tile's halo goes to LDS first (the barrier closing weight chunk 4 guarantees every wave is done reading the old one, its
+    // vmcnt(0) that the registers have landed): the 13 ds_write_b128 are only issued here and drain while the epilogue below keeps the
+    // VALU and the vector-memory path busy
+    if (pf_next) halo_sstore();
+    stamp(7);
+
     // ---- epilogue: transposed accumulators (row = co = 16n + 4g + r, col = voxel x = li): every lane owns 4 consecutive
     //      channels of one voxel per (x-line, co-tile) -> 8-byte bf16 stores straight from registers, no LDS restaging ----
     {
@@ -319,11 +325,8 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
           }
       }
     }
-    // (the barrier closing weight chunk 4 already guarantees every wave is done reading the halo)
     stamp(6);
     cb = nb; cz0 = nz0; cy0 = ny0; cx0 = nx0;
-    if (pf_next) halo_sstore();
-    stamp(7);
     __syncthreads();
     stamp(8);
   }
