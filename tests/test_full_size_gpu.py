@@ -1,0 +1,100 @@
+"""GPU, BASELINE.json's full size (swin_s, 4x160^3): the hot path against the CPU oracle on one grid (the oracle needs ~20 s for
+forward + backward on the GPU box's host), and size-independent properties of the 160^3 kernels that an oracle at a toy size cannot
+exercise (every tile / halo boundary of the persistent LDS-halo convolutions)."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SWIN_S = dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24])
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+@pytest.fixture(scope="module")
+def oracle_run():
+    """one oracle forward + backward at full size, shared by the fp32 and the bf16 comparison"""
+    import time
+    import psutil
+    from oracle import mae3d_oracle as O
+    torch.set_num_threads(psutil.cpu_count(logical=False) or 8)   # physical cores: the SMT siblings make the CPU convolutions ~10x slower
+    t0 = time.perf_counter()
+    torch.manual_seed(77)
+    ora = O.MAE3DOracle(resolution=160, masking_prob=0.75, stochastic_depth_prob=0.0, **SWIN_S)
+    with torch.no_grad():   # the reference's own initialisation + non-trivial biases / bias tables
+        for n, p in ora.named_parameters():
+            if p.requires_grad and (n.endswith("bias") or "relative_position_bias_table" in n):
+                p.add_(0.02 * torch.randn_like(p))
+    xs = [O.synthetic_grid((160, 132, 96), 5)]        # ragged extents: pad_tensor + the analytic valid mask at full size
+    bm = O.draw_block_mask((40, 40, 40), 0.75, rng=random.Random(123))
+    out = ora(xs, block_mask=bm, return_pred=True)
+    out[0].backward()
+    print(f"[full size] oracle forward+backward: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+    return ora, xs, bm, [o.detach() for o in out]
+
+
+@pytest.mark.parametrize("dtype,ltol,ptol,gcos", [(torch.float32, 1e-4, 1e-3, 0.9999), (torch.bfloat16, 2e-2, 6e-2, 0.99)], ids=["fp32", "bf16"])
+def test_full_size_matches_oracle(oracle_run, dtype, ltol, ptol, gcos):
+    from nerf_mae_amd.model import SwinTransformer_MAE3D
+    ora, xs, bm, lo = oracle_run
+    hip = SwinTransformer_MAE3D(patch_size=[4] * 3, window_size=[4] * 3, resolution=160, masking_prob=0.75, stochastic_depth_prob=0.0,
+                                compute_dtype=dtype, **SWIN_S)
+    hip.load_state_dict(ora.state_dict(), strict=True)
+    hip = hip.cuda()
+    hip.zero_grad()
+    lh = hip([t.cuda() for t in xs], block_mask=bm, return_pred=True)
+    lh[0].backward()
+    torch.cuda.synchronize()
+    for a, b, n in zip(lh[:3], lo[:3], ("loss", "loss_rgb", "loss_alpha")):
+        assert abs(a.item() - b.item()) / abs(b.item()) < ltol, (n, a.item(), b.item())
+    assert relerr(lh[3], lo[3]) < ptol, "reconstructed grid"   # north star: within 1e-3 relative in fp32
+    po = dict(ora.named_parameters())
+    fa, fb = [], []
+    for n, p in hip.named_parameters():
+        if p.requires_grad and p.grad is not None and po[n].grad is not None:
+            fa.append(p.grad.float().cpu().flatten())
+            fb.append(po[n].grad.flatten())
+    fa, fb = torch.cat(fa), torch.cat(fb)
+    assert (torch.dot(fa, fb) / (fa.norm() * fb.norm())).item() > gcos
+    assert abs(fa.norm().item() - fb.norm().item()) / fb.norm().item() < (1e-3 if dtype == torch.float32 else 5e-2)
+
+
+def _pack(w, mode, n):
+    from tests.test_kernels_gpu import _pack_via_kernel
+    return _pack_via_kernel(w, mode, torch.bfloat16, n)
+
+
+def test_conv48_full_size_shift_equivariance_and_linearity():
+    """160^3 x 48 through the persistent LDS-halo kernel: translating the input by (1,3,5) voxels translates the output bit for bit
+    away from the border (every output voxel accumulates the same products in the same order whatever tile it lands in), and
+    conv(a) + conv(b) == conv(a + b) up to the bf16 rounding of the three stores."""
+    from nerf_mae_amd import ops
+    R = 160
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn(48, 48, 3, 3, 3, generator=torch.Generator().manual_seed(1)) * (27 * 48) ** -0.5
+    wk = _pack(w, 6, 41 * 3 * 64 * 8)
+    x = torch.zeros(1, R, R, R, 48, device="cuda", dtype=torch.bfloat16)
+    x[:, 8:-8, 8:-8, 8:-8] = torch.randn(1, R - 16, R - 16, R - 16, 48, device="cuda", generator=g).to(torch.bfloat16)
+    y = ops.conv3d_k3_c48(x, wk)
+    xs = torch.roll(x, shifts=(1, 3, 5), dims=(1, 2, 3))          # the zero margin keeps the wrap-around out of the support
+    ys = ops.conv3d_k3_c48(xs, wk)
+    assert torch.equal(ys, torch.roll(y, shifts=(1, 3, 5), dims=(1, 2, 3)))
+    b = torch.randn(1, R, R, R, 48, device="cuda", generator=g).to(torch.bfloat16)
+    yb, yab = ops.conv3d_k3_c48(b, wk), ops.conv3d_k3_c48((x.float() + b.float()).to(torch.bfloat16), wk)
+    err = (yab.float() - (y.float() + yb.float())).abs().max().item()
+    assert err < 0.06 * yab.float().abs().max().item()
+    # the input gradient is the same kernel with the flipped pack: <conv(x), dy> == <x, conv^T(dy)>  (adjoint identity, fp32 sums)
+    wkd = _pack(w, 7, 41 * 3 * 64 * 8)
+    dy = torch.randn(1, R, R, R, 48, device="cuda", generator=g).to(torch.bfloat16)
+    dx = ops.conv3d_k3_c48(dy, wkd)
+    lhs, rhs = (y.double() * dy.double()).sum().item(), (x.double() * dx.double()).sum().item()
+    assert abs(lhs - rhs) < 2e-3 * (y.double().norm() * dy.double().norm()).item()
+    # weight gradient: <dW, w> == <conv(x), dy>  (the same bilinear form, third argument)
+    dW = torch.zeros(48, 48, 3, 3, 3, device="cuda")
+    ops.conv3d_k3_c48_wgrad(dy, x, dW)
+    wq = w.to(torch.bfloat16).double().cuda()
+    assert abs((dW.double() * wq).sum().item() - lhs) < 2e-3 * (y.double().norm() * dy.double().norm()).item()

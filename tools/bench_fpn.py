@@ -52,7 +52,8 @@ try:
 except Exception as e:  # noqa: BLE001
     print("graph capture failed:", repr(e)[:300])
 if "--no-cpu" not in sys.argv:
-    torch.set_num_threads(os.cpu_count() or 1)
+    import psutil
+    torch.set_num_threads(psutil.cpu_count(logical=False) or 8)
     ora = O.FPNSkipOracle(resolution=160).train()
     xc = x[:1].cpu()
     t0 = time.perf_counter()
