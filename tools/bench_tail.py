@@ -35,8 +35,15 @@ def timeit(f, n=10):
     return (time.perf_counter() - t) / n * 1e3
 
 
+r = torch.randn_like(y)
+
+
 def fused():
     ops.mae_tail_bwd(None, y, stats, dpred, lsums, Wo, sums, dy, dr, dW, db, B, V, Cd, r=r)
+
+
+def fused_stored():
+    ops.mae_tail_bwd(d0, y, stats, dpred, lsums, Wo, sums, dy, dr, dW, db, B, V, Cd)
 
 
 def unfused():
@@ -45,9 +52,9 @@ def unfused():
     ops.instnorm_bwd_apply(dd0, d0, y, stats, sums, dy, B, V, Cd, r=d0, rmode=1, dr=dr)
 
 
-print(f"fused tail bwd  {timeit(fused):.3f} ms   unfused {timeit(unfused):.3f} ms   loss fwd {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None)):.3f} / with dpred {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)):.3f} ms")
+print(f"fused tail bwd  {timeit(fused):.3f} ms (stored d0: {timeit(fused_stored):.3f})   unfused {timeit(unfused):.3f} ms   loss fwd {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None)):.3f} / with dpred {timeit(lambda: ops.mae_loss_fwd(d0, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)):.3f} ms")
 out = torch.empty_like(y)
-r = torch.randn_like(y)
+t_f0 = timeit(lambda: ops.mae_tail_fwd(y, stats, r, None, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred))
 t_f = timeit(lambda: ops.mae_tail_fwd(y, stats, r, out, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred))
 t_u = timeit(lambda: (ops.instnorm_apply(y, stats, out, B, V, Cd, r=r, rmode=1), ops.mae_loss_fwd(out, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)))
-print(f"fused tail fwd {t_f:.3f} ms   unfused (in_apply + loss fwd) {t_u:.3f} ms")
+print(f"fused tail fwd {t_f:.3f} ms (d0 not stored: {t_f0:.3f})   unfused (in_apply + loss fwd) {t_u:.3f} ms")
