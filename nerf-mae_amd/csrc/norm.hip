@@ -784,6 +784,8 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
   const int vl = lane / CL, cl = lane - vl * CL;
   const bool active = vl < VPW;
   const bool leader = active && cl == 0;
+  int p2half = 1;
+  while (p2half * 2 < CL) p2half *= 2;   // largest power of two below CL (CL = 6 -> 4)
   if (threadIdx.x < 8) sacc[threadIdx.x] = 0.f;
   __syncthreads();
   float mu[8], rs[8], w[4][8];
@@ -832,11 +834,15 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
       p[0] += yr * w[0][j]; p[1] += yr * w[1][j]; p[2] += yr * w[2][j]; p[3] += yr * w[3][j];
     }
     if (ok && out) Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv);
-    float tot[4] = {0.f, 0.f, 0.f, 0.f};
-    const int src0 = vl * CL;
-    for (int c = 0; c < CL; ++c) {
+    // only the voxel's leader lane needs the four sums: a shift-down tree over the CL lanes of the voxel (log2 steps instead of CL
+    // broadcasts; partial sums in lanes the leader never reads may include neighbours' values)
+    float tot[4] = {p[0], p[1], p[2], p[3]};
+    for (int sft = p2half; sft >= 1; sft >>= 1) {
 #pragma unroll
-      for (int o = 0; o < 4; ++o) tot[o] += __shfl(p[o], src0 + c, 64);
+      for (int o = 0; o < 4; ++o) {
+        const float q = __shfl_down(tot[o], sft, 64);
+        if (cl + sft < CL) tot[o] += q;
+      }
     }
     if (ok && cl == 0) {
       const float p0 = tot[0] + b0, p1 = tot[1] + b1, p2 = tot[2] + b2, p3 = tot[3] + b3;
