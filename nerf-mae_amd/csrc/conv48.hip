@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   for (int q = 0; q < 2; ++q) { const int r = 4 * q + g; rowoff[q] = (r / 3) * PLANE + (r % 3) * LINE; }
   const int row8 = 2 * PLANE + 2 * LINE;
 
-  // fused InstanceNorm statistics: lane (li, g) owns channels 16n + 4g + r of voxel column li.  Per tile the wave's partial sums are
+  // fused InstanceNorm statistics: lane (li, g) owns channels 12g + 4n + r of voxel column li.  Per tile the wave's partial sums are
   // folded over its 16 voxel columns (DPP row scan) and added to a workgroup accumulator in LDS (ds_add_f32, [2][48][2] floats: the
   // registers they used to occupy across tiles are what lets the k-loop keep its prefetch depth); the accumulator is flushed with fp64
   // atomics when the workgroup moves to another sample.  Two accumulators alternate, so the flush (threads 0-95, during the first
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     if (pf_next) halo_sstore();
     stamp(7);
 
-    // ---- epilogue: transposed accumulators (row = co = 16n + 4g + r, col = voxel x = li): every lane owns 4 consecutive
-    //      channels of one voxel per (x-line, co-tile) -> 8-byte bf16 stores straight from registers, no LDS restaging ----
+    // ---- epilogue: transposed accumulators (row 4g + r of co-tile n = channel 12g + 4n + r, col = voxel x = li): every lane owns 12
+    //      consecutive channels of one voxel per x-line -> a 16-byte and an 8-byte bf16 store straight from registers, no LDS restaging ----
     {
       const int b = cb, z0 = cz0, y0 = cy0, x0 = cx0;
       const int z = z0 + z_l, x = x0 + li;
@@ -290,23 +290,31 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       for (int i = 0; i < 4; ++i) {
         const int y = y0 + y_l + i;
         if (z < a.D && y < a.H && x < a.W && (!(DBG & 1) || a.accumulate == 77)) {
-          bf16_t* dst = a.Y + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + 4 * g;
+          // lane (li, g) owns channels 12g .. 12g+11 of voxel x = li (pack: row 4g+r of co-tile n <-> channel 12g + 4n + r)
+          bf16_t* dst = a.Y + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + 12 * g;
+          float v[3][4];
 #pragma unroll
-          for (int n = 0; n < 3; ++n) {
-            float v0 = acc[i][n][0], v1 = acc[i][n][1], v2 = acc[i][n][2], v3 = acc[i][n][3];
-            if (a.accumulate) {
-              const uint2 o = *reinterpret_cast<const uint2*>(dst + 16 * n);
-              v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xffff0000u);
-              v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xffff0000u);
-            }
-            uint2 w2;
-            w2.x = pk_bf16(v0, v1);
-            w2.y = pk_bf16(v2, v3);
-            *reinterpret_cast<uint2*>(dst + 16 * n) = w2;
-            if (stats) {  // statistics of exactly what the normalisation pass will read back
-              const float q0 = __uint_as_float(w2.x << 16), q1 = __uint_as_float(w2.x & 0xffff0000u), q2 = __uint_as_float(w2.y << 16), q3 = __uint_as_float(w2.y & 0xffff0000u);
-              st1[n][0] += q0; st1[n][1] += q1; st1[n][2] += q2; st1[n][3] += q3;
-              st2[n][0] += q0 * q0; st2[n][1] += q1 * q1; st2[n][2] += q2 * q2; st2[n][3] += q3 * q3;
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[n][r] = acc[i][n][r];
+          if (a.accumulate) {
+            const uint4 o = *reinterpret_cast<const uint4*>(dst);
+            const uint2 o2 = *reinterpret_cast<const uint2*>(dst + 8);
+            const unsigned ow[6] = {o.x, o.y, o.z, o.w, o2.x, o2.y};
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { v[q >> 1][(q & 1) * 2] += __uint_as_float(ow[q] << 16); v[q >> 1][(q & 1) * 2 + 1] += __uint_as_float(ow[q] & 0xffff0000u); }
+          }
+          unsigned w6[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w6[q] = pk_bf16(v[q >> 1][(q & 1) * 2], v[q >> 1][(q & 1) * 2 + 1]);
+          *reinterpret_cast<uint4*>(dst) = make_uint4(w6[0], w6[1], w6[2], w6[3]);   // (8-byte aligned 16-byte store: dword alignment suffices)
+          *reinterpret_cast<uint2*>(dst + 8) = make_uint2(w6[4], w6[5]);
+          if (stats) {  // statistics of exactly what the normalisation pass will read back
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+              const float q0 = __uint_as_float(w6[q] << 16), q1 = __uint_as_float(w6[q] & 0xffff0000u);
+              st1[q >> 1][(q & 1) * 2] += q0; st1[q >> 1][(q & 1) * 2 + 1] += q1;
+              st2[q >> 1][(q & 1) * 2] += q0 * q0; st2[q >> 1][(q & 1) * 2 + 1] += q1 * q1;
             }
           }
         }
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
           for (int r = 0; r < 4; ++r) {
             const float a1 = row_sum(st1[n][r]), a2 = row_sum(st2[n][r]);
             if (li == 15) {
-              float* dst = sacc + scur * 96 + (16 * n + 4 * g + r) * 2;
+              float* dst = sacc + scur * 96 + (12 * g + 4 * n + r) * 2;
               atomicAdd(dst, a1);
               atomicAdd(dst + 1, a2);
             }

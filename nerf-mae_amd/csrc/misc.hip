@@ -376,7 +376,7 @@ int k_fill_f32(float* p, float v, long n, hipStream_t st) {
 //  mode 4 convT fwd      src [Ci=d0][Co=d1][k3=d2] -> dst [(t*Co+co)][ci]
 //  mode 5 convT dgrad    dst [ci][(t*Co+co)]
 //  mode 6/7 conv48 fragment order (conv48.hip): dst [step 41][ntile 3][lane 64][8] from the mode-2 (fwd) / mode-3 (dgrad) view
-//           W'[n][tap][k]: lane (li = n%16, g), slot j; steps < 36: tap-row r = 4*(s/18)+g, vector c = s%18; steps >= 36: row 8,
+//           W'[n][tap][k]: lane (li, g) of co-tile nt holds n = 12*(li>>2) + 4*nt + (li&3), slot j; steps < 36: tap-row r = 4*(s/18)+g, vector c = s%18; steps >= 36: row 8,
 //           c = 4*(s-36)+g (c >= 18 -> zero padding)
 // (32-bit index math: every packed tensor has < 2^31 elements; 64-bit div/mod is ~10x the instructions)
 __device__ __forceinline__ long pack_src_index(const PackDesc& d, long il) {
@@ -390,7 +390,9 @@ __device__ __forceinline__ long pack_src_index(const PackDesc& d, long il) {
     case 6: case 7: {
       const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
       const unsigned sn = i >> 9;
-      const int nt = (int)(sn % 3), st = (int)(sn / 3), g = lane >> 4, n = nt * 16 + (lane & 15);
+      // MFMA row li of co-tile nt carries channel 12*(li>>2) + 4*nt + (li&3): an accumulator lane then owns 12 CONSECUTIVE channels of
+      // its voxel across the three co-tiles (24-byte runs in the epilogue instead of three 8-byte pieces)
+      const int nt = (int)(sn % 3), st = (int)(sn / 3), g = lane >> 4, li = lane & 15, n = 12 * (li >> 2) + 4 * nt + (li & 3);
       int r, c;
       if (st < 36) { r = 4 * (st / 18) + g; c = st % 18; } else { r = 8; c = 4 * (st - 36) + g; }
       if (c >= 18) return -1;
