@@ -17,6 +17,9 @@
 #include "kernels.hpp"
 #include <cstdlib>
 
+// unsigned division by a launch-invariant divisor (kernels.hpp FDiv; 64-bit div/mod on the VALU costs ~150 instructions each)
+__device__ __forceinline__ unsigned c48_fdiv(unsigned n, const FDiv& f) { return f.sh < 0 ? n : (__umulhi(n, f.M) >> f.sh); }
+
 namespace c48 {
 constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
 constexpr int LINE = HX * 96 + 16, PLANE = HY * LINE + 16, HALO = (TZ + 2) * PLANE;
@@ -32,22 +35,24 @@ static_assert(LDS_BYTES <= 163840, "LDS budget");
 struct C48Args {
   const bf16_t* X; const bf16_t* Wk; bf16_t* Y;
   int B, D, H, W, tz, ty, tx;  // tiles per axis
-  long total;                  // B*tz*ty*tx
+  long total;                  // B*tz*ty*tx (< 2^31: checked at launch)
+  FDiv dtx, dty, dtz;
   int accumulate;
   double* stats_acc;           // optional [B][48][2] fp64 accumulators: per-channel sum / sum of squares of the (bf16-rounded) outputs
 };
 
 __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
-  int xt = (int)(t % a.tx); long r = t / a.tx;
-  int yt = (int)(r % a.ty); r /= a.ty;
-  int zt = (int)(r % a.tz);
-  // the tile index is wave-uniform, but the 64-bit divisions above run on the VALU: hand the results back to SGPRs so that the
+  const unsigned tu = (unsigned)t;
+  const unsigned r1 = c48_fdiv(tu, a.dtx), xt = tu - r1 * (unsigned)a.tx;
+  const unsigned r2 = c48_fdiv(r1, a.dty), yt = r1 - r2 * (unsigned)a.ty;
+  const unsigned r3 = c48_fdiv(r2, a.dtz), zt = r2 - r3 * (unsigned)a.tz;
+  // the tile index is wave-uniform, but the arithmetic above runs on the VALU: hand the results back to SGPRs so that the
   // buffer descriptor built from b is provably uniform (otherwise every buffer_load is wrapped in a waterfall loop: measured
   // 270 cycles per load, 3.5k cycles per tile)
-  b = __builtin_amdgcn_readfirstlane((int)(r / a.tz));
-  z0 = __builtin_amdgcn_readfirstlane(zt * c48::TZ);
-  y0 = __builtin_amdgcn_readfirstlane(yt * c48::TY);
-  x0 = __builtin_amdgcn_readfirstlane(xt * c48::TX);
+  b = __builtin_amdgcn_readfirstlane((int)r3);
+  z0 = __builtin_amdgcn_readfirstlane((int)zt * c48::TZ);
+  y0 = __builtin_amdgcn_readfirstlane((int)yt * c48::TY);
+  x0 = __builtin_amdgcn_readfirstlane((int)xt * c48::TX);
 }
 
 // DBG (diagnostic builds only, NMH_C48_DBG): 1 = no output stores, 2 = no halo prefetch / LDS refill, 4 = no weight DMA and no
@@ -358,6 +363,8 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
   a.total = (long)B * a.tz * a.ty * a.tx;
+  if (a.total >= (1L << 31)) return -2;
+  a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
   a.accumulate = accumulate;
   a.stats_acc = stats_acc;
   static const int dbg = getenv("NMH_C48_DBG") ? atoi(getenv("NMH_C48_DBG")) : 0;
@@ -418,19 +425,21 @@ struct W48Args {
   // channel sub-problems: a Cin x Cout convolution is (Cin/48) x (Cout/48) independent 48 x 48 weight-gradient blocks on strided
   // channel slices of X / dY; blockIdx.y = sub-problem (ci slice fastest).  ldx/ldy = channel counts (row strides in elements)
   int ldx, ldy, nci;
+  FDiv dtx, dty, dtz;
 };
 
 __device__ __forceinline__ void w48_tile_origin(const W48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
-  int xt = (int)(t % a.tx); long r = t / a.tx;
-  int yt = (int)(r % a.ty); r /= a.ty;
-  int zt = (int)(r % a.tz);
-  b = __builtin_amdgcn_readfirstlane((int)(r / a.tz));
-  z0 = __builtin_amdgcn_readfirstlane(zt * w48::TZ);
-  y0 = __builtin_amdgcn_readfirstlane(yt * w48::TY);
-  x0 = __builtin_amdgcn_readfirstlane(xt * w48::TX);
+  const unsigned tu = (unsigned)t;
+  const unsigned r1 = c48_fdiv(tu, a.dtx), xt = tu - r1 * (unsigned)a.tx;
+  const unsigned r2 = c48_fdiv(r1, a.dty), yt = r1 - r2 * (unsigned)a.ty;
+  const unsigned r3 = c48_fdiv(r2, a.dtz), zt = r2 - r3 * (unsigned)a.tz;
+  b = __builtin_amdgcn_readfirstlane((int)r3);
+  z0 = __builtin_amdgcn_readfirstlane((int)zt * w48::TZ);
+  y0 = __builtin_amdgcn_readfirstlane((int)yt * w48::TY);
+  x0 = __builtin_amdgcn_readfirstlane((int)xt * w48::TX);
 }
 
-template <int NW>  // waves per workgroup: 16 (<=128 VGPRs, 5 blocks/wave) or 8 (<=256 VGPRs, 10 blocks/wave)
+template <int NW, int DBG = 0>  // waves per workgroup: 16 (<=128 VGPRs, 5 blocks/wave) or 8 (<=256 VGPRs, 10 blocks/wave)
 __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   using namespace w48;
   constexpr int NT = 64 * NW, HREG = (HCH + NT - 1) / NT, UPW = NUNIT / NW;
@@ -523,11 +532,17 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
     halo_sstore();
   }
   __syncthreads();
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto stamp = [&](int slot) {
+    if (DBG) { const long long now = (long long)__builtin_amdgcn_s_memtime(); ph[slot] += now - tlast; tlast = now; }
+  };
+  if (DBG) tlast = (long long)__builtin_amdgcn_s_memtime();
   for (; t < tend; t += jstride) {
     const long tn = t + jstride;
     const bool has_next = tn < tend;
     int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;
     if (has_next) w48_tile_origin(a, tn, nb, nz0, ny0, nx0);
+    stamp(0);
     const char* dyc = dyb + cur * DYT;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -565,10 +580,20 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
         else mma(accx, af[2], bfr);
       }
     }
+    stamp(1);
     __syncthreads();  // everyone is done with halo / dY[cur]; the barrier also drains this wave's DMA + prefetch loads
+    stamp(2);
     if (has_next) halo_sstore();
+    stamp(3);
     __syncthreads();
+    stamp(4);
     cur ^= 1;
+  }
+  if (DBG) {   // (stamps live behind the partial sums: the accumulators must still be flushed or the MFMAs are dead code)
+    if (lane == 0) {
+      long long* o = reinterpret_cast<long long*>(a.ws + 256L * PARTIAL) + ((long)blockIdx.x * NW + wave) * 8;
+      for (int i = 0; i < 8; ++i) o[i] = ph[i];
+    }
   }
   // flush: ws[block][u][ct][row 16][col 16]
   float* wsb = a.ws + ((long)blockIdx.y * gridDim.x + blockIdx.x) * PARTIAL;
@@ -605,7 +630,7 @@ __global__ void conv48_wgrad_reduce_kernel(const float* ws, float* dW, int nbloc
   dW[((long)(os * 48 + ct * 16 + row) * Cin + cs * 48 + cit * 16 + col) * 27 + tap] += s;
 }
 
-long k_conv48_wgrad_ws_floats() { return 256L * w48::PARTIAL; }
+long k_conv48_wgrad_ws_floats() { return 256L * w48::PARTIAL + 65536; }  // (+ room for the diagnostic phase counters)
 
 static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st) {
   using namespace w48;
@@ -614,6 +639,8 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
   a.total = (long)B * a.tz * a.ty * a.tx;
+  if (a.total >= (1L << 31)) return -2;
+  a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
   a.ldx = Cin; a.ldy = Cout; a.nci = Cin / 48;
   const int nsub = (Cin / 48) * (Cout / 48);
   static bool attr_set = false;
@@ -631,6 +658,15 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
     if (nb > a.total) nb = (int)a.total;
   }
   static const int nw = getenv("NMH_W48_WAVES") ? atoi(getenv("NMH_W48_WAVES")) : 8;  // 8 waves x 10 blocks measured 5 % faster than 16 x 5
+  static const int wdbg = getenv("NMH_W48_DBG") ? atoi(getenv("NMH_W48_DBG")) : 0;
+  if (wdbg) {   // phase cycle counters into ws (int64 [block][wave][8]); no gradient is produced
+    hipFuncSetAttribute((const void*)conv48_wgrad_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL((conv48_wgrad_kernel<8, 1>), dim3(nb, nsub), dim3(512), LDS_BYTES, st, a);
+    NMH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(conv48_wgrad_reduce_kernel, dim3((PARTIAL + 255) / 256, nsub), dim3(256), 0, st, ws, dW, nb, a.nci, Cin);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
   if (nw == 8) hipLaunchKernelGGL(conv48_wgrad_kernel<8>, dim3(nb, nsub), dim3(512), LDS_BYTES, st, a);
   else hipLaunchKernelGGL(conv48_wgrad_kernel<16>, dim3(nb, nsub), dim3(1024), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
