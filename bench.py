@@ -220,6 +220,8 @@ def main():
                         out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
                         out["roofline"]["traffic_source"] = os.path.basename(f) + " (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes)"
                         out["roofline"]["algorithmic_bytes_per_launch"] = 2.0 * Bg * R ** 3 * E2 * 2
+                        if pm.get("power"):   # measured context for `frac`: the kernel runs at the socket power cap
+                            out["roofline"]["power_note"] = pm["power"]
                         break
             except Exception:
                 pass
