@@ -226,6 +226,29 @@ def test_g9_training_trace(golden):
     np.testing.assert_allclose(np.array(trace), g["trace"], rtol=8e-2)
 
 
+def test_g13_training_trace_head_dim_32(golden):
+    """the oracle against the reference's own 10-step trace at head_dim 32 on two grids (oracle/gen_golden_trace.py)"""
+    from oracle.gen_golden_trace import KW, STEPS
+    g = golden("g13_train_trace_hd32.npz")
+    torch.set_num_threads(8)
+    m = O.MAE3DOracle(pad_pos_embed=True, **{k: v for k, v in KW.items() if k != "expand_dim"})
+    O.formula_fill_(m)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-3)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-4, total_steps=STEPS)
+    random.seed(13)
+    trace = []
+    for step in range(STEPS):
+        opt.zero_grad()
+        loss, lr_, la_ = m([O.synthetic_grid((32, 32, 32), 200 + step), O.synthetic_grid((30, 32, 27), 300 + step)])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 0.1)
+        opt.step()
+        sch.step()
+        trace.append([float(loss), float(lr_), float(la_)])
+    np.testing.assert_allclose(np.array(trace)[:3], g["trace"][:3], rtol=2e-4)
+    np.testing.assert_allclose(np.array(trace), g["trace"], rtol=8e-2)
+
+
 def test_state_dict_keys_match_reference_contract():
     """key set / shapes / counts (215 keys swin_t, 383 swin_s)."""
     for name, nkeys in [("swin_t", 215), ("swin_s", 383)]:
