@@ -407,6 +407,22 @@ template <typename T> __global__ void pack_kernel(const PackDesc* descs, const i
   const PackDesc d = descs[blk2desc[blockIdx.x]];
   const long base = blkstart[blockIdx.x];
   T* dst = (T*)d.dst;
+  if (d.mode == 1) {
+    // 2-D transpose, one 32x32 tile per block through LDS (blkstart = tile id): source rows and destination rows are both read /
+    // written along their contiguous axis.  (The element-wise gather touched 64 cache lines per wave-load: 420 us for the 50 M
+    // transposed Linear weights of swin_s.)
+    __shared__ float tile[32][33];
+    const int tcn = (d.d1 + 31) >> 5, tr = (int)(base / tcn), tc = (int)(base - (long)tr * tcn);
+    const int r0 = tr * 32, c0 = tc * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+      if (r0 + r < d.d0 && c0 + tx < d.d1) tile[r][tx] = d.src[(long)(r0 + r) * d.d1 + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int c = ty; c < 32; c += 8)
+      if (c0 + c < d.d1 && r0 + tx < d.d0) dst[(long)(c0 + c) * d.d0 + r0 + tx] = from_f<T>(tile[tx][c]);
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     long i = base + u * 256 + threadIdx.x;

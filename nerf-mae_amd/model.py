@@ -110,9 +110,14 @@ class _Packer:
                 self.split = len(blk2desc)
             self.views[key] = self.buf[off:off + n]
             descs += struct.pack("<QQiiiiq", p.data_ptr(), self.buf.data_ptr() + off * esz, mode, dims[0], dims[1], dims[2], n)
-            for s in range(0, n, 1024):
-                blk2desc.append(i)
-                blkstart.append(s)
+            if mode == self.TRANS:   # one block per 32x32 tile of the source matrix (blkstart = tile id)
+                for k in range(((dims[0] + 31) // 32) * ((dims[1] + 31) // 32)):
+                    blk2desc.append(i)
+                    blkstart.append(k)
+            else:
+                for s in range(0, n, 1024):
+                    blk2desc.append(i)
+                    blkstart.append(s)
             off += (n + 63) // 64 * 64
         self.descs = torch.frombuffer(bytearray(descs), dtype=torch.uint8).to(device)
         self.blk2desc = torch.tensor(blk2desc, dtype=torch.int32, device=device)

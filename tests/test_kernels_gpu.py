@@ -572,9 +572,16 @@ def _pack_via_kernel(w, mode, dt, n_out):
     sh = list(w.shape)
     d = (sh[0], sh[1], int(np.prod(sh[2:])) if len(sh) > 2 else 0)
     descs = torch.frombuffer(bytearray(struct.pack("<QQiiiiq", src.data_ptr(), dst.data_ptr(), mode, d[0], d[1], d[2], n_out)), dtype=torch.uint8).cuda()
-    nb = (n_out + 1023) // 1024
+    if mode == 1:   # 2-D transpose: one block per 32x32 tile of the d0 x d1 source, blkstart = tile id
+        d1 = int(np.prod(sh[1:]))
+        d = (sh[0], d1, 0)
+        descs = torch.frombuffer(bytearray(struct.pack("<QQiiiiq", src.data_ptr(), dst.data_ptr(), mode, d[0], d[1], d[2], n_out)), dtype=torch.uint8).cuda()
+        nb = ((d[0] + 31) // 32) * ((d1 + 31) // 32)
+        bst = torch.arange(nb, dtype=torch.int64).cuda()
+    else:
+        nb = (n_out + 1023) // 1024
+        bst = (torch.arange(nb, dtype=torch.int64) * 1024).cuda()
     b2d = torch.zeros(nb, dtype=torch.int32, device="cuda")
-    bst = (torch.arange(nb, dtype=torch.int64) * 1024).cuda()
     ops.pack_weights(1 if dt == torch.bfloat16 else 0, descs, b2d, bst, nb)
     torch.cuda.synchronize()
     return dst
@@ -584,6 +591,8 @@ def _pack_via_kernel(w, mode, dt, n_out):
 def test_pack_weight_modes(dt):
     w2 = rnd(24, 40)
     check(_pack_via_kernel(w2, 1, dt, w2.numel()).view(40, 24), q(w2, dt).T, dt, "transpose")
+    w3 = rnd(70, 33)      # ragged 32x32 tiles on both axes
+    check(_pack_via_kernel(w3, 1, dt, w3.numel()).view(33, 70), q(w3, dt).T, dt, "transpose ragged")
     wc = rnd(16, 24, 3, 3, 3)
     check(_pack_via_kernel(wc, 2, dt, wc.numel()).view(16, 27, 24), q(wc, dt).reshape(16, 24, 27).permute(0, 2, 1), dt, "conv fwd pack")
     check(_pack_via_kernel(wc, 3, dt, wc.numel()).view(24, 27, 16), q(wc, dt).reshape(16, 24, 27).flip(2).permute(1, 2, 0), dt, "conv dgrad pack")
