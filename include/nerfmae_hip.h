@@ -135,8 +135,9 @@ NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
 
 /* fp32 master weights -> compute-dtype GEMM operand layouts, one launch for the whole model.  descs: device array of
  * {const float* src; void* dst; int mode; int d0,d1,d2; int64 n} (40 bytes, see kernels.hpp PackDesc); one block per 1024 dst elements
- * (blkstart = first element), except mode 1 (2-D transpose): one block per 32x32 tile of the d0 x d1 source, blkstart = tile id, row-major
- * over ceil(d0/32) x ceil(d1/32). */
+ * (blkstart = first element), except the tiled modes, where blkstart = block id: mode 1 (2-D transpose) one block per 32x32 tile of the
+ * d0 x d1 source, row-major over ceil(d0/32) x ceil(d1/32); mode 2 (conv fwd) d0 x ceil(d1/32) blocks (co, 32 ci); mode 3 (conv dgrad)
+ * d1 x ceil(d0/32) blocks (ci, 32 co). */
 NMH_API int nmh_pack_weights(int dt, const void* descs_dev, const int* blk2desc_dev, const int64_t* blkstart_dev, int nblocks, void* stream);
 /* clip_grad_norm_ + AdamW (run_swin_mae3d.py:588-592,665-668) over the flat fp32 parameter buffer; hyper (device fp32[8]) =
  * {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, 1-beta2^t, zero_g}; coef (device) = min(1, max_norm/(norm+1e-6)); zero_g != 0:

@@ -423,6 +423,29 @@ template <typename T> __global__ void pack_kernel(const PackDesc* descs, const i
       if (c0 + c < d.d1 && r0 + tx < d.d0) dst[(long)(c0 + c) * d.d0 + r0 + tx] = from_f<T>(tile[tx][c]);
     return;
   }
+  if (d.mode == 2 || d.mode == 3) {
+    // 3x3x3 conv weights [Co][Ci][27] -> [Co][27][Ci] (fwd) / [Ci][27 flipped][Co] (dgrad), one block per 32 channels of the axis that
+    // becomes contiguous (blkstart = block id): the source is read in 108-byte tap rows, the destination written in 32-channel runs
+    __shared__ float tl[32][28];
+    const int Co = d.d0, Ci = d.d1, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (d.mode == 2) {
+      const int cchunks = (Ci + 31) >> 5, co = (int)(base / cchunks), ci0 = (int)(base - (long)co * cchunks) * 32;
+      const float* sp = d.src + ((long)co * Ci + ci0) * 27;
+      const int nci = Ci - ci0 < 32 ? Ci - ci0 : 32;
+      for (int i = threadIdx.x; i < nci * 27; i += 256) tl[i / 27][i % 27] = sp[i];       // contiguous run of nci*27 floats
+      __syncthreads();
+      for (int t = ty; t < 27; t += 8)
+        if (tx < nci) dst[((long)co * 27 + t) * Ci + ci0 + tx] = from_f<T>(tl[tx][t]);
+    } else {
+      const int ochunks = (Co + 31) >> 5, ci = (int)(base / ochunks), co0 = (int)(base - (long)ci * ochunks) * 32;
+      const int nco = Co - co0 < 32 ? Co - co0 : 32;
+      for (int i = threadIdx.x; i < nco * 27; i += 256) { const int c = i / 27, t = i - c * 27; tl[c][t] = d.src[((long)(co0 + c) * Ci + ci) * 27 + t]; }
+      __syncthreads();
+      for (int t = ty; t < 27; t += 8)
+        if (tx < nco) dst[((long)ci * 27 + t) * Co + co0 + tx] = from_f<T>(tl[tx][26 - t]);
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     long i = base + u * 256 + threadIdx.x;

@@ -110,8 +110,10 @@ class _Packer:
                 self.split = len(blk2desc)
             self.views[key] = self.buf[off:off + n]
             descs += struct.pack("<QQiiiiq", p.data_ptr(), self.buf.data_ptr() + off * esz, mode, dims[0], dims[1], dims[2], n)
-            if mode == self.TRANS:   # one block per 32x32 tile of the source matrix (blkstart = tile id)
-                for k in range(((dims[0] + 31) // 32) * ((dims[1] + 31) // 32)):
+            if mode in (self.TRANS, self.CONV_F, self.CONV_D):   # tiled modes: blkstart = block id (nmh_pack_weights)
+                nblk = {self.TRANS: ((dims[0] + 31) // 32) * ((dims[1] + 31) // 32), self.CONV_F: dims[0] * ((dims[1] + 31) // 32),
+                        self.CONV_D: dims[1] * ((dims[0] + 31) // 32)}[mode]
+                for k in range(nblk):
                     blk2desc.append(i)
                     blkstart.append(k)
             else:

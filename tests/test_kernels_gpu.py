@@ -578,6 +578,9 @@ def _pack_via_kernel(w, mode, dt, n_out):
         descs = torch.frombuffer(bytearray(struct.pack("<QQiiiiq", src.data_ptr(), dst.data_ptr(), mode, d[0], d[1], d[2], n_out)), dtype=torch.uint8).cuda()
         nb = ((d[0] + 31) // 32) * ((d1 + 31) // 32)
         bst = torch.arange(nb, dtype=torch.int64).cuda()
+    elif mode in (2, 3):   # conv packs: blkstart = block id over (co, 32 ci) / (ci, 32 co)
+        nb = sh[0] * ((sh[1] + 31) // 32) if mode == 2 else sh[1] * ((sh[0] + 31) // 32)
+        bst = torch.arange(nb, dtype=torch.int64).cuda()
     else:
         nb = (n_out + 1023) // 1024
         bst = (torch.arange(nb, dtype=torch.int64) * 1024).cuda()
@@ -596,6 +599,9 @@ def test_pack_weight_modes(dt):
     wc = rnd(16, 24, 3, 3, 3)
     check(_pack_via_kernel(wc, 2, dt, wc.numel()).view(16, 27, 24), q(wc, dt).reshape(16, 24, 27).permute(0, 2, 1), dt, "conv fwd pack")
     check(_pack_via_kernel(wc, 3, dt, wc.numel()).view(24, 27, 16), q(wc, dt).reshape(16, 24, 27).flip(2).permute(1, 2, 0), dt, "conv dgrad pack")
+    wr = rnd(40, 72, 3, 3, 3)   # ragged 32-channel blocks on both axes
+    check(_pack_via_kernel(wr, 2, dt, wr.numel()).view(40, 27, 72), q(wr, dt).reshape(40, 72, 27).permute(0, 2, 1), dt, "conv fwd pack ragged")
+    check(_pack_via_kernel(wr, 3, dt, wr.numel()).view(72, 27, 40), q(wr, dt).reshape(40, 72, 27).flip(2).permute(1, 2, 0), dt, "conv dgrad pack ragged")
     wt = rnd(24, 16, 2, 2, 2)
     check(_pack_via_kernel(wt, 4, dt, wt.numel()).view(8 * 16, 24), q(wt, dt).reshape(24, 16, 8).permute(2, 1, 0).reshape(128, 24), dt, "convT fwd pack")
     check(_pack_via_kernel(wt, 5, dt, wt.numel()).view(24, 8 * 16), q(wt, dt).reshape(24, 16, 8).permute(0, 2, 1).reshape(24, 128), dt, "convT dgrad pack")
