@@ -9,26 +9,43 @@
 static inline unsigned ew_blocks(long total, int cap = 16384) { long nb = (total + 255) / 256; return (unsigned)(nb > cap ? cap : (nb < 1 ? 1 : nb)); }
 
 // ---- patch embed im2row: A[(b,z,y,x)][ci*64 + kz*16+ky*4+kx] = x[b][ci][4z+kz][4y+ky][4x+kx] ---------------------
-template <typename T> __global__ void embed_gather_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int R) {
+// One block per x-line of tokens (b, tz, ty): its 64 source rows (ci, kz, ky) are read as contiguous runs of R floats and staged in LDS as
+// [token][256] (token stride padded by 8 bytes: the 8-byte LDS writes of 32 consecutive tokens land in distinct banks); the g token rows are
+// then one contiguous run of g*256 elements in A.  (One float4 per lane straight from the 64 rows touched 64 cache lines per wave-load.)
+template <typename T> __global__ __launch_bounds__(256) void embed_gather_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int R) {
+  extern __shared__ __attribute__((aligned(16))) char esm[];
   const int g = R >> 2;
-  const long total = (long)B * g * g * g * 64;  // one thread per (token, ci, kz, ky): 4 contiguous kx
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i & 63);
-    long tok = i >> 6;
+  constexpr int ROWB = 256 * (int)sizeof(T) + 8;   // bytes per staged token row
+  const int line = blockIdx.x;                      // (b, tz, ty)
+  const int ty = line % g, tz = (line / g) % g, b = line / (g * g);
+  for (int idx = threadIdx.x; idx < 64 * g; idx += 256) {
+    const int q = idx / g, tx = idx - q * g;
     const int ci = q >> 4, kz = (q >> 2) & 3, ky = q & 3;
-    const int tx = (int)(tok % g); long t2 = tok / g;
-    const int ty = (int)(t2 % g); t2 /= g;
-    const int tz = (int)(t2 % g);
-    const long b = t2 / g;
-    const float4 v = *reinterpret_cast<const float4*>(x + (((b * 4 + ci) * R + 4 * tz + kz) * R + 4 * ty + ky) * (long)R + 4 * tx);
-    T* o = A + tok * 256 + ci * 64 + kz * 16 + ky * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + ((((long)b * 4 + ci) * R + 4 * tz + kz) * R + 4 * ty + ky) * (long)R + 4 * tx);
+    T* o = reinterpret_cast<T*>(esm + tx * ROWB) + q * 4;
     o[0] = from_f<T>(v.x); o[1] = from_f<T>(v.y); o[2] = from_f<T>(v.z); o[3] = from_f<T>(v.w);
+  }
+  __syncthreads();
+  constexpr int V8 = 256 * (int)sizeof(T) / 8;      // 8-byte pieces per token row
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(A + (long)line * g * 256);
+  for (int idx = threadIdx.x; idx < g * V8; idx += 256) {
+    const int tx = idx / V8, c = idx - tx * V8;
+    out[idx] = *reinterpret_cast<const unsigned long long*>(esm + tx * ROWB + c * 8);
   }
 }
 int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st) {
-  long total = (long)B * (R / 4) * (R / 4) * (R / 4) * 64;
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3(ew_blocks(total)), dim3(256), 0, st, x, (bf16_t*)A, B, R);
-  else hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, st, x, (float*)A, B, R);
+  const int g = R / 4;
+  if (R % 4 || g <= 0) return -2;
+  const long lines = (long)B * g * g;
+  const size_t lds = (size_t)g * (256 * (dt == NMH_DT_BF16 ? 2 : 4) + 8);
+  if (lds > 160 * 1024) return -2;
+  if (dt == NMH_DT_BF16) {
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)embed_gather_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(embed_gather_kernel<bf16_t>, dim3((unsigned)lines), dim3(256), lds, st, x, (bf16_t*)A, B, R);
+  } else {
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)embed_gather_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(embed_gather_kernel<float>, dim3((unsigned)lines), dim3(256), lds, st, x, (float*)A, B, R);
+  }
   NMH_CHECK_LAUNCH();
   return 0;
 }
