@@ -846,7 +846,35 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 // many splits of a small output (the 256000-row stage-0 gradients: 125-250 splits) would write more partial bytes than the operands
 // hold; those keep the atomics
 static int tn_ws_max_splits() { static const int v = getenv("NMH_TN_WS_SPLITS") ? atoi(getenv("NMH_TN_WS_SPLITS")) : 16; return v; }
+// plain row-major output, K % 4 == 0: four output elements per thread (16-byte partial loads and one 16-byte read-modify-write)
+__global__ __launch_bounds__(256) void tn_reduce4_kernel(const float* __restrict__ part, int gz, int N, int K, float* __restrict__ Out, TnGeom gm) {
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x, NK = (long)N * K, NK4 = NK >> 2;
+  if (i4 < NK4) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < gz; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long)z * NK + i4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const long i = i4 * 4;
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    float4* o = reinterpret_cast<float4*>(Out + (long)n * gm.ldo + k);
+    float4 c = *o;
+    c.x += s.x; c.y += s.y; c.z += s.z; c.w += s.w;
+    *o = c;
+  } else if (gm.dbias && i4 < NK4 + N) {
+    const int n = (int)(i4 - NK4);
+    float s = 0.f;
+    for (int z = 0; z < gz; ++z) s += part[(long)gz * NK + (long)z * N + n];
+    gm.dbias[n] += s;
+  }
+}
 static int launch_tn_reduce(const TnGeom& gm, int gz, int N, int K, float* Out, hipStream_t st) {
+  if (gm.omode == 0 && !gm.up_k && K % 4 == 0 && gm.ldo % 4 == 0 && (((uintptr_t)Out | (uintptr_t)gm.part) & 15) == 0) {
+    const long tot4 = (long)N * K / 4 + (gm.dbias ? N : 0);
+    hipLaunchKernelGGL(tn_reduce4_kernel, dim3((unsigned)((tot4 + 255) / 256)), dim3(256), 0, st, gm.part, gz, N, K, Out, gm);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
   const long tot = (long)N * K + (gm.dbias ? N : 0);
   hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gm.part, gz, N, K, Out, gm);
   NMH_CHECK_LAUNCH();
