@@ -3,16 +3,24 @@
 
 One "step" = zero_grad + forward + backward (+ gradient all-reduce when N>1) + clip + AdamW on one batch of synthetic
 160^3 RGB-sigma grids already resident in HBM.  Metric: voxel-grids/s (whole job), swin_s, 160^3, bf16 (BASELINE.json).
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the 3x3x3 48->48 decoder conv, MFMA-bound) and
-`cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
+
+Workload of `value`: BASELINE.json's headline config read literally -- swin_s, GLOBAL batch 8 x (4 x 160^3), DP = N: at N = 1 the
+whole batch of 8 grids runs on the one GPU, at N = 8 every GPU steps on 1 grid ("scaling": "strong").  `--batch-per-gpu B` fixes the
+per-GPU batch instead (weak scaling).  The same JSON line carries, under config.sweep, the 1-, 4- and 8-grids-per-GPU figures of this
+GPU (the headline's weak-scaling share, the reference's training recipe of train_mae3d.sh, and the whole headline batch).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the 3x3x3 48->48 decoder conv, MFMA-bound; plus the three slowest
+HBM-bound kernels against 8 TB/s) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import hashlib
 import json
 import os
 import random
+import statistics
 import sys
 import time
 
@@ -60,18 +68,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--backbone", default="swin_s")
     ap.add_argument("--resolution", type=int, default=160)
-    ap.add_argument("--batch-per-gpu", type=int, default=4,
-                    help="grids per GPU per step (weak scaling).  Default 4 = the reference's training recipe (train_mae3d.sh: batch 32 on 8 GPUs; "
-                         "BASELINE configs[1] is batch 4 on one GPU); 1 = BASELINE configs[2] read literally (global batch 8 at DP=8)")
+    ap.add_argument("--global-batch", type=int, default=8,
+                    help="grids per step over ALL GPUs (strong scaling): BASELINE configs[2], the headline, is global batch 8")
+    ap.add_argument("--batch-per-gpu", type=int, default=0,
+                    help="fix the grids per GPU per step instead (weak scaling): 1 = the headline's share at DP=8, 4 = the reference's training "
+                         "recipe (train_mae3d.sh: batch 32 on 8 GPUs; BASELINE configs[1])")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 1/4/8 grids-per-GPU sweep legs (config.sweep)")
+    ap.add_argument("--e2e", action="store_true", help="also time Trainer.fit on host-resident synthetic scenes (uint8 and fp32 storage)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python each step instead of replaying the captured HIP graph")
     args = ap.parse_args()
 
     from nerf_mae_amd import ops
     from nerf_mae_amd.dist import GradReducer, broadcast_parameters
-    from nerf_mae_amd.model import SWIN_CONFIGS, build_model
+    from nerf_mae_amd.model import SWIN_CONFIGS, build_model, draw_block_mask
     from nerf_mae_amd.trainer import FusedAdamW, GraphedTrainStep, OneCycle
     from nerf_mae_amd import data
 
@@ -79,21 +91,35 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    # dry-run hooks for a 1-GPU box (control flow of the N > 1 path: rank > 0 capture, flat all-reduce, optimizer graph): every rank
+    # dry-run hooks for a 1-GPU box (control flow of the N > 1 path: rank > 0 capture, split graphs, optimizer graph): every rank
     # on device 0 and gloo instead of RCCL (which refuses two ranks on one GPU).  Never set by the driver.
     backend = os.environ.get("NMH_BENCH_BACKEND", "nccl")
     if os.environ.get("NMH_BENCH_SHARE_GPU", "0") == "1":
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # the collective really spans N ranks: all-reduce of a one-hot rank vector must come back all ones
+        assert dist.get_world_size() == args.gpus
+        onehot = torch.zeros(world, device=dev)
+        onehot[rank] = 1.0
+        dist.all_reduce(onehot)
+        torch.cuda.synchronize()
+        assert bool((onehot == 1).all()), f"rank-count check failed: {onehot.tolist()}"
+        rccl_ranks = int(onehot.sum().item())
 
-    R, Bg = args.resolution, args.batch_per_gpu
+    R = args.resolution
+    if args.batch_per_gpu > 0:
+        Bg, scaling = args.batch_per_gpu, "weak"
+    else:
+        assert args.global_batch % world == 0, "--global-batch must be a multiple of --gpus"
+        Bg, scaling = args.global_batch // world, "strong"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
     random.seed(0)
@@ -101,41 +127,23 @@ def main():
     model.train()
     model.flatten_parameters()
     broadcast_parameters(model)
-    reducer = GradReducer(model) if world > 1 else None
+    reducer = GradReducer(model, comm_dtype=torch.bfloat16 if os.environ.get("NMH_COMM_BF16", "1") == "1" else None) if world > 1 else None
     model._reducer = reducer
     opt = FusedAdamW(model, lr=1e-4, weight_decay=1e-3, max_grad_norm=0.1)
-    total_steps = args.steps + args.warmup
-    sched = OneCycle(1e-4, max(total_steps, 2))
+    sched = OneCycle(1e-4, 1000)
+    step_no = [0]
 
     # synthetic inputs: valid extents cycle through {160^3, 160x132x96, 120x160x144}, resident in HBM
     exts = [(R, R, R), (R, int(R * 0.825), int(R * 0.6)), (int(R * 0.75), R, int(R * 0.9))]
+    sweep_sizes = [] if (args.no_sweep or args.eager or world > 1) else [b for b in (1, 4, 8) if b != Bg]
+    nmax = max([Bg] + sweep_sizes)
     # stored-format scenes (W,L,H,4 with raw density) go through the product input pipeline (density->alpha, layout, padding on the GPU)
-    scenes = [data.synthetic_scene(exts[(rank * Bg + i) % 3], seed=rank * 131 + i) for i in range(Bg)]
-    xb0, ext0 = data.GridBatcher(R, dev, normalize_density=True)(scenes, flags=[0] * Bg)
-    grids = [xb0[i, :, :e[0], :e[1], :e[2]].contiguous() for i, e in enumerate(ext0.tolist())]
+    scenes = [data.synthetic_scene(exts[(rank * nmax + i) % 3], seed=rank * 131 + i) for i in range(nmax)]
+    xb0, ext0 = data.GridBatcher(R, dev, normalize_density=True)(scenes, flags=[0] * nmax)
+    grids_all = [xb0[i, :, :e[0], :e[1], :e[2]].contiguous() for i, e in enumerate(ext0.tolist())]
+    del xb0
     mask_rng = random.Random(1000 + rank)
     g = R // 4
-
-    from nerf_mae_amd.model import draw_block_mask
-    graphed = None
-    if not args.eager:
-        model._reducer = None  # graph mode: one flat all-reduce between the backward graph and the optimizer graph
-        graphed = GraphedTrainStep(model, opt, Bg, reducer=reducer)
-        graphed(grids, draw_block_mask((g, g, g), 0.75, rng=mask_rng))  # loads the static batch, captures (lr is 0 until update_hyper)
-
-    def step(i):
-        lr, b1 = sched.at(i)
-        opt.set_hyper(lr=lr, beta1=b1)
-        bm = draw_block_mask((g, g, g), 0.75, rng=mask_rng)   # per-step python-random mask, as the reference
-        if graphed is not None:
-            return graphed(None, bm)[0]
-        model.zero_grad()
-        loss, l_rgb, l_a = model(grids, block_mask=bm)
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
-        opt.step()
-        return loss
 
     def barrier():
         if world > 1:
@@ -146,61 +154,122 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        loss = step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    def run_leg(nb, steps, warmup, use_reducer=True):
+        """`steps` timed steps at nb grids per GPU -> (seconds [max over ranks], last loss, exposed comm ms per step or None)"""
+        grids = grids_all[:nb]
+        graphed = None
+        red = reducer if use_reducer else None
+        if not args.eager:
+            graphed = GraphedTrainStep(model, opt, nb, reducer=red)
+            graphed(grids, draw_block_mask((g, g, g), 0.75, rng=mask_rng))  # loads the static batch, captures (lr is 0 until update_hyper)
+        else:
+            model._reducer = red
+
+        def step():
+            lr, b1 = sched.at(step_no[0])
+            step_no[0] += 1
+            opt.set_hyper(lr=lr, beta1=b1)
+            bm = draw_block_mask((g, g, g), 0.75, rng=mask_rng)   # per-step python-random mask, as the reference
+            if graphed is not None:
+                return graphed(None, bm)[0]
+            model.zero_grad()
+            loss, l_rgb, l_a = model(grids, block_mask=bm)
+            loss.backward()
+            if red is not None:
+                red.finish()
+            opt.step()
+            return loss
+
+        for _ in range(warmup):
+            loss = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        lv = loss.item()
+        del graphed
+        torch.cuda.empty_cache()
+        return dt, lv
+
+    dt, loss_val = run_leg(Bg, args.steps, args.warmup)
+    grids_per_s = args.steps * Bg * world / dt
+    cfg = SWIN_CONFIGS[args.backbone]
+    flops_fb = 3.0 * fwd_flops_per_grid(cfg, R)
+    frac = lambda gps_per_gpu: round(gps_per_gpu * flops_fb / (PEAK_BF16_TFLOPS * 1e12), 4)  # noqa: E731
+
+    comm_exposed = None
+    if world > 1:
+        # the same K steps without the gradient exchange (every rank steps on its local gradients): the difference is the part of the
+        # all-reduce that the backward did not hide
+        dt_local, _ = run_leg(Bg, args.steps, args.warmup, use_reducer=False)
+        comm_exposed = round(1e3 * (dt - dt_local) / args.steps, 3)
+        broadcast_parameters(model)
+
+    sweep = {}
+    for nb in sweep_sizes:
+        ks = max(3, min(args.steps, 10))
+        d2, _ = run_leg(nb, ks, 3)
+        gps = ks * nb * world / d2
+        sweep["%d_grids_per_gpu" % nb] = {"grids_per_s": round(gps, 3), "ms_per_step": round(1e3 * d2 / ks, 3), "whole_step_mfma_frac": frac(gps / world)}
+    sweep["%d_grids_per_gpu" % Bg] = {"grids_per_s": round(grids_per_s, 3), "ms_per_step": round(1e3 * dt / args.steps, 3),
+                                      "whole_step_mfma_frac": frac(grids_per_s / world)}
+
     # per-kernel durations with HIP events on the launch stream: a few extra eager steps on the same model/data right after
     # the timed region (graph replays cannot carry per-launch events; the kernels, shapes and data are identical).  The side stream
     # is off for these steps so that an event pair brackets exactly one kernel (in the replayed step the decoder weight pack and the
     # weight-gradient GEMMs overlap other kernels; rocprofv3 of the replay shows the same per-launch time, profiles/)
     prof = None
+    ksteps = min(3, args.steps)
     if not args.no_kernel_timing and rank == 0:
         side_was, ops.side_stream.enabled = ops.side_stream.enabled, False
+        red_was, model._reducer = model._reducer, None
         ops.PROFILE = {}
-        ksteps = min(3, args.steps)
         for i in range(ksteps + 1):
             if i == 1:
                 torch.cuda.synchronize()
                 ops.PROFILE = {}       # first eager step after the replays: lazy allocations, not timed
             model.zero_grad()
-            l3 = model(grids, block_mask=draw_block_mask((g, g, g), 0.75, rng=mask_rng))
+            l3 = model(grids_all[:Bg], block_mask=draw_block_mask((g, g, g), 0.75, rng=mask_rng))
             l3[0].backward()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         ops.side_stream.enabled = side_was
+        model._reducer = red_was
     barrier()
-    if world > 1:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    loss_val = loss.item()
 
-    grids_per_s = args.steps * Bg * world / dt
-    cfg = SWIN_CONFIGS[args.backbone]
-    flops_fb = 3.0 * fwd_flops_per_grid(cfg, R)
-
+    headline = (args.backbone == "swin_s" and R == 160 and args.dtype == "bf16")
     out = {
         "metric": "voxel-grids/sec (fwd+bwd+optimizer) %s %d^3 %s" % (args.backbone, R, args.dtype),
         "value": round(grids_per_s, 4), "unit": "grids/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%s MAE pretraining step, %d grid(s)/GPU of 4x%d^3 RGB-sigma, mask_ratio 0.75, stochastic depth 0.1, AdamW+clip, DP=%d"
-                               % (args.backbone, Bg, R, world),
-                   "global_batch": Bg * world, "resolution": R, "parallelism": "dp%d" % world, "launch": "eager" if args.eager else "hipgraph",
+        "config": {"workload": "%s MAE pretraining step, global batch %d = %d grid(s)/GPU of 4x%d^3 RGB-sigma, mask_ratio 0.75, stochastic depth 0.1, AdamW+clip, DP=%d%s"
+                               % (args.backbone, Bg * world, Bg, R, world,
+                                  " (BASELINE configs[2], the headline, read literally)" if headline and Bg * world == 8 else ""),
+                   "global_batch": Bg * world, "grids_per_gpu": Bg, "resolution": R, "parallelism": "dp%d" % world,
+                   "launch": "eager" if args.eager else "hipgraph",
                    "algorithmic_tflop_per_grid_fwd_bwd": round(flops_fb / 1e12, 3),
-                   "whole_step_mfma_frac": round(grids_per_s / world * flops_fb / (PEAK_BF16_TFLOPS * 1e12), 4), "final_loss": round(loss_val, 5)},
+                   "whole_step_mfma_frac": frac(grids_per_s / world), "final_loss": round(loss_val, 5),
+                   "sweep": sweep},
     }
+    if world > 1:
+        out["config"]["collective_ranks_verified"] = rccl_ranks
+        out["config"]["comm_ms_exposed"] = comm_exposed
+        out["config"]["grad_comm_dtype"] = "bf16" if (reducer is not None and reducer.comm_dtype == torch.bfloat16) else "fp32"
 
     if rank == 0 and prof:
         # dominant kernel: implicit-GEMM 3x3x3 conv at R^3 with Cin=Cout=E/2 (decoder1 fwd + dgrad launches share one kernel)
         E2 = cfg["embed_dim"] // 2
-        evs = prof.get(("conv3d_k3_c48", Bg, R, E2, E2), []) or prof.get(("conv3d_k3", Bg, R, E2, E2), [])
-        kname = "conv48_kernel (LDS-halo implicit GEMM" if ("conv3d_k3_c48", Bg, R, E2, E2) in prof else "gemm_nt_kernel<bf16,4,3,AConv3> (generic gather implicit GEMM"
+        key = next((k for k in prof if k[0] in ("conv3d_k3_c48", "conv3d_k3_halo") and k[1:] == (Bg, R, E2, E2)), None) or ("conv3d_k3", Bg, R, E2, E2)
+        evs = prof.get(key, [])
+        kname = {"conv3d_k3_c48": "conv48_kernel (LDS-halo implicit GEMM", "conv3d_k3_halo": "conv_halo_kernel (LDS-halo implicit GEMM"}.get(
+            key[0], "gemm_nt_kernel<bf16,4,3,AConv3> (generic gather implicit GEMM")
         if evs:
             ms = [a.elapsed_time(b) for a, b in evs]
             avg = sum(ms) / len(ms)
@@ -209,51 +278,128 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "%s, conv3d 3x3x3 %d->%d @%d^3, fwd+dgrad launches)" % (kname, E2, E2, R),
                                "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                                "avg_launch_ms": round(avg, 4), "launches_timed": len(ms), "traffic": None,
-                               "algorithmic_flop_per_launch": fl}
-            # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes (counters cannot be read in-process); the
-            # committed summary is used when it was taken at the same shape
+                               "algorithmic_flop_per_launch": fl, "algorithmic_bytes_per_launch": 2.0 * Bg * R ** 3 * E2 * 2}
+            # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes (counters cannot be read in-process): the committed
+            # summary is quoted only when it was taken on THIS kernel source (sha256 of conv48.hip) at the same shape
             try:
                 import glob
+                sha = hashlib.sha256(open(os.path.join(ROOT, "nerf-mae_amd", "csrc", "conv48.hip"), "rb").read()).hexdigest()
+                stale = []
                 for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*conv48_pmc.json")))[::-1]:
                     pm = json.load(open(f))
-                    if pm.get("batch_per_gpu") == Bg and pm.get("resolution") == R and "c48" in kname.replace("conv48", "c48"):
-                        out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
-                        out["roofline"]["traffic_source"] = os.path.basename(f) + " (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes)"
-                        out["roofline"]["algorithmic_bytes_per_launch"] = 2.0 * Bg * R ** 3 * E2 * 2
-                        if pm.get("power"):   # measured context for `frac`: the kernel runs at the socket power cap
-                            out["roofline"]["power_note"] = pm["power"]
-                        break
-            except Exception:
-                pass
+                    if key[0] != "conv3d_k3_c48" or pm.get("resolution") != R:
+                        continue
+                    if pm.get("conv48_hip_sha256") != sha:
+                        stale.append(os.path.basename(f))
+                        continue
+                    per_grid = pm["hbm_bytes_per_launch"] / pm["batch_per_gpu"]
+                    out["roofline"]["traffic"] = per_grid * Bg
+                    out["roofline"]["traffic_source"] = "%s (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes at %d grids per launch, scaled per grid; kernel source hash matches)" % (
+                        os.path.basename(f), pm["batch_per_gpu"])
+                    if pm.get("mfma_busy_frac"):
+                        out["roofline"]["mfma_busy_frac_pmc"] = round(pm["mfma_busy_frac"], 4)
+                    if pm.get("rocm_smi_raw"):
+                        out["roofline"]["rocm_smi_raw"] = "profiles/" + pm["rocm_smi_raw"]
+                    break
+                else:
+                    if stale:
+                        out["roofline"]["traffic_refused"] = "PMC summaries %s were taken on a different conv48.hip" % stale[:3]
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["traffic_error"] = repr(e)
+        # HBM-bound kernels: achieved GB/s of algorithmic bytes (ops.PROFILE_BYTES) against the 8 TB/s peak
+        hb = []
+        for k, evs2 in prof.items():
+            nb = ops.PROFILE_BYTES.get(k)
+            if nb:
+                ms2 = [a.elapsed_time(b) for a, b in evs2]
+                avg2 = sum(ms2) / len(ms2)
+                hb.append({"kernel": k[0] + ":" + "x".join(str(v) for v in k[1:]), "ms_per_step": round(sum(ms2) / ksteps, 3), "avg_launch_ms": round(avg2, 4),
+                           "algorithmic_bytes_per_launch": nb, "achieved_GBs": round(nb / (avg2 * 1e-3) / 1e9, 1),
+                           "frac_of_8TBs": round(nb / (avg2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+        hb.sort(key=lambda d: -d["ms_per_step"])
+        if "roofline" in out:
+            out["roofline"]["hbm_kernels"] = hb[:3]
         tot = {}
-        for k, evs in prof.items():
-            tot[k[0] + ":" + "x".join(str(v) for v in k[1:])] = round(sum(a.elapsed_time(b) for a, b in evs) / ksteps, 3)
+        for k, evs2 in prof.items():
+            tot[k[0] + ":" + "x".join(str(v) for v in k[1:])] = round(sum(a.elapsed_time(b) for a, b in evs2) / ksteps, 3)
         out["config"]["timed_kernel_ms_per_step"] = dict(sorted(tot.items(), key=lambda kv: -kv[1])[:8])
 
+    if args.e2e and rank == 0 and world == 1:
+        out["config"]["e2e"] = e2e_leg(model, args, R, sweep)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline: the oracle (a port of the reference's PyTorch path) on the host cores, bounded sample: ONE grid fwd+bwd
-        from oracle import mae3d_oracle as O   # the only use of oracle/ in this file
-        ncores = os.cpu_count() or 1
-        try:
-            import psutil
-            ncores = psutil.cpu_count(logical=False) or ncores
-        except Exception:
-            pass
-        torch.set_num_threads(ncores)
-        ora = O.build_oracle(args.backbone, resolution=R, masking_prob=0.75, stochastic_depth_prob=0.1)
-        ora.train()
-        xg = [O.synthetic_grid(exts[0], seed=7)]
-        random.seed(0)
-        tc = time.perf_counter()
-        lo = ora(xg)
-        lo[0].backward()
-        tcpu = time.perf_counter() - tc
-        out["cpu_baseline"] = {"value": round(1.0 / tcpu, 5), "unit": "grids/s", "cores": ncores, "kind": "port",
-                               "sample": "1 grid %s %d^3 fp32 forward+backward, 1 repetition (%.1f s), torch %s CPU" % (args.backbone, R, tcpu, torch.__version__)}
+        out["cpu_baseline"] = cpu_baseline(args, R, exts)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def e2e_leg(model, args, R, sweep):
+    """Trainer.fit on HOST-resident synthetic scenes (stored format, through the pinned ring / copy stream / grid_prepare kernel):
+    grids/s next to the HBM-resident figure of the same per-GPU batch"""
+    import numpy as np
+    from nerf_mae_amd import data
+    from nerf_mae_amd.trainer import Trainer
+    nb = 4
+    res = {}
+    for name, dt_ in (("uint8_scenes", np.uint8), ("fp32_scenes", np.float32)):
+        scenes = [data.synthetic_scene((R, R, R), seed=50 + i, dtype=dt_) for i in range(8)]
+        tr = Trainer(model, scenes * 5, batch_size=nb, num_epochs=1, log=lambda *_: None)
+        tr.train_epoch(1)      # capture + warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.train_epoch(2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gps = tr.steps_per_epoch * nb / dt
+        res[name] = {"grids_per_s": round(gps, 2), "ms_per_step": round(1e3 * dt / tr.steps_per_epoch, 3), "grids_per_gpu": nb}
+        ref = sweep.get("%d_grids_per_gpu" % nb)
+        if ref:
+            res[name]["frac_of_hbm_resident"] = round(gps / ref["grids_per_s"], 4)
+        del tr
+        torch.cuda.empty_cache()
+    return res
+
+
+def cpu_baseline(args, R, exts):
+    """CPU baseline: the oracle (a port of the reference's PyTorch path) on the host's physical cores,
+    fp32, wall clock: swin_s 160^3 forward+backward, median of 3 repetitions after one warm-up pass at config 1's size; and config 1
+    (swin_t, one 32^3 grid), median of 20 after 3 warm-ups."""
+    from oracle import mae3d_oracle as O   # the only use of oracle/ in this file
+    ncores = os.cpu_count() or 1
+    try:
+        import psutil
+        ncores = psutil.cpu_count(logical=False) or ncores
+    except Exception:  # noqa: BLE001
+        pass
+    torch.set_num_threads(ncores)
+
+    def timed(ora, xg, reps, warm):
+        ts = []
+        for i in range(warm + reps):
+            random.seed(i)
+            for p in ora.parameters():
+                p.grad = None
+            tc = time.perf_counter()
+            lo = ora(xg)
+            lo[0].backward()
+            if i >= warm:
+                ts.append(time.perf_counter() - tc)
+        return ts
+
+    ora_t = O.build_oracle("swin_t", resolution=32, masking_prob=0.75, stochastic_depth_prob=0.1)
+    ora_t.train()
+    t_small = timed(ora_t, [O.synthetic_grid((32, 32, 32), seed=3)], 20, 3)
+    ora = O.build_oracle(args.backbone, resolution=R, masking_prob=0.75, stochastic_depth_prob=0.1)
+    ora.train()
+    t_big = timed(ora, [O.synthetic_grid(exts[0], seed=7)], 3, 0)
+    med = statistics.median(t_big)
+    return {"value": round(1.0 / med, 5), "unit": "grids/s", "cores": ncores, "kind": "port",
+            "sample": "1 grid %s %d^3 fp32 forward+backward, median of 3 repetitions (%s s), torch %s CPU" % (
+                args.backbone, R, "/".join("%.1f" % t for t in t_big), torch.__version__),
+            "config1_swin_t_32": {"value": round(1.0 / statistics.median(t_small), 3), "unit": "grids/s",
+                                  "sample": "swin_t, one 32^3 grid, fp32 forward+backward, median of 20 repetitions after 3 warm-ups (%.3f s)" % statistics.median(t_small)}}
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@
  *     ((b*A0+a0)*A1+a1)*A2+a2 (A2 fastest) -- the reference's (B,H,W,D,C) order;
  *   - `wm` points to 10 host ints {B, H, W, D, PH, PW, PD, s0, s1, s2}: token grid, grid padded to multiples of 4,
  *     effective cyclic shifts (0 where window >= padded size; swin_mae3d.py:62-81).
- * Every line below that starts with NMH_API is parsed by the Python binding and by tests/test_capi_symbols.py.
+ * Every line below that starts with NMH_API is parsed by the Python binding and by tests/test_host_cpu.py::test_capi_library_loads_and_exports_every_declared_symbol.
  */
 #ifndef NERFMAE_HIP_H
 #define NERFMAE_HIP_H

@@ -13,11 +13,14 @@ from ._lib import lib
 F32, BF16 = 0, 1
 WS = 4
 PROFILE = None  # set to a dict by bench.py: {(op, dims...): [(start_event, end_event), ...]} recorded on the launch stream
+PROFILE_BYTES = {}  # key -> algorithmic HBM bytes per launch (the HBM-bound elementwise passes; bench.py's roofline.hbm_kernels)
 
 
-def _prof(key):
+def _prof(key, nbytes=None):
     if PROFILE is None:
         return None
+    if nbytes is not None:
+        PROFILE_BYTES[key] = nbytes
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     PROFILE.setdefault(key, []).append((a, b))
     a.record(torch.cuda.current_stream())
@@ -286,20 +289,30 @@ def instnorm_finalize(acc, stats, B, V, C, eps=1e-5):
 
 def instnorm_apply(x, stats, out, B, V, C, r=None, stats_r=None, rmode=0, slope=0.01):
     _chk(x, stats, out, r, stats_r)
+    ev = _prof(("instnorm_apply", B, V, C, rmode), (2 + (rmode != 0)) * x.numel() * x.element_size())
     lib().call("nmh_instnorm_apply", dt_of(x), x, stats, r, stats_r, rmode, out, B, V, C, slope, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
     return out
 
 
 def instnorm_bwd_reduce(dout, out, x, stats, sums, B, V, C, r=None, stats_r=None, sums_r=None, rmode=0, slope=0.01):
     _chk(dout, out, x, stats, sums, r, stats_r, sums_r)
+    ev = _prof(("instnorm_bwd_reduce", B, V, C, rmode), (2 + (out is not None) + (rmode == 2)) * x.numel() * x.element_size())
     lib().call("nmh_instnorm_bwd_reduce", dt_of(x), dout, out, x, stats, r, stats_r, rmode, sums, sums_r, B, V, C, slope, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
 
 
 def instnorm_bwd_apply(dout, out, x, stats, sums, dx, B, V, C, r=None, stats_r=None, sums_r=None, rmode=0, dr=None,
                        dr_accumulate=False, slope=0.01):
     _chk(dout, out, x, stats, sums, dx, r, stats_r, sums_r, dr)
+    ev = _prof(("instnorm_bwd_apply", B, V, C, rmode),
+               (3 + (out is not None) + (rmode == 2) + (dr is not None) * (1 + int(dr_accumulate))) * x.numel() * x.element_size())
     lib().call("nmh_instnorm_bwd_apply", dt_of(x), dout, out, x, stats, sums, r, stats_r, sums_r, rmode, dx, dr, int(dr_accumulate),
                B, V, C, slope, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
 
 
 def patch_embed_gather(x, A, B, R):
@@ -356,7 +369,11 @@ def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C,
     _chk(y, stats, r, d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred)
     if dpred is not None and sums.numel() < 8:
         raise ValueError("mae_tail_fwd: sums needs 8 entries when dpred is requested")
+    # algorithmic bytes: y and r read once, the fp32 target (4 channels) read once, d(pred) (16 B / voxel) and d0 written if requested
+    ev = _prof(("mae_tail_fwd", B, R, C), (2 + (d0 is not None)) * y.numel() * y.element_size() + B * R ** 3 * 16 * (1 + (dpred is not None) + (pred is not None)))
     lib().call("nmh_mae_tail_fwd", dt_of(y), y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
     return losses
 
 
@@ -365,7 +382,11 @@ def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, d
     _chk(d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout)
     if d0 is None and r is None:
         raise ValueError("mae_tail_bwd needs d0 or r")
+    # two passes (sums, then apply): y and r (or d0) read twice, d(pred) read twice, dy and dr written once
+    ev = _prof(("mae_tail_bwd", B, V, C), 6 * y.numel() * y.element_size() + 2 * B * V * 16)
     lib().call("nmh_mae_tail_bwd", dt_of(y), d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
 
 
 GRID_ROT, GRID_FLIP0, GRID_FLIP1, GRID_DENSITY = 1, 2, 4, 8

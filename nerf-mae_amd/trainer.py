@@ -33,6 +33,32 @@ class OneCycle:
         return self._cos(self.max_lr, self.min_lr, pct), self._cos(self.base_m, self.max_m, pct)
 
 
+class PinnedRing:
+    """Ring of pinned host slots for small per-step uploads (hyper-parameters, token mask, extents).  `upload(src, dst)` copies
+    src -> next slot -> dst (non-blocking, stream-ordered) and records an event; a slot is only rewritten after the event of its
+    previous upload has completed, so the host can run ahead of the device without corrupting a copy that has not executed yet."""
+
+    def __init__(self, shape, dtype, depth: int = 8, pinned: bool = True):
+        self.buf = torch.empty((depth,) + tuple(shape), dtype=dtype)
+        if pinned:
+            self.buf = self.buf.pin_memory()
+        self.events = [None] * depth
+        self.i, self.pinned = 0, pinned
+
+    def upload(self, src: torch.Tensor, dst: torch.Tensor):
+        k = self.i % len(self.events)
+        self.i += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        slot = self.buf[k]
+        slot.copy_(src.reshape(slot.shape))
+        dst.copy_(slot.view(dst.shape), non_blocking=True)
+        if self.pinned and dst.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.events[k] = ev
+
+
 class FusedAdamW:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, max_grad_norm=0.1):
         if model._flat is None:
@@ -46,7 +72,6 @@ class FusedAdamW:
         # {lr, b1, b2, eps, wd, 1-b1^t, 1-b2^t}: lr 0 and unit bias corrections until update_hyper() => a launch is a no-op
         self.hyper = torch.tensor([0.0, betas[0], betas[1], eps, 0.0, 1.0, 1.0, 0.0], device=flat.device)
         self.t = 0
-        self.b1_pow = self.b2_pow = 1.0
         self.zero_grads_after_step = False   # the AdamW kernel also clears the flat gradient buffer (GraphedTrainStep turns it on)
 
     def set_hyper(self, lr=None, beta1=None):
@@ -59,16 +84,16 @@ class FusedAdamW:
         """advance the step counter and upload {lr, betas, eps, wd, bias corrections} (host->device; NOT graph-capturable)"""
         self.t += 1
         b1, b2 = self.betas
-        self.b1_pow *= b1
-        self.b2_pow *= b2
+        # torch.optim.AdamW semantics under OneCycleLR momentum cycling: bias corrections from the CURRENT betas, 1 - beta^t
+        # (not the running product of the per-step beta1 values, which differs by ~20 % a few steps into a cycled schedule)
+        bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
         # through a ring of pinned slots: a pageable source would make the copy (stream-ordered behind the running step) block the
-        # host, serialising the launch of step i+1 with the execution of step i
+        # host, serialising the launch of step i+1 with the execution of step i.  Each slot carries an event recorded after its
+        # H2D copy; the host waits on it before rewriting the slot, so it may run ahead of the device by at most the ring depth.
         if getattr(self, "_pin", None) is None:
-            self._pin = torch.empty((8, 8), dtype=torch.float32).pin_memory() if self.hyper.is_cuda else torch.empty((8, 8))
-        slot = self._pin[self.t % 8]
-        slot.copy_(torch.tensor([self.lr, b1, b2, self.eps, self.wd, 1.0 - self.b1_pow, 1.0 - self.b2_pow,
-                                 1.0 if self.zero_grads_after_step else 0.0], dtype=torch.float32))
-        self.hyper.copy_(slot, non_blocking=True)
+            self._pin = PinnedRing((8,), torch.float32, pinned=self.hyper.is_cuda)
+        self._pin.upload(torch.tensor([self.lr, b1, b2, self.eps, self.wd, bc1, bc2, 1.0 if self.zero_grads_after_step else 0.0],
+                                      dtype=torch.float32), self.hyper)
 
     def launch(self):
         """the three device-side launches (graph-capturable): grad norm, clip coefficient, AdamW update"""
@@ -104,6 +129,12 @@ class GraphedTrainStep:
         self._g1 = self._g2 = None
         self._warm = warmup
 
+    def set_extents(self, ext):
+        """valid extents [B][3] of the batch now in `self.x` (host list / tensor) -> static device buffer, through a pinned ring"""
+        if getattr(self, "_pin_ext", None) is None:
+            self._pin_ext = PinnedRing(tuple(self.ext.shape), torch.int32)
+        self._pin_ext.upload(torch.as_tensor(ext, dtype=torch.int32).cpu(), self.ext)
+
     def _fwd_bwd(self, zero=True):
         if zero:
             self.model.zero_grad()
@@ -112,6 +143,9 @@ class GraphedTrainStep:
         return out
 
     def _capture(self):
+        # the eager path's autograd triggers would issue collectives on the comm stream inside the capture: graph mode owns the
+        # exchange (see __call__), so they are switched off for good on this model
+        self.model._reducer = None
         ops.side_stream.auto(self.x.shape[0])
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -144,14 +178,11 @@ class GraphedTrainStep:
                 a0, a1, a2 = t.shape[1:]
                 self.x[i, :, :a0, :a1, :a2].copy_(t, non_blocking=True)
                 ext.append([a0, a1, a2])
-            self.ext.copy_(torch.tensor(ext, dtype=torch.int32).pin_memory(), non_blocking=True)
-        if block_mask is not None:   # pinned ring, see FusedAdamW.update_hyper
+            self.set_extents(ext)
+        if block_mask is not None:   # event-guarded pinned ring, see FusedAdamW.update_hyper
             if getattr(self, "_pin_mask", None) is None:
-                self._pin_mask, self._pin_i = torch.empty((8, self.mask.numel()), dtype=torch.uint8).pin_memory(), 0
-            slot = self._pin_mask[self._pin_i % 8]
-            self._pin_i += 1
-            slot.copy_(block_mask.to(torch.uint8).reshape(-1))
-            self.mask.copy_(slot, non_blocking=True)
+                self._pin_mask = PinnedRing((self.mask.numel(),), torch.uint8)
+            self._pin_mask.upload(block_mask.to(torch.uint8), self.mask)
         if self._g1 is None:
             self._capture()
         self.opt.update_hyper()
@@ -192,22 +223,22 @@ def save_checkpoint(path: str, model, epoch: int, train_args: dict, opt: "FusedA
     cannot resume its optimizer): AdamW moments over the flat buffer, step count, beta powers, schedule position."""
     ck = {"epoch": epoch, "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "train_args": dict(train_args)}
     if opt is not None:
-        ck["resume"] = {"m": opt.m.detach().cpu(), "v": opt.v.detach().cpu(), "t": opt.t, "b1_pow": opt.b1_pow, "b2_pow": opt.b2_pow,
-                        "lr": opt.lr, "betas": opt.betas, "step": step}
+        ck["resume"] = {"m": opt.m.detach().cpu(), "v": opt.v.detach().cpu(), "t": opt.t, "lr": opt.lr, "betas": opt.betas, "step": step}
     torch.save(ck, path)
 
 
 def load_checkpoint(path: str, model, opt: "FusedAdamW" = None, strict: bool = True) -> dict:
     """loads a reference-format checkpoint (also one written by the reference itself); returns the checkpoint dict.  With `opt` and
     a "resume" section the optimizer continues where it stopped."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    # tensors, numbers, strings, dicts/lists/tuples only: nothing in either checkpoint format needs unpickling of arbitrary objects
+    ck = torch.load(path, map_location="cpu", weights_only=True)
     model.load_state_dict(ck["state_dict"], strict=strict)
     if opt is not None and "resume" in ck:
         r = ck["resume"]
         if model._flat is None or not model._flat.is_cuda:
             raise RuntimeError("load_checkpoint: move the model to the HIP device before restoring the optimizer")
         opt.m.copy_(r["m"]); opt.v.copy_(r["v"])
-        opt.t, opt.b1_pow, opt.b2_pow, opt.lr, opt.betas = r["t"], r["b1_pow"], r["b2_pow"], r["lr"], tuple(r["betas"])
+        opt.t, opt.lr, opt.betas = r["t"], r["lr"], tuple(r["betas"])
     return ck
 
 
@@ -231,7 +262,12 @@ class Trainer:
         self.batcher = data.GridBatcher(model.resolution, dev, normalize_density, flip_prob, rotate_prob)
         self.val_batcher = data.GridBatcher(model.resolution, dev, normalize_density)
         self.opt = FusedAdamW(model, lr=lr, weight_decay=weight_decay, max_grad_norm=clip_grad_norm)
-        self.steps_per_epoch = max(1, len(self._shard(len(train_scenes), rank, world, 0)) // batch_size)
+        # the reference's DataLoader has no drop_last: len(train_loader) is the ceiling, and it sizes OneCycleLR (run_swin_mae3d.py:594-598)
+        self.steps_per_epoch = -(-len(self._shard(len(train_scenes), rank, world, 0)) // batch_size)
+        if self.steps_per_epoch < 1:
+            raise ValueError("Trainer: empty training shard")
+        if world > 1:
+            _dist.broadcast_parameters(model)   # DDP's initial broadcast: every rank starts from rank 0's weights
         self.sched = OneCycle(lr, num_epochs * self.steps_per_epoch)
         self.step_fn = GraphedTrainStep(model, self.opt, batch_size, reducer=reducer)
         self.global_step, self.best_metric, self.history = 0, None, []
@@ -250,6 +286,12 @@ class Trainer:
         for b in range(self.steps_per_epoch):
             scenes = [self._scene(self.train_scenes[i]) for i in idx[b * self.batch:(b + 1) * self.batch]]
             xb, ext = self.batcher(scenes, out=self.step_fn.x)           # straight into the graph's static input
+            if len(scenes) < self.batch:
+                # ragged last batch of the epoch (no drop_last in the reference): the unused slots of the static batch become empty
+                # grids with zero valid extent -- no voxel of them enters either loss mask, so losses and gradients equal those of
+                # the smaller batch
+                self.step_fn.x[len(scenes):].zero_()
+                ext = torch.cat([ext, torch.zeros((self.batch - len(scenes), 3), dtype=torch.int32, device=ext.device)])
             self.step_fn.ext.copy_(ext)
             lr, b1 = self.sched.at(self.global_step)
             self.opt.set_hyper(lr=lr, beta1=b1)

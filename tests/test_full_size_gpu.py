@@ -1,5 +1,5 @@
-"""GPU, BASELINE.json's full size (swin_s, 4x160^3): the hot path against the CPU oracle on one grid (the oracle needs ~20 s for
-forward + backward on the GPU box's host), and size-independent properties of the 160^3 kernels that an oracle at a toy size cannot
+"""GPU, BASELINE.json's full sizes (swin_s = configs[2], swin_b* = configs[3], 4x160^3): the hot path against the CPU oracle on one
+grid (the oracle needs ~20-40 s for forward + backward on the GPU box's host), and size-independent properties of the 160^3 kernels that an oracle at a toy size cannot
 exercise (every tile / halo boundary of the persistent LDS-halo convolutions)."""
 import random
 
@@ -8,6 +8,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 SWIN_S = dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24])
+# BASELINE configs[3]; the defined deviation of SURVEY 8(c): canonical Swin-B heads, 3 x 42-channel sincos pos-embed zero-padded to 128
+SWIN_B = dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32])
+BACKBONES = {"swin_s": SWIN_S, "swin_b": SWIN_B}
 
 
 def relerr(a, b):
@@ -15,16 +18,18 @@ def relerr(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
 
 
-@pytest.fixture(scope="module")
-def oracle_run():
-    """one oracle forward + backward at full size, shared by the fp32 and the bf16 comparison"""
+@pytest.fixture(scope="module", params=["swin_s", "swin_b"])
+def oracle_run(request):
+    """one oracle forward + backward at full size per backbone, shared by the fp32 and the bf16 comparison"""
+    cfg = BACKBONES[request.param]
+    extra = dict(pad_pos_embed=True) if request.param == "swin_b" else {}
     import time
     import psutil
     from oracle import mae3d_oracle as O
     torch.set_num_threads(psutil.cpu_count(logical=False) or 8)   # physical cores: the SMT siblings make the CPU convolutions ~10x slower
     t0 = time.perf_counter()
     torch.manual_seed(77)
-    ora = O.MAE3DOracle(resolution=160, masking_prob=0.75, stochastic_depth_prob=0.0, **SWIN_S)
+    ora = O.MAE3DOracle(resolution=160, masking_prob=0.75, stochastic_depth_prob=0.0, **cfg, **extra)
     with torch.no_grad():   # the reference's own initialisation + non-trivial biases / bias tables
         for n, p in ora.named_parameters():
             if p.requires_grad and (n.endswith("bias") or "relative_position_bias_table" in n):
@@ -33,16 +38,16 @@ def oracle_run():
     bm = O.draw_block_mask((40, 40, 40), 0.75, rng=random.Random(123))
     out = ora(xs, block_mask=bm, return_pred=True)
     out[0].backward()
-    print(f"[full size] oracle forward+backward: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
-    return ora, xs, bm, [o.detach() for o in out]
+    print(f"[full size {request.param}] oracle forward+backward: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+    return ora, xs, bm, [o.detach() for o in out], cfg
 
 
 @pytest.mark.parametrize("dtype,ltol,ptol,gcos", [(torch.float32, 1e-4, 1e-3, 0.9999), (torch.bfloat16, 2e-2, 6e-2, 0.99)], ids=["fp32", "bf16"])
 def test_full_size_matches_oracle(oracle_run, dtype, ltol, ptol, gcos):
     from nerf_mae_amd.model import SwinTransformer_MAE3D
-    ora, xs, bm, lo = oracle_run
+    ora, xs, bm, lo, cfg = oracle_run
     hip = SwinTransformer_MAE3D(patch_size=[4] * 3, window_size=[4] * 3, resolution=160, masking_prob=0.75, stochastic_depth_prob=0.0,
-                                compute_dtype=dtype, **SWIN_S)
+                                compute_dtype=dtype, **cfg)
     hip.load_state_dict(ora.state_dict(), strict=True)
     hip = hip.cuda()
     hip.zero_grad()
