@@ -40,6 +40,14 @@ NMH_API int nmh_gemm_nt_window_scatter(int dt, const void* A, int64_t lda, const
  * ws (optional, ws_floats fp32): scratch for the partial tiles of a split contraction; with it the splits are summed by a second
  * launch instead of fp32 global atomics (one scratch per stream: concurrent calls must not share it). */
 NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale, int omode, int64_t ldo, int p0, int p1, float* dbias, float* ws, int64_t ws_floats, void* stream);
+/* Grouped form of nmh_gemm_tn for bf16 operands (dt must be 1): `probs` is a HOST array of nprob descriptors; every problem is
+ * dW[N,K] += sum_m rowscale[m / rows_per_sample] * A[m,N]^T . B[m,K] (+ dbias[N] += column sums of A), M a multiple of rows_per_sample.
+ * The four Linear weight gradients of every Swin block of a stage (swin_mae3d.py:366-369 backward: attn.qkv, attn.proj, mlp.0, mlp.3)
+ * and the PatchMerging reduction (:413) are issued through this entry once the stage's input-gradient chain is done: up to 16 problems
+ * per kernel launch (descriptors travel as kernel arguments: graph-capturable), one 96x96 output tile per workgroup, contraction
+ * splits only when a launch has too few tiles to fill the chip (partials in ws, summed by one reduce launch per group). */
+typedef struct nmh_tn_problem { const void* A; int64_t lda; const void* B; int64_t ldb; float* dW; int64_t ldo; float* dbias; const float* rowscale; int64_t M; int N; int K; int rows_per_sample; } nmh_tn_problem;
+NMH_API int nmh_gemm_tn_grouped(int dt, const nmh_tn_problem* probs, int nprob, float* ws, int64_t ws_floats, void* stream);
 /* Y[(b,z,y,x)][Cout] (+)= conv3d(k=3,pad=1) of channels-last X with packed weights [Cout][27][Cin] (nn.Conv3d in
  * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout]. */
 NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);

@@ -9,6 +9,7 @@ static inline WinMap to_wm(const int* w) {
   return m;
 }
 #define ST ((hipStream_t)stream)
+#define NMH_DT_BF16_C 1
 // hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left behind, so that the
 // post-launch check in the k_* launchers reports only this call's launch status
 #define CLR() (void)hipGetLastError()
@@ -46,6 +47,13 @@ int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, 
   gm.omode = omode; gm.ldo = ldo; gm.dbias = dbias; gm.ws = ws; gm.ws_floats = ws ? (long)ws_floats : 0;
   if (omode == 2) { gm.Cin = p0; gm.V = (unsigned)p1; gm.dC = make_fdiv(p0); }
   return k_gemm_tn(dt, A, lda, B, ldb, dW, M, N, K, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, gm, ST);
+}
+int nmh_gemm_tn_grouped(int dt, const nmh_tn_problem* probs, int nprob, float* ws, int64_t ws_floats, void* stream) {
+  CLR();
+  if (nprob <= 0) return 0;
+  if (dt != NMH_DT_BF16_C || probs == nullptr) return -4;
+  static_assert(sizeof(nmh_tn_problem) == sizeof(TnProblemHost), "descriptor layouts must agree");
+  return k_gemm_tn_grouped(reinterpret_cast<const TnProblemHost*>(probs), nprob, ws, ws ? (long)ws_floats : 0, ST);
 }
 int nmh_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, int64_t ldc, int B, int v, int k, int Cin, int Cout, void* stream) {
   CLR();

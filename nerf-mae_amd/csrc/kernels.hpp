@@ -85,6 +85,16 @@ int k_upconv_dgrad(int dt, const void* dcat, long ldc, const void* Wd, void* dx,
 int k_upconv_wgrad(int dt, const void* dcat, long ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, hipStream_t st);
 int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st);
 int k_gemm_tn(int dt, const void* A, long lda, const void* Bm, long ldb, float* Out, long M, int N, int K, const float* rowscale, int rows_per_scale, const TnGeom& gm, hipStream_t st);
+// one problem of a grouped weight-gradient launch (host-side descriptor; mirrors nmh_tn_problem in include/nerfmae_hip.h)
+struct TnProblemHost {
+  const void* A; long lda;        // [M][N] rows = contraction index (dY)
+  const void* B; long ldb;        // [M][K] (layer input)
+  float* dW; long ldo;            // [N][K] fp32, accumulated
+  float* dbias;                   // optional [N]: += column sums of A (times rowscale)
+  const float* rowscale;          // optional [M / rows_per_sample]: factor per sample on the rows of A
+  long M; int N, K; int rows_per_sample;
+};
+int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st);
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st);
 int k_in_finalize(int dt, const double* acc, float* stats, int B, long V, int C, float eps, hipStream_t st);
 int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st);

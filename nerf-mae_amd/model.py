@@ -184,7 +184,13 @@ class _EmbedFn(torch.autograd.Function):
         dy0 = torch.empty_like(y0)
         ops.layernorm_bwd(dtok.contiguous(), y0, ln.weight, mean, rstd, dy0, _gradbuf(ln.weight), _gradbuf(ln.bias), T, C,
                           mask=mask_dev, dmask_token=_gradbuf(m.mask_token) if mask_dev is not None else None, tokens_per_sample=g ** 3)
-        ops.gemm_tn(dy0, A, _gradbuf(conv.weight), dbias=_gradbuf(conv.bias))
+        q = m._wq if (ops.GROUPED_WGRAD and dy0.dtype == torch.bfloat16) else None
+        if q is not None:
+            q.add(dy0, A, _gradbuf(conv.weight).view(C, 256), dbias=_gradbuf(conv.bias), rows_per_sample=g ** 3)
+            q.flush()
+            q.join()      # the backward pass ends here: every deferred weight gradient has been issued and joined
+        else:
+            ops.gemm_tn(dy0, A, _gradbuf(conv.weight), dbias=_gradbuf(conv.bias))
         return None, None, None, None
 
 
@@ -225,31 +231,54 @@ class _BlockFn(torch.autograd.Function):
         T, C, heads = geom.tokens, b.dim, b.num_heads
         tps = T // geom.B
         dx2 = dx2.contiguous()
+        # weight/bias gradients are off the critical path.  bf16: they are queued (the operands stay referenced by the queue) and issued
+        # per stage as grouped launches (ops.WgradQueue); fp32 parity mode: one launch each on the forked side stream.
+        q = b._wq if (ops.GROUPED_WGRAD and dx2.dtype == torch.bfloat16) else None
+
+        def wgrad(A, Bm, lin, rowscale=None, rps=tps):
+            if q is not None:
+                q.add(A, Bm, _gradbuf(lin.weight), dbias=_gradbuf(lin.bias), rowscale=rowscale, rows_per_sample=rps)
+            else:
+                with ops.side_stream(enable=T >= ops.side_stream.min_rows):
+                    ops.gemm_tn(A, Bm, _gradbuf(lin.weight), rowscale=rowscale, rows_per_scale=rps, dbias=_gradbuf(lin.bias))
         # ---- MLP branch
-        # weight/bias gradients are off the critical path: they run on a forked side stream and overlap the dgrad chain
         dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
-        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dx2, h_act, _gradbuf(b.mlp[3].weight), rowscale=sd2, rows_per_scale=tps, dbias=_gradbuf(b.mlp[3].bias))
+        wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
         dx1n = ops.gemm_nt(dh, pk[key + "fc1.wT"].view(C, 4 * C))
-        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dh, x1n, _gradbuf(b.mlp[0].weight), dbias=_gradbuf(b.mlp[0].bias))
+        wgrad(dh, x1n, b.mlp[0])
         dx1 = torch.empty_like(x)
         dyw = torch.empty_like(xnw)   # = sd1 * dx1 in window order (adjoint of the window reverse), second output of the LN backward
         ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
                           geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1)
         # ---- attention branch
         do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
-        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dyw, o, _gradbuf(b.attn.proj.weight), dbias=_gradbuf(b.attn.proj.bias))
+        wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
         dqkv = torch.empty_like(qkv)
         ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
         dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
-        with ops.side_stream(enable=T >= ops.side_stream.min_rows):
-            ops.gemm_tn(dqkv, xnw, _gradbuf(b.attn.qkv.weight), dbias=_gradbuf(b.attn.qkv.bias))
+        wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
         dx = torch.empty_like(x)
         ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
         ops.join_side()  # before any temporary of this block is released
         return dx, None, None, None, None
+
+
+class _StageFlushFn(torch.autograd.Function):
+    """identity at the input of an encoder stage; its backward runs when the stage's input-gradient chain is complete and issues the
+    weight gradients queued by the stage's blocks (and its patch merging) as grouped launches"""
+
+    @staticmethod
+    def forward(ctx, x, wq):
+        ctx.wq = wq
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.wq.join()     # the previous stage's launch (if any) has had a whole stage of input-gradient work to finish under
+        ctx.wq.flush()
+        if ctx.wq.sync_after_flush:
+            ctx.wq.join()
+        return g, None
 
 
 class _MergeFn(torch.autograd.Function):
@@ -275,7 +304,10 @@ class _MergeFn(torch.autograd.Function):
         Cin = m.dim
         dy = dy.contiguous()
         dxg = ops.gemm_nt(dy, m._pk[m._key + "red.wT"].view(8 * Cin, 2 * Cin))
-        ops.gemm_tn(dy, xg, _gradbuf(m.reduction.weight))
+        if ops.GROUPED_WGRAD and dy.dtype == torch.bfloat16:
+            m._wq.add(dy, xg, _gradbuf(m.reduction.weight), rows_per_sample=rows // geom.B)
+        else:
+            ops.gemm_tn(dy, xg, _gradbuf(m.reduction.weight))
         dx = torch.empty_like(x)
         ops.layernorm_bwd(dxg, x, m.norm.weight, mean, rstd, dx, _gradbuf(m.norm.weight), _gradbuf(m.norm.bias), rows, 8 * Cin, src_mode=2, geom=geom)
         return dx, None, None
@@ -516,6 +548,8 @@ class _Stage(nn.Sequential):
         m._ensure_ready(x.device)
         if x.dtype != m.compute_dtype:
             x = x.to(m.compute_dtype)
+        if ops.GROUPED_WGRAD and m.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad:
+            x = _StageFlushFn.apply(x, m._wq)
         for mod in self:
             x = mod(x.contiguous())
         return x
@@ -674,9 +708,11 @@ class SwinTransformer_MAE3D_New(nn.Module):
         P.build(self.compute_dtype, device)
         self._packer = P
         self._pk = P
+        self._wq = ops.WgradQueue()   # deferred encoder weight gradients (grouped launches, issued per stage)
         for mod in self.modules():
             if isinstance(mod, (SwinBlock3D, PatchMerging3D, UpBlock3D)):
                 mod._pk = P
+                mod._wq = self._wq
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
 
     def _ensure_ready(self, device):
@@ -726,9 +762,13 @@ class SwinTransformer_MAE3D_New(nn.Module):
         red = self._reducer
         if sd_noise is None:
             sd_noise = self._draw_sd_noise(tok.shape[0], tok.device)
+        grouped = ops.GROUPED_WGRAD and self.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad
+        self._wq.sync_after_flush = red is not None   # a gradient all-reduce of the stage follows the flush: join before it
         for si, st in enumerate(self.stages):
             if red is not None:
                 x = red.trigger(x, si + 1)  # backward reaching here => stage si gradients are complete
+            if grouped:
+                x = _StageFlushFn.apply(x, self._wq)   # backward order: blocks of the stage, this flush, then the trigger above
             for mod in st:
                 if isinstance(mod, SwinBlock3D):
                     x = mod(x, None if sd_noise is None else sd_noise[bi])

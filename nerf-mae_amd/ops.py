@@ -152,6 +152,66 @@ def gemm_tn(A, B, dW, rowscale=None, rows_per_scale=1, omode=0, ldo=None, p0=0, 
     return dW
 
 
+class _TnProblem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_tn_problem
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64), ("dW", ctypes.c_void_p),
+                ("ldo", ctypes.c_int64), ("dbias", ctypes.c_void_p), ("rowscale", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int),
+                ("K", ctypes.c_int), ("rows_per_sample", ctypes.c_int)]
+
+
+GROUPED_WGRAD = __import__("os").environ.get("NMH_TNG", "1") != "0"
+
+
+class WgradQueue:
+    """Deferred weight gradients of the encoder (bf16): `add` records one dW[N,K] += A[M,N]^T . B[M,K] problem (and keeps its operands
+    alive), `flush` issues everything recorded so far through nmh_gemm_tn_grouped -- on the forked side stream when that is enabled, so
+    the launch overlaps the input-gradient chain of the next stage -- and `join` makes the current stream wait for it and releases the
+    operands.  The input-gradient chain of a stage thus runs without any weight-gradient launch in between."""
+
+    def __init__(self):
+        self.pending, self.inflight, self._cb, self.sync_after_flush = [], [], False, False
+
+    def add(self, A, B, dW, dbias=None, rowscale=None, rows_per_sample=None):
+        _chk(A, B, dW, dbias, rowscale)
+        if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16:
+            raise RuntimeError("WgradQueue: the grouped weight-gradient kernel takes bf16 operands")
+        self.pending.append((A, B, dW, dbias, rowscale, A.shape[0] if rows_per_sample is None else rows_per_sample))
+        if not self._cb:   # safety net: whatever is still queued when the backward pass ends is issued and joined there
+            self._cb = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._final)
+
+    def _final(self):
+        self._cb = False
+        self.flush()
+        self.join()
+
+    def _launch(self, group):
+        arr = (_TnProblem * len(group))()
+        for i, (A, B, dW, dbias, rs, rps) in enumerate(group):
+            arr[i] = _TnProblem(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), dW.data_ptr(), B.shape[1],
+                                0 if dbias is None else dbias.data_ptr(), 0 if rs is None else rs.data_ptr(), A.shape[0], A.shape[1], B.shape[1], rps)
+        ws = _tn_workspace(group[0][0].device)
+        lib().call("nmh_gemm_tn_grouped", BF16, arr, len(group), ws, 0 if ws is None else ws.numel(), _st())
+
+    def flush(self):
+        if not self.pending:
+            return
+        todo, self.pending = self.pending, []
+        with side_stream():
+            group, seen = [], set()
+            for pr in todo:
+                if pr[2].data_ptr() in seen:   # the same parameter twice (two forward passes before one backward): separate launches
+                    self._launch(group)
+                    group, seen = [], set()
+                group.append(pr)
+                seen.add(pr[2].data_ptr())
+            self._launch(group)
+        self.inflight.extend(todo)   # operands stay referenced until the issuing stream has been joined
+
+    def join(self):
+        join_side()
+        self.inflight = []
+
+
 def conv3d_k3(X, Wp, Cout, out=None, accumulate=False):
     """X (B,D,H,W,Cin) channels-last, Wp packed [Cout][27][Cin] -> (B,D,H,W,Cout)."""
     _chk(X, Wp, out)

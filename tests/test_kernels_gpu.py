@@ -656,3 +656,39 @@ def test_copy_cols_strided(dtype):
     assert torch.equal(back, skip)
     with pytest.raises(RuntimeError):
         ops.copy_cols(skip, cat[:, C:C + 8])
+
+
+@pytest.mark.parametrize("case", ["flat_many_tiles", "split_few_tiles", "mixed_ragged"])
+def test_gemm_tn_grouped(case):
+    """nmh_gemm_tn_grouped (bf16): several weight-gradient problems per launch -- flat (a workgroup walks every sample), split at
+    sample-aligned ranges (+ grouped reduce), stochastic-depth row scales applied per sample, fused bias gradients, ragged N / K tiles,
+    rows per sample that are not a multiple of the 64-row chunk -- against fp32 matmuls on the bf16-rounded operands; accumulates
+    into dW (+=)."""
+    ops = _ops()
+    dt = torch.bfloat16
+    if case == "flat_many_tiles":      # >= 384 tiles in the launch: nobody splits
+        specs = [(4, 500, 384, 1536, True, True), (4, 500, 1536, 384, False, True), (4, 512, 384, 384, False, True), (4, 512, 1152, 384, False, False)]
+    elif case == "split_few_tiles":    # stage-0-like: 12 tiles -> sample-aligned splits + reduce launch
+        specs = [(2, 3000, 96, 384, True, True), (2, 3000, 384, 96, False, True), (2, 3000, 96, 96, False, True), (2, 3000, 288, 96, False, False)]
+    else:                              # 17 problems (two launches), widths that are not multiples of 96, one sample, tiny M
+        specs = [(1, 70, 128, 512, True, True), (3, 130, 512, 128, False, True), (2, 64, 64, 256, False, False)] + [(2, 200, 192, 96, i % 2 == 0, True) for i in range(14)]
+    q_ = ops.WgradQueue()
+    refs, outs = [], []
+    for i, (nsamp, rps, N, K, scaled, bias) in enumerate(specs):
+        M = nsamp * rps
+        A, Bm = q(rnd(M, N, seed=3 * i), dt), q(rnd(M, K, seed=3 * i + 1), dt)
+        rs = (torch.rand(nsamp, generator=torch.Generator().manual_seed(i)) > 0.3).float() / 0.7 if scaled else None
+        dW0 = rnd(N, K, seed=3 * i + 2)
+        db0 = rnd(N, seed=i + 50)
+        As = A if rs is None else A * rs.repeat_interleave(rps)[:, None]
+        refs.append((dW0 + As.T @ Bm, db0 + As.sum(0)))
+        dW, db = dev(dW0), dev(db0) if bias else None
+        outs.append((dW, db))
+        q_.pending.append((dev(A, dt), dev(Bm, dt), dW, db, None if rs is None else dev(rs), rps))
+    q_.flush()
+    q_.join()
+    torch.cuda.synchronize()
+    for i, ((dW, db), (rW, rb)) in enumerate(zip(outs, refs)):
+        assert relerr(dW, rW) < 2e-3, (case, i, specs[i], relerr(dW, rW))    # bf16 operands, fp32 accumulation: only summation order differs
+        if db is not None:
+            assert relerr(db, rb) < 2e-3, (case, i, "bias", relerr(db, rb))

@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o bench -- python "$REPO/bench.py" --batch-per-gpu "$BPG" --no-cpu-baseline --no-kernel-timing --steps 12 --warmup 3 "$@" > "$OUT/b.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o bench -- python "$REPO/bench.py" --batch-per-gpu "$BPG" --no-cpu-baseline --no-kernel-timing --no-sweep --steps 12 --warmup 3 "$@" > "$OUT/b.log" 2>&1
 cd "$REPO"
 TR=$(find "$OUT" -name '*kernel_trace.csv' | head -1)
 if [ -n "$TR" ]; then
