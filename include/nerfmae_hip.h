@@ -140,6 +140,11 @@ NMH_API int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, f
 NMH_API int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream);
 NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream);
 NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
+/* bf16 gradient buckets of the data-parallel exchange (DDP's gradient all-reduce, run_swin_mae3d.py:355-357, with half the bytes on the
+ * xGMI links): a contiguous range of the flat fp32 gradient buffer -> bf16 bucket (round to nearest even) before the collective, and
+ * bucket * scale -> fp32 gradients after it (scale = 1/world for backends that sum).  n % 8 == 0, 16-byte aligned pointers. */
+NMH_API int nmh_grad_to_bf16(const float* g, void* bucket, int64_t n, void* stream);
+NMH_API int nmh_grad_from_bf16(const void* bucket, float* g, int64_t n, float scale, void* stream);
 
 /* fp32 master weights -> compute-dtype GEMM operand layouts, one launch for the whole model.  descs: device array of
  * {const float* src; void* dst; int mode; int d0,d1,d2; int64 n} (40 bytes, see kernels.hpp PackDesc); one block per 1024 dst elements

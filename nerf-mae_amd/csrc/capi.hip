@@ -218,6 +218,18 @@ int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const flo
 }
 int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream) {
   CLR(); return k_add_inplace(dt, a, b, (long)n, ST); }
+int nmh_grad_to_bf16(const float* g, void* bucket, int64_t n, void* stream) {
+  CLR();
+  if (n <= 0) return 0;
+  if (!g || !bucket) return -4;
+  return k_grad_cast(1, g, bucket, (long)n, 1.0f, ST);
+}
+int nmh_grad_from_bf16(const void* bucket, float* g, int64_t n, float scale, void* stream) {
+  CLR();
+  if (n <= 0) return 0;
+  if (!g || !bucket) return -4;
+  return k_grad_cast(0, bucket, g, (long)n, scale, ST);
+}
 int nmh_fill_f32(float* p, float v, int64_t n, void* stream) {
   CLR(); return k_fill_f32(p, v, (long)n, ST); }
 int nmh_pack_weights(int dt, const void* descs_dev, const int* blk2desc_dev, const int64_t* blkstart_dev, int nblocks, void* stream) {

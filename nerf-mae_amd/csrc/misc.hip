@@ -376,6 +376,30 @@ int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st) {
   NMH_CHECK_LAUNCH();
   return 0;
 }
+// gradient buckets for the data-parallel exchange: fp32 flat gradient segment -> bf16 staging (and back, optionally scaled), 8 elements per thread
+__global__ void grad_f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    Vec8<float>::load(src + i * 8, v);
+    Vec8<bf16_t>::store(dst + i * 8, v);
+  }
+}
+__global__ void grad_bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n8, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    Vec8<bf16_t>::load(src + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= scale;
+    Vec8<float>::store(dst + i * 8, v);
+  }
+}
+int k_grad_cast(int to_bf16, const void* src, void* dst, long n, float scale, hipStream_t st) {
+  if (n % 8 || ((uintptr_t)src | (uintptr_t)dst) & 15) return -2;
+  if (to_bf16) hipLaunchKernelGGL(grad_f32_to_bf16_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n / 8);
+  else hipLaunchKernelGGL(grad_bf16_to_f32_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n / 8, scale);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
 __global__ void fill_kernel(float* p, float v, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -54,43 +54,60 @@ class GradReducer:
             return x
         return _Trigger.apply(x, self, seg)
 
+    def _exchange(self, lo: int, hi: int):
+        """mean over ranks of flat_grad[lo:hi] on the CURRENT stream; bf16 buckets when comm_dtype is bf16 (HIP cast kernels, no ATen
+        arithmetic).  RCCL averages inside the collective; other backends (gloo: CPU tests, single-GPU dry runs) sum and scale."""
+        g = self.model._flat_grad[lo:hi]
+        nccl = self.on_gpu and dist.get_backend(self.group) == "nccl"
+        if self.staging is not None and self.on_gpu:
+            from . import ops
+            s = self.staging[lo:hi]
+            ops.grad_to_bf16(g, s)
+            dist.all_reduce(s, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
+            ops.grad_from_bf16(s, g, 1.0 if nccl else 1.0 / self.world)
+        elif nccl:
+            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.div_(self.world)
+
+    def allreduce_range(self, lo: int, hi: int, overlap: bool = True):
+        """gradient mean of flat_grad[lo:hi] (element offsets, multiples of 8).  RCCL + overlap: issued on the comm stream after everything
+        queued on the current stream so far (the producers of that range), so the caller can go on launching backward work; `wait()`
+        joins.  Otherwise (gloo dry runs, overlap off): on the current stream."""
+        if self.world == 1 or hi <= lo:
+            return
+        if overlap and self.comm_stream is not None and dist.get_backend(self.group) == "nccl":
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self._exchange(lo, hi)
+        else:
+            self._exchange(lo, hi)
+
+    def wait(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
     def launch(self, seg: int):
         if self.world == 1:
             return
         lo, hi = self.bounds[seg], self.bounds[seg + 1]
-        g = self.model._flat_grad[lo:hi]
         if not self.on_gpu:  # CPU/gloo (tests): synchronous
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.div_(self.world)
+            self._exchange(lo, hi)
             self.pending.append(seg)
             return
         if dist.get_backend(self.group) != "nccl":
             # device tensors over gloo (single-GPU dry runs): no stream-ordered collectives, and a blocking all-reduce issued from the
             # autograd thread deadlocks -- nothing to overlap anyway, finish() reduces the whole buffer from the calling thread
             return
-        cur = torch.cuda.current_stream()
-        self.comm_stream.wait_stream(cur)
-        with torch.cuda.stream(self.comm_stream):
-            if self.staging is not None:
-                s = self.staging[lo:hi]
-                s.copy_(g)
-                dist.all_reduce(s, op=dist.ReduceOp.AVG, group=self.group)
-                g.copy_(s)
-            else:
-                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+        self.allreduce_range(lo, hi)
         self.pending.append(seg)
 
     def allreduce_flat(self):
-        """the whole flat gradient buffer in one message on the current stream (graph mode: between the backward graph and the
-        optimizer graph).  RCCL averages in the collective; other backends (gloo: CPU tests and single-GPU dry runs) sum and scale."""
+        """the whole flat gradient buffer in one message on the current stream"""
         if self.world == 1:
             return
-        g = self.model._flat_grad
-        if self.on_gpu and dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.div_(self.world)
+        self._exchange(0, self.model._flat_grad.numel())
 
     def finish(self):
         """call after backward: reduce any segment whose trigger did not fire, then join the comm stream"""
@@ -104,7 +121,7 @@ class GradReducer:
             if seg not in self.pending:
                 self.launch(seg)
         if self.on_gpu:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self.wait()
         self.pending = []
 
 

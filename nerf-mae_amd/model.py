@@ -657,7 +657,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
         """Re-home every trainable parameter (and its .grad) as a view of one flat fp32 buffer."""
         ps = self._trainable()
         device = device or ps[0].device
-        n = sum((p.numel() + 3) // 4 * 4 for p in ps)
+        n = sum((p.numel() + 7) // 8 * 8 for p in ps)   # 8-element granules: every segment boundary is 16-byte aligned in fp32 AND in bf16 buckets
         flat = torch.zeros(n, device=device)
         fg = torch.zeros(n, device=device)
         off = 0
@@ -668,7 +668,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
             p.data = flat[off:off + k].view(p.shape)
             p.grad = fg[off:off + k].view(p.shape)
             self._offsets[id(p)] = off
-            off += (k + 3) // 4 * 4
+            off += (k + 7) // 8 * 8
         self._flat, self._flat_grad = flat, fg
         self._build_packer(device)
         return flat, fg
@@ -757,24 +757,29 @@ class SwinTransformer_MAE3D_New(nn.Module):
         noise = torch.bernoulli(keep).div_(keep)
         return [(noise[2 * i], noise[2 * i + 1]) for i in range(len(blocks))]
 
+    def _run_stage(self, si: int, x: Tensor, sd_noise, bi: int):
+        """stage `si` on channels-last x; `bi` = index of the stage's first block in `sd_noise`.  Returns (output, next block index)."""
+        grouped = ops.GROUPED_WGRAD and self.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad
+        if grouped:
+            x = _StageFlushFn.apply(x, self._wq)   # backward order: blocks of the stage, this flush (, then the reducer trigger)
+        for mod in self.stages[si]:
+            if isinstance(mod, SwinBlock3D):
+                x = mod(x, None if sd_noise is None else sd_noise[bi])
+                bi += 1
+            else:
+                x = mod(x)
+        return x, bi
+
     def forward_encoder(self, tok: Tensor, sd_noise=None):
         feats, x, bi = [], tok, 0
         red = self._reducer
         if sd_noise is None:
             sd_noise = self._draw_sd_noise(tok.shape[0], tok.device)
-        grouped = ops.GROUPED_WGRAD and self.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad
         self._wq.sync_after_flush = red is not None   # a gradient all-reduce of the stage follows the flush: join before it
-        for si, st in enumerate(self.stages):
+        for si in range(len(self.stages)):
             if red is not None:
                 x = red.trigger(x, si + 1)  # backward reaching here => stage si gradients are complete
-            if grouped:
-                x = _StageFlushFn.apply(x, self._wq)   # backward order: blocks of the stage, this flush, then the trigger above
-            for mod in st:
-                if isinstance(mod, SwinBlock3D):
-                    x = mod(x, None if sd_noise is None else sd_noise[bi])
-                    bi += 1
-                else:
-                    x = mod(x)
+            x, bi = self._run_stage(si, x, sd_noise, bi)
             feats.append(x)
         return feats
 

@@ -467,6 +467,19 @@ def bias_grad(dY, db, M, N, rowscale=None, rows_per_scale=1):
     lib().call("nmh_bias_grad", dt_of(dY), dY, db, M, N, rowscale, rows_per_scale, _st())
 
 
+def grad_to_bf16(g, bucket):
+    """fp32 gradient range -> bf16 bucket (data-parallel exchange at half the bytes)"""
+    _chk(g, bucket)
+    lib().call("nmh_grad_to_bf16", g, bucket, g.numel(), _st())
+    return bucket
+
+
+def grad_from_bf16(bucket, g, scale=1.0):
+    _chk(g, bucket)
+    lib().call("nmh_grad_from_bf16", bucket, g, g.numel(), scale, _st())
+    return g
+
+
 def add_inplace(a, b):
     _chk(a, b)
     lib().call("nmh_add_inplace", dt_of(a), a, b, a.numel(), _st())

@@ -126,8 +126,11 @@ class GraphedTrainStep:
         self.ext = torch.full((batch, 3), R, dtype=torch.int32, device=dev)
         self.mask = torch.zeros(g ** 3, dtype=torch.uint8, device=dev)
         self.losses = None
-        self._g1 = self._g2 = None
+        self._g1 = self._g2 = self._gb1 = self._gb2 = None
         self._warm = warmup
+        self.overlap = True    # False: every collective on the main stream (A/B measurement of what the overlap hides)
+        if reducer is not None and reducer.world > 1 and len(reducer.bounds) != 7:
+            raise ValueError("GraphedTrainStep: the split data-parallel step expects the 6 gradient segments of a 4-stage encoder + decoder")
 
     def set_extents(self, ext):
         """valid extents [B][3] of the batch now in `self.x` (host list / tensor) -> static device buffer, through a pinned ring"""
@@ -147,11 +150,16 @@ class GraphedTrainStep:
         # exchange (see __call__), so they are switched off for good on this model
         self.model._reducer = None
         ops.side_stream.auto(self.x.shape[0])
+        split = self.reducer is not None and self.reducer.world > 1
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(self._warm):
-                self._fwd_bwd()     # warm-up touches no optimizer state (lazy kernel attributes / allocator pools only)
+                # warm-up touches no optimizer state (lazy kernel attributes / allocator pools only)
+                if split:
+                    self._split_a(zero=True); self._split_b1(); self._split_b2()
+                else:
+                    self._fwd_bwd()
         torch.cuda.current_stream().wait_stream(s)
         # inside the replayed step the gradient buffer is cleared by the optimizer kernel of the previous step (hyper[7]); only the
         # first replay needs it cleared here
@@ -159,15 +167,64 @@ class GraphedTrainStep:
         self.model.zero_grad()
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
+        if not split:
+            with torch.cuda.graph(self._g1):
+                out = self._fwd_bwd(zero=False)
+                self.losses = torch.stack([o.detach() for o in out[:3]])
+                self.opt.launch()
+            return
+        # data parallel: the step is cut where gradient segments complete, and the collectives run BETWEEN the replays on the comm
+        # stream (RCCL stays outside the captured regions), overlapping the next piece of the backward:
+        #   g1 = forward + decoder backward          -> all-reduce [decoders, head]
+        #   gb1 = backward of stages 3 and 2         -> all-reduce [stage 2, stage 3]
+        #   gb2 = backward of stages 1, 0, the embed -> all-reduce [mask token, embed, stage 0, stage 1]
+        #   g2 = clip + AdamW
         with torch.cuda.graph(self._g1):
-            out = self._fwd_bwd(zero=False)
+            out = self._split_a(zero=False)
             self.losses = torch.stack([o.detach() for o in out[:3]])
-            if self.reducer is None or self.reducer.world == 1:
-                self.opt.launch()
-        if self.reducer is not None and self.reducer.world > 1:
-            self._g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g2):
-                self.opt.launch()
+        pool = self._g1.pool()
+        self._gb1, self._gb2, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._gb1, pool=pool):
+            self._split_b1()
+        with torch.cuda.graph(self._gb2, pool=pool):
+            self._split_b2()
+        with torch.cuda.graph(self._g2, pool=pool):
+            self.opt.launch()
+
+    # ---- the step in three autograd pieces (data-parallel graph mode) ----------------------------------------------------------------
+    def _split_a(self, zero=True):
+        """forward + decoder backward.  The encoder features enter the decoder (and stage 1's output enters stage 2) through detached
+        leaves, so each later piece is its own autograd graph whose incoming gradients are the `.grad` of those leaves."""
+        from .model import _EmbedFn
+        m = self.model
+        if zero:
+            m.zero_grad()
+        B, R = self.x.shape[0], m.resolution
+        g = R // 4
+        m._packer.run()
+        tok = _EmbedFn.apply(m._anchor, m, self.x, self.mask).view(B, g, g, g, m.embed_dim)
+        sd = m._draw_sd_noise(B, tok.device)
+        m._wq.sync_after_flush = False
+        f0, bi = m._run_stage(0, tok, sd, 0)
+        f1, bi = m._run_stage(1, f0, sd, bi)
+        e1 = f1.detach().requires_grad_()
+        f2, bi = m._run_stage(2, e1, sd, bi)
+        f3, bi = m._run_stage(3, f2, sd, bi)
+        d = [f.detach().requires_grad_() for f in (f0, f1, f2, f3)]
+        losses = m._decode_and_loss(d, self.x, self.ext, self.mask, None)
+        losses[0].backward()
+        self._pieces = ((f0, f1, f2, f3), e1, d)
+        return losses[0], losses[1], losses[2]
+
+    def _split_b1(self):
+        (f0, f1, f2, f3), e1, d = self._pieces
+        torch.autograd.backward([f3, f2], [d[3].grad, d[2].grad])
+
+    def _split_b2(self):
+        (f0, f1, f2, f3), e1, d = self._pieces
+        ops.add_inplace(e1.grad, d[1].grad)     # stage 1's output feeds stage 2 and decoder3's skip connection
+        torch.autograd.backward([f1, f0], [e1.grad, d[0].grad])
+        self._pieces = None
 
     def __call__(self, grids=None, block_mask=None):
         """grids: optional list of (4,a0,a1,a2) tensors (copied into the static batch); block_mask: uint8 (g,g,g) host tensor"""
@@ -188,7 +245,13 @@ class GraphedTrainStep:
         self.opt.update_hyper()
         self._g1.replay()
         if self._g2 is not None:
-            self.reducer.allreduce_flat()
+            red, b = self.reducer, self.reducer.bounds
+            red.allreduce_range(b[5], b[6], overlap=self.overlap)
+            self._gb1.replay()
+            red.allreduce_range(b[3], b[5], overlap=self.overlap)
+            self._gb2.replay()
+            red.allreduce_range(b[0], b[3], overlap=self.overlap)
+            red.wait()
             self._g2.replay()
         return self.losses
 

@@ -98,3 +98,40 @@ def test_two_ranks_one_gpu_match_single_process_average(mode):
     torch.cuda.synchronize()
     ref = m._flat.detach().cpu()
     assert ((flat2 - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-3)], ids=["fp32", "bf16"])
+def test_split_graph_step_equals_monolithic_step(dtype, tol):
+    """the data-parallel graph step cuts the backward into three captured pieces (decoder | stages 3,2 | stages 1,0,embed) with the
+    gradient exchange between the replays; with a no-op exchange it must reproduce the single-graph step (same masks, same inputs,
+    stochastic depth off): equal losses and equal parameters after three optimizer steps"""
+    import random
+    from nerf_mae_amd.dist import GradReducer
+    from nerf_mae_amd.model import SwinTransformer_MAE3D
+    from nerf_mae_amd.trainer import FusedAdamW, GraphedTrainStep
+    from oracle import mae3d_oracle as O
+    grids = [O.synthetic_grid((32, 32, 32), 3).cuda(), O.synthetic_grid((32, 28, 30), 4).cuda()]
+    res = []
+    for split in (False, True):
+        torch.manual_seed(5)
+        m = SwinTransformer_MAE3D(patch_size=[4] * 3, window_size=[4] * 3, resolution=32, masking_prob=0.75, stochastic_depth_prob=0.0,
+                                  compute_dtype=dtype, **TINY).cuda()
+        m.train()
+        m.flatten_parameters()
+        opt = FusedAdamW(m, lr=1e-3, weight_decay=1e-3, max_grad_norm=0.1, eps=1.0)
+        red = None
+        if split:
+            red = GradReducer(m)
+            red.world = 2                      # take the split path ...
+            red._exchange = lambda lo, hi: None  # ... with an identity exchange (single process)
+        step = GraphedTrainStep(m, opt, 2, reducer=red)
+        rng = random.Random(11)
+        losses = []
+        for i in range(3):
+            losses.append(step(grids if i == 0 else None, O.draw_block_mask((8, 8, 8), 0.75, rng=rng)).clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses).cpu(), m._flat.detach().cpu().clone()))
+        assert (step._gb1 is not None) == split
+    (l0, p0), (l1, p1) = res
+    assert torch.allclose(l0, l1, rtol=tol * 10, atol=0), (l0, l1)
+    assert ((p0 - p1).abs().max() / p0.abs().max()).item() < tol

@@ -692,3 +692,15 @@ def test_gemm_tn_grouped(case):
         assert relerr(dW, rW) < 2e-3, (case, i, specs[i], relerr(dW, rW))    # bf16 operands, fp32 accumulation: only summation order differs
         if db is not None:
             assert relerr(db, rb) < 2e-3, (case, i, "bias", relerr(db, rb))
+
+
+def test_grad_bucket_casts():
+    """nmh_grad_to_bf16 / nmh_grad_from_bf16 (bf16 gradient buckets of the data-parallel exchange): RNE cast and scaled widening, bit-exact"""
+    ops = _ops()
+    g = rnd(8 * 1237, seed=4, scale=3.0).cuda()
+    b = torch.empty_like(g, dtype=torch.bfloat16)
+    ops.grad_to_bf16(g, b)
+    assert torch.equal(b, g.to(torch.bfloat16))
+    out = torch.empty_like(g)
+    ops.grad_from_bf16(b, out, 0.5)
+    assert torch.equal(out, b.float() * 0.5)
