@@ -140,6 +140,13 @@ NMH_API int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, f
 NMH_API int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream);
 NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream);
 NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
+/* Per-step host parameters of the training step in ONE launch, passed as kernel arguments (no host-to-device copies):
+ *  - block_bits (HOST, nb^3 bits, bit (a*nb+b)*nb+c = 1: the 4x4x4-token block (a,b,c) is removed; window_masking_3d's raster order,
+ *    swin_mae3d.py:1366-1373) is expanded to the token mask tokmask[g^3] (device, uint8; tokens outside the nb^3 blocks stay 0);
+ *  - hyper (HOST, 8 floats {lr, beta1, beta2, eps, wd, 1-beta1^t, 1-beta2^t, zero_g}) -> hyper_dev (nmh_adamw_step);
+ *  - extents (HOST, n_ext <= 48 ints: [B][3] valid voxels per axis) -> extents_dev (nmh_mae_loss_fwd / nmh_mae_tail_fwd).
+ * Any of the three groups may be NULL.  nb^3 <= 4096. */
+NMH_API int nmh_step_params(const uint32_t* block_bits, int nb, int g, unsigned char* tokmask, const float* hyper, float* hyper_dev, const int* extents, int n_ext, int* extents_dev, void* stream);
 /* bf16 gradient buckets of the data-parallel exchange (DDP's gradient all-reduce, run_swin_mae3d.py:355-357, with half the bytes on the
  * xGMI links): a contiguous range of the flat fp32 gradient buffer -> bf16 bucket (round to nearest even) before the collective, and
  * bucket * scale -> fp32 gradients after it (scale = 1/world for backends that sum).  n % 8 == 0, 16-byte aligned pointers. */

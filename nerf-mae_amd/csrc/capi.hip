@@ -218,6 +218,12 @@ int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const flo
 }
 int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream) {
   CLR(); return k_add_inplace(dt, a, b, (long)n, ST); }
+int nmh_step_params(const uint32_t* block_bits, int nb, int g, unsigned char* tokmask, const float* hyper, float* hyper_dev, const int* extents, int n_ext, int* extents_dev,
+                    void* stream) {
+  CLR();
+  if ((tokmask && !block_bits) || (hyper && !hyper_dev) || (extents && !extents_dev)) return -4;
+  return k_step_params(block_bits, nb, g, tokmask, hyper, hyper_dev, extents, n_ext, extents_dev, ST);
+}
 int nmh_grad_to_bf16(const float* g, void* bucket, int64_t n, void* stream) {
   CLR();
   if (n <= 0) return 0;

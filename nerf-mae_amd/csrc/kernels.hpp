@@ -172,6 +172,7 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
 int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rowscale, int rows_per_scale, hipStream_t st);
 int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st);
 int k_fill_f32(float* p, float v, long n, hipStream_t st);
+int k_step_params(const unsigned* bits, int nb, int g, unsigned char* tokmask, const float* hyper_host, float* hyper_dev, const int* ext_host, int n_ext, int* ext_dev, hipStream_t st);
 int k_grad_cast(int to_bf16, const void* src, void* dst, long n, float scale, hipStream_t st);
 
 struct PackDesc { const float* src; void* dst; int mode; int d0, d1, d2; long n; };

@@ -376,6 +376,49 @@ int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st) {
   NMH_CHECK_LAUNCH();
   return 0;
 }
+// Per-step host parameters without host-to-device copies: the block mask (one bit per 4x4x4-token block, drawn on the host with the
+// reference's python RNG), the optimizer hyper-parameters and the valid extents travel as KERNEL ARGUMENTS of one tiny launch that
+// expands / stores them into their device buffers.  (Small hipMemcpyAsync uploads were measured to block the calling thread until the
+// stream had drained -- the host could never queue the next step behind the running one.)
+struct StepParams {
+  unsigned bits[128];      // block (a,b,c) of an nb^3 raster, bit index (a*nb+b)*nb+c; 1 = removed
+  float hyper[8];
+  int ext[48];
+  int nb, g, n_ext, has_hyper;
+};
+__global__ void step_params_kernel(StepParams p, unsigned char* __restrict__ tokmask, float* __restrict__ hyper, int* __restrict__ ext) {
+  const int g = p.g, n = g * g * g;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = i % g, b = (i / g) % g, a = i / (g * g);
+    const int ba = a >> 2, bb = b >> 2, bc = c >> 2;
+    unsigned char m = 0;
+    if (ba < p.nb && bb < p.nb && bc < p.nb) {
+      const int bit = (ba * p.nb + bb) * p.nb + bc;
+      m = (p.bits[bit >> 5] >> (bit & 31)) & 1u;
+    }
+    tokmask[i] = m;
+  }
+  if (blockIdx.x == 0) {
+    if (p.has_hyper && hyper && threadIdx.x < 8) hyper[threadIdx.x] = p.hyper[threadIdx.x];
+    if (ext && (int)threadIdx.x < p.n_ext) ext[threadIdx.x] = p.ext[threadIdx.x];
+  }
+}
+int k_step_params(const unsigned* bits, int nb, int g, unsigned char* tokmask, const float* hyper_host, float* hyper_dev, const int* ext_host, int n_ext, int* ext_dev,
+                  hipStream_t st) {
+  if (nb < 0 || nb * nb * nb > 128 * 32 || n_ext < 0 || n_ext > 48 || (tokmask && g <= 0)) return -4;
+  StepParams p{};
+  const int nbits = nb * nb * nb;
+  for (int i = 0; i < (nbits + 31) / 32; ++i) p.bits[i] = bits ? bits[i] : 0u;
+  if (hyper_host) for (int i = 0; i < 8; ++i) p.hyper[i] = hyper_host[i];
+  for (int i = 0; i < n_ext; ++i) p.ext[i] = ext_host[i];
+  p.nb = nb; p.g = g; p.n_ext = ext_host ? n_ext : 0; p.has_hyper = hyper_host != nullptr;
+  const int n = tokmask ? g * g * g : 0;
+  p.g = tokmask ? g : 0;
+  hipLaunchKernelGGL(step_params_kernel, dim3(n ? (n + 255) / 256 : 1), dim3(256), 0, st, p, tokmask, hyper_dev, ext_dev);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
 // gradient buckets for the data-parallel exchange: fp32 flat gradient segment -> bf16 staging (and back, optionally scaled), 8 elements per thread
 __global__ void grad_f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {

@@ -60,45 +60,152 @@ def synthetic_scene(shape: Sequence[int] = (160, 160, 160), seed: int = 0, dtype
     return g
 
 
+def _wait_event(ev):
+    """host-side wait by polling: a blocking hipEventSynchronize from the producer thread was measured to stall the kernel / graph
+    launches of the training thread for the whole wait (runtime-internal locking), tripling the step time"""
+    import time
+    while not ev.query():
+        time.sleep(2e-4)
+
+
+class _PinnedSlot:
+    """ring of pinned host buffers + device staging buffers for one slot of the batch; a buffer is rewritten only after the event
+    recorded behind its previous H2D copy + grid_prepare launch has completed (the host may run several steps ahead of the device)"""
+
+    def __init__(self, depth: int, device):
+        self.depth, self.device = depth, device
+        self.pin, self.dev, self.ev, self.i = [None] * depth, [None] * depth, [None] * depth, 0
+
+    def acquire(self, numel: int, dtype):
+        k = self.i % self.depth
+        self.i += 1
+        if self.ev[k] is not None:
+            _wait_event(self.ev[k])
+            self.ev[k] = None
+        if self.pin[k] is None or self.pin[k].numel() < numel or self.pin[k].dtype != dtype:
+            self.pin[k] = torch.empty(numel, dtype=dtype).pin_memory()
+            self.dev[k] = torch.empty(numel, dtype=dtype, device=self.device)
+        return k, self.pin[k][:numel], self.dev[k][:numel]
+
+    def release_after(self, k: int, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.ev[k] = ev
+
+
 class GridBatcher:
     """Turns a list of stored scenes into the network input `(xb (B,4,R,R,R) fp32, extents (B,3) int32)` on `device`.
 
-    Host side: one pinned staging buffer per slot of the batch (reused every step; the copy engine overlaps the previous step's
-    compute when the caller runs on a side stream).  Device side: `ops.grid_prepare` per scene.  `normalize_density` applies to
-    float scenes (uint8 scenes are stored with alpha already normalised, as the reference's /255 branch assumes)."""
+    Host side: a ring of `depth` pinned staging buffers per slot of the batch, each guarded by an event (see _PinnedSlot), so a
+    caller that runs ahead of the device never overwrites a buffer whose H2D copy has not executed yet.  Device side:
+    `ops.grid_prepare` per scene on the current stream.  `normalize_density` applies to float scenes (uint8 scenes are stored with
+    alpha already normalised, as the reference's /255 branch assumes).  `Prefetcher` runs this on a background thread + copy stream."""
 
-    def __init__(self, resolution: int, device, normalize_density: bool = True, flip_prob: float = 0.0, rotate_prob: float = 0.0):
+    def __init__(self, resolution: int, device, normalize_density: bool = True, flip_prob: float = 0.0, rotate_prob: float = 0.0, depth: int = 3):
         self.R, self.device = resolution, torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("GridBatcher needs a HIP device (no CPU fallback)")
-        self.normalize_density, self.flip_prob, self.rotate_prob = normalize_density, flip_prob, rotate_prob
-        self._pinned = {}
-        self._staged = {}
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.normalize_density, self.flip_prob, self.rotate_prob, self.depth = normalize_density, flip_prob, rotate_prob, depth
+        self._slots = {}
 
-    def _stage(self, slot: int, scene: Scene) -> torch.Tensor:
+    def _stage(self, slot: int, scene: Scene):
+        """-> (device tensor holding the stored scene, ring index or None)"""
         if isinstance(scene, torch.Tensor) and scene.is_cuda:
-            return scene.contiguous()
+            return scene.contiguous(), None
         t = torch.from_numpy(scene) if isinstance(scene, np.ndarray) else scene
         t = t.contiguous()
-        key = (slot, t.dtype)
-        pin = self._pinned.get(key)
-        if pin is None or pin.numel() < t.numel():
-            pin = self._pinned[key] = torch.empty(t.numel(), dtype=t.dtype).pin_memory()
-            self._staged[key] = torch.empty(t.numel(), dtype=t.dtype, device=self.device)
-        pin[: t.numel()].copy_(t.reshape(-1))
-        dev = self._staged[key][: t.numel()]
-        dev.copy_(pin[: t.numel()], non_blocking=True)
-        return dev.view(t.shape)
+        sl = self._slots.get(slot)
+        if sl is None:
+            sl = self._slots[slot] = _PinnedSlot(self.depth, self.device)
+        k, pin, dev = sl.acquire(t.numel(), t.dtype)
+        if t.is_pinned():
+            dev.copy_(t.reshape(-1), non_blocking=True)      # already page-locked (data.pin_scene): no host-side copy
+        else:
+            pin.copy_(t.reshape(-1))
+            dev.copy_(pin, non_blocking=True)
+        return dev.view(t.shape), k
 
     def __call__(self, scenes: List[Scene], flags: Optional[List[int]] = None, out: Optional[torch.Tensor] = None,
                  rng=_random) -> Tuple[torch.Tensor, torch.Tensor]:
+        xb, ext = self.prepare(scenes, flags, out, rng)
+        return xb, torch.tensor(ext, dtype=torch.int32).to(self.device, non_blocking=True)
+
+    def prepare(self, scenes: List[Scene], flags: Optional[List[int]] = None, out: Optional[torch.Tensor] = None, rng=_random):
+        """as __call__, but the extents come back as a host list (no device round trip)"""
         B, R = len(scenes), self.R
         xb = out if out is not None else torch.empty((B, 4, R, R, R), dtype=torch.float32, device=self.device)
         ext = []
+        st = torch.cuda.current_stream()
         for i, sc in enumerate(scenes):
             f = flags[i] if flags is not None else draw_augmentation(self.flip_prob, self.rotate_prob, rng)
-            src = self._stage(i, sc)
+            src, k = self._stage(i, sc)
             if self.normalize_density and src.dtype == torch.float32:
                 f |= ops.GRID_DENSITY
-            ext.append(ops.grid_prepare(src, xb[i], R, f))
-        return xb, torch.tensor(ext, dtype=torch.int32).to(self.device, non_blocking=True)
+            ext.append(list(ops.grid_prepare(src, xb[i], R, f)))
+            if k is not None:
+                self._slots[i].release_after(k, st)
+        return xb, ext
+
+
+def pin_scene(scene: np.ndarray) -> torch.Tensor:
+    """page-locked copy of a stored scene: datasets that fit in host memory can be pinned once, after which every epoch's H2D copy
+    reads the scene in place"""
+    return torch.from_numpy(np.ascontiguousarray(scene)).pin_memory()
+
+
+class Prefetcher:
+    """Asynchronous input pipeline (the reference's DataLoader(num_workers=2, pin_memory=True), run_swin_mae3d.py:578-586): a
+    background thread loads the scenes of batch k+1, stages them through the pinned rings and runs the H2D copies and the
+    `grid_prepare` kernels on its own copy stream while step k computes; the consumer gets `(xb, extents, event)` and makes its
+    stream wait for the event.  `depth` device batches rotate, guarded by events the consumer records when it is done with one
+    (`done(slot)`), so the producer can run at most depth-1 batches ahead."""
+
+    def __init__(self, batcher: GridBatcher, batches, batch_size: int, load=None, depth: int = 2, rng=_random):
+        import queue
+        import threading
+        self.b, self.load, self.rng = batcher, load or (lambda s: s), rng
+        R, dev = batcher.R, batcher.device
+        self.bufs = [torch.empty((batch_size, 4, R, R, R), dtype=torch.float32, device=dev) for _ in range(depth)]
+        self.free = [None] * depth                      # event after which buffer j may be overwritten
+        self.stream = torch.cuda.Stream(device=dev)
+        self.q = queue.Queue(maxsize=depth - 1 if depth > 1 else 1)
+        self.batches = batches
+        self.err = None
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        try:
+            torch.cuda.set_device(self.b.device)
+            for n, batch in enumerate(self.batches):
+                j = n % len(self.bufs)
+                scenes = [self.load(s) for s in batch]
+                flags = [draw_augmentation(self.b.flip_prob, self.b.rotate_prob, self.rng) for _ in scenes]
+                if self.free[j] is not None:
+                    _wait_event(self.free[j])
+                with torch.cuda.stream(self.stream):
+                    xb, ext = self.b.prepare(scenes, flags, out=self.bufs[j][:len(scenes)])
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                self.q.put((j, xb, ext, ev))
+            self.q.put(None)
+        except BaseException as e:  # noqa: BLE001
+            self.err = e
+            self.q.put(None)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                if self.err is not None:
+                    raise self.err
+                return
+            yield item
+
+    def done(self, j: int, stream=None):
+        """the consumer has queued its last read of buffer j on `stream`"""
+        ev = torch.cuda.Event()
+        ev.record(stream or torch.cuda.current_stream())
+        self.free[j] = ev

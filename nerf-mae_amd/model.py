@@ -59,6 +59,25 @@ def relative_position_index(ws: int = WS) -> Tensor:
     return (rel[0] * m * m + rel[1] * m + rel[2]).flatten()
 
 
+def draw_block_bits(g: Sequence[int], p_remove: float, block: int = 4, rng=random) -> np.ndarray:
+    """the draws of `draw_block_mask` only: uint8 array (nb0, nb1, nb2), 1 = block removed (same RNG stream, same order)"""
+    nb = [max(0, (gi - block) // block + 1) for gi in g]
+    return np.fromiter((rng.random() < p_remove for _ in range(nb[0] * nb[1] * nb[2])), dtype=np.uint8, count=nb[0] * nb[1] * nb[2]).reshape(nb)
+
+
+def block_bits_of_mask(m, block: int = 4):
+    """inverse of the block fill: (g,g,g) {0,1} mask -> its (nb,nb,nb) block bits, or None if the mask is not block-structured on a cube"""
+    m = np.asarray(m, dtype=np.uint8)
+    if m.ndim != 3 or len(set(m.shape)) != 1:
+        return None
+    nb = max(0, (m.shape[0] - block) // block + 1)
+    bits = m[::block, ::block, ::block][:nb, :nb, :nb]
+    full = np.zeros_like(m)
+    if nb:
+        full[:nb * block, :nb * block, :nb * block] = bits.repeat(block, 0).repeat(block, 1).repeat(block, 2)
+    return bits if np.array_equal(full, m) else None
+
+
 def draw_block_mask(g: Sequence[int], p_remove: float, block: int = 4, rng=random) -> Tensor:
     """swin_mae3d.py:1366-1373: one python-`random` draw per 4x4x4-token block in raster order -> uint8 (g0,g1,g2), 1 = removed.
     The draws keep the reference's order (same RNG stream, same pattern); only the block fill is vectorised (the per-block tensor

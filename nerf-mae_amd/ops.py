@@ -467,6 +467,26 @@ def bias_grad(dY, db, M, N, rowscale=None, rows_per_scale=1):
     lib().call("nmh_bias_grad", dt_of(dY), dY, db, M, N, rowscale, rows_per_scale, _st())
 
 
+def step_params(tokmask=None, block_bits=None, nb=0, g=0, hyper=None, hyper_dev=None, extents=None, extents_dev=None):
+    """per-step host parameters as kernel arguments of one launch (no H2D copies): block_bits = numpy uint8 array of nb^3 {0,1} in raster
+    order -> token mask [g^3]; hyper = 8 floats -> hyper_dev; extents = [B][3] ints -> extents_dev"""
+    import numpy as np
+    _chk(tokmask, hyper_dev, extents_dev)
+    bits = hy = ex = None
+    if tokmask is not None:
+        packed = np.packbits(np.asarray(block_bits, dtype=np.uint8).reshape(-1), bitorder="little")
+        packed = np.concatenate([packed, np.zeros((-len(packed)) % 4, dtype=np.uint8)])
+        bits = (ctypes.c_uint32 * max(1, len(packed) // 4)).from_buffer_copy(packed.tobytes() or b"\0\0\0\0")
+    if hyper is not None:
+        hy = (ctypes.c_float * 8)(*[float(v) for v in hyper])
+    n_ext = 0
+    if extents is not None:
+        flat = [int(v) for row in extents for v in row]
+        n_ext = len(flat)
+        ex = (ctypes.c_int * max(1, n_ext))(*flat)
+    lib().call("nmh_step_params", bits, nb, g, tokmask, hy, hyper_dev, ex, n_ext, extents_dev, _st())
+
+
 def grad_to_bf16(g, bucket):
     """fp32 gradient range -> bf16 bucket (data-parallel exchange at half the bytes)"""
     _chk(g, bucket)

@@ -7,6 +7,9 @@ beta1 cycling .95->.85->.95), stepped every iteration."""
 from __future__ import annotations
 
 import math
+import time
+
+import numpy as np
 
 import torch
 
@@ -49,7 +52,10 @@ class PinnedRing:
         k = self.i % len(self.events)
         self.i += 1
         if self.events[k] is not None:
-            self.events[k].synchronize()
+            # polled, not hipEventSynchronize: on this runtime a blocking wait on an (already complete) event was measured to return
+            # only when the stream had drained (~100 ms per step in Trainer.fit, the device idle meanwhile)
+            while not self.events[k].query():
+                time.sleep(1e-4)
         slot = self.buf[k]
         slot.copy_(src.reshape(slot.shape))
         dst.copy_(slot.view(dst.shape), non_blocking=True)
@@ -80,20 +86,20 @@ class FusedAdamW:
         if beta1 is not None:
             self.betas = (beta1, self.betas[1])
 
-    def update_hyper(self):
-        """advance the step counter and upload {lr, betas, eps, wd, bias corrections} (host->device; NOT graph-capturable)"""
+    def update_hyper(self, upload: bool = True):
+        """advance the step counter and hand {lr, betas, eps, wd, bias corrections} to the device (NOT graph-capturable: the values are
+        kernel arguments of a tiny launch, ops.step_params -- no host-to-device copy, so the host never waits for the stream).
+        upload=False: only compute `self.hyper_host` (GraphedTrainStep sends it together with the mask and the extents)."""
         self.t += 1
         b1, b2 = self.betas
         # torch.optim.AdamW semantics under OneCycleLR momentum cycling: bias corrections from the CURRENT betas, 1 - beta^t
         # (not the running product of the per-step beta1 values, which differs by ~20 % a few steps into a cycled schedule)
-        bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        # through a ring of pinned slots: a pageable source would make the copy (stream-ordered behind the running step) block the
-        # host, serialising the launch of step i+1 with the execution of step i.  Each slot carries an event recorded after its
-        # H2D copy; the host waits on it before rewriting the slot, so it may run ahead of the device by at most the ring depth.
-        if getattr(self, "_pin", None) is None:
-            self._pin = PinnedRing((8,), torch.float32, pinned=self.hyper.is_cuda)
-        self._pin.upload(torch.tensor([self.lr, b1, b2, self.eps, self.wd, bc1, bc2, 1.0 if self.zero_grads_after_step else 0.0],
-                                      dtype=torch.float32), self.hyper)
+        self.hyper_host = [self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0 if self.zero_grads_after_step else 0.0]
+        if upload:
+            if self.hyper.is_cuda:
+                ops.step_params(hyper=self.hyper_host, hyper_dev=self.hyper)
+            else:
+                self.hyper.copy_(torch.tensor(self.hyper_host, dtype=torch.float32))
 
     def launch(self):
         """the three device-side launches (graph-capturable): grad norm, clip coefficient, AdamW update"""
@@ -126,6 +132,7 @@ class GraphedTrainStep:
         self.ext = torch.full((batch, 3), R, dtype=torch.int32, device=dev)
         self.mask = torch.zeros(g ** 3, dtype=torch.uint8, device=dev)
         self.losses = None
+        self._ext_host = None
         self._g1 = self._g2 = self._gb1 = self._gb2 = None
         self._warm = warmup
         self.overlap = True    # False: every collective on the main stream (A/B measurement of what the overlap hides)
@@ -134,9 +141,7 @@ class GraphedTrainStep:
 
     def set_extents(self, ext):
         """valid extents [B][3] of the batch now in `self.x` (host list / tensor) -> static device buffer, through a pinned ring"""
-        if getattr(self, "_pin_ext", None) is None:
-            self._pin_ext = PinnedRing(tuple(self.ext.shape), torch.int32)
-        self._pin_ext.upload(torch.as_tensor(ext, dtype=torch.int32).cpu(), self.ext)
+        self._ext_host = [[int(v) for v in row] for row in (ext.tolist() if hasattr(ext, "tolist") else ext)]   # sent with the next step's parameters
 
     def _fwd_bwd(self, zero=True):
         if zero:
@@ -236,13 +241,22 @@ class GraphedTrainStep:
                 self.x[i, :, :a0, :a1, :a2].copy_(t, non_blocking=True)
                 ext.append([a0, a1, a2])
             self.set_extents(ext)
-        if block_mask is not None:   # event-guarded pinned ring, see FusedAdamW.update_hyper
-            if getattr(self, "_pin_mask", None) is None:
-                self._pin_mask = PinnedRing((self.mask.numel(),), torch.uint8)
-            self._pin_mask.upload(block_mask.to(torch.uint8), self.mask)
         if self._g1 is None:
             self._capture()
-        self.opt.update_hyper()
+        self.opt.update_hyper(upload=False)
+        g = self.model.resolution // 4
+        bits = None
+        if block_mask is not None:
+            from .model import block_bits_of_mask
+            bits = block_mask if isinstance(block_mask, np.ndarray) and block_mask.shape != (g, g, g) else block_bits_of_mask(block_mask)
+            if bits is None:   # an arbitrary (not block-structured) token mask: uploaded through the event-guarded pinned ring
+                if getattr(self, "_pin_mask", None) is None:
+                    self._pin_mask = PinnedRing((self.mask.numel(),), torch.uint8)
+                self._pin_mask.upload(torch.as_tensor(block_mask).to(torch.uint8), self.mask)
+        ext, self._ext_host = self._ext_host, None
+        # mask bits + optimizer hyper-parameters + extents as kernel arguments of one launch: nothing in the step waits on a copy
+        ops.step_params(tokmask=self.mask if bits is not None else None, block_bits=bits, nb=0 if bits is None else bits.shape[0], g=g,
+                        hyper=self.opt.hyper_host, hyper_dev=self.opt.hyper, extents=ext, extents_dev=self.ext if ext is not None else None)
         self._g1.replay()
         if self._g2 is not None:
             red, b = self.reducer, self.reducer.bounds
@@ -341,27 +355,38 @@ class Trainer:
 
     def train_epoch(self, epoch: int):
         import random
+        from . import data
         from .model import draw_block_mask
         self.model.train()
         idx = self._shard(len(self.train_scenes), self.rank, self.world, epoch, seed=self.seed)
         g = self.model.resolution // 4
-        tot = 0.0
-        for b in range(self.steps_per_epoch):
-            scenes = [self._scene(self.train_scenes[i]) for i in idx[b * self.batch:(b + 1) * self.batch]]
-            xb, ext = self.batcher(scenes, out=self.step_fn.x)           # straight into the graph's static input
-            if len(scenes) < self.batch:
+        batches = [[self.train_scenes[i] for i in idx[b * self.batch:(b + 1) * self.batch]] for b in range(self.steps_per_epoch)]
+        # input pipeline: batch k+1 is loaded, staged through pinned rings, copied and prepared on a copy stream by a background thread
+        # while step k runs (the reference's DataLoader workers); the losses are read back once per epoch, not per step, so the host
+        # keeps queueing replays ahead of the device
+        if self.step_fn._g1 is None:
+            self.step_fn._capture()    # before the producer thread exists: its allocations / copies would invalidate a global-mode capture
+        pf = data.Prefetcher(self.batcher, batches, self.batch, load=self._scene, rng=random)
+        main = torch.cuda.current_stream()
+        loss_acc = torch.zeros((), device=self.step_fn.x.device)
+        for j, xb, ext, ev in pf:
+            main.wait_event(ev)
+            n = xb.shape[0]
+            self.step_fn.x[:n].copy_(xb, non_blocking=True)          # device-to-device into the graph's static input
+            pf.done(j, main)
+            if n < self.batch:
                 # ragged last batch of the epoch (no drop_last in the reference): the unused slots of the static batch become empty
                 # grids with zero valid extent -- no voxel of them enters either loss mask, so losses and gradients equal those of
                 # the smaller batch
-                self.step_fn.x[len(scenes):].zero_()
-                ext = torch.cat([ext, torch.zeros((self.batch - len(scenes), 3), dtype=torch.int32, device=ext.device)])
-            self.step_fn.ext.copy_(ext)
+                self.step_fn.x[n:].zero_()
+                ext = ext + [[0, 0, 0]] * (self.batch - n)
+            self.step_fn.set_extents(ext)
             lr, b1 = self.sched.at(self.global_step)
             self.opt.set_hyper(lr=lr, beta1=b1)
             losses = self.step_fn(None, draw_block_mask((g, g, g), self.model.masking_prob, rng=random))
             self.global_step += 1
-            tot += float(losses[0])
-        return tot / self.steps_per_epoch
+            loss_acc += losses[0]
+        return float(loss_acc) / self.steps_per_epoch
 
     @torch.no_grad()
     def evaluate(self):

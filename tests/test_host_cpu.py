@@ -126,3 +126,19 @@ def test_window_geometry():
     g = WinGeom(2, 5, 10, 2, [2, 2, 2])
     assert g.P == [8, 12, 4] and g.shift == [2, 2, 0] and g.rows == 2 * 8 * 12 * 4 and g.tokens == 200
     assert list(g.carr) == [2, 5, 10, 2, 8, 12, 4, 2, 2, 0]
+
+
+def test_block_bits_roundtrip_and_rng_stream():
+    """draw_block_bits consumes the python RNG exactly like draw_block_mask (the reference's window_masking_3d raster, swin_mae3d.py:
+    1366-1373) and block_bits_of_mask inverts the block fill; non-block-structured masks are rejected (-> the upload fallback)"""
+    import random
+    import numpy as np
+    from nerf_mae_amd.model import block_bits_of_mask, draw_block_bits, draw_block_mask
+    for g in (8, 10, 40):
+        m = draw_block_mask((g, g, g), 0.75, rng=random.Random(7)).numpy()
+        bits = draw_block_bits((g, g, g), 0.75, rng=random.Random(7))
+        back = block_bits_of_mask(m)
+        assert back is not None and np.array_equal(back, bits)
+    bad = draw_block_mask((8, 8, 8), 0.5, rng=random.Random(1)).numpy().copy()
+    bad[1, 2, 3] ^= 1
+    assert block_bits_of_mask(bad) is None

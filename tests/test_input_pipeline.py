@@ -76,3 +76,53 @@ def test_grid_prepare_kernel_matches_golden_and_oracle():
         np.testing.assert_allclose(xb[i].cpu().numpy(), ref.numpy(), rtol=2e-6, atol=2e-7)
     with pytest.raises(Exception):
         ops.grid_prepare(torch.zeros(200, 4, 4, 4, device="cuda"), xb[0], 160, 0)   # does not fit the resolution
+
+
+@pytest.mark.gpu
+def test_staging_ring_survives_host_running_ahead():
+    """the host queues six batches behind a device that is still busy (a long sleep kernel on the stream): every batch must arrive
+    intact.  With one pinned buffer per slot (round 1) the host overwrote the buffer of a copy that had not executed yet; the ring's
+    per-buffer events make the host wait instead.  Contents are verified on the device (exact fp32 sums of uint8-derived grids)."""
+    import numpy as np
+    from nerf_mae_amd import data
+    R = 32
+    bt = data.GridBatcher(R, "cuda", normalize_density=True, depth=3)
+    scenes = [[data.synthetic_scene((32, 30 - b, 28), seed=100 * b + i, dtype=np.uint8) for i in range(2)] for b in range(6)]
+    torch.cuda._sleep(400_000_000)   # ~0.2 s of device time: all six calls below are issued while it runs
+    outs = [bt.prepare(batch, flags=[0, 0]) for batch in scenes]
+    torch.cuda.synchronize()
+    for (xb, ext), batch in zip(outs, scenes):
+        for i, sc in enumerate(batch):
+            want = torch.from_numpy(sc.astype(np.float32) / 255.0).permute(3, 0, 1, 2)
+            a0, a1, a2 = ext[i]
+            assert (a0, a1, a2) == tuple(sc.shape[:3])
+            got = xb[i, :, :a0, :a1, :a2].cpu()
+            assert torch.allclose(got, want, rtol=2e-6, atol=1e-7), (i, (got - want).abs().max())
+            assert abs(float(xb[i].double().sum()) - float(got.double().sum())) < 1e-9   # the padding is zero
+
+
+@pytest.mark.gpu
+def test_prefetcher_delivers_batches_in_order_with_a_slow_and_a_fast_consumer():
+    """background-thread pipeline (pinned rings -> copy stream -> grid_prepare): every batch equals the synchronous batcher's output,
+    also when the consumer is slower than the producer (device buffers are only reused after `done`) and for a ragged last batch"""
+    import time
+    import numpy as np
+    from nerf_mae_amd import data
+    R = 32
+    scenes = [data.synthetic_scene((32, 32 - (i % 3), 29), seed=i, dtype=np.float32 if i % 2 else np.uint8) for i in range(7)]
+    batches = [scenes[0:2], scenes[2:4], scenes[4:6], scenes[6:7]]
+    ref = data.GridBatcher(R, "cuda", normalize_density=True)
+    for delay in (0.0, 0.05):
+        pf = data.Prefetcher(data.GridBatcher(R, "cuda", normalize_density=True), batches, 2)
+        main = torch.cuda.current_stream()
+        n = 0
+        for j, xb, ext, ev in pf:
+            main.wait_event(ev)
+            got = xb.clone()
+            pf.done(j, main)
+            want, wext = ref.prepare(batches[n], flags=[0] * len(batches[n]))
+            torch.cuda.synchronize()
+            assert ext == wext and torch.equal(got, want), n
+            time.sleep(delay)
+            n += 1
+        assert n == len(batches)

@@ -704,3 +704,24 @@ def test_grad_bucket_casts():
     out = torch.empty_like(g)
     ops.grad_from_bf16(b, out, 0.5)
     assert torch.equal(out, b.float() * 0.5)
+
+
+def test_step_params_kernel_expands_block_mask_and_stores_hyper_and_extents():
+    """nmh_step_params: block bits / hyper-parameters / extents as kernel arguments -> token mask (== draw_block_mask), hyper, extents"""
+    import random
+    from nerf_mae_amd.model import draw_block_bits, draw_block_mask
+    ops = _ops()
+    for g in (8, 10, 40):
+        want = draw_block_mask((g, g, g), 0.6, rng=random.Random(g))
+        bits = draw_block_bits((g, g, g), 0.6, rng=random.Random(g))
+        tok = torch.full((g ** 3,), 7, dtype=torch.uint8, device="cuda")
+        hy = torch.zeros(8, device="cuda")
+        ex = torch.zeros((3, 3), dtype=torch.int32, device="cuda")
+        ops.step_params(tokmask=tok, block_bits=bits, nb=bits.shape[0], g=g, hyper=[1e-4, 0.9, 0.999, 1e-8, 1e-3, 0.1, 0.001, 1.0], hyper_dev=hy,
+                        extents=[[g, g - 1, 3], [1, 2, 3], [4, 5, 6]], extents_dev=ex)
+        assert torch.equal(tok.cpu().view(g, g, g), want)
+        assert torch.allclose(hy.cpu(), torch.tensor([1e-4, 0.9, 0.999, 1e-8, 1e-3, 0.1, 0.001, 1.0]))
+        assert ex.cpu().tolist() == [[g, g - 1, 3], [1, 2, 3], [4, 5, 6]]
+    hy2 = torch.zeros(8, device="cuda")
+    ops.step_params(hyper=[float(i) for i in range(8)], hyper_dev=hy2)     # hyper only (FusedAdamW.update_hyper)
+    assert hy2.cpu().tolist() == [float(i) for i in range(8)]
