@@ -464,6 +464,40 @@ def formula_fill_(module: nn.Module) -> None:
                 p.copy_(formula_tensor(name, p.shape, 1.2 / math.sqrt(max(fan_in, 1))))
 
 
+def seeded_reference_init_(module: nn.Module, seed: int = 0) -> None:
+    """The reference's initialisation DISTRIBUTIONS (swin_mae3d.py:1272-1276,1312: trunc_normal(0.02) Linear weights / zero biases /
+    normal(0.02) mask token; PyTorch defaults elsewhere: kaiming-uniform(a=sqrt 5) conv weights and U(-1/sqrt(fan_in), ..) conv biases,
+    LayerNorm ones/zeros, trunc_normal(0.02) relative-position tables), drawn from one generator PER PARAMETER seeded by (seed, name):
+    the reference model, the oracle and the HIP model get bit-identical weights whatever their construction order."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if not p.requires_grad:
+                continue
+            g = torch.Generator().manual_seed(seed * 1000003 + int(_name_phase(name) * 1000) + len(name))
+            is_norm = name.endswith("norm.weight") or ".norm1." in name or ".norm2." in name or name.startswith("patch_partition.2.") or name.endswith(".norm.bias")
+            if is_norm:
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            elif name == "mask_token":
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif "relative_position_bias_table" in name:
+                p.copy_(torch.nn.init.trunc_normal_(torch.empty(p.shape), std=0.02, generator=g))
+            elif "conv" in name or name.startswith("patch_partition.0."):   # Conv3d / ConvTranspose3d: PyTorch defaults
+                w_shape = p.shape if p.ndim > 1 else None
+                if w_shape is not None:
+                    fan_in = int(np.prod(p.shape[1:]))          # (ConvTranspose3d: weight is (Cin, Cout, k,k,k); PyTorch uses size(1)*k^3 as well)
+                    b = 1.0 / math.sqrt(fan_in)
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * b)
+                else:   # bias: bound from the layer's weight fan-in
+                    wname = name[:-4] + "weight"
+                    w = dict(module.named_parameters())[wname]
+                    b = 1.0 / math.sqrt(int(np.prod(w.shape[1:])))
+                    p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * b)
+            elif p.ndim == 2:            # nn.Linear weights
+                p.copy_(torch.nn.init.trunc_normal_(torch.empty(p.shape), std=0.02, generator=g))
+            else:                        # Linear biases
+                p.zero_()
+
+
 def synthetic_grid(shape=(160, 160, 160), seed: int = 0) -> Tensor:
     """SURVEY 8(d) synthetic RGB-sigma grid: RGB ~ U[0,1); alpha = clip(1-exp(-exp(sigma)/100),0,1),
     sigma ~ N(0,3^2) inside a 60% sub-box, -10 outside (mirrors nerf_rpn/datasets.py:247-248)."""

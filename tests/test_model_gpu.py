@@ -260,3 +260,45 @@ def test_training_trace_matches_reference_golden(golden):
     np.testing.assert_allclose(tr[:, 1:], g["trace"][:, 1:], rtol=0.35)
     assert abs(tr[-3:, 0].mean() - g["trace"][-3:, 0].mean()) < 0.08 * g["trace"][-3:, 0].mean()
     assert tr[-1, 0] < 0.45 * tr[0, 0]
+
+
+@pytest.mark.parametrize("dtype,tol,use_graph", [(torch.float32, 2e-2, False), (torch.bfloat16, 5e-2, False), (torch.bfloat16, 5e-2, True)],
+                         ids=["fp32", "bf16", "bf16-hipgraph"])
+def test_well_conditioned_training_trace_within_2_percent_every_step(golden, dtype, tol, use_graph):
+    """recon-loss curve against the REAL reference at every step (golden g14, oracle/gen_golden_trace2.py: reference init distributions,
+    torch AdamW(eps 1e-3) + OneCycleLR + clip_grad_norm_, ten steps on two fixed grids with python-random block masks; reproducible to
+    0.35 % between 1 and 8 CPU threads): fp32 within 2 %, bf16 within 5 % -- loss, loss_rgb, loss_alpha and the pre-clip gradient norm.
+    A wrong beta1 cycle, bias correction, weight decay or schedule step moves the curve by more than that from step 2 on (checked by
+    breaking each of them).  The graph variant runs the same steps through GraphedTrainStep (the benched path)."""
+    from nerf_mae_amd.model import SwinTransformer_MAE3D, draw_block_mask
+    from nerf_mae_amd.trainer import FusedAdamW, GraphedTrainStep, OneCycle
+    from oracle import mae3d_oracle as O
+    from oracle.gen_golden_trace2 import CLIP, EPS, KW, LR, SEED, STEPS, WD, grids
+    g = golden("g14_train_trace_wellcond.npz")
+    hip = SwinTransformer_MAE3D(compute_dtype=dtype, **KW)
+    O.seeded_reference_init_(hip, SEED)     # per-parameter generators: bit-identical to the weights the reference trained from
+    hip = hip.cuda().train()
+    opt = FusedAdamW(hip, lr=LR, weight_decay=WD, max_grad_norm=CLIP, eps=EPS)
+    sched = OneCycle(LR, STEPS)
+    random.seed(14)
+    xs = [t.cuda() for t in grids()]
+    step_fn = GraphedTrainStep(hip, opt, 2) if use_graph else None
+    trace, gn = [], []
+    for step in range(STEPS):
+        lr, b1 = sched.at(step)
+        opt.set_hyper(lr=lr, beta1=b1)
+        if use_graph:
+            losses = step_fn(xs if step == 0 else None, draw_block_mask((8, 8, 8), 0.75, rng=random))
+            trace.append([float(v) for v in losses])
+        else:
+            hip.zero_grad()
+            loss, l_rgb, l_a = hip(xs)
+            loss.backward()
+            opt.step()
+            trace.append([loss.item(), l_rgb.item(), l_a.item()])
+        gn.append(opt.norm.item())
+    tr = np.array(trace)
+    print("hip:", tr[:, 0].round(5).tolist())
+    print("ref:", g["trace"][:, 0].round(5).tolist())
+    np.testing.assert_allclose(tr, g["trace"], rtol=tol)
+    np.testing.assert_allclose(np.array(gn), g["grad_norm"], rtol=2 * tol)
