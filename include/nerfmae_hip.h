@@ -69,6 +69,18 @@ NMH_API int nmh_ncdhw_to_ndhwc(int dt, const float* src, void* dst, int B, int64
 /* The same convolution specialised for Cin = Cout = 48, bf16 (decoder1.conv_block at 160^3 -- 75 % of the model's FLOPs): persistent
  * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad). */
 NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, void* stream);
+/* The same convolution on 64-channel blocks, bf16, Cin and Cout multiples of 64 (swin_b's decoder1 64 -> 64 at 160^3, BASELINE
+ * configs[3]; the FPN neck's 256 -> 256 convolutions, nerf_rpn/model/fpn.py:104): persistent LDS-halo implicit GEMM that loops over the
+ * input-channel blocks with the accumulators in registers.  Wk = fragment-ordered pack [Cout/64][Cin/64][54 steps][4][64 lanes][8]
+ * (pack modes 8 fwd / 9 dgrad; nmh_conv3d_k3_c64_pack_numel elements).  stats_acc as for the 48-channel kernel: fp64 [B][Cout][2];
+ * bias (optional fp32 [Cout]) is added before the store (the FPN convolutions carry a bias, the decoder's do not need theirs). */
+NMH_API int nmh_conv3d_k3_c64(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, double* stats_acc, const float* bias, void* stream);
+NMH_API int64_t nmh_conv3d_k3_c64_pack_numel(int Cin, int Cout);
+/* weight gradient of the 64-channel-block layer (dW fp32 [Cout][Cin][3][3][3], accumulated): X halo + DMA-double-buffered dY tile in
+ * swizzled 128-byte LDS rows, both operands by transpose reads, taps split over two workgroup groups; ws = fp32 scratch of
+ * nmh_conv3d_k3_c64_wgrad_ws_floats() elements (per-workgroup partials, summed by a second launch). */
+NMH_API int nmh_conv3d_k3_c64_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, void* stream);
+NMH_API int64_t nmh_conv3d_k3_c64_wgrad_ws_floats(void);
 /* stats_acc (optional, fp64 [B][48][2], zeroed by the call): the conv epilogue also accumulates per-(sample,channel) sum and sum of squares of
  * its outputs, i.e. the InstanceNorm3d statistics of the following norm layer; nmh_instnorm_finalize turns them into {mean, rstd}. */
 NMH_API int nmh_instnorm_finalize(const double* acc, float* stats, int B, int64_t V, int C, float eps, void* stream);

@@ -77,6 +77,18 @@ int nmh_conv3d_k3_bias(int dt, const void* X, const void* Wp, const float* bias,
   EpiParams ep{Y, Cout, bias, 0, nullptr, nullptr, nullptr, 1, 0};
   return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
 }
+int nmh_conv3d_k3_c64(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, double* stats_acc, const float* bias, void* stream) {
+  CLR();
+  if (!X || !Wk || !Y) return -4;
+  return k_conv64(X, Wk, Y, B, D, H, W, Cin, Cout, accumulate, stats_acc, bias, ST);
+}
+int nmh_conv3d_k3_c64_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
+  CLR();
+  if (!dY || !X || !dW || !ws) return -4;
+  return k_conv64_wgrad(dY, X, dW, ws, B, D, H, W, Cin, Cout, ST);
+}
+int64_t nmh_conv3d_k3_c64_wgrad_ws_floats(void) { return (int64_t)k_conv64_wgrad_ws_floats(); }
+int64_t nmh_conv3d_k3_c64_pack_numel(int Cin, int Cout) { return (Cin % 64 || Cout % 64) ? -1 : (int64_t)k_conv64_pack_numel(Cin, Cout); }
 int nmh_nearest_upsample_add(int dt, const void* coarse, void* fine, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream) {
   CLR();
   return k_nearest_up_add(dt, coarse, fine, B, Dc, Hc, Wc, Df, Hf, Wf, C, 0, ST);

@@ -459,6 +459,7 @@ int k_fill_f32(float* p, float v, long n, hipStream_t st) {
 //  mode 3 conv3 dgrad    dst [Ci][27][Co], tap flipped (26 - t)
 //  mode 4 convT fwd      src [Ci=d0][Co=d1][k3=d2] -> dst [(t*Co+co)][ci]
 //  mode 5 convT dgrad    dst [ci][(t*Co+co)]
+//  mode 8/9 conv64 fragment order (conv64.hip), see pack_src_index
 //  mode 6/7 conv48 fragment order (conv48.hip): dst [step 41][ntile 3][lane 64][8] from the mode-2 (fwd) / mode-3 (dgrad) view
 //           W'[n][tap][k]: lane (li, g) of co-tile nt holds n = 12*(li>>2) + 4*nt + (li&3), slot j; steps < 36: tap-row r = 4*(s/18)+g, vector c = s%18; steps >= 36: row 8,
 //           c = 4*(s-36)+g (c >= 18 -> zero padding)
@@ -483,6 +484,17 @@ __device__ __forceinline__ long pack_src_index(const PackDesc& d, long il) {
       const int tap = r * 3 + c / 6, k = (c % 6) * 8 + j;  // tap = (dz+1)*9+(dy+1)*3+(dx+1), r = (dz+1)*3+(dy+1)
       // W'[n][tap][k]: fwd  = W[co=n][ci=k][tap];  dgrad = W[co=k][ci=n][26-tap]
       return d.mode == 6 ? ((long)n * 48 + k) * 27 + tap : ((long)k * 48 + n) * 27 + (26 - tap);
+    }
+    case 8: case 9: {
+      // conv64.hip fragment order [os][cs][step 54][co-tile 4][lane 64][8]: lane (li, g) of co-tile nt holds output channel
+      // 64 os + 16 (li>>2) + 4 nt + (li&3) (an accumulator lane owns 16 consecutive channels), contraction slot cs*64 + (step&1)*32 + 8g + j of tap step>>1
+      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+      const unsigned sn = i >> 9;
+      const int nt = (int)(sn & 3), sg = (int)(sn >> 2), blk = sg / 54, st = sg - blk * 54;
+      const int ncs = (d.mode == 8 ? (int)d1 : (int)d0) / 64, os = blk / ncs, cs = blk - os * ncs;
+      const int g = lane >> 4, li = lane & 15, n = os * 64 + 16 * (li >> 2) + 4 * nt + (li & 3), k = cs * 64 + (st & 1) * 32 + 8 * g + j, tap = st >> 1;
+      // W'[n][tap][k]: fwd = W[co=n][ci=k][tap]; dgrad = W[co=k][ci=n][26-tap]   (src layout [Co=d0][Ci=d1][27])
+      return d.mode == 8 ? ((long)n * d1 + k) * 27 + tap : ((long)k * d1 + n) * 27 + (26 - tap);
     }
     default: return il;
   }

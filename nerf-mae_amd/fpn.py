@@ -37,7 +37,10 @@ class _FPNFn(torch.autograd.Function):
             ops.nearest_upsample_add(lats[i], lats[i - 1])
         outs = []
         for i, lat in enumerate(lats):
-            y = ops.conv3d_k3_bias(lat, pk[f"f{i}.w"], fpn.fpn_convs[i].bias, Co)
+            if ops.use_conv64(lat, Co) and f"f{i}.w64" in pk.views:   # LDS-halo kernel on 64-channel blocks (bias in its epilogue)
+                y = ops.conv3d_k3_c64(lat, pk[f"f{i}.w64"], Co, bias=fpn.fpn_convs[i].bias)
+            else:
+                y = ops.conv3d_k3_bias(lat, pk[f"f{i}.w"], fpn.fpn_convs[i].bias, Co)
             outs.append(ops.ndhwc_to_ncdhw(y))
         ctx.fpn, ctx.saved = fpn, (feats, lats)
         return tuple(outs)
@@ -58,7 +61,10 @@ class _FPNFn(torch.autograd.Function):
             with ops.side_stream():
                 ops.conv3d_k3_wgrad(dy, lat, _gradbuf(conv.weight))
                 ops.bias_grad(dy.view(-1, Co), _gradbuf(conv.bias), B * D * H * W, Co)
-            dlats.append(ops.conv3d_k3(dy, pk[f"f{i}.wd"], Co))
+            if ops.use_conv64(dy, Co) and f"f{i}.w64d" in pk.views:
+                dlats.append(ops.conv3d_k3_c64(dy, pk[f"f{i}.w64d"], Co))
+            else:
+                dlats.append(ops.conv3d_k3(dy, pk[f"f{i}.wd"], Co))
         for i in range(1, n):   # d lat_i += adjoint of the nearest upsample of d lat_{i-1} (which is final by then)
             ops.nearest_upsample_add_bwd(dlats[i - 1], dlats[i])
         dfeats = []
@@ -112,6 +118,9 @@ class FPN(nn.Module):
                 P.add(f"l{i}.wT", l.weight, P.TRANS)
                 P.add(f"f{i}.w", c.weight, P.CONV_F)
                 P.add(f"f{i}.wd", c.weight, P.CONV_D)
+                if self.compute_dtype == torch.bfloat16 and c.weight.shape[0] % 64 == 0 and c.weight.shape[1] % 64 == 0:
+                    P.add(f"f{i}.w64", c.weight, P.C64_F)
+                    P.add(f"f{i}.w64d", c.weight, P.C64_D)
             P.build(self.compute_dtype, ps[0].device)
             P.split = None
             self._pk, self._pk_key = P, key

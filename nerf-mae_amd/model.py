@@ -98,7 +98,7 @@ class _Packer:
     """Owns the flat compute-dtype buffer holding every GEMM operand layout derived from the fp32 master
     parameters, and the device descriptor table for the single-launch pack kernel."""
 
-    CAST, TRANS, CONV_F, CONV_D, CONVT_F, CONVT_D, C48_F, C48_D = 0, 1, 2, 3, 4, 5, 6, 7
+    CAST, TRANS, CONV_F, CONV_D, CONVT_F, CONVT_D, C48_F, C48_D, C64_F, C64_D = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
     C48_NUMEL = 41 * 3 * 64 * 8  # conv48.hip fragment order [step][ntile][lane][8]
 
     def __init__(self):
@@ -111,11 +111,12 @@ class _Packer:
             dims = (0, 0, 0)
         elif mode == self.TRANS:
             dims = (sh[0], int(np.prod(sh[1:])), 0)
-        elif mode in (self.CONV_F, self.CONV_D, self.C48_F, self.C48_D):
+        elif mode in (self.CONV_F, self.CONV_D, self.C48_F, self.C48_D, self.C64_F, self.C64_D):
             dims = (sh[0], sh[1], 27)
         else:
             dims = (sh[0], sh[1], int(np.prod(sh[2:])))
-        self.items.append((key, p, mode, dims, self.C48_NUMEL if mode in (self.C48_F, self.C48_D) else p.numel()))
+        numel = self.C48_NUMEL if mode in (self.C48_F, self.C48_D) else ops.conv64_pack_numel(sh[1], sh[0]) if mode in (self.C64_F, self.C64_D) else p.numel()
+        self.items.append((key, p, mode, dims, numel))
 
     def build(self, dtype: torch.dtype, device):
         total = sum((n + 63) // 64 * 64 for *_, n in self.items)
@@ -353,13 +354,20 @@ class _UpBlockFn(torch.autograd.Function):
             ops.copy_cols(skip.reshape(B * V, Cout), cat[:, Cout:])
         S = v * k
         scratch = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
+        ctx.c64 = False
         c48 = (key + "c1.wk") in pk.views and (key + "c2.wk") in pk.views
+        c64 = (not c48 and (key + "c1.w64") in pk.views and (key + "c2.w64") in pk.views and S ** 3 >= ops.C64_MIN_VOXELS > 0
+               and S ** 3 * Cc * 2 < 2 ** 32)
         if c48:   # Cin = Cout = 48 in bf16: LDS-halo kernel with fragment-ordered weights ("c1.w" -> "c1.wk", "c1.wd" -> "c1.wkd")
             conv = lambda X, nm, co, **kw: ops.conv3d_k3_c48(X, pk[key + nm.replace(".w", ".wk")], **kw)  # noqa: E731
+        elif c64:  # channel counts multiples of 64 (swin_b): LDS-halo kernel on 64-channel blocks ("c1.w" -> "c1.w64", "c1.wd" -> "c1.w64d")
+            conv = lambda X, nm, co, **kw: ops.conv3d_k3_c64(X, pk[key + nm.replace(".w", ".w64")], co, **kw)  # noqa: E731
         else:
             conv = lambda X, nm, co, **kw: ops.conv3d_k3(X, pk[key + nm], co, **kw)  # noqa: E731
+        ctx.c64 = c64
+        halo_stats = c48 or c64    # InstanceNorm statistics come out of the conv epilogue
         st1 = torch.empty((B, Cout, 2), device=dev)
-        if c48:   # InstanceNorm statistics come out of the conv epilogue (no extra pass over the 160^3 tensor)
+        if halo_stats:   # InstanceNorm statistics come out of the conv epilogue (no extra pass over the 160^3 tensor)
             y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st1, B, V, Cout)
         else:
@@ -368,7 +376,7 @@ class _UpBlockFn(torch.autograd.Function):
         a1 = torch.empty_like(y1)
         ops.instnorm_apply(y1, st1, a1, B, V, Cout)
         st2 = torch.empty((B, Cout, 2), device=dev)
-        if c48:
+        if halo_stats:
             y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st2, B, V, Cout)
         else:
@@ -435,14 +443,14 @@ class _UpBlockFn(torch.autograd.Function):
         # Weight gradients run on the forked side stream -- except the persistent 160^3 kernels, which own every CU: overlapping
         # them with the next MFMA kernel OR with the HBM-bound InstanceNorm passes measured slower (51.2 vs 50.4 ms at 4 grids,
         # 34.8 vs 30.8 ms at 1), so they stay on the main stream.
-        with ops.side_stream(enable=not ctx.c48):
+        with ops.side_stream(enable=not (ctx.c48 or ctx.c64)):
             wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
         sums1 = torch.empty_like(sums2)
         ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
-        with ops.side_stream(enable=not ctx.c48):
+        with ops.side_stream(enable=not (ctx.c48 or ctx.c64)):
             wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
         if m.has_proj:
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
@@ -721,6 +729,10 @@ class SwinTransformer_MAE3D_New(nn.Module):
                 if self.compute_dtype == torch.bfloat16 and tuple(conv.weight.shape[:2]) == (48, 48):
                     P.add(key + cn + ".wk", conv.weight, P.C48_F)     # specialised LDS-halo kernel (decoder1 @160^3)
                     P.add(key + cn + ".wkd", conv.weight, P.C48_D)
+                elif (self.compute_dtype == torch.bfloat16 and conv.weight.shape[0] % 64 == 0 and conv.weight.shape[1] % 64 == 0
+                      and (d.k * (self.resolution // 4) // {"decoder4": 8, "decoder3": 4, "decoder2": 2, "decoder1": 1}[name]) ** 3 >= ops.C64_MIN_VOXELS > 0):
+                    P.add(key + cn + ".w64", conv.weight, P.C64_F)    # 64-channel-block LDS-halo kernel (swin_b decoder levels >= 32^3)
+                    P.add(key + cn + ".w64d", conv.weight, P.C64_D)
             if d.has_proj:
                 P.add(key + "c3.w", d.conv_block.conv3.weight, P.CAST)
                 P.add(key + "c3.wT", d.conv_block.conv3.weight, P.TRANS)

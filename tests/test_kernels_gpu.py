@@ -725,3 +725,40 @@ def test_step_params_kernel_expands_block_mask_and_stores_hyper_and_extents():
     hy2 = torch.zeros(8, device="cuda")
     ops.step_params(hyper=[float(i) for i in range(8)], hyper_dev=hy2)     # hyper only (FusedAdamW.update_hyper)
     assert hy2.cpu().tolist() == [float(i) for i in range(8)]
+
+
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(1, 8, 16, 32, 64, 64), (2, 4, 8, 16, 64, 64), (1, 6, 10, 20, 64, 64), (1, 12, 9, 33, 128, 64),
+                                              (2, 5, 7, 18, 64, 128), (1, 20, 20, 20, 192, 128), (1, 40, 40, 40, 64, 64)])
+def test_conv64_block_kernel_matches_reference_conv(B, D, H, W, Cin, Cout):
+    """LDS-halo 64-channel-block bf16 kernel (swin_b decoder1 / FPN neck; forward pack, dgrad pack + accumulate, fused InstanceNorm
+    statistics, several input / output channel blocks, ragged tiles on every axis) vs F.conv3d"""
+    ops = _ops()
+    dt = torch.bfloat16
+    x = q(rnd(B, Cin, D, H, W), dt)
+    w = q(rnd(Cout, Cin, 3, 3, 3, seed=1, scale=(27 * Cin) ** -0.5), dt)
+    dy = q(rnd(B, Cout, D, H, W, seed=2), dt)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv3d(xr, w, padding=1)
+    y.backward(dy)
+    n = ops.conv64_pack_numel(Cin, Cout)
+    wk_f, wk_d = _pack_via_kernel(w, 8, dt, n), _pack_via_kernel(w, 9, dt, n)
+    xcl = dev(x.permute(0, 2, 3, 4, 1), dt)
+    acc = torch.empty(B, Cout, 2, dtype=torch.float64, device="cuda")
+    yk = ops.conv3d_k3_c64(xcl, wk_f, Cout, stats_acc=acc)
+    check(yk.permute(0, 4, 1, 2, 3), y, dt, "conv64 fwd")
+    st = torch.empty(B, Cout, 2, device="cuda")
+    ops.instnorm_finalize(acc, st, B, D * H * W, Cout)
+    yf = yk.float().reshape(B, -1, Cout)
+    check(st[..., 0], yf.mean(1), torch.float32, "fused IN mean", 5)
+    check(st[..., 1], (yf.var(1, unbiased=False) + 1e-5).rsqrt(), torch.float32, "fused IN rstd", 5)
+    base = q(rnd(B, D, H, W, Cin, seed=3), dt)
+    out = dev(base, dt)
+    dycl = dev(dy.permute(0, 2, 3, 4, 1), dt)
+    ops.conv3d_k3_c64(dycl, wk_d, Cin, out=out, accumulate=True)
+    check(out.permute(0, 4, 1, 2, 3), xr.grad + base.permute(0, 4, 1, 2, 3), dt, "conv64 dgrad+accumulate")
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(x, wr, padding=1).backward(dy)
+    dW = torch.full((Cout, Cin, 3, 3, 3), 0.5, device="cuda")
+    ws = torch.empty(ops.lib().call("nmh_conv3d_k3_c64_wgrad_ws_floats"), device="cuda")
+    ops.lib().call("nmh_conv3d_k3_c64_wgrad", dycl, xcl, dW, ws, B, D, H, W, Cin, Cout, torch.cuda.current_stream().cuda_stream)
+    check(dW, wr.grad + 0.5, dt, "conv64 wgrad")
