@@ -485,10 +485,12 @@ __global__ void in_finalize_kernel(const double* acc, float* stats, const T* x, 
     stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
-static inline long in_vox_per_block(long V) {
-  // <= 256 blocks per sample (their fp64 atomics hit the same 2*C addresses) but >= 128 voxels per block so small volumes still
-  // spread over the chip
-  long vpb = (V + 255) / 256;
+static inline long in_vox_per_block(long V, int B = 4) {
+  // <= 256 blocks per sample (their fp64 atomics hit the same 2*C addresses) -- up to 1024 blocks in total for small batches: one
+  // workgroup per CU cannot hide its load latency (160^3, 1 sample: 286 -> ~150 us) -- but >= 128 voxels per block so small volumes
+  // still spread over the chip
+  const long per_sample = B >= 4 ? 256 : 1024 / (B < 1 ? 1 : B);
+  long vpb = (V + per_sample - 1) / per_sample;
   vpb = (vpb + 63) / 64 * 64;
   return vpb < 128 ? 128 : vpb;
 }
@@ -521,7 +523,7 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
   hipError_t e = nmh_zero_async(sums, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
   if (rmode == 2) { e = nmh_zero_async(sums_r, sizeof(double) * 2 * B * C, st); if (e != hipSuccess) return (int)e; }
-  const long vpb = in_vox_per_block(V);
+  const long vpb = in_vox_per_block(V, B);
   dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
   size_t lds = (4 * C + 32 * 256) * sizeof(float);
   if (dt == NMH_DT_BF16) hipLaunchKernelGGL((in_reduce_kernel<bf16_t, 1>), grid, dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)out, stats, (const bf16_t*)r, stats_r, rmode, sums, sums_r, V, C, slope, vpb);
@@ -751,7 +753,7 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
   if (C % 8 || C / 8 > 256 || (!d0 && !r)) return -2;
   hipError_t e = nmh_zero_async(in_sums, sizeof(double) * 2 * B * C, st);
   if (e != hipSuccess) return (int)e;
-  const long vpb = in_vox_per_block(V);
+  const long vpb = in_vox_per_block(V, B);
   const long vpa = in_apply_vpb(V, B, C);
   dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + vpa - 1) / vpa), B);
   const size_t lds = 6 * C * sizeof(float);
