@@ -152,6 +152,29 @@ NMH_API int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, f
 NMH_API int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream);
 NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream);
 NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
+/* ---- dense-prediction heads on the pretrained encoder + decoder (nerf_rpn/model/feature_extractor.py:1898-2244 VoxelSR, 2521-2848
+ * VoxelSemantics).  Their convolutions / norms / GEMMs are the entries above; these are the head-specific pieces. ----
+ * nmh_grid_to_cl8: (B,4,V) fp32 NCDHW grid -> [B*V][8] channels-last in dt (channels 4..7 zero): input of `encoder1`, whose first
+ *   3x3x3 conv (4 -> E/2, unetr_block.py:35-44) and 1x1x1 residual conv run on weights padded to 8 input channels (pack mode 12).
+ * nmh_head_upsample_fwd: y [B*R^3][Cp] (dt, head GEMM output, first Co columns) -> pred (B,Co,Ro,Ro,Ro) fp32 with nn.Upsample(scale_factor,
+ *   mode="nearest") source indices min(floorf(dst * inv_scale), R-1) (feature_extractor.py:2036,2224-2229; a 1x1x1 conv commutes with
+ *   nearest upsampling, so `voxel_out` runs before it); Ro == R, inv_scale == 1: plain channels-last -> NCDHW (the semantics head).
+ * nmh_head_upsample_bwd: its adjoint, g [B*R^3][Cp] (dt) = sum of dpred over the output voxels that read each source voxel (columns >= Co zero).
+ * nmh_add_cols_f32: dst[m][0:C] += src[m][0:C] (row strides in elements): un-padding of gradients computed on padded operands. */
+NMH_API int nmh_grid_to_cl8(int dt, const float* grid, void* out, int B, int64_t V, void* stream);
+NMH_API int nmh_head_upsample_fwd(int dt, const void* y, float* pred, int B, int Co, int Cp, int R, int Ro, float inv_scale, void* stream);
+NMH_API int nmh_head_upsample_bwd(int dt, const float* dpred, void* g, int B, int Co, int Cp, int R, int Ro, float inv_scale, void* stream);
+NMH_API int nmh_add_cols_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream);
+/* VoxelSR loss (feature_extractor.py:2133-2160): loss = sum_v m (pred_rgb - target_rgb)^2 / sum_v m, m = target_alpha > 0.01; pred and
+ * target (B,4,V) fp32; sums fp64[2] = {numerator, sum m}.  _bwd: dpred = gscale * d(loss)/d(pred) (alpha plane 0). */
+NMH_API int nmh_voxel_sr_loss_fwd(const float* pred, const float* target, int B, int64_t V, double* sums, float* loss, void* stream);
+NMH_API int nmh_voxel_sr_loss_bwd(const float* pred, const float* target, int B, int64_t V, const double* sums, float gscale, float* dpred, void* stream);
+/* VoxelSemantics loss (nerf_rpn/model/metrics.py:540-553 with nn.CrossEntropyLoss(weight), feature_extractor.py:2700-2722): logits (B,K,V)
+ * fp32, labels (B,V) fp32 class ids (0 = unlabelled), mask m = label > 0, cross entropy over ALL voxels of (logits*m, label*m) with
+ * optional class weights [K]; sums fp64[2] = {sum w nll, sum w}; iou_sums fp64 [B][K-1][3] = {sum m p_k, #(label = k), sum_{label=k} p_k}
+ * (mIoULoss_new, metrics.py:194-245); out fp32[2] = {loss, mean soft IoU}.  _bwd: dlogits = gscale * d(loss)/d(logits).  K <= 32. */
+NMH_API int nmh_masked_ce_fwd(const float* logits, const float* labels, const float* class_weights, int B, int K, int64_t V, double* sums, double* iou_sums, float* out, void* stream);
+NMH_API int nmh_masked_ce_bwd(const float* logits, const float* labels, const float* class_weights, int B, int K, int64_t V, const double* sums, float gscale, float* dlogits, void* stream);
 /* Per-step host parameters of the training step in ONE launch, passed as kernel arguments (no host-to-device copies):
  *  - block_bits (HOST, nb^3 bits, bit (a*nb+b)*nb+c = 1: the 4x4x4-token block (a,b,c) is removed; window_masking_3d's raster order,
  *    swin_mae3d.py:1366-1373) is expanded to the token mask tokmask[g^3] (device, uint8; tokens outside the nb^3 blocks stay 0);

@@ -230,6 +230,46 @@ int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const flo
 }
 int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream) {
   CLR(); return k_add_inplace(dt, a, b, (long)n, ST); }
+int nmh_grid_to_cl8(int dt, const float* grid, void* out, int B, int64_t V, void* stream) {
+  CLR();
+  if (!grid || !out) return -4;
+  return k_grid_to_cl8(dt, grid, out, B, (long)V, ST);
+}
+int nmh_head_upsample_fwd(int dt, const void* y, float* pred, int B, int Co, int Cp, int R, int Ro, float inv_scale, void* stream) {
+  CLR();
+  if (!y || !pred || Co > Cp) return -4;
+  return k_cl_to_ncdhw_up(dt, y, pred, B, Co, Cp, R, Ro, inv_scale, ST);
+}
+int nmh_head_upsample_bwd(int dt, const float* dpred, void* g, int B, int Co, int Cp, int R, int Ro, float inv_scale, void* stream) {
+  CLR();
+  if (!dpred || !g || Co > Cp) return -4;
+  return k_ncdhw_up_adjoint(dt, dpred, g, B, Co, Cp, R, Ro, inv_scale, ST);
+}
+int nmh_add_cols_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t M, int C, void* stream) {
+  CLR();
+  if (!src || !dst) return -4;
+  return k_add_cols_f32(src, (long)lds, dst, (long)ldd, (long)M, C, ST);
+}
+int nmh_voxel_sr_loss_fwd(const float* pred, const float* target, int B, int64_t V, double* sums, float* loss, void* stream) {
+  CLR();
+  if (!pred || !target || !sums || !loss) return -4;
+  return k_sr_loss_fwd(pred, target, B, (long)V, sums, loss, ST);
+}
+int nmh_voxel_sr_loss_bwd(const float* pred, const float* target, int B, int64_t V, const double* sums, float gscale, float* dpred, void* stream) {
+  CLR();
+  if (!pred || !target || !sums || !dpred) return -4;
+  return k_sr_loss_bwd(pred, target, B, (long)V, sums, gscale, dpred, ST);
+}
+int nmh_masked_ce_fwd(const float* logits, const float* labels, const float* class_weights, int B, int K, int64_t V, double* sums, double* iou_sums, float* out, void* stream) {
+  CLR();
+  if (!logits || !labels || !sums || !iou_sums || !out) return -4;
+  return k_masked_ce_fwd(logits, labels, class_weights, B, K, (long)V, sums, iou_sums, out, ST);
+}
+int nmh_masked_ce_bwd(const float* logits, const float* labels, const float* class_weights, int B, int K, int64_t V, const double* sums, float gscale, float* dlogits, void* stream) {
+  CLR();
+  if (!logits || !labels || !sums || !dlogits) return -4;
+  return k_masked_ce_bwd(logits, labels, class_weights, B, K, (long)V, sums, gscale, dlogits, ST);
+}
 int nmh_step_params(const uint32_t* block_bits, int nb, int g, unsigned char* tokmask, const float* hyper, float* hyper_dev, const int* extents, int n_ext, int* extents_dev,
                     void* stream) {
   CLR();

@@ -176,6 +176,15 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
 int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rowscale, int rows_per_scale, hipStream_t st);
 int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st);
 int k_fill_f32(float* p, float v, long n, hipStream_t st);
+// ---- heads.hip (voxel super-resolution / semantics heads) ----
+int k_grid_to_cl8(int dt, const float* src, void* dst, int B, long V, hipStream_t st);
+int k_cl_to_ncdhw_up(int dt, const void* src, float* dst, int B, int Co, int Cp, int R, int Ro, float inv_scale, hipStream_t st);
+int k_ncdhw_up_adjoint(int dt, const float* dpred, void* g, int B, int Co, int Cp, int R, int Ro, float inv_scale, hipStream_t st);
+int k_add_cols_f32(const float* src, long lds, float* dst, long ldd, long M, int C, hipStream_t st);
+int k_sr_loss_fwd(const float* pred, const float* tgt, int B, long V, double* sums, float* loss, hipStream_t st);
+int k_sr_loss_bwd(const float* pred, const float* tgt, int B, long V, const double* sums, float gscale, float* dpred, hipStream_t st);
+int k_masked_ce_fwd(const float* logits, const float* labels, const float* cw, int B, int K, long V, double* sums, double* iou, float* out, hipStream_t st);
+int k_masked_ce_bwd(const float* logits, const float* labels, const float* cw, int B, int K, long V, const double* sums, float gscale, float* dlogits, hipStream_t st);
 int k_step_params(const unsigned* bits, int nb, int g, unsigned char* tokmask, const float* hyper_host, float* hyper_dev, const int* ext_host, int n_ext, int* ext_dev, hipStream_t st);
 int k_grad_cast(int to_bf16, const void* src, void* dst, long n, float scale, hipStream_t st);
 

@@ -460,6 +460,7 @@ int k_fill_f32(float* p, float v, long n, hipStream_t st) {
 //  mode 4 convT fwd      src [Ci=d0][Co=d1][k3=d2] -> dst [(t*Co+co)][ci]
 //  mode 5 convT dgrad    dst [ci][(t*Co+co)]
 //  mode 8/9 conv64 fragment order (conv64.hip), see pack_src_index
+//  mode 10/11 zero-padded rows / transposed with zero-padded columns (head weights, N padded to 8); mode 12 conv weights with Cin padded to 8
 //  mode 6/7 conv48 fragment order (conv48.hip): dst [step 41][ntile 3][lane 64][8] from the mode-2 (fwd) / mode-3 (dgrad) view
 //           W'[n][tap][k]: lane (li, g) of co-tile nt holds n = 12*(li>>2) + 4*nt + (li&3), slot j; steps < 36: tap-row r = 4*(s/18)+g, vector c = s%18; steps >= 36: row 8,
 //           c = 4*(s-36)+g (c >= 18 -> zero padding)
@@ -485,6 +486,9 @@ __device__ __forceinline__ long pack_src_index(const PackDesc& d, long il) {
       // W'[n][tap][k]: fwd  = W[co=n][ci=k][tap];  dgrad = W[co=k][ci=n][26-tap]
       return d.mode == 6 ? ((long)n * 48 + k) * 27 + tap : ((long)k * 48 + n) * 27 + (26 - tap);
     }
+    case 10: { unsigned r = i / d1; return r < d0 ? (long)i : -1; }                                   // [d0][d1] -> [d2 >= d0 rows][d1], zero rows
+    case 11: { unsigned c = i / d2, r = i - c * d2; return r < d0 ? (long)(r * d1 + c) : -1; }          // [d0][d1] -> transposed [d1][d2 >= d0], zero columns
+    case 12: { unsigned ci = i & 7u, t2 = i >> 3, co = t2 / d2, t = t2 - co * d2; return ci < d1 ? (long)((co * d1 + ci) * d2 + t) : -1; }   // [Co][Ci<=8][taps] -> [Co][taps][8]
     case 8: case 9: {
       // conv64.hip fragment order [os][cs][step 54][co-tile 4][lane 64][8]: lane (li, g) of co-tile nt holds output channel
       // 64 os + 16 (li>>2) + 4 nt + (li&3) (an accumulator lane owns 16 consecutive channels), contraction slot cs*64 + (step&1)*32 + 8g + j of tap step>>1

@@ -98,7 +98,7 @@ class _Packer:
     """Owns the flat compute-dtype buffer holding every GEMM operand layout derived from the fp32 master
     parameters, and the device descriptor table for the single-launch pack kernel."""
 
-    CAST, TRANS, CONV_F, CONV_D, CONVT_F, CONVT_D, C48_F, C48_D, C64_F, C64_D = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+    CAST, TRANS, CONV_F, CONV_D, CONVT_F, CONVT_D, C48_F, C48_D, C64_F, C64_D, PAD_ROWS, PAD_ROWS_T, PAD_CIN8 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
     C48_NUMEL = 41 * 3 * 64 * 8  # conv48.hip fragment order [step][ntile][lane][8]
 
     def __init__(self):
@@ -116,6 +116,11 @@ class _Packer:
         else:
             dims = (sh[0], sh[1], int(np.prod(sh[2:])))
         numel = self.C48_NUMEL if mode in (self.C48_F, self.C48_D) else ops.conv64_pack_numel(sh[1], sh[0]) if mode in (self.C64_F, self.C64_D) else p.numel()
+        if mode in (self.PAD_ROWS, self.PAD_ROWS_T):     # [Co][C] -> [Cop][C] / [C][Cop], Cop = Co rounded up to 8 (GEMM N granule)
+            cop = (sh[0] + 7) // 8 * 8
+            dims, numel = (sh[0], int(np.prod(sh[1:])), cop), cop * int(np.prod(sh[1:]))
+        elif mode == self.PAD_CIN8:                      # conv weights [Co][Ci <= 8][taps] -> [Co][taps][8]
+            dims, numel = (sh[0], sh[1], int(np.prod(sh[2:]))), sh[0] * int(np.prod(sh[2:])) * 8
         self.items.append((key, p, mode, dims, numel))
 
     def build(self, dtype: torch.dtype, device):

@@ -616,3 +616,59 @@ def copy_cols(src, dst):
     M, C = src.shape
     lib().call("nmh_copy_cols", dt_of(src), src, src.stride(0), dst, dst.stride(0), M, C, _st())
     return dst
+
+
+# ---- voxel super-resolution / semantics heads (csrc/heads.hip) -----------------------------------------------------
+def grid_to_cl8(xb, dtype):
+    """(B,4,R,R,R) fp32 grid -> (B,R,R,R,8) channels-last in `dtype`, channels 4..7 zero"""
+    _chk(xb)
+    B, _, D, H, W = xb.shape
+    out = torch.empty((B, D, H, W, 8), dtype=dtype, device=xb.device)
+    lib().call("nmh_grid_to_cl8", dt_of(out), xb, out, B, D * H * W, _st())
+    return out
+
+
+def head_upsample_fwd(y, Co, B, R, Ro, inv_scale):
+    """y [B*R^3][Cp] -> pred (B,Co,Ro,Ro,Ro) fp32 NCDHW, nearest upsampling with ATen's explicit-scale source index"""
+    _chk(y)
+    pred = torch.empty((B, Co, Ro, Ro, Ro), dtype=torch.float32, device=y.device)
+    lib().call("nmh_head_upsample_fwd", dt_of(y), y, pred, B, Co, y.shape[1], R, Ro, inv_scale, _st())
+    return pred
+
+
+def head_upsample_bwd(dpred, Cp, R, dtype, inv_scale):
+    _chk(dpred)
+    B, Co, Ro = dpred.shape[0], dpred.shape[1], dpred.shape[2]
+    g = torch.empty((B * R ** 3, Cp), dtype=dtype, device=dpred.device)
+    lib().call("nmh_head_upsample_bwd", dt_of(g), dpred, g, B, Co, Cp, R, Ro, inv_scale, _st())
+    return g
+
+
+def add_cols_f32(src, dst, C):
+    """dst[m][:C] += src[m][:C] for fp32 2-D views (rows = leading dim)"""
+    _chk(src, dst)
+    lib().call("nmh_add_cols_f32", src, src.stride(0), dst, dst.stride(0), src.shape[0], C, _st())
+    return dst
+
+
+def voxel_sr_loss_fwd(pred, target, sums, loss):
+    _chk(pred, target, sums, loss)
+    B = pred.shape[0]
+    lib().call("nmh_voxel_sr_loss_fwd", pred, target, B, pred[0, 0].numel(), sums, loss, _st())
+
+
+def voxel_sr_loss_bwd(pred, target, sums, gscale, dpred):
+    _chk(pred, target, sums, dpred)
+    lib().call("nmh_voxel_sr_loss_bwd", pred, target, pred.shape[0], pred[0, 0].numel(), sums, gscale, dpred, _st())
+
+
+def masked_ce_fwd(logits, labels, class_weights, sums, iou_sums, out):
+    _chk(logits, labels, class_weights, sums, iou_sums, out)
+    B, K = logits.shape[:2]
+    lib().call("nmh_masked_ce_fwd", logits, labels, class_weights, B, K, logits[0, 0].numel(), sums, iou_sums, out, _st())
+
+
+def masked_ce_bwd(logits, labels, class_weights, sums, gscale, dlogits):
+    _chk(logits, labels, class_weights, sums, dlogits)
+    B, K = logits.shape[:2]
+    lib().call("nmh_masked_ce_bwd", logits, labels, class_weights, B, K, logits[0, 0].numel(), sums, gscale, dlogits, _st())

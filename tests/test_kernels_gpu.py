@@ -104,7 +104,7 @@ def test_gemm_tn(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 5, 6, 7, 16, 24), (1, 8, 8, 8, 48, 48), (1, 4, 9, 5, 96, 48), (1, 10, 10, 10, 24, 96), (2, 10, 10, 10, 192, 96), (1, 5, 6, 20, 96, 192)])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(2, 5, 6, 7, 16, 24), (1, 8, 8, 8, 48, 48), (1, 4, 9, 5, 96, 48), (1, 10, 10, 10, 24, 96), (2, 10, 10, 10, 192, 96), (1, 5, 6, 20, 96, 192), (2, 32, 32, 32, 96, 48), (2, 32, 32, 32, 48, 48)])
 def test_conv3d_fwd_dgrad_wgrad(dt, B, D, H, W, Cin, Cout):
     ops = _ops()
     x = q(rnd(B, Cin, D, H, W), dt)
@@ -296,7 +296,7 @@ def test_window_attention_core(dt, shape, shift, heads):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("B,V,C,rmode", [(2, 1000, 48, 0), (2, 343, 96, 1), (1, 5000, 48, 1), (2, 216, 384, 2), (1, 8 ** 3, 192, 2)])
+@pytest.mark.parametrize("B,V,C,rmode", [(2, 1000, 48, 0), (2, 343, 96, 1), (1, 5000, 48, 1), (2, 216, 384, 2), (1, 8 ** 3, 192, 2), (2, 32 ** 3, 48, 2), (2, 32 ** 3, 48, 0)])
 def test_instnorm_fwd_bwd(dt, B, V, C, rmode):
     ops = _ops()
     x = q(rnd(B, V, C) * 1.5 + 0.3, dt)
@@ -332,7 +332,7 @@ def test_instnorm_fwd_bwd(dt, B, V, C, rmode):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("k,Cin,Cout,v,skip", [(2, 96, 48, 3, True), (4, 48, 24, 2, False), (2, 768, 384, 2, True)])
+@pytest.mark.parametrize("k,Cin,Cout,v,skip", [(2, 96, 48, 3, True), (4, 48, 24, 2, False), (2, 768, 384, 2, True), (4, 96, 48, 8, True)])
 def test_upconv_block_pieces(dt, k, Cin, Cout, v, skip):
     """ConvTranspose3d(k=s) = GEMM + pixel shuffle (+bias, +skip concat); backward pieces incl. weight grad remap."""
     ops = _ops()
