@@ -345,13 +345,16 @@ def e2e_leg(model, args, R, sweep):
     res = {}
     for name, dt_ in (("uint8_scenes", np.uint8), ("fp32_scenes", np.float32)):
         scenes = [data.synthetic_scene((R, R, R), seed=50 + i, dtype=dt_) for i in range(8)]
-        tr = Trainer(model, scenes * 5, batch_size=nb, num_epochs=1, log=lambda *_: None)
-        tr.train_epoch(1)      # capture + warm
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        tr.train_epoch(2)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        tr = Trainer(model, scenes * 8, batch_size=nb, num_epochs=1, log=lambda *_: None)
+        tr.train_epoch(1)      # capture + warm (pinned rings, copy stream)
+        dt = None
+        for ep in (2, 3):      # steady state: the better of two timed epochs of 16 steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.train_epoch(ep)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t0
+            dt = d1 if dt is None else min(dt, d1)
         gps = tr.steps_per_epoch * nb / dt
         res[name] = {"grids_per_s": round(gps, 2), "ms_per_step": round(1e3 * dt / tr.steps_per_epoch, 3), "grids_per_gpu": nb}
         ref = sweep.get("%d_grids_per_gpu" % nb)
