@@ -748,14 +748,42 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
   for (int i = threadIdx.x; i < 4 * C; i += 256) atomicAdd(&dWout[i], sred[2 * C + i] * (i / C < 3 ? inv_occ : inv_rm));
   if (blockIdx.x == 0 && b == 0 && threadIdx.x < 4) atomicAdd(&dbout[threadIdx.x], (float)(lsums[4 + threadIdx.x] * (threadIdx.x < 3 ? 1.0 / lsums[1] : 1.0 / lsums[3])));
 }
+// the forward's un-normalised reductions (k_tail_fwd, bwd_sums) -> in_sums[b][c] = {sum g, sum g*xhat}, dWout += , dbout += , with the loss normalisers
+__global__ void tail_sums_finalize_kernel(const double* __restrict__ bs, const double* __restrict__ lsums, double* __restrict__ in_sums, float* __restrict__ dWout,
+                                          float* __restrict__ dbout, int B, int C) {
+  const double inv_occ = 1.0 / lsums[1], inv_rm = 1.0 / lsums[3];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * C) {
+    in_sums[2 * i] = bs[4 * i] * inv_occ + bs[4 * i + 2] * inv_rm;
+    in_sums[2 * i + 1] = bs[4 * i + 1] * inv_occ + bs[4 * i + 3] * inv_rm;
+  } else if (i < B * C + 4 * C) {
+    const int k = i - B * C;
+    dWout[k] += (float)(bs[(long)B * C * 4 + k] * (k / C < 3 ? inv_occ : inv_rm));
+  } else if (i < B * C + 4 * C + 4) {
+    const int o = i - B * C - 4 * C;
+    dbout[o] += (float)(lsums[4 + o] * (o < 3 ? inv_occ : inv_rm));
+  }
+}
 int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
-               void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, hipStream_t st) {
+               void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, const double* bwd_sums, hipStream_t st) {
   if (C % 8 || C / 8 > 256 || (!d0 && !r)) return -2;
-  hipError_t e = nmh_zero_async(in_sums, sizeof(double) * 2 * B * C, st);
-  if (e != hipSuccess) return (int)e;
   const long vpb = in_vox_per_block(V, B);
   const long vpa = in_apply_vpb(V, B, C);
   dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + vpa - 1) / vpa), B);
+  if (bwd_sums) {   // the reductions were taken by the forward pass: one apply pass is all that is left
+    const int n = B * C + 4 * C + 4;
+    hipLaunchKernelGGL(tail_sums_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bwd_sums, loss_sums, in_sums, dWout, dbout, B, C);
+    if (dt == NMH_DT_BF16)
+      hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
+                         (bf16_t*)dr, slope, dWout, dbout, V, C, vpa);
+    else
+      hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), g1, dim3(256), 0, st, (const float*)d0, (const float*)r, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)dx,
+                         (float*)dr, slope, dWout, dbout, V, C, vpa);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
+  hipError_t e = nmh_zero_async(in_sums, sizeof(double) * 2 * B * C, st);
+  if (e != hipSuccess) return (int)e;
   const size_t lds = 6 * C * sizeof(float);
   if (dt == NMH_DT_BF16) {
     hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 0>), g0, dim3(256), lds, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)nullptr,
@@ -777,10 +805,15 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
 // partial dot of its 8 channels, the C/8 lanes of a voxel are summed with ds_bpermute (a wave holds floor(64/(C/8)) whole voxels, the
 // rest of its lanes idle), and the voxel's leader lane evaluates the loss terms / writes d(pred) -- the separate loss kernel (one more
 // read of d0) disappears.  Same math as loss_kernel<T,0> (misc.hip); the head sees the stored (rounded) d0, as the backward does.
-template <typename T>
+// BS (a.bwd_sums): the reductions of the tail BACKWARD are taken here as well -- the pass already holds d0 and x-hat in registers and
+// learns d(pred) per voxel, so {sum g, sum g*xhat} of the last InstanceNorm and the head's weight gradient come out of the forward
+// (kept separately for the RGB and the alpha part of the loss: their normalisers are only known once the pass is complete), and the
+// backward is a single apply pass (k_tail_bwd with bwd_sums): one 3-tensor read pass over 160^3 x C less per step.
+template <typename T, bool BS>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, const float* __restrict__ stats, const T* __restrict__ r, T* __restrict__ out, LossArgs a,
                                                        long V, int C, float slope, long vpb) {
   __shared__ float sacc[8];
+  extern __shared__ float slab[];   // BS: [64][256] block-reduction slab
   const int CL = C >> 3, VPW = 64 / CL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
   const int vl = lane / CL, cl = lane - vl * CL;
@@ -803,6 +836,13 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
   const unsigned Ru = (unsigned)a.R;
   const int g = a.R >> 2;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float bs[BS ? 8 : 1][8];   // BS: rows 0..3 = {s1_rgb, s2_rgb, s1_a, s2_a}, rows 4..7 = head weight-gradient sums for the 4 outputs
+  if (BS) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bs[BS ? k : 0][j] = 0.f;
+  }
   const long v0 = (long)blockIdx.x * vpb;
   long v1 = v0 + vpb;
   if (v1 > V) v1 = V;
@@ -827,12 +867,15 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
       }
     }
     float p[4] = {0.f, 0.f, 0.f, 0.f};
+    float xh[BS ? 8 : 1], yq[BS ? 8 : 1];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float y = (xv[j] - mu[j]) * rs[j] + rv[j];
+      const float xhat = (xv[j] - mu[j]) * rs[j];
+      float y = xhat + rv[j];
       y = y > 0.f ? y : slope * y;
       xv[j] = y;
       const float yr = to_f<T>(from_f<T>(y));   // the value the backward (and the reference's next op) sees
+      if (BS) { xh[BS ? j : 0] = xhat; yq[BS ? j : 0] = yr; }
       p[0] += yr * w[0][j]; p[1] += yr * w[1][j]; p[2] += yr * w[2][j]; p[3] += yr * w[3][j];
     }
     if (ok && out) Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv);
@@ -860,7 +903,40 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
         d.w = rm ? 2.f * (sg - t3) * sg * (1.f - sg) : 0.f;
         *reinterpret_cast<float4*>(a.dp + ((long)b * V + v) * 4) = d;
         acc[4] += d.x; acc[5] += d.y; acc[6] += d.z; acc[7] += d.w;
+        if (BS) { tot[0] = d.x; tot[1] = d.y; tot[2] = d.z; tot[3] = d.w; }   // handed to the voxel's other lanes below
       }
+    }
+    if (BS) {
+      const int src = lane - cl;   // the voxel's leader lane
+      const float d0x = __shfl(tot[0], src, 64), d0y = __shfl(tot[1], src, 64), d0z = __shfl(tot[2], src, 64), d0w = __shfl(tot[3], src, 64);
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float lr = yq[BS ? j : 0] > 0.f ? 1.0f : slope;
+          const float gr = (d0x * w[0][j] + d0y * w[1][j] + d0z * w[2][j]) * lr, ga = d0w * w[3][j] * lr;
+          const float xq = xh[BS ? j : 0], yv = yq[BS ? j : 0];
+          bs[0][j] += gr; bs[BS ? 1 : 0][j] += gr * xq; bs[BS ? 2 : 0][j] += ga; bs[BS ? 3 : 0][j] += ga * xq;
+          bs[BS ? 4 : 0][j] += d0x * yv; bs[BS ? 5 : 0][j] += d0y * yv; bs[BS ? 6 : 0][j] += d0z * yv; bs[BS ? 7 : 0][j] += d0w * yv;
+        }
+      }
+    }
+  }
+  if (BS) {
+    // block reduction through an LDS slab (no same-address atomics): thread t parks its 64 partials in column t; the sums of a channel
+    // chunk cl live in the threads wave*64 + vl*CL + cl
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) slab[(k * 8 + j) * 256 + threadIdx.x] = active ? bs[BS ? k : 0][j] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * CL; i += 256) {
+      const int kk = i / CL, c8 = i - kk * CL, k = kk >> 3, j = kk & 7;
+      float t = 0.f;
+      for (int wv = 0; wv < 4; ++wv)
+        for (int q = 0; q < VPW; ++q) t += slab[kk * 256 + wv * 64 + q * CL + c8];
+      const int c = c8 * 8 + j;
+      double* dst = k < 4 ? a.bwd_sums + ((long)b * C + c) * 4 + k : a.bwd_sums + (long)a.B * C * 4 + (long)(k - 4) * C + c;
+      atomicAdd(dst, (double)t);
     }
   }
 #pragma unroll
@@ -881,8 +957,25 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
   if (vpb < 160) vpb = 160;
   if (vpb > 2048) vpb = 2048;
   dim3 grid((unsigned)((V + vpb - 1) / vpb), a.B);
-  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL(tail_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, (bf16_t*)out, a, V, C, slope, vpb);
-  else hipLaunchKernelGGL(tail_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, (const float*)r, (float*)out, a, V, C, slope, vpb);
+  if (a.bwd_sums) {
+    if (!a.dp) return -4;   // the fused backward sums are built from d(pred)
+    e = nmh_zero_async(a.bwd_sums, sizeof(double) * ((size_t)a.B * C * 4 + 4 * C), st);
+    if (e != hipSuccess) return (int)e;
+    const size_t lds = 64 * 256 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      e = hipFuncSetAttribute((const void*)tail_fwd_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tail_fwd_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((tail_fwd_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)x, stats, (const bf16_t*)r, (bf16_t*)out, a, V, C, slope, vpb);
+    else hipLaunchKernelGGL((tail_fwd_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, stats, (const float*)r, (float*)out, a, V, C, slope, vpb);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
+  if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((tail_fwd_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, (bf16_t*)out, a, V, C, slope, vpb);
+  else hipLaunchKernelGGL((tail_fwd_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, stats, (const float*)r, (float*)out, a, V, C, slope, vpb);
   NMH_CHECK_LAUNCH();
   return 0;
 }

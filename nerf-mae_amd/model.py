@@ -407,10 +407,12 @@ class _UpBlockFn(torch.autograd.Function):
             lsums = torch.empty(8, dtype=torch.float64, device=dev)
             losses = torch.empty(3, device=dev)
             dpred = torch.empty((B * V, 4), device=dev) if ctx.needs_input_grad[0] else None
+            # the reductions of the tail BACKWARD (InstanceNorm-backward sums, head weight gradient) are taken by the same pass
+            bsum = torch.empty(B * Cout * 4 + 4 * Cout, dtype=torch.float64, device=dev) if (dpred is not None and model.fuse_tail_sums) else None
             # last InstanceNorm + residual + LeakyReLU, the 1x1 head and the loss terms in one pass over (y2, cat)
             ops.mae_tail_fwd(y2, st2, cat, out, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask, B, S, Cout, lsums, losses,
-                             pred_out, dpred)
-            ctx.tail = (model, lsums, dpred)
+                             pred_out, dpred, bwd_sums=bsum)
+            ctx.tail = (model, lsums, dpred, bsum)
             return losses
         return out
 
@@ -429,9 +431,9 @@ class _UpBlockFn(torch.autograd.Function):
         dy2 = torch.empty_like(y2)
         dcat = torch.empty_like(cat)
         if ctx.tail is not None:   # d(loss)/d(losses[0]) == 1 (the reference calls loss.backward()); d(d0) is never materialised
-            model, lsums, dpred = ctx.tail
+            model, lsums, dpred, bsum = ctx.tail
             ops.mae_tail_bwd(None, y2, st2, dpred, lsums, model.out.conv.weight, sums2, dy2, dcat,
-                             _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout, r=cat)
+                             _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout, r=cat, bwd_sums=bsum)
         elif m.has_proj:
             dout = dout.contiguous()
             sums3 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
@@ -830,6 +832,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
         return self.decoder1(d, tail=tail)
 
     fuse_tail = True   # loss backward fused with the last decoder level's InstanceNorm backward (False: separate kernels)
+    fuse_tail_sums = __import__("os").environ.get("NMH_TAIL_SUMS", "1") != "0"   # the tail backward's reductions taken in the tail forward pass
 
     def _decode_and_loss(self, feats, xb, ext, mask_dev, pred):
         if self.fuse_tail:

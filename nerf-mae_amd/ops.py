@@ -461,27 +461,29 @@ def mae_loss_bwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, 
     lib().call("nmh_mae_loss_bwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, dpred8, dWout, dbout, _st())
 
 
-def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred=None, dpred=None, slope=0.01):
+def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred=None, dpred=None, slope=0.01, bwd_sums=None):
     """d0 = lrelu(IN(y) + r), 1x1 head and loss terms in one pass (instnorm_apply rmode 1 + mae_loss_fwd); d0 = None: not stored"""
-    _chk(y, stats, r, d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred)
+    _chk(y, stats, r, d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred, bwd_sums)
     if dpred is not None and sums.numel() < 8:
         raise ValueError("mae_tail_fwd: sums needs 8 entries when dpred is requested")
+    if bwd_sums is not None and (dpred is None or bwd_sums.numel() < B * C * 4 + 4 * C):
+        raise ValueError("mae_tail_fwd: bwd_sums needs dpred and B*C*4 + 4*C entries")
     # algorithmic bytes: y and r read once, the fp32 target (4 channels) read once, d(pred) (16 B / voxel) and d0 written if requested
     ev = _prof(("mae_tail_fwd", B, R, C), (2 + (d0 is not None)) * y.numel() * y.element_size() + B * R ** 3 * 16 * (1 + (dpred is not None) + (pred is not None)))
-    lib().call("nmh_mae_tail_fwd", dt_of(y), y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope, _st())
+    lib().call("nmh_mae_tail_fwd", dt_of(y), y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope, bwd_sums, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return losses
 
 
-def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01, r=None):
+def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01, r=None, bwd_sums=None):
     """d0 may be None when r (the forward's residual input) is given: the kernel rebuilds d0 from y, stats and r"""
-    _chk(d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout)
+    _chk(d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, bwd_sums)
     if d0 is None and r is None:
         raise ValueError("mae_tail_bwd needs d0 or r")
     # two passes (sums, then apply): y and r (or d0) read twice, d(pred) read twice, dy and dr written once
-    ev = _prof(("mae_tail_bwd", B, V, C), 6 * y.numel() * y.element_size() + 2 * B * V * 16)
-    lib().call("nmh_mae_tail_bwd", dt_of(y), d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, _st())
+    ev = _prof(("mae_tail_bwd", B, V, C), (4 if bwd_sums is not None else 6) * y.numel() * y.element_size() + (1 if bwd_sums is not None else 2) * B * V * 16)
+    lib().call("nmh_mae_tail_bwd", dt_of(y), d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, bwd_sums, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
 

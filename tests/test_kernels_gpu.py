@@ -496,6 +496,17 @@ def test_tail_backward_fused(dt):
     assert torch.equal(dr3, drk)                                                        # elementwise: bit-identical
     assert torch.allclose(dy3.float(), dyk.float(), rtol=1e-2 if dt == torch.bfloat16 else 1e-4, atol=1e-6)   # goes through the fp64-atomic channel sums
     assert torch.allclose(dW3, dWk, rtol=1e-5, atol=1e-6)
+    # reductions of the backward taken by the forward pass (bwd_sums): the backward is one apply pass, same gradients
+    lsums4, losses4, dpred4 = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda"), torch.empty(B * V, 4, device="cuda")
+    bsum = torch.empty(B * Cd * 4 + 4 * Cd, dtype=torch.float64, device="cuda")
+    ops.mae_tail_fwd(yd.view(-1, Cd), stats, rd.view(-1, Cd), None, args[1], args[2], args[3], args[4], args[5], B, R, Cd, lsums4, losses4, None, dpred4, bwd_sums=bsum)
+    assert torch.equal(dpred4, dpred2) and torch.allclose(losses4, losses2, rtol=1e-6)
+    dy4, dr4, dW4, db4, in_sums4 = torch.empty_like(dy), torch.empty_like(dr), torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda"), torch.empty_like(in_sums)
+    ops.mae_tail_bwd(None, yd.view(-1, Cd), stats, dpred4, lsums4, args[1], in_sums4, dy4, dr4, dW4, db4, B, V, Cd, r=rd.view(-1, Cd), bwd_sums=bsum)
+    assert torch.equal(dr4, dr3)
+    assert torch.allclose(in_sums4, in_sums3, rtol=1e-4, atol=1e-7)
+    assert torch.allclose(dy4.float(), dy3.float(), rtol=1e-2 if dt == torch.bfloat16 else 1e-4, atol=1e-6)
+    assert torch.allclose(dW4, dW3, rtol=1e-4, atol=1e-6) and torch.allclose(db4, db3, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("dt", DTS)
