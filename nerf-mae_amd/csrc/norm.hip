@@ -846,26 +846,59 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
   const long v0 = (long)blockIdx.x * vpb;
   long v1 = v0 + vpb;
   if (v1 > V) v1 = V;
+  // software pipeline: the loads of iteration i+1 (x, r chunks as raw 16-byte words; the leader's target / mask values) are issued before
+  // iteration i is processed -- with the backward sums this kernel runs at 2 waves per SIMD and every iteration is one long dependent
+  // chain (dot -> shuffle tree -> loss terms -> broadcast -> accumulate), so the memory latency has to be hidden inside the wave
+  constexpr int RW = sizeof(T) == 2 ? 1 : 2;     // 16-byte words per 8-element chunk
+  uint4 nx[RW], nr[RW];
+  float nt0 = 0.f, nt1 = 0.f, nt2 = 0.f, nt3 = 0.f;
+  unsigned char ntm = 0;
+  auto issue = [&](long bs0) {
+    const long vq = bs0 + vl;
+#pragma unroll
+    for (int q = 0; q < RW; ++q) { nx[q] = make_uint4(0, 0, 0, 0); nr[q] = make_uint4(0, 0, 0, 0); }
+    nt0 = nt1 = nt2 = nt3 = 0.f; ntm = 0;
+    if (active && vq < v1) {
+      const long o = ((long)b * V + vq) * C + cl * 8;
+#pragma unroll
+      for (int q = 0; q < RW; ++q) {
+        nx[q] = reinterpret_cast<const uint4*>(x + o)[q];
+        nr[q] = reinterpret_cast<const uint4*>(r + o)[q];
+      }
+      if (cl == 0) {
+        const unsigned vox = (unsigned)vq, tq = vox / Ru, zq = tq / Ru;
+        const int xq = (int)(vox - tq * Ru), yq_ = (int)(tq - zq * Ru), zq_ = (int)zq;
+        const float* tg = a.target + (long)b * 4 * V + vq;
+        nt0 = tg[0]; nt1 = tg[V]; nt2 = tg[2 * V]; nt3 = tg[3 * V];
+        ntm = a.tokmask[((zq_ >> 2) * g + (yq_ >> 2)) * g + (xq >> 2)];
+      }
+    }
+  };
+  auto unpack = [&](const uint4 (&wv)[RW], float (&f)[8]) {
+    if constexpr (sizeof(T) == 2) {
+      const unsigned ww[4] = {wv[0].x, wv[0].y, wv[0].z, wv[0].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(ww[i] << 16); f[2 * i + 1] = __uint_as_float(ww[i] & 0xffff0000u); }
+    } else {
+      f[0] = __uint_as_float(wv[0].x); f[1] = __uint_as_float(wv[0].y); f[2] = __uint_as_float(wv[0].z); f[3] = __uint_as_float(wv[0].w);
+      f[4] = __uint_as_float(wv[RW - 1].x); f[5] = __uint_as_float(wv[RW - 1].y); f[6] = __uint_as_float(wv[RW - 1].z); f[7] = __uint_as_float(wv[RW - 1].w);
+    }
+  };
+  if (v0 + wave * VPW < v1) issue(v0 + wave * VPW);
   for (long base = v0 + wave * VPW; base < v1; base += 4 * VPW) {   // wave-uniform trip count: the shuffles below need every lane
     const long v = base + vl;
     const bool ok = active && v < v1;
-    float xv[8], rv[8], t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    unsigned char tmk = 0;
+    float xv[8], rv[8];
+    unpack(nx, xv);
+    unpack(nr, rv);
+    const float t0 = nt0, t1 = nt1, t2 = nt2, t3 = nt3;
+    const unsigned char tmk = ntm;
     int zz = 0, yy = 0, xx = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { xv[j] = 0.f; rv[j] = 0.f; }
-    if (ok) {
-      const long o = ((long)b * V + v) * C + cl * 8;
-      Vec8<T>::load(x + o, xv);
-      Vec8<T>::load(r + o, rv);
-      if (cl == 0) {
-        const unsigned vox = (unsigned)v, tq = vox / Ru, zq = tq / Ru;
-        xx = (int)(vox - tq * Ru); yy = (int)(tq - zq * Ru); zz = (int)zq;
-        const float* tg = a.target + (long)b * 4 * V + v;
-        t0 = tg[0]; t1 = tg[V]; t2 = tg[2 * V]; t3 = tg[3 * V];
-        tmk = a.tokmask[((zz >> 2) * g + (yy >> 2)) * g + (xx >> 2)];
-      }
+    if (ok && cl == 0) {
+      const unsigned vox = (unsigned)v, tq = vox / Ru, zq = tq / Ru;
+      xx = (int)(vox - tq * Ru); yy = (int)(tq - zq * Ru); zz = (int)zq;
     }
+    if (base + 4 * VPW < v1) issue(base + 4 * VPW);
     float p[4] = {0.f, 0.f, 0.f, 0.f};
     float xh[BS ? 8 : 1], yq[BS ? 8 : 1];
 #pragma unroll
