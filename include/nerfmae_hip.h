@@ -5,7 +5,8 @@
  * the native-op surface a maintainer would bind in place of those calls (INTEGRATION.md shows the ctypes / pybind
  * stubs); each entry cites the reference op it replaces.  Conventions:
  *   - plain device pointers + sizes, no torch types; all launches are asynchronous on `stream` (a hipStream_t);
- *   - return 0 on success, a hipError_t (>0) or a negative argument-error code otherwise (nmh_error_string);
+ *   - return 0 on success, a hipError_t (>0) or a negative argument-error code otherwise (nmh_error_string); a NULL in a required
+ *     pointer argument returns -4 (invalid argument), never a device fault;
  *   - `dt`: storage/compute type of activations and packed weights: 0 = fp32 (exact fp32 MFMA; the 1e-3-parity
  *     mode), 1 = bf16 (bf16 MFMA, fp32 accumulate).  Parameters, gradients and statistics are always fp32.
  *   - activations are channels-last token/voxel-major matrices [rows, C]; rows of a (B,A0,A1,A2,C) volume are
@@ -154,6 +155,9 @@ NMH_API int nmh_mae_tail_bwd(int dt, const void* d0, const void* r, const void* 
 NMH_API int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst, int R, int flags, void* stream);
 NMH_API int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const float* rowscale, int rows_per_scale, void* stream);
 NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream);
+/* out = a + b (out may alias a): the sum of the two gradients of an encoder feature map that feeds both the next stage and a decoder
+ * skip connection (swin_mae3d.py:1465-1470 + unetr_block.py:196-197: autograd's accumulation, as a HIP kernel). */
+NMH_API int nmh_add(int dt, const void* a, const void* b, void* out, int64_t n, void* stream);
 NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
 /* ---- dense-prediction heads on the pretrained encoder + decoder (nerf_rpn/model/feature_extractor.py:1898-2244 VoxelSR, 2521-2848
  * VoxelSemantics).  Their convolutions / norms / GEMMs are the entries above; these are the head-specific pieces. ----

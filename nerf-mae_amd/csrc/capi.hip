@@ -10,6 +10,8 @@ static inline WinMap to_wm(const int* w) {
 }
 #define ST ((hipStream_t)stream)
 #define NMH_DT_BF16_C 1
+// required pointers: a NULL yields the argument-error code -4 instead of a device fault
+#define REQ(...) do { const void* req_[] = {__VA_ARGS__}; for (const void* q_ : req_) if (!q_) return -4; } while (0)
 // hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left behind, so that the
 // post-launch check in the k_* launchers reports only this call's launch status
 #define CLR() (void)hipGetLastError()
@@ -27,6 +29,7 @@ const char* nmh_error_string(int code) {
 int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* C, int64_t ldc, const float* bias, int act, void* C2,
                 const void* resid, const float* rowscale, int rows_per_scale, int accumulate, void* stream) {
   CLR();
+  REQ(A, W, C);
   if (M <= 0) return 0;
   EpiParams ep{C, ldc, bias, act, C2, resid, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, accumulate};
   return k_gemm_nt(dt, A, lda, W, ldw, M, N, K, ep, ST);
@@ -34,6 +37,7 @@ int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, 
 int nmh_gemm_nt_window_scatter(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* out, const void* resid, const float* bias,
                                const float* rowscale, int tokens_per_sample, const int* wm, void* stream) {
   CLR();
+  REQ(A, W, out, resid, wm);
   if (M <= 0) return 0;
   EpiParams ep{out, N, bias, 0, nullptr, resid, rowscale, tokens_per_sample > 0 ? tokens_per_sample : 1, 0};
   ep.win_on = 1; ep.wm = to_wm(wm);
@@ -42,6 +46,7 @@ int nmh_gemm_nt_window_scatter(int dt, const void* A, int64_t lda, const void* W
 int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale,
                 int omode, int64_t ldo, int p0, int p1, float* dbias, float* ws, int64_t ws_floats, void* stream) {
   CLR();
+  REQ(A, B, dW);
   if (M <= 0) return 0;
   TnGeom gm{};
   gm.omode = omode; gm.ldo = ldo; gm.dbias = dbias; gm.ws = ws; gm.ws_floats = ws ? (long)ws_floats : 0;
@@ -57,23 +62,28 @@ int nmh_gemm_tn_grouped(int dt, const nmh_tn_problem* probs, int nprob, float* w
 }
 int nmh_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, int64_t ldc, int B, int v, int k, int Cin, int Cout, void* stream) {
   CLR();
+  REQ(x, Wt, cat);
   return k_upconv_fwd(dt, x, Wt, bias, cat, (long)ldc, B, v, k, Cin, Cout, ST);
 }
 int nmh_upconv_dgrad(int dt, const void* dcat, int64_t ldc, const void* Wd, void* dx, int B, int v, int k, int Cin, int Cout, void* stream) {
   CLR();
+  REQ(dcat, Wd, dx);
   return k_upconv_dgrad(dt, dcat, (long)ldc, Wd, dx, B, v, k, Cin, Cout, ST);
 }
 int nmh_upconv_wgrad(int dt, const void* dcat, int64_t ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, void* stream) {
   CLR();
+  REQ(dcat, x, dW);
   return k_upconv_wgrad(dt, dcat, (long)ldc, x, dW, dbias, B, v, k, Cin, Cout, ST);
 }
 int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
   CLR();
+  REQ(X, Wp, Y);
   EpiParams ep{Y, Cout, nullptr, 0, nullptr, nullptr, nullptr, 1, accumulate};
   return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
 }
 int nmh_conv3d_k3_bias(int dt, const void* X, const void* Wp, const float* bias, void* Y, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
   CLR();
+  REQ(X, Wp, bias, Y);
   EpiParams ep{Y, Cout, bias, 0, nullptr, nullptr, nullptr, 1, 0};
   return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
 }
@@ -91,14 +101,17 @@ int64_t nmh_conv3d_k3_c64_wgrad_ws_floats(void) { return (int64_t)k_conv64_wgrad
 int64_t nmh_conv3d_k3_c64_pack_numel(int Cin, int Cout) { return (Cin % 64 || Cout % 64) ? -1 : (int64_t)k_conv64_pack_numel(Cin, Cout); }
 int nmh_nearest_upsample_add(int dt, const void* coarse, void* fine, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream) {
   CLR();
+  REQ(coarse, fine);
   return k_nearest_up_add(dt, coarse, fine, B, Dc, Hc, Wc, Df, Hf, Wf, C, 0, ST);
 }
 int nmh_nearest_upsample_add_bwd(int dt, const void* dfine, void* dcoarse, int B, int Dc, int Hc, int Wc, int Df, int Hf, int Wf, int C, void* stream) {
   CLR();
+  REQ(dfine, dcoarse);
   return k_nearest_up_add(dt, dcoarse, const_cast<void*>(dfine), B, Dc, Hc, Wc, Df, Hf, Wf, C, 1, ST);
 }
 int nmh_copy_cols(int dt, const void* src, int64_t lds, void* dst, int64_t ldd, int64_t M, int C, void* stream) {
   CLR();
+  REQ(src, dst);
   return k_copy_cols(dt, src, (long)lds, dst, (long)ldd, (long)M, C, ST);
 }
 int nmh_ndhwc_to_ncdhw(int dt, const void* src, float* dst, int B, int64_t V, int C, void* stream) {
@@ -227,6 +240,12 @@ int nmh_bias_grad(int dt, const void* dY, float* db, int64_t M, int N, const flo
   CLR();
   if (M <= 0) return 0;
   return k_bias_grad(dt, dY, db, (long)M, N, rowscale, rows_per_scale > 0 ? rows_per_scale : 1, ST);
+}
+int nmh_add(int dt, const void* a, const void* b, void* out, int64_t n, void* stream) {
+  CLR();
+  if (n <= 0) return 0;
+  if (!a || !b || !out) return -4;
+  return k_add(dt, out, a, b, (long)n, ST);
 }
 int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* stream) {
   CLR(); return k_add_inplace(dt, a, b, (long)n, ST); }

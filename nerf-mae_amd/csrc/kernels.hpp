@@ -177,6 +177,7 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
                void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, const double* bwd_sums, hipStream_t st);
 int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rowscale, int rows_per_scale, hipStream_t st);
 int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st);
+int k_add(int dt, void* out, const void* a, const void* b, long n, hipStream_t st);
 int k_fill_f32(float* p, float v, long n, hipStream_t st);
 // ---- heads.hip (voxel super-resolution / semantics heads) ----
 int k_grid_to_cl8(int dt, const float* src, void* dst, int B, long V, hipStream_t st);

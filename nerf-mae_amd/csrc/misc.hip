@@ -359,23 +359,24 @@ int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* r
   return 0;
 }
 
-template <typename T> __global__ void add_inplace_kernel(T* a, const T* b, long n8) {
+template <typename T> __global__ void add_kernel(T* out, const T* a, const T* b, long n8) {   // out may alias a
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float x[8], y[8];
     Vec8<T>::load(a + i * 8, x);
     Vec8<T>::load(b + i * 8, y);
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] += y[j];
-    Vec8<T>::store(a + i * 8, x);
+    Vec8<T>::store(out + i * 8, x);
   }
 }
-int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st) {
+int k_add(int dt, void* out, const void* a, const void* b, long n, hipStream_t st) {
   if (n % 8) return -2;
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (bf16_t*)a, (const bf16_t*)b, n / 8);
-  else hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (float*)a, (const float*)b, n / 8);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (bf16_t*)out, (const bf16_t*)a, (const bf16_t*)b, n / 8);
+  else hipLaunchKernelGGL(add_kernel<float>, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (float*)out, (const float*)a, (const float*)b, n / 8);
   NMH_CHECK_LAUNCH();
   return 0;
 }
+int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st) { return k_add(dt, a, a, b, n, st); }
 // Per-step host parameters without host-to-device copies: the block mask (one bit per 4x4x4-token block, drawn on the host with the
 // reference's python RNG), the optimizer hyper-parameters and the valid extents travel as KERNEL ARGUMENTS of one tiny launch that
 // expands / stores them into their device buffers.  (Small hipMemcpyAsync uploads were measured to block the calling thread until the

@@ -306,6 +306,24 @@ class _StageFlushFn(torch.autograd.Function):
         return g, None
 
 
+class _Fork2Fn(torch.autograd.Function):
+    """a feature map with two consumers (the next encoder stage and a decoder skip connection / the FPN neck): identity forward, the two
+    incoming gradients are summed by a HIP kernel (autograd's own accumulation would be an ATen add on the dependent chain)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        g1, g2 = g1.contiguous(), g2.contiguous()
+        if g1.numel() % 8:
+            return g1 + g2
+        return ops.add(g1, g2)
+
+
 class _MergeFn(torch.autograd.Function):
     """2x2x2 gather -> LayerNorm(8C) -> Linear(8C,2C,no bias)  (swin_mae3d.py:390-414)."""
 
@@ -818,7 +836,11 @@ class SwinTransformer_MAE3D_New(nn.Module):
             if red is not None:
                 x = red.trigger(x, si + 1)  # backward reaching here => stage si gradients are complete
             x, bi = self._run_stage(si, x, sd_noise, bi)
-            feats.append(x)
+            if si + 1 < len(self.stages) and torch.is_grad_enabled() and x.requires_grad:
+                x, skip = _Fork2Fn.apply(x)     # consumed by the next stage and by a decoder / neck
+                feats.append(skip)
+            else:
+                feats.append(x)
         return feats
 
     def forward_decoder(self, feats: List[Tensor], tail=None) -> Tensor:

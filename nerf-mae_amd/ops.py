@@ -539,6 +539,14 @@ def grad_from_bf16(bucket, g, scale=1.0):
     return g
 
 
+def add(a, b):
+    """a + b into a fresh tensor (HIP kernel; used for the two gradients of a feature map with two consumers)"""
+    _chk(a, b)
+    out = torch.empty_like(a)
+    lib().call("nmh_add", dt_of(a), a, b, out, a.numel(), _st())
+    return out
+
+
 def add_inplace(a, b):
     _chk(a, b)
     lib().call("nmh_add_inplace", dt_of(a), a, b, a.numel(), _st())

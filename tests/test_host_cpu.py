@@ -142,3 +142,17 @@ def test_block_bits_roundtrip_and_rng_stream():
     bad = draw_block_mask((8, 8, 8), 0.5, rng=random.Random(1)).numpy().copy()
     bad[1, 2, 3] ^= 1
     assert block_bits_of_mask(bad) is None
+
+
+def test_capi_rejects_null_required_pointers_without_touching_the_device():
+    """boundary contract (include/nerfmae_hip.h): a NULL in a required pointer argument returns the argument-error code -4 -- no launch,
+    no device fault -- so the check runs on a box without a GPU"""
+    import ctypes
+    from nerf_mae_amd._lib import lib
+    L = lib().cdll
+    null = ctypes.c_void_p(None)
+    assert L.nmh_gemm_nt(1, null, 96, null, 96, 64, 96, 96, null, 96, null, 0, null, null, null, 1, 0, null) == -4
+    assert L.nmh_conv3d_k3(1, null, null, null, 1, 8, 8, 8, 48, 48, 0, null) == -4
+    assert L.nmh_gemm_tn_grouped(1, null, 3, null, 0, null) == -4
+    assert L.nmh_conv3d_k3_c64(null, null, null, 1, 8, 8, 8, 64, 64, 0, null, null, null) == -4
+    assert L.nmh_error_string(-4).decode().startswith("nmh:")
