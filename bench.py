@@ -317,6 +317,28 @@ def main():
                            "algorithmic_bytes_per_launch": nb, "achieved_GBs": round(nb / (avg2 * 1e-3) / 1e9, 1),
                            "frac_of_8TBs": round(nb / (avg2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
         hb.sort(key=lambda d: -d["ms_per_step"])
+        # rocprofv3-reported HBM bytes of the same kernels (separate --pmc passes, tools/pmc_step.sh), quoted only when they were taken
+        # on this source of csrc/norm.hip at the same per-GPU batch
+        try:
+            import glob
+            shan = hashlib.sha256(open(os.path.join(ROOT, "nerf-mae_amd", "csrc", "norm.hip"), "rb").read()).hexdigest()
+            kmap = {"mae_tail_fwd": "tail_fwd_kernel", "mae_tail_bwd": "tail_bwd_kernel", "instnorm_apply": "in_apply_kernel", "instnorm_bwd_apply": "in_bwd_apply_kernel",
+                    "instnorm_bwd_reduce": "in_reduce_kernel"}
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_kernels_pmc.json")))[::-1]:
+                pm = json.load(open(f))
+                if pm.get("norm_hip_sha256") != shan or pm.get("batch_per_gpu") != Bg:
+                    continue
+                for h in hb:
+                    kn = kmap.get(h["kernel"].split(":")[0])
+                    cands = [v for k, v in pm["kernels"].items() if kn and k.startswith(kn)]
+                    if cands:
+                        tot_b = sum(c["hbm_bytes_per_launch"] for c in cands) if kn == "tail_bwd_kernel" else max(c["hbm_bytes_per_launch"] for c in cands)
+                        h["pmc_hbm_bytes_per_launch"] = tot_b
+                        h["pmc_GBs"] = round(tot_b / (h["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                        h["pmc_source"] = os.path.basename(f)
+                break
+        except Exception as e:  # noqa: BLE001
+            out.setdefault("roofline", {})["hbm_pmc_error"] = repr(e)
         if "roofline" in out:
             out["roofline"]["hbm_kernels"] = hb[:3]
         tot = {}

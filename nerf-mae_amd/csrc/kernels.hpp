@@ -46,32 +46,41 @@ struct TnGeom {
 
 #ifdef __HIPCC__
 // window order <-> token order of the 4x4x4 shifted-window partition (pad -> roll(-shift) -> partition; swin_mae3d.py:62-101)
+// (32-bit unsigned arithmetic: every row / token count of this path is < 2^31, and a 64-bit div/mod costs ~150 VALU instructions on
+//  gfx950 against ~30 for the 32-bit form -- six of them per row made the window gathers / scatters VALU-bound at stage 0)
 __device__ __forceinline__ long win_to_tok(const WinMap& w, long m) {
-  const int t = (int)(m & 63);
-  long win = m >> 6;
-  const int nwy = w.PW >> 2, nwx = w.PD >> 2, nwz = w.PH >> 2;
-  int wx = (int)(win % nwx); win /= nwx;
-  int wy = (int)(win % nwy); win /= nwy;
-  int wz = (int)(win % nwz);
-  long b = win / nwz;
+  const unsigned mu = (unsigned)m;
+  const int t = (int)(mu & 63u);
+  unsigned win = mu >> 6;
+  const unsigned nwy = (unsigned)w.PW >> 2, nwx = (unsigned)w.PD >> 2, nwz = (unsigned)w.PH >> 2;
+  unsigned q = win / nwx;
+  const int wx = (int)(win - q * nwx);
+  win = q; q = win / nwy;
+  const int wy = (int)(win - q * nwy);
+  win = q; q = win / nwz;
+  const int wz = (int)(win - q * nwz);
+  const unsigned b = q;
   int sz = wz * 4 + (t >> 4) + w.s0, sy = wy * 4 + ((t >> 2) & 3) + w.s1, sx = wx * 4 + (t & 3) + w.s2;
   if (sz >= w.PH) sz -= w.PH;
   if (sy >= w.PW) sy -= w.PW;
   if (sx >= w.PD) sx -= w.PD;
   if (sz >= w.H || sy >= w.W || sx >= w.D) return -1;
-  return ((b * w.H + sz) * w.W + sy) * w.D + sx;
+  return (long)(((b * (unsigned)w.H + (unsigned)sz) * (unsigned)w.W + (unsigned)sy) * (unsigned)w.D + (unsigned)sx);
 }
 __device__ __forceinline__ long tok_to_win(const WinMap& w, long tok) {
-  int x = (int)(tok % w.D); tok /= w.D;
-  int y = (int)(tok % w.W); tok /= w.W;
-  int z = (int)(tok % w.H);
-  long b = tok / w.H;
+  const unsigned tu = (unsigned)tok;
+  unsigned q = tu / (unsigned)w.D;
+  const int x = (int)(tu - q * (unsigned)w.D);
+  unsigned q2 = q / (unsigned)w.W;
+  const int y = (int)(q - q2 * (unsigned)w.W);
+  const unsigned b = q2 / (unsigned)w.H;
+  const int z = (int)(q2 - b * (unsigned)w.H);
   int pz = z - w.s0, py = y - w.s1, px = x - w.s2;
   if (pz < 0) pz += w.PH;
   if (py < 0) py += w.PW;
   if (px < 0) px += w.PD;
-  long win = ((b * (w.PH >> 2) + (pz >> 2)) * (w.PW >> 2) + (py >> 2)) * (w.PD >> 2) + (px >> 2);
-  return win * 64 + ((pz & 3) << 4) + ((py & 3) << 2) + (px & 3);
+  const unsigned win = ((b * ((unsigned)w.PH >> 2) + ((unsigned)pz >> 2)) * ((unsigned)w.PW >> 2) + ((unsigned)py >> 2)) * ((unsigned)w.PD >> 2) + ((unsigned)px >> 2);
+  return (long)win * 64 + ((pz & 3) << 4) + ((py & 3) << 2) + (px & 3);
 }
 
 #endif
@@ -93,6 +102,10 @@ struct TnProblemHost {
   float* dbias;                   // optional [N]: += column sums of A (times rowscale)
   const float* rowscale;          // optional [M / rows_per_sample]: factor per sample on the rows of A
   long M; int N, K; int rows_per_sample;
+  long stride_k;                  // 0: dW[n*ldo + k]; > 0: dW[n*ldo + k*stride_k] (e.g. the [Cin][Cout][k^3] layout of a ConvTranspose3d weight)
+  int up_k, up_v;                 // up_k > 0: A is the pixel-shuffled view of a fine-grid tensor (ConvTranspose3d kernel = stride = up_k backward):
+                                  // row m = coarse voxel (b,z,y,x) of an up_v^3 grid -> fine row ((b*V+z*k)*V+y*k)*V+x*k, V = up_v*up_k (A already offset by the tap)
+  int bias_atomic;                // dbias is shared with other problems of the call: atomic adds
 };
 int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st);
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st);

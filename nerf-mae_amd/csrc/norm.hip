@@ -20,11 +20,14 @@ template <int LPR> __device__ __forceinline__ float group_sum(float v) {
 // patch-merge source of chunk (8 elements starting at column col) of output row `row`; nullptr = zero pad
 template <typename T> __device__ __forceinline__ const T* merge_src(const T* x, const WinMap& w, long row, int col, int Cin, long* tok_out) {
   const int H2 = (w.H + 1) >> 1, W2 = (w.W + 1) >> 1, D2 = (w.D + 1) >> 1;
-  long r = row;
-  int x2 = (int)(r % D2); r /= D2;
-  int y2 = (int)(r % W2); r /= W2;
-  int z2 = (int)(r % H2);
-  long b = r / H2;
+  unsigned r = (unsigned)row;   // (32-bit div/mod: rows < 2^31)
+  unsigned q = r / (unsigned)D2;
+  const int x2 = (int)(r - q * (unsigned)D2);
+  r = q; q = r / (unsigned)W2;
+  const int y2 = (int)(r - q * (unsigned)W2);
+  r = q; q = r / (unsigned)H2;
+  const int z2 = (int)(r - q * (unsigned)H2);
+  const long b = (long)q;
   int seg = col / Cin, off = col - seg * Cin;
   int z = 2 * z2 + (seg & 1), y = 2 * y2 + ((seg >> 1) & 1), xx = 2 * x2 + (seg >> 2);
   if (z >= w.H || y >= w.W || xx >= w.D) { *tok_out = -1; return nullptr; }
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     const float rstd = rsqrtf(group_sum<LPR>(q) * invC + a.eps);
     bool masked = false;
     long tl = 0;
-    if (MODE == 0 && a.mask) { tl = row % a.tokens_per_sample; masked = a.mask[tl] != 0; }
+    if (MODE == 0 && a.mask) { tl = (long)((unsigned)row % (unsigned)a.tokens_per_sample); masked = a.mask[tl] != 0; }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = sub + i * LPR;
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * a.gamma[c * 8 + j] + a.beta[c * 8 + j];
           if (MODE == 0 && a.pos) {
-            const long tp = a.mask ? tl : row % a.tokens_per_sample;
+            const long tp = a.mask ? tl : (long)((unsigned)row % (unsigned)a.tokens_per_sample);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += a.pos[tp * C + c * 8 + j];
           }
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     long dyrow = row;
     if (MODE == 1) dyrow = tok_to_win(a.wm, row);
     bool masked = false;
-    if (MODE == 0 && a.mask) masked = a.mask[row % a.tokens_per_sample] != 0;
+    if (MODE == 0 && a.mask) masked = a.mask[(unsigned)row % (unsigned)a.tokens_per_sample] != 0;
     float xv[NCH][8], gv[NCH][8];
     long toks[NCH];
     float s1 = 0.f, s2 = 0.f;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
           }
           Vec8<T>::store(dx + row * C + c * 8, o);
           if (MODE == 0 && a.dyw) {   // adjoint of the window scatter fused here: dyw[win(row)] = s_b * dx[row] (pad rows pre-zeroed)
-            const float sc = a.dyw_scale ? a.dyw_scale[row / a.tokens_per_sample] : 1.0f;
+            const float sc = a.dyw_scale ? a.dyw_scale[(unsigned)row / (unsigned)a.tokens_per_sample] : 1.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] *= sc;
             Vec8<T>::store((T*)a.dyw + tok_to_win(a.wm, row) * C + c * 8, o);

@@ -35,6 +35,9 @@ struct Prob {
   int zs;             // contraction splits: 1 (the workgroup walks every sample) or nsamp * sub
   int wbegin;         // first workgroup of this problem
   int rbegin;         // first reduce workgroup (zs > 1)
+  long son, sok;      // output strides: element (n, k) lives at Out[n * son + k * sok] (plain row-major: son = ldo, sok = 1)
+  int up_k, up_v;     // > 0: A row m (a coarse voxel of a (nsamp, v, v, v) grid) is row ((b*V + z*k)*V + y*k)*V + x*k, V = v*k, of the fine tensor
+  int bias_atomic;    // several problems of the launch share dbias: atomic adds
 };
 struct Args { Prob p[MAXP]; int nprob; };
 }  // namespace tng
@@ -109,7 +112,16 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(tng::Args ga) {
       const int r = r0 + prow[i];
       const int n = n0 + pcol[i];
       unsigned long long src = zpage;
-      if (r < seglen && n < N) src = (unsigned long long)(A + (segbase + r) * lda + n);
+      if (r < seglen && n < N) {
+        long arow = segbase + r;
+        if (P.up_k) {   // pixel-shuffled view (ConvTranspose3d k = stride backward): coarse voxel -> the fine row of this problem's tap
+          const unsigned vv = (unsigned)P.up_v, kk = (unsigned)P.up_k, m = (unsigned)arow;
+          const unsigned q = m / vv, x = m - q * vv, q2 = q / vv, y = q - q2 * vv, bb = q2 / vv, zq = q2 - bb * vv;
+          const long Vf = (long)vv * kk;
+          arow = (((long)bb * Vf + zq * kk) * Vf + y * kk) * Vf + x * kk;
+        }
+        src = (unsigned long long)(A + arow * lda + n);
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + i * 4096), 16, 0, 0);
     }
 #pragma unroll
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(tng::Args ga) {
         if (n < N && k < K) {
           const float v = scaled ? tot[RSC ? a : 0][RSC ? b : 0][r] : acc[a][b][r];
           if (P.zs > 1) P.part[((long)z * N + n) * K + k] = v;
-          else P.Out[(long)n * P.ldo + k] += v;   // sole owner of this output element
+          else P.Out[(long)n * P.son + (long)k * P.sok] += v;   // sole owner of this output element
         }
       }
   if (want_bias && li == 0) {
@@ -206,6 +218,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(tng::Args ga) {
         if (n < N) {
           const float v = scaled ? btot[RSC ? a : 0][r] : bacc[a][r];
           if (P.zs > 1) P.part[(long)P.zs * N * K + (long)z * N + n] = v;
+          else if (P.bias_atomic) atomicAdd(P.dbias + n, v);
           else P.dbias[n] += v;
         }
       }
@@ -231,13 +244,14 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args g
     }
     const long i = i4 * 4;
     const int n = (int)(i / P.K), k = (int)(i - (long)n * P.K);
-    float* o = P.Out + (long)n * P.ldo + k;
-    o[0] += s.x; o[1] += s.y; o[2] += s.z; o[3] += s.w;
+    float* o = P.Out + (long)n * P.son + (long)k * P.sok;
+    o[0] += s.x; o[P.sok] += s.y; o[2 * P.sok] += s.z; o[3 * P.sok] += s.w;
   } else if (P.dbias && i4 < NK4 + P.N) {
     const int n = (int)(i4 - NK4);
     float s = 0.f;
     for (int z = 0; z < P.zs; ++z) s += P.part[(long)P.zs * NK + (long)z * P.N + n];
-    P.dbias[n] += s;
+    if (P.bias_atomic) atomicAdd(P.dbias + n, s);
+    else P.dbias[n] += s;
   }
 }
 
@@ -261,10 +275,13 @@ int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_
     bool any_rs = false;
     for (int i = 0; i < np; ++i) {
       const TnProblemHost& h = probs[base + i];
-      if (h.K % 8 || h.lda % 8 || h.ldb % 8 || h.ldo % 4 || h.rows_per_sample <= 0 || h.M % h.rows_per_sample || !h.A || !h.B || !h.dW) return -4;
+      if (h.K % 8 || h.lda % 8 || h.ldb % 8 || h.rows_per_sample <= 0 || h.M % h.rows_per_sample || !h.A || !h.B || !h.dW) return -4;
+      if (h.up_k > 0 && (h.up_v <= 0 || h.rows_per_sample != (long)h.up_v * h.up_v * h.up_v)) return -4;
       Prob& p = ga.p[i];
       p.A = (const bf16_t*)h.A; p.B = (const bf16_t*)h.B; p.Out = h.dW; p.dbias = h.dbias; p.rowscale = h.rowscale; p.part = nullptr;
       p.lda = h.lda; p.ldb = h.ldb; p.ldo = h.ldo; p.N = h.N; p.K = h.K;
+      p.son = h.stride_k > 0 ? h.ldo : h.ldo; p.sok = h.stride_k > 0 ? h.stride_k : 1;
+      p.up_k = h.up_k; p.up_v = h.up_v; p.bias_atomic = h.bias_atomic;
       p.rps = h.rows_per_sample; p.nsamp = (int)(h.M / h.rows_per_sample);
       p.tk = (h.K + BK - 1) / BK;
       p.ntile = ((h.N + BN - 1) / BN) * p.tk;

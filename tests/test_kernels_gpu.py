@@ -384,6 +384,11 @@ def test_upconv_block_pieces(dt, k, Cin, Cout, v, skip):
     ops.upconv_wgrad(dc, xcl, dW2, db2, B, v, k, Cin, Cout)
     check(dW2, wr.grad, dt, "fused upconv dW", 2)
     check(db2, br.grad, dt, "fused upconv dbias", 2)
+    if dt == torch.bfloat16:   # the grouped-kernel variant (one problem per tap, strided output, atomic bias sums)
+        dW3, db3 = torch.zeros(Cin, Cout, k, k, k, device="cuda"), torch.zeros(Cout, device="cuda")
+        ops.upconv_wgrad_grouped(dc, xcl, dW3, db3, B, v, k, Cin, Cout)
+        check(dW3, wr.grad, dt, "grouped upconv dW", 2)
+        check(db3, br.grad, dt, "grouped upconv dbias", 2)
 
 
 @pytest.mark.parametrize("dt", DTS)
