@@ -54,8 +54,10 @@ typedef struct nmh_tn_problem { const void* A; int64_t lda; const void* B; int64
   int64_t stride_k; int up_k; int up_v; int bias_atomic; } nmh_tn_problem;
 NMH_API int nmh_gemm_tn_grouped(int dt, const nmh_tn_problem* probs, int nprob, float* ws, int64_t ws_floats, void* stream);
 /* Y[(b,z,y,x)][Cout] (+)= conv3d(k=3,pad=1) of channels-last X with packed weights [Cout][27][Cin] (nn.Conv3d in
- * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout]. */
-NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+ * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout].
+ * ws (optional, ws_floats fp32): scratch for a split contraction -- on small volumes (the 10^3 / 20^3 decoder levels: < 256 output tiles,
+ * K = 27*Cin up to 20736) the K loop is cut into up to 8 splits whose fp32 partial tiles are summed by a second launch. */
+NMH_API int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, float* ws, int64_t ws_floats, void* stream);
 /* The same convolution with a per-output-channel bias in the epilogue (nn.Conv3d(C, C, 3, padding=1) of the FPN neck,
  * nerf_rpn/model/fpn.py:104). */
 NMH_API int nmh_conv3d_k3_bias(int dt, const void* X, const void* Wp, const float* bias, void* Y, int B, int D, int H, int W, int Cin, int Cout, void* stream);

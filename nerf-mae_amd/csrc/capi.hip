@@ -75,11 +75,11 @@ int nmh_upconv_wgrad(int dt, const void* dcat, int64_t ldc, const void* x, float
   REQ(dcat, x, dW);
   return k_upconv_wgrad(dt, dcat, (long)ldc, x, dW, dbias, B, v, k, Cin, Cout, ST);
 }
-int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+int nmh_conv3d_k3(int dt, const void* X, const void* Wp, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, float* ws, int64_t ws_floats, void* stream) {
   CLR();
   REQ(X, Wp, Y);
   EpiParams ep{Y, Cout, nullptr, 0, nullptr, nullptr, nullptr, 1, accumulate};
-  return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST);
+  return k_conv3_nt(dt, X, Wp, B, D, H, W, Cin, Cout, ep, ST, ws, ws ? (long)ws_floats : 0);
 }
 int nmh_conv3d_k3_bias(int dt, const void* X, const void* Wp, const float* bias, void* Y, int B, int D, int H, int W, int Cin, int Cout, void* stream) {
   CLR();

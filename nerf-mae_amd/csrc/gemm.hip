@@ -39,8 +39,8 @@ template <typename T> struct ADirect {
   const T* A; long lda; long rows_per_z;  // rows_per_z = M when gridDim.z == 1
   struct Row { const T* p; };
   struct Kst { int k; bool ok; };
-  __device__ __forceinline__ void init_row(Row& r, int m, int M) const {
-    r.p = (m < M) ? A + ((long)blockIdx.z * rows_per_z + m) * lda : nullptr;
+  __device__ __forceinline__ void init_row(Row& r, int m, int M, int zb) const {
+    r.p = (m < M) ? A + ((long)zb * rows_per_z + m) * lda : nullptr;
   }
   __device__ __forceinline__ Kst init_k(int k, int K) const { return Kst{k, k < K}; }
   __device__ __forceinline__ uint4 load(const Row& r, const Kst& ks) const {
@@ -54,7 +54,7 @@ template <typename T> struct AUp {
   const T* X; long ldc; int v, k, Cout; FDiv dv, dk, dc;
   struct Row { long fine0; bool ok; };
   struct Kst { long off; bool ok; };
-  __device__ __forceinline__ void init_row(Row& r, int m, int M) const {
+  __device__ __forceinline__ void init_row(Row& r, int m, int M, int /*zb*/) const {
     r.ok = m < M;
     unsigned q = fdiv((unsigned)m, dv), x = m - q * v;
     unsigned q2 = fdiv(q, dv), y = q - q2 * v;
@@ -84,14 +84,14 @@ template <typename T> struct AConv3 {
   const T* X; int Cin, D, H, W; FDiv dW, dH, dC;
   struct Row { long vox; int z, y, x; bool ok; };
   struct Kst { int dz, dy, dx, ci; long off; bool ok; };
-  __device__ __forceinline__ void init_row(Row& r, int m, int M) const {
+  __device__ __forceinline__ void init_row(Row& r, int m, int M, int zb) const {
     r.ok = m < M;
     unsigned q = fdiv((unsigned)m, dW);
     r.x = m - q * W;
     unsigned q2 = fdiv(q, dH);
     r.y = q - q2 * H;
     r.z = q2;
-    r.vox = (long)blockIdx.z * ((long)D * H * W) + m;
+    r.vox = (long)zb * ((long)D * H * W) + m;
   }
   __device__ __forceinline__ Kst init_k(int k, int K) const {
     Kst s;
@@ -171,11 +171,11 @@ template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams&
 
 // epilogue shared by the NT kernels: per wave, one 16-row m-tile at a time through a private LDS slab (16-byte row stores)
 template <typename T, int MT, int NT>
-__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, const EpiParams& ep, int m0, int n0, int M, int N, int wave, int lane) {
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, const EpiParams& ep, int m0, int n0, int M, int N, int wave, int lane, int zb = -1) {
   constexpr int BN = 16 * NT, SLD = BN + 4;
   const int g = lane >> 4, li = lane & 15;
   float* stg = reinterpret_cast<float*>(smem) + wave * 16 * SLD;
-  const long zrow = (long)blockIdx.z * M;
+  const long zrow = (long)(zb < 0 ? (int)blockIdx.z : zb) * M;
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -213,10 +213,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int lc = tid & 7, lr = tid >> 3;
+  const int nbz = ep.ksplit > 1 ? ep.nbatch : (int)gridDim.z;      // grid.z = batch (x contraction splits)
+  const int zb = (int)blockIdx.z % nbz, ksp = (int)blockIdx.z / nbz;
 
   typename AL::Row arow[AR];
 #pragma unroll
-  for (int i = 0; i < AR; ++i) al.init_row(arow[i], m0 + lr + 32 * i, M);
+  for (int i = 0; i < AR; ++i) al.init_row(arow[i], m0 + lr + 32 * i, M, zb);
   const T* brow[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
@@ -248,11 +250,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K + KT - 1) / KT;
-  gload(0);
-  sstore(0);
+  int nk = (K + KT - 1) / KT, kt0 = 0;
+  if (ep.ksplit > 1) {   // this workgroup's share of the contraction
+    const int per = (nk + ep.ksplit - 1) / ep.ksplit;
+    kt0 = ksp * per;
+    nk = kt0 + per < nk ? kt0 + per : nk;
+  }
+  if (kt0 < nk) { gload(kt0); sstore(kt0 & 1); }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
     const char* As = smem + cur * STAGE;
@@ -273,7 +279,41 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
     __syncthreads();
   }
 
-  nt_epilogue<T, MT, NT>(acc, smem, ep, m0, n0, M, N, wave, lane);
+  if (ep.ksplit > 1) {   // raw fp32 partial tile; summed (and `accumulate` applied) by nt_ksplit_reduce_kernel
+    float* part = ep.kpart + ((long)(ksp * nbz + zb) * M) * N;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wave * 16 * MT + a * 16 + 4 * g + r, col = n0 + b * 16 + li;
+          if (row < M && col < N) part[(long)row * N + col] = acc[a][b][r];
+        }
+    return;
+  }
+  nt_epilogue<T, MT, NT>(acc, smem, ep, m0, n0, M, N, wave, lane, zb);
+}
+
+// sums the contraction splits: out[row][col] (T, leading dimension ldc) = sum_s part[s][row][col] (+ out if accumulate); 8 columns per thread
+template <typename T> __global__ void nt_ksplit_reduce_kernel(const float* __restrict__ part, int ksplit, long rows, int N, T* __restrict__ out, long ldc, int accumulate) {
+  const long n8 = rows * (N / 8);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / (N / 8);
+    const int c8 = (int)(i - row * (N / 8)) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ksplit; ++s) {
+      const float4 p0 = *reinterpret_cast<const float4*>(part + ((long)s * rows + row) * N + c8), p1 = *reinterpret_cast<const float4*>(part + ((long)s * rows + row) * N + c8 + 4);
+      v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    }
+    if (accumulate) {
+      float o[8];
+      Vec8<T>::load(out + row * ldc + c8, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += o[j];
+    }
+    Vec8<T>::store(out + row * ldc + c8, v);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,7 +445,7 @@ static int launch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K
     int rc = 0;
     if (try_dma<T, MT, NT, AL>(al, Bw, ldb, M, N, K, batch, ep, st, &rc)) return rc;
   }
-  dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch);
+  dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch * (ep.ksplit > 1 ? ep.ksplit : 1));
   static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, MT, NT, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -457,14 +497,50 @@ int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, 
   return dispatch_nt<float>(al, Bw, ldb, M, N, K, 1, ep, st);
 }
 
-int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st) {
+// output tiles of the tile shape dispatch_nt picks for a conv (see there): used to decide the contraction split
+static long conv_nt_tiles(long M, int N, int batch, int K) {
+  const int t16 = (N + 15) / 16;
+  int bm, bn;
+  if ((M * batch <= 8192 || K <= 1024) && t16 >= 4) { bm = 64; bn = t16 % 6 == 0 ? 96 : (t16 % 4 == 0 ? 64 : (t16 % 3 == 0 ? 48 : 64)); }
+  else if (t16 <= 3) { bm = 256; bn = 48; }
+  else if (t16 == 4) { bm = 256; bn = 64; }
+  else { bm = 128; bn = t16 % 6 == 0 ? 96 : 128; }
+  return ((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
+}
+int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep0, hipStream_t st, float* ws, long ws_floats) {
   const int M = D * H * W, K = 27 * Cin;
+  EpiParams ep = ep0;
+  ep.ksplit = 1; ep.nbatch = B; ep.kpart = nullptr;
+  // Small volumes (the 10^3 / 20^3 decoder levels): a 768 -> 384 conv at 10^3 is 64 output tiles with 324 k-tiles each -- a quarter of
+  // the chip, every workgroup latency-bound (218 us for 16 GFLOP).  Split the contraction so that ~512 workgroups exist.
+  static const int ks_max = getenv("NMH_CONV_KSPLIT") ? atoi(getenv("NMH_CONV_KSPLIT")) : 8;
+  const bool plain = !ep.bias && !ep.act && !ep.resid && !ep.rowscale && !ep.up_k && !ep.win_on && Cout % 8 == 0;
+  // (bf16 only: the fp32 parity mode keeps one accumulation chain per output element -- the chaotic golden trace g13 is sensitive to the
+  //  summation order of its 6.7e4-norm gradients)
+  if (plain && ws && ks_max > 1 && dt == NMH_DT_BF16) {
+    const long tiles = conv_nt_tiles(M, Cout, B, K);
+    const int nk = (K + (dt == NMH_DT_BF16 ? 64 : 32) - 1) / (dt == NMH_DT_BF16 ? 64 : 32);
+    int s = (int)((512 + tiles - 1) / tiles);
+    if (s > ks_max) s = ks_max;
+    if (s > nk / 16) s = nk / 16;
+    while (s > 1 && (long)s * B * M * Cout > ws_floats) --s;
+    if (tiles <= 160 && s > 1) { ep.ksplit = s; ep.kpart = ws; }
+  }
+  int rc;
   if (dt == NMH_DT_BF16) {
     AConv3<bf16_t> al{(const bf16_t*)X, Cin, D, H, W, make_fdiv(W), make_fdiv(H), make_fdiv(Cin)};
-    return dispatch_nt<bf16_t>(al, Wp, K, M, Cout, K, B, ep, st);
+    rc = dispatch_nt<bf16_t>(al, Wp, K, M, Cout, K, B, ep, st);
+  } else {
+    AConv3<float> al{(const float*)X, Cin, D, H, W, make_fdiv(W), make_fdiv(H), make_fdiv(Cin)};
+    rc = dispatch_nt<float>(al, Wp, K, M, Cout, K, B, ep, st);
   }
-  AConv3<float> al{(const float*)X, Cin, D, H, W, make_fdiv(W), make_fdiv(H), make_fdiv(Cin)};
-  return dispatch_nt<float>(al, Wp, K, M, Cout, K, B, ep, st);
+  if (rc || ep.ksplit <= 1) return rc;
+  const long rows = (long)B * M, n8 = rows * (Cout / 8);
+  unsigned nb = (unsigned)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(nt_ksplit_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, ws, ep.ksplit, rows, Cout, (bf16_t*)ep.C, ep.ldc, ep.accumulate);
+  else hipLaunchKernelGGL(nt_ksplit_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, ws, ep.ksplit, rows, Cout, (float*)ep.C, ep.ldc, ep.accumulate);
+  NMH_CHECK_LAUNCH();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

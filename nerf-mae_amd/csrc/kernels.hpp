@@ -25,6 +25,9 @@ struct EpiParams {
   // window reverse folded into the store (win_on): GEMM row = window-ordered row -> token row (pad rows dropped); bias, rowscale
   // (indexed by token / rows_per_scale) and resid (token order) as usual: x1[tok] = x[tok] + s_b * (o . Wproj^T + b)
   int win_on; WinMap wm;
+  // split contraction (implicit-GEMM convs on small volumes: too few output tiles to fill the chip, K = 27*Cin long): grid.z = batch * ksplit,
+  // every split stores its fp32 accumulators to kpart[split][batch*M][N]; a second launch sums them and applies `accumulate` (no other epilogue)
+  int ksplit; int nbatch; float* kpart;
 };
 
 // geometry for gemm_tn gather / output remap
@@ -92,7 +95,7 @@ int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, 
 int k_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, long ldc, int B, int v, int k, int Cin, int Cout, hipStream_t st);
 int k_upconv_dgrad(int dt, const void* dcat, long ldc, const void* Wd, void* dx, int B, int v, int k, int Cin, int Cout, hipStream_t st);
 int k_upconv_wgrad(int dt, const void* dcat, long ldc, const void* x, float* dW, float* dbias, int B, int v, int k, int Cin, int Cout, hipStream_t st);
-int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st);
+int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W, int Cin, int Cout, const EpiParams& ep, hipStream_t st, float* ws = nullptr, long ws_floats = 0);
 int k_gemm_tn(int dt, const void* A, long lda, const void* Bm, long ldb, float* Out, long M, int N, int K, const float* rowscale, int rows_per_scale, const TnGeom& gm, hipStream_t st);
 // one problem of a grouped weight-gradient launch (host-side descriptor; mirrors nmh_tn_problem in include/nerfmae_hip.h)
 struct TnProblemHost {

@@ -220,7 +220,8 @@ def conv3d_k3(X, Wp, Cout, out=None, accumulate=False):
     if out is None:
         out = torch.empty((B, D, H, W, Cout), dtype=X.dtype, device=X.device)
     ev = _prof(("conv3d_k3", B, D, Cin, Cout))
-    lib().call("nmh_conv3d_k3", dt_of(X), X, Wp, out, B, D, H, W, Cin, Cout, int(accumulate), _st())
+    ws = _tn_workspace(X.device) if B * D * H * W <= 65536 else None     # split contraction on the small decoder levels
+    lib().call("nmh_conv3d_k3", dt_of(X), X, Wp, out, B, D, H, W, Cin, Cout, int(accumulate), ws, 0 if ws is None else ws.numel(), _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return out
