@@ -511,8 +511,8 @@ int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W
   const int M = D * H * W, K = 27 * Cin;
   EpiParams ep = ep0;
   ep.ksplit = 1; ep.nbatch = B; ep.kpart = nullptr;
-  // Small volumes (the 10^3 / 20^3 decoder levels): a 768 -> 384 conv at 10^3 is 64 output tiles with 324 k-tiles each -- a quarter of
-  // the chip, every workgroup latency-bound (218 us for 16 GFLOP).  Split the contraction so that ~512 workgroups exist.
+  // Small volumes (the 10^3 / 20^3 decoder levels): a 768 -> 384 conv at 10^3 is 64 output tiles per grid with 324 k-tiles each -- a quarter of
+  // the chip, every workgroup latency-bound (218 us for 16 GFLOP).  Split the contraction so that ~1024 workgroups exist (up to 600 tiles).
   static const int ks_max = getenv("NMH_CONV_KSPLIT") ? atoi(getenv("NMH_CONV_KSPLIT")) : 8;
   const bool plain = !ep.bias && !ep.act && !ep.resid && !ep.rowscale && !ep.up_k && !ep.win_on && Cout % 8 == 0;
   // (bf16 only: the fp32 parity mode keeps one accumulation chain per output element -- the chaotic golden trace g13 is sensitive to the
@@ -520,11 +520,12 @@ int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W
   if (plain && ws && ks_max > 1 && dt == NMH_DT_BF16) {
     const long tiles = conv_nt_tiles(M, Cout, B, K);
     const int nk = (K + (dt == NMH_DT_BF16 ? 64 : 32) - 1) / (dt == NMH_DT_BF16 ? 64 : 32);
-    int s = (int)((512 + tiles - 1) / tiles);
+    static const long ks_tiles = getenv("NMH_CONV_KS_TILES") ? atol(getenv("NMH_CONV_KS_TILES")) : 600, ks_target = getenv("NMH_CONV_KS_TARGET") ? atol(getenv("NMH_CONV_KS_TARGET")) : 1024;
+    int s = (int)((ks_target + tiles - 1) / tiles);
     if (s > ks_max) s = ks_max;
     if (s > nk / 16) s = nk / 16;
     while (s > 1 && (long)s * B * M * Cout > ws_floats) --s;
-    if (tiles <= 160 && s > 1) { ep.ksplit = s; ep.kpart = ws; }
+    if (tiles <= ks_tiles && s > 1) { ep.ksplit = s; ep.kpart = ws; }
   }
   int rc;
   if (dt == NMH_DT_BF16) {
