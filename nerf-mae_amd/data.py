@@ -169,7 +169,7 @@ class Prefetcher:
         R, dev = batcher.R, batcher.device
         self.bufs = [torch.empty((batch_size, 4, R, R, R), dtype=torch.float32, device=dev) for _ in range(depth)]
         self.free = [None] * depth                      # event after which buffer j may be overwritten
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = torch.cuda.Stream(device=dev, priority=-1)   # high priority: its small copy/prepare kernels slot in between the step's kernels
         self.q = queue.Queue(maxsize=depth - 1 if depth > 1 else 1)
         self.batches = batches
         self.err = None

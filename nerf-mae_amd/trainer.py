@@ -113,6 +113,11 @@ class FusedAdamW:
         self.launch()
 
 
+# thread-local capture mode: HIP calls made meanwhile by OTHER threads (the input prefetcher's pinned allocations and copies, the RCCL
+# watchdog's event queries) must not invalidate the capture of the training thread
+_CAPTURE_MODE = "thread_local"
+
+
 class GraphedTrainStep:
     """One pre-training step (zero_grad, forward, backward, [all-reduce], clip+AdamW) replayed from HIP graphs.
 
@@ -173,7 +178,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
         if not split:
-            with torch.cuda.graph(self._g1):
+            with torch.cuda.graph(self._g1, capture_error_mode=_CAPTURE_MODE):
                 out = self._fwd_bwd(zero=False)
                 self.losses = torch.stack([o.detach() for o in out[:3]])
                 self.opt.launch()
@@ -184,16 +189,16 @@ class GraphedTrainStep:
         #   gb1 = backward of stages 3 and 2         -> all-reduce [stage 2, stage 3]
         #   gb2 = backward of stages 1, 0, the embed -> all-reduce [mask token, embed, stage 0, stage 1]
         #   g2 = clip + AdamW
-        with torch.cuda.graph(self._g1):
+        with torch.cuda.graph(self._g1, capture_error_mode=_CAPTURE_MODE):
             out = self._split_a(zero=False)
             self.losses = torch.stack([o.detach() for o in out[:3]])
         pool = self._g1.pool()
         self._gb1, self._gb2, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._gb1, pool=pool):
+        with torch.cuda.graph(self._gb1, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self._split_b1()
-        with torch.cuda.graph(self._gb2, pool=pool):
+        with torch.cuda.graph(self._gb2, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self._split_b2()
-        with torch.cuda.graph(self._g2, pool=pool):
+        with torch.cuda.graph(self._g2, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.opt.launch()
 
     # ---- the step in three autograd pieces (data-parallel graph mode) ----------------------------------------------------------------
