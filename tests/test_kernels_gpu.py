@@ -674,20 +674,28 @@ def test_copy_cols_strided(dtype):
         ops.copy_cols(skip, cat[:, C:C + 8])
 
 
-@pytest.mark.parametrize("case", ["flat_many_tiles", "split_few_tiles", "mixed_ragged"])
-def test_gemm_tn_grouped(case):
+@pytest.mark.parametrize("variant", ["dma", "reg", "big", "big_reg"])
+@pytest.mark.parametrize("case", ["flat_many_tiles", "split_few_tiles", "mixed_ragged", "all192"])
+def test_gemm_tn_grouped(case, variant, monkeypatch):
     """nmh_gemm_tn_grouped (bf16): several weight-gradient problems per launch -- flat (a workgroup walks every sample), split at
     sample-aligned ranges (+ grouped reduce), stochastic-depth row scales applied per sample, fused bias gradients, ragged N / K tiles,
     rows per sample that are not a multiple of the 64-row chunk -- against fp32 matmuls on the bf16-rounded operands; accumulates
     into dW (+=)."""
     ops = _ops()
     dt = torch.bfloat16
+    # kernel variants (read per call): register-staged chunk transport, 192x192 tiles (taken when every N, K of the launch is a multiple of 192)
+    monkeypatch.setenv("NMH_TNG_REG", "1" if "reg" in variant else "0")
+    monkeypatch.setenv("NMH_TNG_BIG", "1" if "big" in variant else "0")
     if case == "flat_many_tiles":      # >= 384 tiles in the launch: nobody splits
         specs = [(4, 500, 384, 1536, True, True), (4, 500, 1536, 384, False, True), (4, 512, 384, 384, False, True), (4, 512, 1152, 384, False, False)]
     elif case == "split_few_tiles":    # stage-0-like: 12 tiles -> sample-aligned splits + reduce launch
         specs = [(2, 3000, 96, 384, True, True), (2, 3000, 384, 96, False, True), (2, 3000, 96, 96, False, True), (2, 3000, 288, 96, False, False)]
-    else:                              # 17 problems (two launches), widths that are not multiples of 96, one sample, tiny M
-        specs = [(1, 70, 128, 512, True, True), (3, 130, 512, 128, False, True), (2, 64, 64, 256, False, False)] + [(2, 200, 192, 96, i % 2 == 0, True) for i in range(14)]
+    elif case == "all192":             # every width a multiple of 192 (the large-tile variant's domain): flat and, with few tiles, split
+        specs = [(3, 300, 384, 1536, True, True), (3, 300, 1536, 384, False, True), (3, 320, 384, 384, False, True), (3, 320, 1152, 384, False, False)]
+        if variant == "big":
+            specs = specs[2:3] + [(2, 2100, 192, 384, True, True)]
+    else:                              # 45 problems (two launches), widths that are not multiples of 96, one sample, tiny M
+        specs = [(1, 70, 128, 512, True, True), (3, 130, 512, 128, False, True), (2, 64, 64, 256, False, False)] + [(2, 200, 192, 96, i % 2 == 0, True) for i in range(42)]
     q_ = ops.WgradQueue()
     refs, outs = [], []
     for i, (nsamp, rps, N, K, scaled, bias) in enumerate(specs):
