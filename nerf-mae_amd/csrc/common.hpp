@@ -132,6 +132,27 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf
 __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
+// bf16 epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute, three orders below the bf16 rounding of the result) --
+// one v_rcp_f32, one v_exp_f32 and six FMAs instead of the two-branch libm erff.  The Linear(C -> 4C) + GELU epilogue at 40^3 tokens is
+// VALU-bound on erff (K = 96: three k-steps of MFMAs against 24 GELUs per lane); the fp32 parity mode keeps erff.
+__device__ __forceinline__ void erf_as_parts(float z, float& erfz, float& e) {   // erf(z) and exp(-z^2)
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+  e = __expf(-az * az);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f; p = p * t + 1.421413741f; p = p * t - 0.284496736f; p = p * t + 0.254829592f;
+  erfz = copysignf(1.0f - p * t * e, z);
+}
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  float er, e;
+  erf_as_parts(x * 0.70710678118654752f, er, e);
+  return 0.5f * x * (1.0f + er);
+}
+__device__ __forceinline__ float gelu_grad_fast_f(float x) {   // Phi(x) + x phi(x); exp(-x^2/2) is the erf formula's own exponential
+  float er, e;
+  erf_as_parts(x * 0.70710678118654752f, er, e);
+  return 0.5f * (1.0f + er) + x * 0.39894228040143268f * e;
+}
 
 // Small accumulators are cleared by a kernel instead of hipMemsetAsync: inside a captured graph a memset node costs 20-30 us on the
 // dependent chain (rocprofv3: __amd_rocclr_fillBufferAligned, 2-3 workgroups), a kernel node ~5 us.  bytes must be a multiple of 4.

@@ -142,12 +142,12 @@ template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams&
   if (ep.act == 1) {
     Vec8<T>::store((T*)ep.C2 + o, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+    for (int j = 0; j < 8; ++j) v[j] = sizeof(T) == 2 ? gelu_fast_f(v[j]) : gelu_f(v[j]);
   } else if (ep.act == 2) {
     float a[8];
     Vec8<T>::load((const T*)ep.C2 + o, a);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(a[j]);
+    for (int j = 0; j < 8; ++j) v[j] *= sizeof(T) == 2 ? gelu_grad_fast_f(a[j]) : gelu_grad_f(a[j]);
   }
   if (ep.rowscale) {
     float s = ep.rowscale[grow / ep.rows_per_scale];

@@ -109,6 +109,7 @@ struct TnProblemHost {
   int up_k, up_v;                 // up_k > 0: A is the pixel-shuffled view of a fine-grid tensor (ConvTranspose3d kernel = stride = up_k backward):
                                   // row m = coarse voxel (b,z,y,x) of an up_v^3 grid -> fine row ((b*V+z*k)*V+y*k)*V+x*k, V = up_v*up_k (A already offset by the tap)
   int bias_atomic;                // dbias is shared with other problems of the call: atomic adds
+  int n_inner; long stride_n2;    // n_inner > 0: column n = (n / n_inner, n % n_inner) -> dW[(n % n_inner)*ldo + (n / n_inner)*stride_n2 + k*stride_k], dbias[n % n_inner]
 };
 int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st);
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st);

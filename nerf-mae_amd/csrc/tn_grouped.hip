@@ -39,13 +39,18 @@ struct Prob {
   int upflags;        // bits 0-7 up_k, bit 8 bias_atomic, bits 16-31 up_v.  up_k > 0: A row m (a coarse voxel of a (nsamp, v, v, v) grid) is
                       // row ((b*V + z*k)*V + y*k)*V + x*k, V = v*k, of the fine tensor; bias_atomic: several problems of the launch share dbias
   int partoff;        // zs > 1: offset (floats) of this problem's partials in the launch workspace
-  int pad_;
+  int ncol2;          // 0, or n_inner | stride_n2 << 16: column n = (n / n_inner, n % n_inner) -> Out[(n % n_inner) * son + (n / n_inner) * stride_n2 + k * sok]
   __device__ __host__ int tk(int bt) const { return (K + bt - 1) / bt; }
   __device__ __host__ int ntile(int bt) const { return ((N + bt - 1) / bt) * tk(bt); }   // bt: 96, or 192 in the 8-wave variant
   __device__ __host__ int mps() const { return ((rps + sub - 1) / sub + 63) / 64 * 64; }
   __device__ int up_k() const { return upflags & 0xff; }
   __device__ int up_v() const { return (int)((unsigned)upflags >> 16); }
   __device__ bool bias_atomic() const { return (upflags >> 8) & 1; }
+  __device__ long out_off(int n, int k) const {
+    if (ncol2) { const int ni = ncol2 & 0xffff, q = n / ni; return (long)(n - q * ni) * son + (long)q * (ncol2 >> 16) + (long)k * sok; }
+    return (long)n * son + (long)k * sok;
+  }
+  __device__ int bias_col(int n) const { return ncol2 ? n % (ncol2 & 0xffff) : n; }
 };
 static_assert(sizeof(Prob) == 96, "kernel-argument budget");
 struct Args { Prob p[MAXP]; int wbegin[MAXP]; float* ws; int nprob; int xcd; };   // wbegin[i]: first workgroup of problem i
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
         if (n < N && k < K) {
           const float v = scaled ? tot[RSC ? a : 0][RSC ? b : 0][r] : acc[a][b][r];
           if (P.zs > 1) ppart[((long)z * N + n) * K + k] = v;
-          else P.Out[(long)n * P.son + (long)k * P.sok] += v;   // sole owner of this output element
+          else P.Out[P.out_off(n, k)] += v;   // sole owner of this output element
         }
       }
   if (want_bias && li == 0) {
@@ -276,8 +281,8 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
         if (n < N) {
           const float v = scaled ? btot[RSC ? a : 0][r] : bacc[a][r];
           if (P.zs > 1) ppart[(long)P.zs * N * K + (long)z * N + n] = v;
-          else if (P.bias_atomic()) atomicAdd(P.dbias + n, v);
-          else P.dbias[n] += v;
+          else if (P.bias_atomic()) atomicAdd(P.dbias + P.bias_col(n), v);
+          else P.dbias[P.bias_col(n)] += v;
         }
       }
   }
@@ -303,14 +308,14 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args g
     }
     const long i = i4 * 4;
     const int n = (int)(i / P.K), k = (int)(i - (long)n * P.K);
-    float* o = P.Out + (long)n * P.son + (long)k * P.sok;
+    float* o = P.Out + P.out_off(n, k);
     o[0] += s.x; o[P.sok] += s.y; o[2 * P.sok] += s.z; o[3 * P.sok] += s.w;
   } else if (P.dbias && i4 < NK4 + P.N) {
     const int n = (int)(i4 - NK4);
     float s = 0.f;
     for (int z = 0; z < P.zs; ++z) s += ppart[(long)P.zs * NK + (long)z * P.N + n];
-    if (P.bias_atomic()) atomicAdd(P.dbias + n, s);
-    else P.dbias[n] += s;
+    if (P.bias_atomic()) atomicAdd(P.dbias + P.bias_col(n), s);
+    else P.dbias[P.bias_col(n)] += s;
   }
 }
 
@@ -355,7 +360,9 @@ int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_
       p.A = (const bf16_t*)h.A; p.B = (const bf16_t*)h.B; p.Out = h.dW; p.dbias = h.dbias; p.rowscale = h.rowscale;
       p.lda = (int)h.lda; p.ldb = (int)h.ldb; p.N = h.N; p.K = h.K;
       p.son = (int)h.ldo; p.sok = h.stride_k > 0 ? (int)h.stride_k : 1;
-      p.upflags = (h.up_k & 0xff) | ((h.bias_atomic ? 1 : 0) << 8) | (h.up_k > 0 ? (h.up_v << 16) : 0);
+      if (h.n_inner < 0 || h.n_inner > 65535 || (h.n_inner > 0 && (h.stride_n2 < 0 || h.stride_n2 > 32767 || h.N % h.n_inner))) return -4;
+      p.ncol2 = h.n_inner > 0 ? (h.n_inner | ((int)h.stride_n2 << 16)) : 0;
+      p.upflags = (h.up_k & 0xff) | ((h.bias_atomic || h.n_inner > 0 ? 1 : 0) << 8)   /* folded columns share dbias entries */ | (h.up_k > 0 ? (h.up_v << 16) : 0);
       p.rps = h.rows_per_sample; p.nsamp = (int)(h.M / h.rows_per_sample);
       tiles += p.ntile(96);
       tiles_big += p.ntile(192);

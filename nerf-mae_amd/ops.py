@@ -156,7 +156,7 @@ class _TnProblem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_tn_problem
     _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64), ("dW", ctypes.c_void_p),
                 ("ldo", ctypes.c_int64), ("dbias", ctypes.c_void_p), ("rowscale", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int),
                 ("K", ctypes.c_int), ("rows_per_sample", ctypes.c_int), ("stride_k", ctypes.c_int64), ("up_k", ctypes.c_int), ("up_v", ctypes.c_int),
-                ("bias_atomic", ctypes.c_int)]
+                ("bias_atomic", ctypes.c_int), ("n_inner", ctypes.c_int), ("stride_n2", ctypes.c_int64)]
 
 
 GROUPED_WGRAD = __import__("os").environ.get("NMH_TNG", "1") != "0"
@@ -435,31 +435,42 @@ def upconv_dgrad(dcat, Wd, dx, B, v, k, Cin, Cout):
 
 def upconv_wgrad(dcat, x, dW, dbias, B, v, k, Cin, Cout):
     _chk(dcat, x, dW, dbias)
-    if GROUPED_UPCONV_WGRAD and dcat.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and B * v ** 3 < 2 ** 31:
+    if (GROUPED_UPCONV_WGRAD and dcat.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and B * v ** 3 < 2 ** 31
+            and (GROUPED_UPCONV_WGRAD >= 2 or dcat.stride(0) == Cout)):
         return upconv_wgrad_grouped(dcat, x, dW, dbias, B, v, k, Cin, Cout)
     lib().call("nmh_upconv_wgrad", dt_of(dcat), dcat, dcat.stride(0), x, dW, dbias, B, v, k, Cin, Cout, _st())
 
 
-# measured slower than the shuffled-view gemm_tn (8 grids: 63.8 -> 65.3 ms/step: 48-row half-empty tiles, 64 strided passes over the fine
-# gradient): kept as a tested variant, off by default
-GROUPED_UPCONV_WGRAD = __import__("os").environ.get("NMH_TNG_UP", "0") == "1"
+# One grouped call for the whole gradient.  With a contiguous fine gradient (row stride == Cout: decoder1, no skip half) the k taps
+# along x of a (tz, ty) tap row are one problem -- its A rows are the contiguous k*Cout-element runs of dcat, folded back to
+# (tx, co) by the kernel's two-level column map -- i.e. k^2 problems with full tiles, dcat read exactly once (1 grid/GPU, 40^3 -> 160^3:
+# 416 -> ~120 us against the split shuffled-view gemm_tn).  With a skip half (row stride 2*Cout) the per-tap variant (k^3 problems of
+# Cout <= 96 columns) measured slower than the shuffled-view gemm_tn and stays off unless NMH_TNG_UP=2.
+GROUPED_UPCONV_WGRAD = int(__import__("os").environ.get("NMH_TNG_UP", "1"))
 
 
 def upconv_wgrad_grouped(dcat, x, dW, dbias, B, v, k, Cin, Cout):
-    """the same gradient as one grouped call (bf16): one problem per tap, A = the tap's pixel-shuffled view of dcat (read once in total),
-    dW[ci][co][tap] written through output strides, the bias gradient by atomic adds from every tap problem"""
+    """ConvTranspose3d(kernel = stride = k) weight / bias gradient as one nmh_gemm_tn_grouped call (bf16): dW[ci][co][tap] written
+    through output strides, the bias gradient by atomic adds from every problem"""
     _chk(dcat, x, dW, dbias)
     k3, ldc, Vf = k ** 3, dcat.stride(0), v * k
-    arr = (_TnProblem * k3)()
     esz = dcat.element_size()
-    for tap in range(k3):
-        tz, ty, tx = tap // (k * k), (tap // k) % k, tap % k
-        off = ((tz * Vf + ty) * Vf + tx) * ldc
-        # problem: N = Cout rows (dY channels), K = Cin: element (n = co, k = ci) -> dW[(ci*Cout + co)*k3 + tap]
-        arr[tap] = _TnProblem(dcat.data_ptr() + off * esz, ldc, x.data_ptr(), x.stride(0), dW.data_ptr() + tap * 4, k3, dbias.data_ptr(), 0,
-                              B * v ** 3, Cout, Cin, v ** 3, Cout * k3, k, v, 1)
+    fold = ldc == Cout and k * Cout <= 65535
+    n = k * k if fold else k3
+    arr = (_TnProblem * n)()
+    for t in range(n):
+        if fold:     # problem (tz, ty): N = k*Cout columns (tx, co), tap index (tz*k + ty)*k + tx
+            tz, ty = t // k, t % k
+            off = ((tz * Vf + ty) * Vf) * ldc
+            arr[t] = _TnProblem(dcat.data_ptr() + off * esz, ldc, x.data_ptr(), x.stride(0), dW.data_ptr() + (tz * k + ty) * k * 4, k3, dbias.data_ptr(), 0,
+                                B * v ** 3, k * Cout, Cin, v ** 3, Cout * k3, k, v, 1, Cout, 1)
+        else:        # problem tap: N = Cout rows (dY channels), K = Cin: element (n = co, k = ci) -> dW[(ci*Cout + co)*k3 + tap]
+            tz, ty, tx = t // (k * k), (t // k) % k, t % k
+            off = ((tz * Vf + ty) * Vf + tx) * ldc
+            arr[t] = _TnProblem(dcat.data_ptr() + off * esz, ldc, x.data_ptr(), x.stride(0), dW.data_ptr() + t * 4, k3, dbias.data_ptr(), 0,
+                                B * v ** 3, Cout, Cin, v ** 3, Cout * k3, k, v, 1, 0, 0)
     ws = _tn_workspace(dcat.device)
-    lib().call("nmh_gemm_tn_grouped", BF16, arr, k3, ws, 0 if ws is None else ws.numel(), _st())
+    lib().call("nmh_gemm_tn_grouped", BF16, arr, n, ws, 0 if ws is None else ws.numel(), _st())
 
 
 def upconv_shuffle_fwd(upre, bias, skip, out, B, v, k, Cout):
