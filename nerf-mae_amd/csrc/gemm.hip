@@ -420,16 +420,18 @@ static int launch_nt_dma(const ADirect<bf16_t>& al, const void* Bw, long ldb, in
   NMH_CHECK_LAUNCH();
   return 0;
 }
-// The pipelined kernel pays off where one workgroup's K loop is long and few workgroups exist to hide it (measured, M <= 8192:
-// fc2 4000x384x1536 21.9 -> 15.2 us, 500x768x3072 34.6 -> 24.5 us); with K <= 384 or >= 1000 workgroups the register-prefetch
-// kernel's smaller LDS footprint (more co-resident workgroups) wins.  NMH_GEMM_DMA=0 disables, =3/4 forces it (ring depth).
+// The pipelined kernel pays off where few workgroups exist to hide a global-load latency per k-tile (measured, M <= 8192:
+// fc2 4000x384x1536 21.9 -> 15.2 us, 500x768x3072 34.6 -> 24.5 us; with K = 384 the 4-deep ring holds most of the contraction at once:
+// whole step at 1 grid/GPU 13.75 -> 13.35 ms with the threshold lowered from K >= 1024 to K >= 384); with >= 1000 workgroups the
+// register-prefetch kernel's smaller LDS footprint (more co-resident workgroups) wins.  NMH_GEMM_DMA=0 disables, =3/4 forces it.
 template <typename T, int MT, int NT, class AL>
 static bool try_dma(const AL& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st, int* rc) {
   if constexpr (std::is_same<AL, ADirect<bf16_t>>::value && MT == 1) {
     static const int dma_st = [] { const char* e = getenv("NMH_GEMM_DMA"); return e ? atoi(e) : -1; }();
     if (dma_st == 0 || !lda_ok(al.lda, ldb)) return false;
-    static const int min_k = [] { const char* e = getenv("NMH_GEMM_DMA_MINK"); return e ? atoi(e) : 1024; }();
-    const bool auto_on = dma_st < 0 && K >= min_k && (long)M * batch <= 8192;
+    static const int min_k = [] { const char* e = getenv("NMH_GEMM_DMA_MINK"); return e ? atoi(e) : 384; }();
+    static const long max_m = [] { const char* e = getenv("NMH_GEMM_DMA_MAXM"); return e ? atol(e) : 8192L; }();
+    const bool auto_on = dma_st < 0 && K >= min_k && (long)M * batch <= max_m;
     if (dma_st == 3) { *rc = launch_nt_dma<MT, NT, 3>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
     if (dma_st == 4 || auto_on) { *rc = launch_nt_dma<MT, NT, 4>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
   }

@@ -148,6 +148,7 @@ struct LnBwdArgs {
   long rows; int C; WinMap wm;
   const unsigned char* mask; float* dmask_token; long tokens_per_sample;
   void* dyw; const float* dyw_scale;    // MODE 0 only: second output in window order (wm), scaled per sample (fused window gather)
+  int dyw_pads;                         // set by k_ln_bwd: the window-ordered tensor has pad rows (no token) -- the kernel writes their zeros
 };
 int k_ln_bwd(const LnBwdArgs& a, hipStream_t st);
 

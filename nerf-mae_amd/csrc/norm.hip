@@ -166,6 +166,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) pm[i][j] = 0.f;
 
+  if (MODE == 0 && a.dyw && a.dyw_pads) {   // pad rows of the window-ordered output (they receive no token): zeroed here, not by a launch of their own
+    const long wrows = (long)a.wm.B * a.wm.PH * a.wm.PW * a.wm.PD;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wrows * nch; i += (long)gridDim.x * 256) {
+      const unsigned m = (unsigned)i / (unsigned)nch, c = (unsigned)i - m * (unsigned)nch;
+      if (win_to_tok(a.wm, (long)m) < 0) { const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; Vec8<T>::store((T*)a.dyw + (long)m * C + c * 8, z8); }
+    }
+  }
   for (long row = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; row < a.rows; row += gstride) {
     long dyrow = row;
     if (MODE == 1) dyrow = tok_to_win(a.wm, row);
@@ -304,15 +311,14 @@ template <typename T, int MODE> static int ln_bwd_dispatch(const LnBwdArgs& a, h
   NMH_CHECK_LAUNCH();
   return 0;
 }
-int k_ln_bwd(const LnBwdArgs& a, hipStream_t st) {
+int k_ln_bwd(const LnBwdArgs& a0, hipStream_t st) {
+  LnBwdArgs a = a0;
+  a.dyw_pads = 0;
   if (a.dyw) {
     if (a.src_mode != 0) return -2;
     const WinMap& w = a.wm;
-    if ((long)w.PH * w.PW * w.PD != (long)w.H * w.W * w.D) {   // pad rows of the window-ordered tensor receive no token
-      const size_t es = a.dt == NMH_DT_BF16 ? 2 : 4;
-      hipError_t e = nmh_zero_async(a.dyw, (size_t)w.B * w.PH * w.PW * w.PD * a.C * es, st);
-      if (e != hipSuccess) return (int)e;
-    }
+    if ((long)w.B * w.PH * w.PW * w.PD * (a.C / 8) >= (1L << 32)) return -2;
+    a.dyw_pads = (long)w.PH * w.PW * w.PD != (long)w.H * w.W * w.D;   // pad rows of the window-ordered tensor receive no token
   }
   if (a.dt == NMH_DT_BF16) {
     if (a.src_mode == 0) return ln_bwd_dispatch<bf16_t, 0>(a, st);
