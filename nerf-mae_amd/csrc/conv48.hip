@@ -91,18 +91,24 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * 96 + c6 * 16) : 0xFFFFFFF0u;
     hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };
+  // LDS byte offset / 16 of halo request i (tile-invariant): two per VGPR.  Recomputing them per tile (two integer divisions by
+  // multiply-shift, predication and a serial within/line update per store: ~17 VALU instructions of which two quarter-rate
+  // multiplies) made the refill phase VALU-bound -- ~95 cycles per store and wave, 2.6k cycles per tile with two waves per SIMD --
+  // although the 13 ds_write_b128 themselves need ~1.3k; 7 VGPRs buy that back.
+  unsigned hoff[(HREG + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < HREG; ++i) {
+    const int cid = tid + 512 * i;
+    const int line = (cid * 4855) >> 19, within = cid - line * (HX * 6);
+    const int hz = (line * 205) >> 11, hy = line - hz * HY;
+    const unsigned u = (unsigned)(hz * PLANE + hy * LINE + within * 16) >> 4;   // < 2^13 (garbage for cid >= HCH: never stored)
+    if (i & 1) hoff[i >> 1] |= u << 16; else hoff[i >> 1] = u;
+  }
   auto halo_sstore = [&]() {
-    int tv = tid;
-    asm volatile("" : "+v"(tv));
-    int line = tv / (HX * 6), within = tv - line * (HX * 6);
 #pragma unroll
     for (int i = 0; i < HREG; ++i) {
-      if (line < (TZ + 2) * HY) {
-        const int hz = (line * 205) >> 11, hy = line - hz * HY;
-        *reinterpret_cast<uint4*>(halo + hz * PLANE + hy * LINE + within * 16) = hreg[i];  // within*16 = hx*96 + c6*16
-      }
-      within += 80; line += 4;
-      if (within >= HX * 6) { within -= HX * 6; line += 1; }
+      const unsigned off = (i & 1) ? ((hoff[i >> 1] >> 12) & 0xFFFF0u) : ((hoff[i >> 1] << 4) & 0xFFFF0u);
+      if (i < HREG - 1 || tid < HCH - 512 * (HREG - 1)) *reinterpret_cast<uint4*>(halo + off) = hreg[i];
     }
   };
   // weight chunk ck (steps [9ck, min(9ck+9,41))) -> LDS ring slot `buf` by LDS-DMA: the image is lane-linear
