@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 // unsigned division by a launch-invariant divisor (kernels.hpp FDiv; 64-bit div/mod on the VALU costs ~150 instructions each)
 __device__ __forceinline__ unsigned c48_fdiv(unsigned n, const FDiv& f) { return f.sh < 0 ? n : (__umulhi(n, f.M) >> f.sh); }
@@ -292,57 +293,68 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
         if (st_b >= 0) scur ^= 1;
         st_b = b;
       }
-      float st1[3][4], st2[3][4];
-#pragma unroll
-      for (int n = 0; n < 3; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { st1[n][r] = 0.f; st2[n][r] = 0.f; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int y = y0 + y_l + i;
-        if (z < a.D && y < a.H && x < a.W && (!(DBG & 1) || a.accumulate == 77)) {
-          // lane (li, g) owns channels 12g .. 12g+11 of voxel x = li (pack: row 4g+r of co-tile n <-> channel 12g + 4n + r)
-          bf16_t* dst = a.Y + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + 12 * g;
-          float v[3][4];
+      // lane (li, g) owns channels 12g .. 12g+11 of voxel x = li (pack: row 4g+r of co-tile n <-> channel 12g + 4n + r).  One 64-bit
+      // address per tile, + one row stride per x-line (the per-line form cost two 32-bit multiplies and three v_mad_u64_u32 each); the
+      // statistics variant is a separate instantiation so that the plain one carries no accumulator moves
+      bf16_t* const dst0 = a.Y + ((((long)b * a.D + z) * a.H + (y0 + y_l)) * a.W + x) * 48 + 12 * g;
+      const long rowstride = (long)a.W * 48;
+      const bool zx_ok = z < a.D && x < a.W && (!(DBG & 1) || a.accumulate == 77);
+      auto epilogue = [&](auto with_stats) {
+        constexpr bool ST = decltype(with_stats)::value;
+        float st1[ST ? 3 : 1][4], st2[ST ? 3 : 1][4];
+        if (ST) {
 #pragma unroll
           for (int n = 0; n < 3; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[n][r] = acc[i][n][r];
-          if (a.accumulate) {
-            const uint4 o = *reinterpret_cast<const uint4*>(dst);
-            const uint2 o2 = *reinterpret_cast<const uint2*>(dst + 8);
-            const unsigned ow[6] = {o.x, o.y, o.z, o.w, o2.x, o2.y};
+            for (int r = 0; r < 4; ++r) { st1[ST ? n : 0][r] = 0.f; st2[ST ? n : 0][r] = 0.f; }
+        }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { v[q >> 1][(q & 1) * 2] += __uint_as_float(ow[q] << 16); v[q >> 1][(q & 1) * 2 + 1] += __uint_as_float(ow[q] & 0xffff0000u); }
-          }
-          unsigned w6[6];
+        for (int i = 0; i < 4; ++i) {
+          if (zx_ok && y0 + y_l + i < a.H) {
+            bf16_t* dst = dst0 + i * rowstride;
+            float v[3][4];
 #pragma unroll
-          for (int q = 0; q < 6; ++q) w6[q] = pk_bf16(v[q >> 1][(q & 1) * 2], v[q >> 1][(q & 1) * 2 + 1]);
-          *reinterpret_cast<uint4*>(dst) = make_uint4(w6[0], w6[1], w6[2], w6[3]);   // (8-byte aligned 16-byte store: dword alignment suffices)
-          *reinterpret_cast<uint2*>(dst + 8) = make_uint2(w6[4], w6[5]);
-          if (stats) {  // statistics of exactly what the normalisation pass will read back
+            for (int n = 0; n < 3; ++n)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-              const float q0 = __uint_as_float(w6[q] << 16), q1 = __uint_as_float(w6[q] & 0xffff0000u);
-              st1[q >> 1][(q & 1) * 2] += q0; st1[q >> 1][(q & 1) * 2 + 1] += q1;
-              st2[q >> 1][(q & 1) * 2] += q0 * q0; st2[q >> 1][(q & 1) * 2 + 1] += q1 * q1;
+              for (int r = 0; r < 4; ++r) v[n][r] = acc[i][n][r];
+            if (a.accumulate) {
+              const uint4 o = *reinterpret_cast<const uint4*>(dst);
+              const uint2 o2 = *reinterpret_cast<const uint2*>(dst + 8);
+              const unsigned ow[6] = {o.x, o.y, o.z, o.w, o2.x, o2.y};
+#pragma unroll
+              for (int q = 0; q < 6; ++q) { v[q >> 1][(q & 1) * 2] += __uint_as_float(ow[q] << 16); v[q >> 1][(q & 1) * 2 + 1] += __uint_as_float(ow[q] & 0xffff0000u); }
+            }
+            unsigned w6[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) w6[q] = pk_bf16(v[q >> 1][(q & 1) * 2], v[q >> 1][(q & 1) * 2 + 1]);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(w6[0], w6[1], w6[2], w6[3]);   // (8-byte aligned 16-byte store: dword alignment suffices)
+            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(w6[4], w6[5]);
+            if (ST) {  // statistics of exactly what the normalisation pass will read back
+#pragma unroll
+              for (int q = 0; q < 6; ++q) {
+                const float q0 = __uint_as_float(w6[q] << 16), q1 = __uint_as_float(w6[q] & 0xffff0000u);
+                st1[ST ? q >> 1 : 0][(q & 1) * 2] += q0; st1[ST ? q >> 1 : 0][(q & 1) * 2 + 1] += q1;
+                st2[ST ? q >> 1 : 0][(q & 1) * 2] += q0 * q0; st2[ST ? q >> 1 : 0][(q & 1) * 2 + 1] += q1 * q1;
+              }
             }
           }
         }
-      }
-      if (stats) {
+        if (ST) {
 #pragma unroll
-        for (int n = 0; n < 3; ++n)
+          for (int n = 0; n < 3; ++n)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a1 = row_sum(st1[n][r]), a2 = row_sum(st2[n][r]);
-            if (li == 15) {
-              float* dst = sacc + scur * 96 + (12 * g + 4 * n + r) * 2;
-              atomicAdd(dst, a1);
-              atomicAdd(dst + 1, a2);
+            for (int r = 0; r < 4; ++r) {
+              const float a1 = row_sum(st1[ST ? n : 0][r]), a2 = row_sum(st2[ST ? n : 0][r]);
+              if (li == 15) {
+                float* dst = sacc + scur * 96 + (12 * g + 4 * n + r) * 2;
+                atomicAdd(dst, a1);
+                atomicAdd(dst + 1, a2);
+              }
             }
-          }
-      }
+        }
+      };
+      if (stats) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
     }
     stamp(6);
     cb = nb; cz0 = nz0; cy0 = ny0; cx0 = nx0;
