@@ -79,6 +79,10 @@ NMH_API int nmh_ncdhw_to_ndhwc(int dt, const float* src, void* dst, int B, int64
 /* The same convolution specialised for Cin = Cout = 48, bf16 (decoder1.conv_block at 160^3 -- 75 % of the model's FLOPs): persistent
  * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad). */
 NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, void* stream);
+/* The LDS-halo kernel on 48-channel blocks: Cin, Cout multiples of 48 (the 40^3 decoder level of swin_t/s: 96 / 192 channels;
+ * UnetResBlock convs, unetr_block.py:35-44); Wk = one fragment-ordered image per (output block, input block), output-block-major
+ * (pack modes 6 / 7 on a [Cout][Cin][27] weight).  No fused statistics. */
+NMH_API int nmh_conv3d_k3_c48mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 /* The same convolution on 64-channel blocks, bf16, Cin and Cout multiples of 64 (swin_b's decoder1 64 -> 64 at 160^3, BASELINE
  * configs[3]; the FPN neck's 256 -> 256 convolutions, nerf_rpn/model/fpn.py:104): persistent LDS-halo implicit GEMM that loops over the
  * input-channel blocks with the accumulators in registers.  Wk = fragment-ordered pack [Cout/64][Cin/64][54 steps][4][64 lanes][8]

@@ -126,6 +126,11 @@ int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int 
   CLR();
   return k_conv48(X, Wk, Y, B, D, H, W, accumulate, stats_acc, ST);
 }
+int nmh_conv3d_k3_c48mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+  CLR();
+  if (!X || !Wk || !Y) return -4;
+  return k_conv48_mb(X, Wk, Y, B, D, H, W, Cin, Cout, accumulate, ST);
+}
 int nmh_instnorm_finalize(const double* acc, float* stats, int B, int64_t V, int C, float eps, void* stream) {
   CLR();
   return k_in_finalize(0, acc, stats, B, (long)V, C, eps, ST);

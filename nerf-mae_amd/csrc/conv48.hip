@@ -40,6 +40,9 @@ struct C48Args {
   FDiv dtx, dty, dtz;
   int accumulate;
   double* stats_acc;           // optional [B][48][2] fp64 accumulators: per-channel sum / sum of squares of the (bf16-rounded) outputs
+  // multi-block variant (MB): Cin = 48 ncib, Cout = 48 ncob; a work item is (tile, output block cob, input block cib), cib innermost:
+  // the accumulators persist over cib, the epilogue runs after the last one; Wk holds one fragment-ordered image per (cob, cib)
+  int ncib, ncob, ldx, ldy;    // ldx / ldy: channels per voxel of X / Y
 };
 
 __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
@@ -58,9 +61,10 @@ __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b
 
 // DBG (diagnostic builds only, NMH_C48_DBG): 1 = no output stores, 2 = no halo prefetch / LDS refill, 4 = no weight DMA and no
 // chunk barriers, 8 = no MFMAs (operand traffic only), 16 = no operand reads in the k-loop (MFMAs only).  DBG = 0 is the product.
-template <int DBG>
+template <int DBG, bool MB = false>
 __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   using namespace c48;
+  constexpr long WBLK = (long)NSTEP * 3 * 512;   // elements of one (cob, cib) weight image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wbuf = smem + HALO;
@@ -72,14 +76,15 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
 
   uint4 hreg[HREG];
-  const unsigned sample_bytes = (unsigned)a.D * a.H * a.W * 96u;  // one sample of X (< 4 GiB)
+  const unsigned vox_bytes = MB ? (unsigned)a.ldx * 2u : 96u;
+  const unsigned sample_bytes = (unsigned)a.D * a.H * a.W * vox_bytes;  // one sample of X (< 4 GiB: checked at launch)
   // halo request i (of 13) of the tile at origin (b, z0, y0, x0): chunk id cid = tid + 512 i -> (line, within).  The requests of the
   // NEXT tile are dealt one at a time over the k-steps of the current tile (see the chunk loop): a burst of 13 x 8 wave-loads backs
   // up the CU's vector-memory path (measured ~40-75 cycles per 1-KB wave-load, latency-bound misses) and every wave then sits at
   // issue in front of its MFMAs; one request every few k-steps never queues.
   // `bytes` = sample_bytes, or 0 when there is no next tile: the request is still issued (no branch inside the k-loop) but every lane
   // is out of range and reads zero without touching memory
-  auto halo_gload_one = [&](int i, int b, int z0, int y0, int x0, unsigned bytes) {
+  auto halo_gload_one = [&](int i, int b, int z0, int y0, int x0, unsigned bytes, int cib) {
     int tv = tid;
     asm volatile("" : "+v"(tv));  // opaque: keep the index math below inside the tile loop (no LICM -> no long-lived VGPRs)
     // buffer resource over sample b: offsets are 32-bit, and an offset >= num_records reads as zero (the conv's zero padding)
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     const int hz = (line * 205) >> 11, hy = line - hz * HY, hx = (within * 43) >> 8, c6 = within - hx * 6;  // /10 and /6
     const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
     const bool ok = line < (TZ + 2) * HY && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-    const unsigned off = ok ? (unsigned)(((z * a.H + y) * a.W + x) * 96 + c6 * 16) : 0xFFFFFFF0u;
+    const unsigned off = ok ? (unsigned)((z * a.H + y) * a.W + x) * vox_bytes + (unsigned)((MB ? cib * 96 : 0) + c6 * 16) : 0xFFFFFFF0u;
     hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };
   // LDS byte offset / 16 of halo request i (tile-invariant): two per VGPR.  Recomputing them per tile (two integer divisions by
@@ -114,9 +119,9 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   };
   // weight chunk ck (steps [9ck, min(9ck+9,41))) -> LDS ring slot `buf` by LDS-DMA: the image is lane-linear
   // (dst = wave-uniform base + lane*16), so no VGPR staging and no ds_write pass; completes before the next barrier.
-  auto w_dma = [&](int ck, int buf) {
+  auto w_dma = [&](const bf16_t* wblk, int ck, int buf) {
     const int nunits = ((ck < 4) ? CSTEPS : (NSTEP - 4 * CSTEPS)) * 192;  // 16-B units, multiple of 64
-    const char* src = reinterpret_cast<const char*>(a.Wk) + (long)ck * CSTEPS * 3072;
+    const char* src = reinterpret_cast<const char*>(wblk) + (long)ck * CSTEPS * 3072;
     char* dst = wbuf + buf * WCHUNK;
     for (int u0 = wave * 64; u0 < nunits; u0 += 512) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long)(u0 + lane) * 16),
@@ -124,13 +129,13 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     }
   };
 
-  auto w_dma_one = [&](int ck, int buf, int j) {  // j-th (of <= 4) DMA instruction of this wave for chunk ck
+  auto w_dma_one = [&](const bf16_t* wblk, int ck, int buf, int j) {  // j-th (of <= 4) DMA instruction of this wave for chunk ck
     const int nunits = ((ck < 4) ? CSTEPS : (NSTEP - 4 * CSTEPS)) * 192;
     const int u0 = wave * 64 + 512 * j;
     int lv = lane;
     asm volatile("" : "+v"(lv));  // opaque: the (tile-invariant) 64-bit source addresses would otherwise be hoisted out of the tile loop: 40 VGPRs
     if (u0 < nunits)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.Wk) + (long)ck * CSTEPS * 3072 + (long)(u0 + lv) * 16),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(wblk) + (long)ck * CSTEPS * 3072 + (long)(u0 + lv) * 16),
                                        (__attribute__((address_space(3))) void*)(wbuf + buf * WCHUNK + u0 * 16), 16, 0, 0);
   };
 
@@ -144,9 +149,9 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   int cb, cz0, cy0, cx0;  // origin of the current tile; the next tile's origin is computed once (64-bit divisions) and carried over
   c48_tile_origin(a, t, cb, cz0, cy0, cx0);
 #pragma unroll
-  for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, cx0, sample_bytes);
-  w_dma(0, 0);
-  if (DBG & 4) w_dma(1, 1);
+  for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, cx0, sample_bytes, 0);
+  w_dma(a.Wk, 0, 0);
+  if (DBG & 4) w_dma(a.Wk, 1, 1);
   halo_sstore();
   __syncthreads();
   int wb = 0;  // LDS buffer holding chunk 0 of the current tile
@@ -194,18 +199,30 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   };
   if (DBG & 32) tlast = (long long)__builtin_amdgcn_s_memtime();
   const long long tbegin = tlast;
-  for (; t < tend; t += jstride) {
-    const long tn = t + jstride;
+  int cob = 0, cib = 0;   // MB: output / input channel block of the current work item
+  f32x4 acc[4][3];
+  for (;;) {
+    // next work item: (t, cob, cib + 1) -> (t, cob + 1, 0) -> (t + jstride, 0, 0)
+    long tn = t + jstride;
+    int nco = 0, nci = 0;
+    if (MB) {
+      nci = cib + 1; nco = cob; tn = t;
+      if (nci == a.ncib) { nci = 0; ++nco; }
+      if (nco == a.ncob) { nco = 0; tn = t + jstride; }
+    }
     const bool has_next = tn < tend;
     const bool pf_next = has_next && !(DBG & 2);
-    int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;
-    if (has_next) c48_tile_origin(a, tn, nb, nz0, ny0, nx0);
+    int nb = cb, nz0 = cz0, ny0 = cy0, nx0 = cx0;
+    if (has_next && (!MB || tn != t)) c48_tile_origin(a, tn, nb, nz0, ny0, nx0);
     const unsigned nbytes = pf_next ? sample_bytes : 0u;
-    f32x4 acc[4][3];
+    const bf16_t* const wcur = MB ? a.Wk + (long)(cob * a.ncib + cib) * WBLK : a.Wk;
+    const bf16_t* const wnxt = MB ? a.Wk + (long)(nco * a.ncib + nci) * WBLK : a.Wk;
+    if (!MB || cib == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int n = 0; n < 3; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < 3; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // k-steps are software-pipelined inside a weight chunk: the fragments of step s+1 (3 B, linear lane*16; 4 A, one per x-line)
     // are in flight while the 12 MFMAs of step s issue.  aoff(s): LDS byte offset of the A fragment of x-line 0.
@@ -245,11 +262,11 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       for (int sl = 0; sl < CSTEPS; ++sl) {
         if (sl < nst) {
           if (!(DBG & 16) && sl + 1 < nst) ld_frags((sl + 1) & 1, wsrc, sl + 1, ck * CSTEPS + sl + 1);
-          if (do_dma && sl < 4) w_dma_one(nxt, (wb + ck + 1) & 1, sl);
+          if (do_dma && sl < 4) w_dma_one(ck < 4 ? wcur : wnxt, nxt, (wb + ck + 1) & 1, sl);
           if (sl >= 4) {
             // chunk 0: steps 4,5,6,8; chunks 1-3: steps 4,6,8
             const int k = (hcnt == 4) ? (sl == 4 ? 0 : sl == 5 ? 1 : sl == 6 ? 2 : sl == 8 ? 3 : -1) : (hcnt == 3) ? (sl == 4 ? 0 : sl == 6 ? 1 : sl == 8 ? 2 : -1) : -1;
-            if (k >= 0) halo_gload_one(hbase + k, nb, nz0, ny0, nx0, nbytes);
+            if (k >= 0) halo_gload_one(hbase + k, nb, nz0, ny0, nx0, nbytes, nci);
           }
           if (DBG & 8) {
 #pragma unroll
@@ -284,10 +301,10 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 
     // ---- epilogue: transposed accumulators (row 4g + r of co-tile n = channel 12g + 4n + r, col = voxel x = li): every lane owns 12
     //      consecutive channels of one voxel per x-line -> a 16-byte and an 8-byte bf16 store straight from registers, no LDS restaging ----
-    {
+    if (!MB || cib == a.ncib - 1) {
       const int b = cb, z0 = cz0, y0 = cy0, x0 = cx0;
       const int z = z0 + z_l, x = x0 + li;
-      const bool stats = !(DBG & 32) && a.stats_acc;
+      const bool stats = !MB && !(DBG & 32) && a.stats_acc;
       if (stats && b != st_b) {
         stats_flush();
         if (st_b >= 0) scur ^= 1;
@@ -296,8 +313,9 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       // lane (li, g) owns channels 12g .. 12g+11 of voxel x = li (pack: row 4g+r of co-tile n <-> channel 12g + 4n + r).  One 64-bit
       // address per tile, + one row stride per x-line (the per-line form cost two 32-bit multiplies and three v_mad_u64_u32 each); the
       // statistics variant is a separate instantiation so that the plain one carries no accumulator moves
-      bf16_t* const dst0 = a.Y + ((((long)b * a.D + z) * a.H + (y0 + y_l)) * a.W + x) * 48 + 12 * g;
-      const long rowstride = (long)a.W * 48;
+      const int ldy = MB ? a.ldy : 48;
+      bf16_t* const dst0 = a.Y + ((((long)b * a.D + z) * a.H + (y0 + y_l)) * a.W + x) * ldy + (MB ? cob * 48 : 0) + 12 * g;
+      const long rowstride = (long)a.W * ldy;
       const bool zx_ok = z < a.D && x < a.W && (!(DBG & 1) || a.accumulate == 77);
       auto epilogue = [&](auto with_stats) {
         constexpr bool ST = decltype(with_stats)::value;
@@ -360,6 +378,8 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     cb = nb; cz0 = nz0; cy0 = ny0; cx0 = nx0;
     __syncthreads();
     stamp(8);
+    if (!has_next) break;
+    t = tn; cob = nco; cib = nci;
   }
   if (DBG & 32) {
     if (lane == 0) {
@@ -385,6 +405,7 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
   a.accumulate = accumulate;
   a.stats_acc = stats_acc;
+  a.ncib = a.ncob = 1; a.ldx = a.ldy = 48;
   static const int dbg = getenv("NMH_C48_DBG") ? atoi(getenv("NMH_C48_DBG")) : 0;
   if (stats_acc && !(dbg & 32)) {
     hipError_t e = nmh_zero_async(stats_acc, sizeof(double) * 2 * 48 * B, st);
@@ -409,6 +430,35 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
     return 0;
   }
   hipLaunchKernelGGL(conv48_kernel<0>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// The same kernel on 48-channel blocks: Cin = 48 ncib, Cout = 48 ncob (decoder level 40^3: 96 / 192 channels).  Every (tile, cob, cib) work
+// item is one halo fill + one 41-step contraction against its own weight image; the halo of an input block is re-fetched per output block
+// (L2 hits).  No fused statistics in this variant.
+int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, hipStream_t st) {
+  using namespace c48;
+  if (Cin % 48 || Cout % 48 || Cin <= 0 || Cout <= 0) return -2;
+  if ((long)D * H * W * Cin * 2 >= (1L << 32)) return -2;   // 32-bit buffer offsets inside one sample
+  C48Args a;
+  a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
+  a.B = B; a.D = D; a.H = H; a.W = W;
+  a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
+  a.total = (long)B * a.tz * a.ty * a.tx;
+  if (a.total >= (1L << 31)) return -2;
+  a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
+  a.accumulate = accumulate;
+  a.stats_acc = nullptr;
+  a.ncib = Cin / 48; a.ncob = Cout / 48; a.ldx = Cin; a.ldy = Cout;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long nb = a.total < 256 ? ((a.total + 7) / 8 * 8) : 256;
+  hipLaunchKernelGGL((conv48_kernel<0, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
 }

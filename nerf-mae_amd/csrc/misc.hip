@@ -475,17 +475,21 @@ __device__ __forceinline__ long pack_src_index(const PackDesc& d, long il) {
     case 4: { unsigned t2 = i / d0, ci = i - t2 * d0, t = t2 / d1, co = t2 - t * d1; return (long)((ci * d1 + co) * d2 + t); }
     case 5: { unsigned n = d1 * d2, ci = i / n, r = i - ci * n, t = r / d1, co = r - t * d1; return (long)((ci * d1 + co) * d2 + t); }
     case 6: case 7: {
-      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-      const unsigned sn = i >> 9;
+      // one 41 x 3 x 64 x 8 image per (output block ob, contraction block kb) of W'[n][tap][k], ob-major; Co = Ci = 48: a single image
+      constexpr unsigned IMG = 41u * 3u * 512u;
+      const unsigned blk = i / IMG, iw = i - blk * IMG;
+      const unsigned nkb = (d.mode == 6 ? d1 : d0) / 48u, ob = blk / nkb, kb = blk - ob * nkb;
+      const int j = (int)(iw & 7), lane = (int)((iw >> 3) & 63);
+      const unsigned sn = iw >> 9;
       // MFMA row li of co-tile nt carries channel 12*(li>>2) + 4*nt + (li&3): an accumulator lane then owns 12 CONSECUTIVE channels of
       // its voxel across the three co-tiles (24-byte runs in the epilogue instead of three 8-byte pieces)
-      const int nt = (int)(sn % 3), st = (int)(sn / 3), g = lane >> 4, li = lane & 15, n = 12 * (li >> 2) + 4 * nt + (li & 3);
+      const int nt = (int)(sn % 3), st = (int)(sn / 3), g = lane >> 4, li = lane & 15, n = (int)ob * 48 + 12 * (li >> 2) + 4 * nt + (li & 3);
       int r, c;
       if (st < 36) { r = 4 * (st / 18) + g; c = st % 18; } else { r = 8; c = 4 * (st - 36) + g; }
       if (c >= 18) return -1;
-      const int tap = r * 3 + c / 6, k = (c % 6) * 8 + j;  // tap = (dz+1)*9+(dy+1)*3+(dx+1), r = (dz+1)*3+(dy+1)
-      // W'[n][tap][k]: fwd  = W[co=n][ci=k][tap];  dgrad = W[co=k][ci=n][26-tap]
-      return d.mode == 6 ? ((long)n * 48 + k) * 27 + tap : ((long)k * 48 + n) * 27 + (26 - tap);
+      const int tap = r * 3 + c / 6, k = (int)kb * 48 + (c % 6) * 8 + j;  // tap = (dz+1)*9+(dy+1)*3+(dx+1), r = (dz+1)*3+(dy+1)
+      // W'[n][tap][k]: fwd  = W[co=n][ci=k][tap];  dgrad = W[co=k][ci=n][26-tap]   (src layout [Co=d0][Ci=d1][27])
+      return d.mode == 6 ? ((long)n * d1 + k) * 27 + tap : ((long)k * d1 + n) * 27 + (26 - tap);
     }
     case 10: { unsigned r = i / d1; return r < d0 ? (long)i : -1; }                                   // [d0][d1] -> [d2 >= d0 rows][d1], zero rows
     case 11: { unsigned c = i / d2, r = i - c * d2; return r < d0 ? (long)(r * d1 + c) : -1; }          // [d0][d1] -> transposed [d1][d2 >= d0], zero columns

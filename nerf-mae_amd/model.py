@@ -115,7 +115,8 @@ class _Packer:
             dims = (sh[0], sh[1], 27)
         else:
             dims = (sh[0], sh[1], int(np.prod(sh[2:])))
-        numel = self.C48_NUMEL if mode in (self.C48_F, self.C48_D) else ops.conv64_pack_numel(sh[1], sh[0]) if mode in (self.C64_F, self.C64_D) else p.numel()
+        numel = (self.C48_NUMEL * (sh[0] // 48) * (sh[1] // 48) if mode in (self.C48_F, self.C48_D)
+                 else ops.conv64_pack_numel(sh[1], sh[0]) if mode in (self.C64_F, self.C64_D) else p.numel())
         if mode in (self.PAD_ROWS, self.PAD_ROWS_T):     # [Co][C] -> [Cop][C] / [C][Cop], Cop = Co rounded up to 8 (GEMM N granule)
             cop = (sh[0] + 7) // 8 * 8
             dims, numel = (sh[0], int(np.prod(sh[1:])), cop), cop * int(np.prod(sh[1:]))
@@ -379,10 +380,14 @@ class _UpBlockFn(torch.autograd.Function):
         scratch = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
         ctx.c64 = False
         c48 = (key + "c1.wk") in pk.views and (key + "c2.wk") in pk.views
-        c64 = (not c48 and (key + "c1.w64") in pk.views and (key + "c2.w64") in pk.views and S ** 3 >= ops.C64_MIN_VOXELS > 0
+        c48mb = (not c48 and (key + "c1.wkm") in pk.views and (key + "c2.wkm") in pk.views and S ** 3 >= ops.C48MB_MIN_VOXELS > 0
+                 and S ** 3 * Cc * 2 < 2 ** 32)
+        c64 = (not c48 and not c48mb and (key + "c1.w64") in pk.views and (key + "c2.w64") in pk.views and S ** 3 >= ops.C64_MIN_VOXELS > 0
                and S ** 3 * Cc * 2 < 2 ** 32)
         if c48:   # Cin = Cout = 48 in bf16: LDS-halo kernel with fragment-ordered weights ("c1.w" -> "c1.wk", "c1.wd" -> "c1.wkd")
             conv = lambda X, nm, co, **kw: ops.conv3d_k3_c48(X, pk[key + nm.replace(".w", ".wk")], **kw)  # noqa: E731
+        elif c48mb:  # channel counts multiples of 48 at a volume that fills the chip (40^3, 96 / 192 channels): the same kernel on 48-channel blocks
+            conv = lambda X, nm, co, **kw: ops.conv3d_k3_c48mb(X, pk[key + nm.replace(".w", ".wkm")], co, **kw)  # noqa: E731
         elif c64:  # channel counts multiples of 64 (swin_b): LDS-halo kernel on 64-channel blocks ("c1.w" -> "c1.w64", "c1.wd" -> "c1.w64d")
             conv = lambda X, nm, co, **kw: ops.conv3d_k3_c64(X, pk[key + nm.replace(".w", ".w64")], co, **kw)  # noqa: E731
         else:
@@ -754,6 +759,10 @@ class SwinTransformer_MAE3D_New(nn.Module):
                 if self.compute_dtype == torch.bfloat16 and tuple(conv.weight.shape[:2]) == (48, 48):
                     P.add(key + cn + ".wk", conv.weight, P.C48_F)     # specialised LDS-halo kernel (decoder1 @160^3)
                     P.add(key + cn + ".wkd", conv.weight, P.C48_D)
+                elif (self.compute_dtype == torch.bfloat16 and conv.weight.shape[0] % 48 == 0 and conv.weight.shape[1] % 48 == 0
+                      and (d.k * (self.resolution // 4) // {"decoder4": 8, "decoder3": 4, "decoder2": 2, "decoder1": 1}[name]) ** 3 >= ops.C48MB_MIN_VOXELS > 0):
+                    P.add(key + cn + ".wkm", conv.weight, P.C48_F)    # the LDS-halo kernel on 48-channel blocks (swin_t/s decoder level 40^3)
+                    P.add(key + cn + ".wkmd", conv.weight, P.C48_D)
                 elif (self.compute_dtype == torch.bfloat16 and conv.weight.shape[0] % 64 == 0 and conv.weight.shape[1] % 64 == 0
                       and (d.k * (self.resolution // 4) // {"decoder4": 8, "decoder3": 4, "decoder2": 2, "decoder1": 1}[name]) ** 3 >= ops.C64_MIN_VOXELS > 0):
                     P.add(key + cn + ".w64", conv.weight, P.C64_F)    # 64-channel-block LDS-halo kernel (swin_b decoder levels >= 32^3)

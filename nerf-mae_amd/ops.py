@@ -243,6 +243,25 @@ def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None):
     return out
 
 
+C48MB_MIN_VOXELS = int(__import__("os").environ.get("NMH_C48MB_MIN_VOXELS", "32768"))   # 0 disables the 48-channel-block multi-block kernel
+
+
+def conv3d_k3_c48mb(X, Wk, Cout, out=None, accumulate=False):
+    """3x3x3 conv on 48-channel blocks (bf16, Cin and Cout multiples of 48; one fragment-ordered image per (output block, input block), pack
+    modes 6/7 on the [Cout][Cin][27] weight): the decoder1 LDS-halo kernel with (tile, output block, input block) work items"""
+    _chk(X, Wk, out)
+    B, D, H, W, Cin = X.shape
+    if Cin % 48 or Cout % 48 or X.dtype != torch.bfloat16:
+        raise RuntimeError("conv3d_k3_c48mb needs bf16 activations with channel counts that are multiples of 48")
+    if out is None:
+        out = torch.empty((B, D, H, W, Cout), dtype=X.dtype, device=X.device)
+    ev = _prof(("conv3d_k3_halo", B, D, Cin, Cout))
+    lib().call("nmh_conv3d_k3_c48mb", X, Wk, out, B, D, H, W, Cin, Cout, int(accumulate), _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 def conv3d_k3_c64(X, Wk, Cout, out=None, accumulate=False, stats_acc=None, bias=None):
     """3x3x3 conv on 64-channel blocks (bf16, Cin and Cout multiples of 64; fragment-ordered weights Wk, pack modes 8/9); stats_acc:
     optional fp64 [B,Cout,2] buffer receiving the fused InstanceNorm statistics"""

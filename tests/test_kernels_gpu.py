@@ -664,6 +664,33 @@ def test_conv48_specialised_matches_reference_conv(B, D, H, W):
     check(dW, wr.grad + 0.5, dt, "conv48 wgrad")
 
 
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(1, 8, 16, 32, 96, 96), (2, 6, 10, 20, 192, 96), (1, 12, 9, 40, 96, 192), (1, 4, 8, 16, 144, 48)])
+def test_conv48_multiblock_matches_reference_conv(B, D, H, W, Cin, Cout):
+    """the LDS-halo kernel on 48-channel blocks (Cin, Cout multiples of 48: (tile, output block, input block) work items, one weight image
+    per block pair): forward pack, dgrad pack with accumulate, ragged tiles -- vs F.conv3d"""
+    ops = _ops()
+    dt = torch.bfloat16
+    x = q(rnd(B, Cin, D, H, W), dt)
+    w = q(rnd(Cout, Cin, 3, 3, 3, seed=1, scale=(27 * Cin) ** -0.5), dt)
+    dy = q(rnd(B, Cout, D, H, W, seed=2), dt)
+    xr = x.clone().requires_grad_(True)
+    y = F.conv3d(xr, w, padding=1)
+    y.backward(dy)
+    n = 41 * 3 * 64 * 8 * (Cin // 48) * (Cout // 48)
+    wk_f, wk_d = _pack_via_kernel(w, 6, dt, n), _pack_via_kernel(w, 7, dt, n)
+    xcl = dev(x.permute(0, 2, 3, 4, 1), dt)
+    yk = ops.conv3d_k3_c48mb(xcl, wk_f, Cout)
+    check(yk.permute(0, 4, 1, 2, 3), y, dt, "conv48mb fwd")
+    base = q(rnd(B, D, H, W, Cin, seed=3), dt)
+    out = dev(base, dt)
+    dycl = dev(dy.permute(0, 2, 3, 4, 1), dt)
+    ops.conv3d_k3_c48mb(dycl, wk_d, Cin, out=out, accumulate=True)
+    check(out.permute(0, 4, 1, 2, 3), xr.grad + base.permute(0, 4, 1, 2, 3), dt, "conv48mb dgrad+accumulate", 2)
+    out2 = torch.empty_like(out)
+    ops.conv3d_k3_c48mb(dycl, wk_d, Cin, out=out2)
+    check(out2.permute(0, 4, 1, 2, 3), xr.grad, dt, "conv48mb dgrad", 2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_copy_cols_strided(dtype):
     """skip connection into / out of the concatenated decoder tensor (torch.cat(dim=1) in channels-last = column block copy)"""
