@@ -35,5 +35,5 @@ def run(rows, C):
     print(f"ln_bwd rows={rows} C={C}: {(time.perf_counter() - t) / 10 / N * 1e6:.1f} us per call")
 
 
-for rows, C in ((4000, 384), (32000, 192), (256000, 96), (500, 768)):
+for rows, C in ((8000, 384), (64000, 192), (512000, 96), (64000, 96), (1000, 384)):
     run(rows, C)
