@@ -152,7 +152,8 @@ def test_capi_rejects_null_required_pointers_without_touching_the_device():
     L = lib().cdll
     null = ctypes.c_void_p(None)
     assert L.nmh_gemm_nt(1, null, 96, null, 96, 64, 96, 96, null, 96, null, 0, null, null, null, 1, 0, null) == -4
-    assert L.nmh_conv3d_k3(1, null, null, null, 1, 8, 8, 8, 48, 48, 0, null) == -4
+    assert L.nmh_conv3d_k3(1, null, null, null, 1, 8, 8, 8, 48, 48, 0, null, 0, null) == -4
+    assert L.nmh_conv3d_k3_c48mb(null, null, null, 1, 8, 8, 8, 96, 96, 0, null) == -4
     assert L.nmh_gemm_tn_grouped(1, null, 3, null, 0, null) == -4
     assert L.nmh_conv3d_k3_c64(null, null, null, 1, 8, 8, 8, 64, 64, 0, null, null, null) == -4
     assert L.nmh_error_string(-4).decode().startswith("nmh:")
