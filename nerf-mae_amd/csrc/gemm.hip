@@ -470,6 +470,7 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
     int mt = ov[0] - '0', nt = atoi(ov + 2);
     if (mt == 1 && nt == 4) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (mt == 1 && nt == 6) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (mt == 1 && nt == 8) return launch_nt<T, 1, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (mt == 2 && nt == 6) return launch_nt<T, 2, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (mt == 2 && nt == 8) return launch_nt<T, 2, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (mt == 4 && nt == 6) return launch_nt<T, 4, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
@@ -480,6 +481,9 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
   // are HBM-bound with a latency-bound prologue/epilogue per workgroup, and co-resident workgroups are what hides it
   // (measured on 256000x288x96: 145 us with 256x128 tiles, 67 us with 64x96)
   if (((long)M * batch <= 8192 || K <= 1024) && t16 >= 4) {
+    // wide outputs of the 40^3-token Linears (fc1 / fc2-dgrad: N = 384, K = 96, >= 256 k rows) are write-bound: 128-column tiles store
+    // 256-byte-aligned row segments (96-column tiles split every second 128-byte line between two workgroups): 393 -> 312 us at 512 k rows
+    if (t16 % 8 == 0 && K <= 128 && (long)M * batch >= 100000) return launch_nt<T, 1, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 6 == 0) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 4 == 0) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 3 == 0) return launch_nt<T, 1, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
