@@ -367,10 +367,11 @@ def e2e_leg(model, args, R, sweep):
     res = {}
     for name, dt_ in (("uint8_scenes", np.uint8), ("fp32_scenes", np.float32)):
         scenes = [data.synthetic_scene((R, R, R), seed=50 + i, dtype=dt_) for i in range(8)]
-        tr = Trainer(model, scenes * 8, batch_size=nb, num_epochs=1, log=lambda *_: None)
+        tr = Trainer(model, scenes * 32, batch_size=nb, num_epochs=1, log=lambda *_: None)   # 64 steps per epoch: the per-epoch pipeline fill
+        # (first batch not overlapped, producer thread start-up, one loss read-back) is 20-40 ms, i.e. invisible in a real epoch and 2 ms/step in a 16-step one
         tr.train_epoch(1)      # capture + warm (pinned rings, copy stream)
         dt = None
-        for ep in (2, 3):      # steady state: the better of two timed epochs of 16 steps
+        for ep in (2, 3):      # steady state: the better of two timed epochs of 64 steps
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             tr.train_epoch(ep)
