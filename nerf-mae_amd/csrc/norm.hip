@@ -989,6 +989,225 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
   __syncthreads();
   if (threadIdx.x < (a.dp ? 8 : 4)) atomicAdd(&a.sums[threadIdx.x], (double)sacc[threadIdx.x]);
 }
+// ---- the same pass on the matrix cores (bf16, C = 48, training: d(pred) + backward sums, d0 not stored) ------------------------------------
+// tail_fwd_kernel<bf16, true> is VALU-bound (354 packed-fp32 instructions per 10 voxels, 2.4 TB/s): the 48 -> 4 head is a dot product per lane
+// plus a shuffle tree, the loss terms run on one lane in six, and the backward sums are 128 FMAs per lane and iteration.  Here a wave
+// takes 32 voxels per step as two 16-voxel MFMA tiles:
+//  * lane (vi, g) loads the 16-byte chunk g of voxel vi of either tile (channels 8g..8g+7) plus one chunk of channels 32..47 (lanes g < 2:
+//    tile 0, g >= 2: tile 1) -- three dense wave-loads per operand and step -- and forms x-hat, d0 = lrelu(x-hat + r) rounded to bf16;
+//  * the packed d0 chunks ARE the A fragments of the head GEMM P[voxel][o] = sum_c d0[c] W[o][c] (k-slot = channel; the shared third chunk
+//    is multiplied by a B fragment that is zero on the other tile's k-slots); W as bf16 hi + lo parts (fp32-exact to 2^-17);
+//  * the product leaves lane (o, g) with P[voxels 4g..4g+3][o]: lanes o < 4 evaluate the loss terms and d(pred) of four consecutive voxels of
+//    ONE output each (16-byte target loads along x);
+//  * their d(pred) values, as they sit, are the A fragment D[o][voxel] of the reduction GEMMs S_q[o][c] = sum_v D[o][v] F_q[v][c] over the
+//    32 voxels, F = {[d0>0], [d0>0] x-hat, x-hat, d0} in bf16 ([d0>0] and d0 exact), written by the loading lanes to a wave-private LDS image
+//    [voxel][48] (96-byte rows: conflict-free ds_read_b64_tr_b16) and read back transposed as B fragments: 12 MFMAs per 32 voxels replace
+//    the per-lane FMAs.  The LeakyReLU slope enters as lr = slope + (1 - slope) [d0 > 0] when the block combines its sums, so no operand
+//    carries the inexact bf16 value of the slope.
+__global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ r, LossArgs a,
+                                                            long V, float slope, long vpb) {
+  constexpr int C = 48, OPB = 32 * 96, WLDS = 4 * OPB;   // per wave: 4 operand images of 32 voxel rows x 96 bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float sacc[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, vi = lane & 15, g = lane >> 4, b = blockIdx.y;
+  char* const wl = smem + wave * WLDS;
+  if (tid < 8) sacc[tid] = 0.f;
+  __syncthreads();
+  // channel chunks of this lane: sets 0 / 1 = channels 8g.. of tile 0 / 1, set 2 = channels 32 + 8(g&1).. of tile g>>1
+  const int c0 = 8 * g, c1 = 32 + 8 * (g & 1), t2 = g >> 1;
+  float mu0[8], rs0[8], mu1[8], rs1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mu0[j] = stats[((long)b * C + c0 + j) * 2]; rs0[j] = stats[((long)b * C + c0 + j) * 2 + 1];
+    mu1[j] = stats[((long)b * C + c1 + j) * 2]; rs1[j] = stats[((long)b * C + c1 + j) * 2 + 1];
+  }
+  // head weight fragments (B operand: lane (o = vi, g), k-slot j = channel): k-step 0 = channels 8g + j; the shared chunk: tile 0 reads
+  // lanes g < 2 (channels 32 + 8g + j), tile 1 lanes g >= 2 (channels 32 + 8(g-2) + j); hi + lo bf16 parts of the fp32 weights
+  Frag<bf16_t> w0h, w0l, wah, wal, w1h, w1l, wbh, wbl;   // w0*/wa*: tile 0 (output o in lane vi = o); w1*/wb*: tile 1 (output o in lane vi = 4 + o)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ow = vi & 3;
+    const float wa = vi < 8 ? a.Wout[ow * C + c0 + j] : 0.f, wb = vi < 8 ? a.Wout[ow * C + c1 + j] : 0.f;
+    const bf16_t ah = f2bf(wa), bh = f2bf(wb);
+    const bf16_t al = f2bf(wa - bf2f(ah)), bl = f2bf(wb - bf2f(bh));
+    const bool t0 = vi < 4, t1 = vi >= 4 && vi < 8;
+    w0h.v[j] = t0 ? (short)ah : (short)0; w0l.v[j] = t0 ? (short)al : (short)0;
+    w1h.v[j] = t1 ? (short)ah : (short)0; w1l.v[j] = t1 ? (short)al : (short)0;
+    wah.v[j] = (t0 && g < 2) ? (short)bh : (short)0; wal.v[j] = (t0 && g < 2) ? (short)bl : (short)0;
+    wbh.v[j] = (t1 && g >= 2) ? (short)bh : (short)0; wbl.v[j] = (t1 && g >= 2) ? (short)bl : (short)0;
+  }
+  const float bias_l = a.bout[vi & 3];                // the loss part runs on lanes vi < 8: output vi & 3 of tile vi >> 2
+  const int e0 = a.extents[b * 3], e1 = a.extents[b * 3 + 1], e2 = a.extents[b * 3 + 2];
+  const unsigned Ru = (unsigned)a.R;
+  const int gd = a.R >> 2;
+  f32x4 S[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) S[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float lsq = 0.f, cnt = 0.f, dsum = 0.f;
+  const long v0 = (long)blockIdx.x * vpb;
+  long v1 = v0 + vpb;
+  if (v1 > V) v1 = V;
+  const bf16_t* const xb = x + (long)b * V * C;
+  const bf16_t* const rb = r + (long)b * V * C;
+  uint4 nx[3], nr[3];
+  auto issue = [&](long base) {   // base + 32 <= V (V is a multiple of 64: R is a multiple of 4)
+    const long o0 = (base + vi) * C + c0, o1 = (base + 16 + vi) * C + c0, o2 = (base + 16 * t2 + vi) * C + c1;
+    nx[0] = *reinterpret_cast<const uint4*>(xb + o0); nr[0] = *reinterpret_cast<const uint4*>(rb + o0);
+    nx[1] = *reinterpret_cast<const uint4*>(xb + o1); nr[1] = *reinterpret_cast<const uint4*>(rb + o1);
+    nx[2] = *reinterpret_cast<const uint4*>(xb + o2); nr[2] = *reinterpret_cast<const uint4*>(rb + o2);
+  };
+  // one chunk: x-hat, d0 (bf16), and the four packed operand rows for the reduction GEMMs
+  auto chunk = [&](const uint4& xw, const uint4& rw, const float (&mu)[8], const float (&rs)[8], uint4& ypk, uint4& mpk, uint4& mxpk, uint4& xpk) {
+    const unsigned xs[4] = {xw.x, xw.y, xw.z, xw.w}, rr[4] = {rw.x, rw.y, rw.z, rw.w};
+    unsigned yo[4], mo[4], mxo[4], xo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xa = (__uint_as_float(xs[i] << 16) - mu[2 * i]) * rs[2 * i], xc = (__uint_as_float(xs[i] & 0xffff0000u) - mu[2 * i + 1]) * rs[2 * i + 1];
+      float ya = xa + __uint_as_float(rr[i] << 16), yc = xc + __uint_as_float(rr[i] & 0xffff0000u);
+      // (the sign of the fp32 value is the sign of its bf16 rounding: same exponent range)
+      const float ma = ya > 0.f ? 1.0f : 0.0f, mc = yc > 0.f ? 1.0f : 0.0f;
+      ya = fmaxf(ya, slope * ya); yc = fmaxf(yc, slope * yc);   // LeakyReLU, 0 < slope < 1
+      const unsigned yp = pk_bf16(ya, yc);
+      yo[i] = yp;
+      mo[i] = pk_bf16(ma, mc);
+      mxo[i] = pk_bf16(ma * xa, mc * xc);
+      xo[i] = pk_bf16(xa, xc);
+    }
+    ypk = make_uint4(yo[0], yo[1], yo[2], yo[3]); mpk = make_uint4(mo[0], mo[1], mo[2], mo[3]);
+    mxpk = make_uint4(mxo[0], mxo[1], mxo[2], mxo[3]); xpk = make_uint4(xo[0], xo[1], xo[2], xo[3]);
+  };
+  auto put = [&](int row, int cb, const uint4& mpk, const uint4& mxpk, const uint4& xpk, const uint4& ypk) {
+    char* p = wl + row * 96 + cb * 2;
+    *reinterpret_cast<uint4*>(p) = mpk;
+    *reinterpret_cast<uint4*>(p + OPB) = mxpk;
+    *reinterpret_cast<uint4*>(p + 2 * OPB) = xpk;
+    *reinterpret_cast<uint4*>(p + 3 * OPB) = ypk;
+  };
+  const long gstep = 4 * 32;
+  long base = v0 + wave * 32;
+  if (base < v1) issue(base);
+  for (; base < v1; base += gstep) {
+    uint4 cx[3], cr[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { cx[k] = nx[k]; cr[k] = nr[k]; }
+    if (base + gstep < v1) issue(base + gstep);
+    uint4 y0, y1, y2, mp, mxp, xp;
+    chunk(cx[0], cr[0], mu0, rs0, y0, mp, mxp, xp); put(vi, c0, mp, mxp, xp, y0);
+    chunk(cx[1], cr[1], mu0, rs0, y1, mp, mxp, xp); put(16 + vi, c0, mp, mxp, xp, y1);
+    chunk(cx[2], cr[2], mu1, rs1, y2, mp, mxp, xp); put(16 * t2 + vi, c1, mp, mxp, xp, y2);
+    // head: P[voxel][o] for both tiles
+    Frag<bf16_t> f0, f1, f2;
+    f0.v = __builtin_bit_cast(bf16x8, y0); f1.v = __builtin_bit_cast(bf16x8, y1); f2.v = __builtin_bit_cast(bf16x8, y2);
+    f32x4 P[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    mma(P[0], f0, w0h); mma(P[0], f0, w0l); mma(P[0], f2, wah); mma(P[0], f2, wal);
+    mma(P[1], f1, w1h); mma(P[1], f1, w1l); mma(P[1], f2, wbh); mma(P[1], f2, wbl);
+    // loss terms and d(pred): lane (o, g) of P[t] holds output o of voxels 4g..4g+3 of tile t (o = vi < 4)
+    // (tile 1's product uses weight fragments whose output o sits in column 4 + o, so ONE pass over lanes vi < 8 -- tile vi >> 2, output
+    //  vi & 3 -- covers both tiles without moving data between lanes)
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vi < 8) {
+      const int tl = vi >> 2, ol = vi & 3;
+      const long vq = base + 16 * tl + 4 * g;
+      const unsigned vox = (unsigned)vq, tq = vox / Ru, zq = tq / Ru;
+      const int x0 = (int)(vox - tq * Ru), yy = (int)(tq - zq * Ru), zz = (int)zq;
+      const float4 tg = *reinterpret_cast<const float4*>(a.target + ((long)b * 4 + ol) * V + vq);
+      const float4 t3 = *reinterpret_cast<const float4*>(a.target + ((long)b * 4 + 3) * V + vq);
+      const bool rowok = zz < e0 && yy < e1 && a.tokmask[((zz >> 2) * gd + (yy >> 2)) * gd + (x0 >> 2)] != 0;
+      const float tv[4] = {tg.x, tg.y, tg.z, tg.w}, t3v[4] = {t3.x, t3.y, t3.z, t3.w};
+      const bool alpha = ol == 3;
+      float pv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // branch-free over the lane's output: RGB terms (o < 3) and the alpha term (o = 3) differ in selects only
+        const float p = (tl ? P[1][q] : P[0][q]) + bias_l;
+        pv[q] = p;
+        const bool on = alpha ? (rowok && x0 + q < e2) : (t3v[q] > 0.01f);
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-p));
+        const float val = alpha ? sg : p, df = val - tv[q];
+        const float dfac = alpha ? 2.f * sg * (1.f - sg) : 2.f;
+        const float l = on ? df * df : 0.f, d = on ? dfac * df : 0.f;
+        lsq += l; dsum += d; dq[q] = d;
+        cnt += (on && (ol == 0 || alpha)) ? 1.f : 0.f;
+        a.dp[((long)b * V + vq + q) * 4 + ol] = d;
+      }
+      if (a.pred) *reinterpret_cast<float4*>(a.pred + ((long)b * 4 + ol) * V + vq) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    }
+    // reduction GEMMs over the 32 voxels: A = D (k-slot 4t + q <-> voxel 16t + 4g + q = LDS row), B = the operand images
+    // rows 0-3 of A: output o over tile 0's voxels (k-slots 0-3), rows 4-7: output o over tile 1's voxels (k-slots 4-7); the two row groups
+    // of S are added in the block reduction
+    Frag<bf16_t> df;
+    {
+      const unsigned lo01 = pk_bf16(dq[0], dq[1]), lo23 = pk_bf16(dq[2], dq[3]);
+      const bool t1 = (vi & 4) != 0;
+      df.v = __builtin_bit_cast(bf16x8, make_uint4(t1 ? 0u : lo01, t1 ? 0u : lo23, t1 ? lo01 : 0u, t1 ? lo23 : 0u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const char* pa = wl + q * OPB + (4 * g + (vi >> 2)) * 96 + (n * 4 + (vi & 3)) * 8;
+        const bf16x4 lo = ds_read_tr16(pa), hi = ds_read_tr16(pa + 16 * 96);
+        Frag<bf16_t> bf;
+        bf.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        mma(S[q][n], df, bf);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- block reduction: S[q][n][r] of lane (c = vi, g = tile) is that tile's sum for (operand q, output o = r, channel 16n + c) ---------
+  __syncthreads();   // every wave is done with its operand images
+  float* red = reinterpret_cast<float*>(smem);   // [wave * 2 + tile][q][o][48]
+  if (g < 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) red[(((wave * 2 + g) * 4 + q) * 4 + rr) * C + 16 * n + vi] = S[q][n][rr];
+  }
+  // loss sums
+  {
+    float l = vi < 8 ? lsq : 0.f, c = vi < 8 ? cnt : 0.f, d = vi < 8 ? dsum : 0.f;   // lane (vi, g): output vi & 3
+    l += __shfl_xor(l, 4, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+    c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+    d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 16, 64); d += __shfl_xor(d, 32, 64);
+    if (lane < 4) {
+      if (lane < 3) atomicAdd(&sacc[0], l); else atomicAdd(&sacc[2], l);
+      if (lane == 0) atomicAdd(&sacc[1], c);
+      if (lane == 3) atomicAdd(&sacc[3], c);
+      atomicAdd(&sacc[4 + lane], d);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 8 * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    float T[4][4];   // [operand][o]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int oo = 0; oo < 4; ++oo) {
+        float t = 0.f;
+        for (int w = 0; w < 8; ++w) t += red[((w * 4 + q) * 4 + oo) * C + c];
+        T[q][oo] = t;
+      }
+    float val;
+    if (k < 4) {
+      const bool xh = k & 1;                        // k = 0: sum g_rgb, 1: sum g_rgb x-hat, 2: sum g_a, 3: sum g_a x-hat
+      val = 0.f;
+      const int o_lo = k < 2 ? 0 : 3, o_hi = k < 2 ? 3 : 4;
+      for (int oo = o_lo; oo < o_hi; ++oo) {
+        const float plain = xh ? T[2][oo] : sacc[4 + oo], masked = xh ? T[1][oo] : T[0][oo];   // sum_v d [* x-hat],  sum_v d [d0>0] [* x-hat]
+        val += a.Wout[oo * C + c] * (slope * plain + (1.0f - slope) * masked);
+      }
+    } else val = T[3][k - 4];
+    double* dst = k < 4 ? a.bwd_sums + ((long)b * C + c) * 4 + k : a.bwd_sums + (long)a.B * C * 4 + (long)(k - 4) * C + c;
+    atomicAdd(dst, (double)val);
+  }
+  if (tid < 8) atomicAdd(&a.sums[tid], (double)sacc[tid]);
+}
 int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void* r, void* out, float slope, hipStream_t st) {
   const int C = a.Cd;
   if (C % 8 || C > 512) return -2;
@@ -1003,6 +1222,14 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
     if (!a.dp) return -4;   // the fused backward sums are built from d(pred)
     e = nmh_zero_async(a.bwd_sums, sizeof(double) * ((size_t)a.B * C * 4 + 4 * C), st);
     if (e != hipSuccess) return (int)e;
+    const int use_mfma = getenv("NMH_TAIL_MFMA") ? atoi(getenv("NMH_TAIL_MFMA")) : 1;
+    if (use_mfma && a.dt == NMH_DT_BF16 && C == 48 && !out && a.R % 4 == 0 && V < (1L << 31) && slope > 0.f && slope < 1.f) {
+      const long vpm = (vpb + 127) / 128 * 128;   // whole 32-voxel steps per wave
+      dim3 gm((unsigned)((V + vpm - 1) / vpm), a.B);
+      hipLaunchKernelGGL(tail_fwd_mfma_kernel, gm, dim3(256), 4 * 4 * 32 * 96, st, (const bf16_t*)x, stats, (const bf16_t*)r, a, V, slope, vpm);
+      NMH_CHECK_LAUNCH();
+      return 0;
+    }
     const size_t lds = 64 * 256 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -511,13 +511,28 @@ def test_tail_backward_fused(dt):
     lsums4, losses4, dpred4 = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda"), torch.empty(B * V, 4, device="cuda")
     bsum = torch.empty(B * Cd * 4 + 4 * Cd, dtype=torch.float64, device="cuda")
     ops.mae_tail_fwd(yd.view(-1, Cd), stats, rd.view(-1, Cd), None, args[1], args[2], args[3], args[4], args[5], B, R, Cd, lsums4, losses4, None, dpred4, bwd_sums=bsum)
-    assert torch.equal(dpred4, dpred2) and torch.allclose(losses4, losses2, rtol=1e-6)
+    mfma = dt == torch.bfloat16 and Cd == 48   # matrix-core variant of the pass: the head dot products are summed in another order, the reduction
+    #                                            operands (d(pred), x-hat) enter the MFMAs rounded to bf16
+    if mfma:
+        assert torch.allclose(dpred4, dpred2, rtol=1e-4, atol=1e-4) and torch.allclose(losses4, losses2, rtol=1e-5)   # head weights as bf16 hi+lo: 2^-17
+    else:
+        assert torch.equal(dpred4, dpred2) and torch.allclose(losses4, losses2, rtol=1e-6)
     dy4, dr4, dW4, db4, in_sums4 = torch.empty_like(dy), torch.empty_like(dr), torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda"), torch.empty_like(in_sums)
     ops.mae_tail_bwd(None, yd.view(-1, Cd), stats, dpred4, lsums4, args[1], in_sums4, dy4, dr4, dW4, db4, B, V, Cd, r=rd.view(-1, Cd), bwd_sums=bsum)
-    assert torch.equal(dr4, dr3)
-    assert torch.allclose(in_sums4, in_sums3, rtol=1e-4, atol=1e-7)
+    if mfma:
+        import os
+        if os.environ.get("NMH_TEST_VERBOSE"):
+            print("tail mfma: in_sums rel", ((in_sums4 - in_sums3).abs().max() / in_sums3.abs().max()).item(), "dW rel", ((dW4 - dW3).abs().max() / dW3.abs().max()).item(),
+                  "dr mismatches", (dr4 != dr3).float().mean().item(), "dy rel", ((dy4.float() - dy3.float()).abs().max() / dy3.float().abs().max()).item())
+        assert (dr4 != dr3).float().mean().item() < 1e-3 and torch.allclose(dr4.float(), dr3.float(), rtol=1e-2, atol=1e-6)   # bf16 ties of the last place only
+        scale = in_sums3.abs().max().item()
+        assert torch.allclose(in_sums4, in_sums3, rtol=2e-3, atol=2e-4 * scale)
+        assert torch.allclose(dW4, dW3, rtol=2e-3, atol=2e-4 * dW3.abs().max().item()) and torch.allclose(db4, db3, rtol=1e-5, atol=1e-7)
+    else:
+        assert torch.equal(dr4, dr3)
+        assert torch.allclose(in_sums4, in_sums3, rtol=1e-4, atol=1e-7)
+        assert torch.allclose(dW4, dW3, rtol=1e-4, atol=1e-6) and torch.allclose(db4, db3, rtol=1e-5, atol=1e-7)
     assert torch.allclose(dy4.float(), dy3.float(), rtol=1e-2 if dt == torch.bfloat16 else 1e-4, atol=1e-6)
-    assert torch.allclose(dW4, dW3, rtol=1e-4, atol=1e-6) and torch.allclose(db4, db3, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("dt", DTS)
