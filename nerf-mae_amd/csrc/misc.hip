@@ -551,6 +551,18 @@ template <typename T> __global__ void pack_kernel(const PackDesc* descs, const i
     }
     return;
   }
+  if (d.mode == 0) {   // plain cast (every Linear weight's forward operand): 4 consecutive elements per thread, 16-byte loads (blocks start at
+    //                   multiples of 1024 elements of 64-element-aligned tensors)
+    const long i = base + 4 * threadIdx.x;
+    if (i + 3 < d.n) {
+      const float4 v = *reinterpret_cast<const float4*>(d.src + i);
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst + i) = make_uint2(pk_bf16(v.x, v.y), pk_bf16(v.z, v.w));
+      else *reinterpret_cast<float4*>(dst + i) = v;
+    } else {
+      for (long j = i; j < d.n && j < i + 4; ++j) dst[j] = from_f<T>(d.src[j]);
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     long i = base + u * 256 + threadIdx.x;
@@ -601,15 +613,28 @@ __global__ void adamw_kernel(float* p, float* g, float* m, float* v, long n, con
   const bool zero_g = hyper[7] != 0.f;   // leave the gradient buffer cleared for the next step (saves the separate 280 MB fill)
   const float cf = coef ? *coef : 1.0f;
   const float step = lr / bc1, isq = 1.0f / sqrtf(bc2);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i] * cf;
-    float pi = p[i] * (1.0f - lr * wd);
-    const float mi = b1 * m[i] + (1.0f - b1) * gi;
-    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    pi -= step * mi / (sqrtf(vi) * isq + eps);
-    p[i] = pi;
-    if (zero_g) g[i] = 0.f;
+  auto upd = [&](float& pi, float& gi, float& mi, float& vi) {
+    const float gc = gi * cf;
+    float pn = pi * (1.0f - lr * wd);
+    mi = b1 * mi + (1.0f - b1) * gc;
+    vi = b2 * vi + (1.0f - b2) * gc * gc;
+    pn -= step * mi / (sqrtf(vi) * isq + eps);
+    pi = pn;
+    if (zero_g) gi = 0.f;
+  };
+  // four parameters per thread and iteration (16-byte accesses: the four flat buffers are 16-byte aligned); scalar tail
+  const long n4 = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) ? n >> 2 : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<float4*>(g)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
+    reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+    if (zero_g) reinterpret_cast<float4*>(g)[i] = gv;
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+    upd(pi, gi, mi, vi);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (zero_g) g[i] = gi;
   }
 }
 int k_adamw(float* p, float* g, float* m, float* v, long n, const float* hyper, const float* coef, hipStream_t st) {

@@ -37,3 +37,24 @@ def run(rows, C):
 
 for rows, C in ((8000, 384), (64000, 192), (512000, 96), (64000, 96), (1000, 384)):
     run(rows, C)
+
+
+def run_dyw(B, S, C, shift):
+    """the LayerNorm-2 backward of a Swin block as the step issues it: + residual gradient, + second output in window order (dyw)"""
+    rows = B * S ** 3
+    geom = ops.WinGeom(B, S, S, S, (shift,) * 3)
+    x = torch.randn(rows, C, device="cuda").to(dt); dy = torch.randn_like(x); dres = torch.randn_like(x)
+    gamma = torch.randn(C, device="cuda"); mean, rstd = torch.zeros(rows, device="cuda"), torch.ones(rows, device="cuda")
+    dx = torch.empty_like(x); dyw = torch.empty(geom.rows, C, device="cuda", dtype=dt); sc = torch.ones(B, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    fn = lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, rows, C, dres=dres, geom=geom, tokens_per_sample=S ** 3, dyw=dyw, dyw_scale=sc)
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10): fn()
+    b.record(); torch.cuda.synchronize()
+    print(f"ln_bwd + dyw B={B} {S}^3 C={C} shift={shift}: {a.elapsed_time(b) / 10 * 1e3:.1f} us")
+
+
+run_dyw(8, 40, 96, 0); run_dyw(8, 40, 96, 2); run_dyw(8, 10, 384, 2)
