@@ -322,7 +322,7 @@ def main():
         try:
             import glob
             shan = hashlib.sha256(open(os.path.join(ROOT, "nerf-mae_amd", "csrc", "norm.hip"), "rb").read()).hexdigest()
-            kmap = {"mae_tail_fwd": "tail_fwd_kernel", "mae_tail_bwd": "tail_bwd_kernel", "instnorm_apply": "in_apply_kernel", "instnorm_bwd_apply": "in_bwd_apply_kernel",
+            kmap = {"mae_tail_fwd": "tail_fwd", "mae_tail_bwd": "tail_bwd_kernel", "instnorm_apply": "in_apply_kernel", "instnorm_bwd_apply": "in_bwd_apply_kernel",
                     "instnorm_bwd_reduce": "in_reduce_kernel"}
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_kernels_pmc.json")))[::-1]:
                 pm = json.load(open(f))
