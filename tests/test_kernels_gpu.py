@@ -56,9 +56,11 @@ def test_gemm_nt_plain_bias(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
-def test_gemm_nt_epilogues(dt):
+@pytest.mark.parametrize("M,N,K,rps", [(640, 384, 96, 320), (33130, 384, 96, 16565), (32800, 288, 128, 16400)], ids=["small", "33k_rows_k96", "33k_rows_k128"])
+def test_gemm_nt_epilogues(dt, M, N, K, rps):
+    """fused epilogues of nmh_gemm_nt; the two large cases are short contractions on many rows (the 40^3-token Linears) with a ragged last
+    row tile"""
     ops = _ops()
-    M, N, K, rps = 640, 384, 96, 320
     A, W, b = q(rnd(M, K), dt), q(rnd(N, K, seed=1, scale=0.1), dt), rnd(N, seed=2, scale=0.1)
     # act 1: dual output gelu
     pre = torch.empty(M, N, dtype=dt, device="cuda")
