@@ -473,28 +473,45 @@ class _UpBlockFn(torch.autograd.Function):
         # Weight gradients run on the forked side stream -- except the persistent 160^3 kernels, which own every CU: overlapping
         # them with the next MFMA kernel OR with the HBM-bound InstanceNorm passes measured slower (51.2 vs 50.4 ms at 4 grids,
         # 34.8 vs 30.8 ms at 1), so they stay on the main stream.
-        with ops.side_stream(enable=not (ctx.c48 or ctx.c64)):
-            wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), _gradbuf(m.conv_block.conv2.weight))
+        # small-level weight gradients: forked to the side stream -- or (NMH_DEFER_DEC) queued on the encoder's weight-gradient queue and issued
+        # with its next flush, one fork for all of them
+        defer = ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None and not (ctx.c48 or ctx.c64)
+
+        def side(fn):
+            if defer:
+                m._wq.defer(fn)
+            else:
+                with ops.side_stream(enable=not (ctx.c48 or ctx.c64)):
+                    fn()
+        g_c2, g_c1 = _gradbuf(m.conv_block.conv2.weight), _gradbuf(m.conv_block.conv1.weight)
+        side(lambda: wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), g_c2))
         sums1 = torch.empty_like(sums2)
         ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
-        with ops.side_stream(enable=not (ctx.c48 or ctx.c64)):
-            wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), _gradbuf(m.conv_block.conv1.weight))
+        side(lambda: wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), g_c1))
         if m.has_proj:
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
-            with ops.side_stream():
-                ops.gemm_tn(dy3, cat, _gradbuf(m.conv_block.conv3.weight))
+            g_c3 = _gradbuf(m.conv_block.conv3.weight)
+            if defer:
+                m._wq.defer(lambda: ops.gemm_tn(dy3, cat, g_c3))
+            else:
+                with ops.side_stream():
+                    ops.gemm_tn(dy3, cat, g_c3)
         dskip = None
         if has_skip:
             dskip = torch.empty((B * V, Cout), dtype=dtype, device=dev)
             ops.copy_cols(dcat[:, Cout:], dskip)
         dx = torch.empty((B * v ** 3, Cin), dtype=dtype, device=dev)
         ops.upconv_dgrad(dcat, pk[key + "t.wd"].view(Cin, k3 * Cout), dx, B, v, k, Cin, Cout)   # reads dcat through the pixel shuffle
-        with ops.side_stream():
-            ops.upconv_wgrad(dcat, x, _gradbuf(m.transp_conv.weight), _gradbuf(m.transp_conv.bias), B, v, k, Cin, Cout)
-        ops.join_side()
+        g_tw, g_tb = _gradbuf(m.transp_conv.weight), _gradbuf(m.transp_conv.bias)
+        if defer or (ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None):
+            m._wq.defer(lambda: ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout))
+        else:
+            with ops.side_stream():
+                ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout)
+            ops.join_side()
         return dx, dskip, None, None, None, None
 
 

@@ -160,6 +160,7 @@ class _TnProblem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_tn_problem
 
 
 GROUPED_WGRAD = __import__("os").environ.get("NMH_TNG", "1") != "0"
+DEFER_DECODER_WGRAD = __import__("os").environ.get("NMH_DEFER_DEC", "1") == "1"
 
 
 class WgradQueue:
@@ -170,6 +171,15 @@ class WgradQueue:
 
     def __init__(self):
         self.pending, self.inflight, self._cb, self.sync_after_flush = [], [], False, False
+        self.deferred = []   # closures (other weight-gradient launches) to issue with the next flush, inside the same fork
+
+    def defer(self, fn):
+        """queue an arbitrary weight-gradient launch (a closure that keeps its operands alive) for the next flush: the decoder's small-level
+        weight gradients then share ONE fork / join with the grouped launch of the first encoder stage instead of a fork each"""
+        self.deferred.append(fn)
+        if not self._cb:
+            self._cb = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._final)
 
     def add(self, A, B, dW, dbias=None, rowscale=None, rows_per_sample=None):
         _chk(A, B, dW, dbias, rowscale)
@@ -194,10 +204,16 @@ class WgradQueue:
         lib().call("nmh_gemm_tn_grouped", BF16, arr, len(group), ws, 0 if ws is None else ws.numel(), _st())
 
     def flush(self):
-        if not self.pending:
+        if not self.pending and not self.deferred:
             return
         todo, self.pending = self.pending, []
+        fns, self.deferred = self.deferred, []
         with side_stream():
+            for fn in fns:
+                fn()
+            if not todo:
+                self.inflight.extend(fns)
+                return
             group, seen = [], set()
             for pr in todo:
                 if pr[2].data_ptr() in seen:   # the same parameter twice (two forward passes before one backward): separate launches
@@ -207,6 +223,7 @@ class WgradQueue:
                 seen.add(pr[2].data_ptr())
             self._launch(group)
         self.inflight.extend(todo)   # operands stay referenced until the issuing stream has been joined
+        self.inflight.extend(fns)
 
     def join(self):
         join_side()
