@@ -179,9 +179,9 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, co
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
 #pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) stg[(4 * g + r) * SLD + b * 16 + li] = acc[a][b][r];
+    for (int b = 0; b < NT; ++b)   // the accumulators hold the TRANSPOSED tile (see the k-loops): four consecutive columns of one row per
+      //                              fragment -> one 16-byte LDS store each (row stride BN + 4 floats: conflict-free for ds_write_b128)
+      *reinterpret_cast<float4*>(stg + li * SLD + b * 16 + 4 * g) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int it = lane; it < 16 * (BN / 8); it += 64) {
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
       for (int a = 0; a < MT; ++a) {
         Frag<T> af = lds_frag(As, wave * 16 * MT + a * 16 + li, s, g, (T*)nullptr);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) mma(acc[a][b], af, bf[b]);
+        for (int b = 0; b < NT; ++b) mma(acc[a][b], bf[b], af);   // transposed product: lane (m = li, g) holds columns 16 b + 4 g + r of row m
       }
     }
     if (kt + 1 < nk) sstore(cur ^ 1);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
       for (int b = 0; b < NT; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wave * 16 * MT + a * 16 + 4 * g + r, col = n0 + b * 16 + li;
+          const int row = m0 + wave * 16 * MT + a * 16 + li, col = n0 + b * 16 + 4 * g + r;
           if (row < M && col < N) part[(long)row * N + col] = acc[a][b][r];
         }
     return;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const bf16_t* __restri
       for (int a = 0; a < MT; ++a) {
         Frag<T> af = lds_frag(As, wave * 16 * MT + a * 16 + li, s, g, (T*)nullptr);
 #pragma unroll
-        for (int b = 0; b < NT; ++b) mma(acc[a][b], af, bf[b]);
+        for (int b = 0; b < NT; ++b) mma(acc[a][b], bf[b], af);   // transposed product: lane (m = li, g) holds columns 16 b + 4 g + r of row m
       }
     }
   }
