@@ -295,6 +295,66 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
   nt_epilogue<T, MT, NT>(acc, smem, ep, m0, n0, M, N, wave, lane, zb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_nt for contractions of at most two k-tiles (bf16, K <= 128) on many rows: the 40^3-token Linears (K = 96), the decoder1 transpose conv.
+// These launches are latency-bound at the workgroups per CU their LDS allows (PMC: a wave lives ~5 us -- load round trip, 0.3 us of MFMAs,
+// then the store drain -- and issues for ~1 us).  With the transposed product the X rows are the MFMA B operand, i.e. lane (m, g) needs
+// X[m][32 s + 8 g ..]: a plain 16-byte global load -- so the row tile never touches LDS, only the weight tile does (both k-tiles at once, one
+// barrier), and the workgroup needs 25-34 KB instead of 40-48 KB: four to six workgroups per CU instead of three.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_nt_k128_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bw, long ldb, int M, int N, int K, EpiParams ep) {
+  constexpr int BN = 16 * NT, BR = (BN + 31) / 32;
+  using T = bf16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * BN, lc = tid & 7, lr = tid >> 3;
+  const int row = m0 + wave * 16 + li;
+  Frag<T> af[4];
+  {
+    const bf16_t* ar = A + (long)(row < M ? row : M - 1) * lda + 8 * g;   // clamped rows are computed but never stored
+#pragma unroll
+    for (int s = 0; s < 4; ++s) af[s].v = 32 * s + 8 * g < K ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ar + 32 * s)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int k = kt * 64 + lc * 8;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int rl = lr + 32 * i, n = n0 + rl;
+      if (rl < BN) {
+        const uint4 v = (n < N && k < K) ? *reinterpret_cast<const uint4*>(Bw + (long)n * ldb + k) : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(smem + kt * BN * 128 + swz_off(rl, lc)) = v;
+      }
+    }
+  }
+  __syncthreads();
+  f32x4 acc[1][NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) acc[0][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (32 * s < K) {
+      const char* Bs = smem + (s >> 1) * BN * 128;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        Frag<T> bf = lds_frag(Bs, b * 16 + li, s & 1, g, (T*)nullptr);
+        mma(acc[0][b], bf, af[s]);
+      }
+    }
+  }
+  __syncthreads();   // the epilogue slabs alias the weight tile
+  nt_epilogue<T, 1, NT>(acc, smem, ep, m0, n0, M, N, wave, lane, 0);
+}
+template <int NT>
+static int launch_nt_k128(const bf16_t* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st) {
+  constexpr int BN = 16 * NT, lds_main = 2 * BN * 128, lds_epi = 4 * 16 * (BN + 4) * 4, lds = lds_main > lds_epi ? lds_main : lds_epi;
+  dim3 grid((M + 63) / 64, (N + BN - 1) / BN, 1);
+  hipLaunchKernelGGL(gemm_nt_k128_kernel<NT>, grid, dim3(256), lds, st, A, lda, (const bf16_t*)Bw, ldb, M, N, K, ep);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
 // sums the contraction splits: out[row][col] (T, leading dimension ldc) = sum_s part[s][row][col] (+ out if accumulate); 8 columns per thread
 template <typename T> __global__ void nt_ksplit_reduce_kernel(const float* __restrict__ part, int ksplit, long rows, int N, T* __restrict__ out, long ldc, int accumulate) {
   const long n8 = rows * (N / 8);
@@ -483,6 +543,15 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
   if (((long)M * batch <= 8192 || K <= 1024) && t16 >= 4) {
     // wide outputs of the 40^3-token Linears (fc1 / fc2-dgrad: N = 384, K = 96, >= 256 k rows) are write-bound: 128-column tiles store
     // 256-byte-aligned row segments (96-column tiles split every second 128-byte line between two workgroups): 393 -> 312 us at 512 k rows
+    if constexpr (std::is_same<AL, ADirect<bf16_t>>::value) {
+      static const int k128_on = getenv("NMH_GEMM_K128") ? atoi(getenv("NMH_GEMM_K128")) : 1;
+      static const long k128_min = getenv("NMH_GEMM_K128_MINM") ? atol(getenv("NMH_GEMM_K128_MINM")) : 16384;
+      if (k128_on && batch == 1 && ep.ksplit <= 1 && K <= 128 && M >= k128_min && lda_ok(al.lda, ldb)) {
+        if (t16 % 8 == 0 && (long)M >= 100000) return launch_nt_k128<8>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+        if (t16 % 6 == 0) return launch_nt_k128<6>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+        if (t16 % 4 == 0) return launch_nt_k128<4>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+      }
+    }
     if (t16 % 8 == 0 && K <= 128 && (long)M * batch >= 100000) return launch_nt<T, 1, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 6 == 0) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (t16 % 4 == 0) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
