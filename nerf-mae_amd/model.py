@@ -874,6 +874,11 @@ class SwinTransformer_MAE3D_New(nn.Module):
         f3 = feats[3]
         if self._reducer is not None:
             f3 = self._reducer.trigger(f3, len(self.stages) + 1)  # decoder4 is the last decoder op in backward order
+            if torch.is_grad_enabled() and f3.requires_grad:
+                # backward order: decoder4, THIS flush (the decoder's queued small-level weight gradients are issued and joined), then the
+                # trigger that starts the decoder segment's all-reduce
+                self._wq.sync_after_flush = True
+                f3 = _StageFlushFn.apply(f3, self._wq)
         d = self.decoder4(f3, feats[2])
         d = self.decoder3(d, feats[1])
         d = self.decoder2(d, feats[0])

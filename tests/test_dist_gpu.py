@@ -135,3 +135,40 @@ def test_split_graph_step_equals_monolithic_step(dtype, tol):
     (l0, p0), (l1, p1) = res
     assert torch.allclose(l0, l1, rtol=tol * 10, atol=0), (l0, l1)
     assert ((p0 - p1).abs().max() / p0.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segment_triggers_fire_after_every_weight_gradient_of_the_segment(dtype):
+    """eager data-parallel mode over RCCL launches a segment's all-reduce from an autograd trigger: every weight-gradient launch of that
+    segment -- including the ones queued for a later grouped / forked issue -- must already be in the stream.  A recording stand-in for the
+    reducer snapshots the flat gradient at each trigger; the slice of the segment must equal the final gradient."""
+    sys.path.insert(0, ROOT)
+    from nerf_mae_amd.dist import GradReducer, _Trigger
+    from nerf_mae_amd.model import SwinTransformer_MAE3D
+    torch.manual_seed(5)
+    m = SwinTransformer_MAE3D(patch_size=[4] * 3, window_size=[4] * 3, resolution=32, masking_prob=0.75, stochastic_depth_prob=0.0,
+                              compute_dtype=dtype, **TINY).cuda()
+    m.train()
+    m.flatten_parameters()
+    real = GradReducer(m)          # world 1: only its segment bounds are used
+
+    class Recorder:
+        bounds, nseg, snaps = real.bounds, real.nseg, {}
+
+        def trigger(self, x, seg):
+            return _Trigger.apply(x, self, seg)
+
+        def launch(self, seg):
+            torch.cuda.synchronize()
+            self.snaps[seg] = m._flat_grad[self.bounds[seg]:self.bounds[seg + 1]].clone()
+
+    rec = Recorder()
+    m._reducer = rec
+    grids, bm = _data(0)
+    m.zero_grad()
+    m(grids, block_mask=bm)[0].backward()
+    torch.cuda.synchronize()
+    assert len(rec.snaps) >= 2, "the stage / decoder triggers did not fire"
+    for seg, snap in rec.snaps.items():
+        final = m._flat_grad[rec.bounds[seg]:rec.bounds[seg + 1]]
+        assert torch.equal(snap, final), (seg, (snap - final).abs().max().item())
