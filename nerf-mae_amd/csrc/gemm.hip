@@ -491,10 +491,10 @@ static bool try_dma(const AL& al, const void* Bw, long ldb, int M, int N, int K,
     if (dma_st == 0 || !lda_ok(al.lda, ldb)) return false;
     static const int min_k = [] { const char* e = getenv("NMH_GEMM_DMA_MINK"); return e ? atoi(e) : 384; }();
     static const long max_m = [] { const char* e = getenv("NMH_GEMM_DMA_MAXM"); return e ? atol(e) : 8192L; }();
-    // (K < 1024: only while the launch has <= ~1000 workgroups -- 8000x1536x384 = 2000 workgroups measured 37 us with the register-prefetch
+    // (K < 1024: only while the launch has <= 640 workgroups -- 4000x1536x384 = 1008 workgroups measured 17.2 us with the register-prefetch kernel against 20.9, 8000x1536x384 = 2000 workgroups 37 us with the register-prefetch
     //  kernel, 50 us with this one)
     const long wgs = ((long)M + 64 * MT - 1) / (64 * MT) * ((N + 16 * NT - 1) / (16 * NT)) * batch;
-    const bool auto_on = dma_st < 0 && (long)M * batch <= max_m && (K >= 1024 || (K >= min_k && wgs <= 1024));
+    const bool auto_on = dma_st < 0 && (long)M * batch <= max_m && (K >= 1024 || (K >= min_k && wgs <= 640));
     if (dma_st == 3) { *rc = launch_nt_dma<MT, NT, 3>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
     if (dma_st == 4 || auto_on) { *rc = launch_nt_dma<MT, NT, 4>(al, Bw, ldb, M, N, K, batch, ep, st); return true; }
   }
