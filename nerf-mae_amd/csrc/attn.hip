@@ -382,9 +382,11 @@ int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, co
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   constexpr int NW = 2;
-  // one wave per (window, head); a wave loops over several windows only when there are more than ~12 waves per CU worth of them
+  // one wave per (window, head); a wave loops over several windows only when there are more waves than the chip holds at once -- 8 per CU in
+  // bf16 (248 VGPRs, 28 KB of LDS per 2-wave workgroup), 6 in fp32: the grid is ONE round of resident workgroups (with the former cap of 12
+  // per CU, stage 2 at 8 grids was 2592 waves on 2048 slots: a full round plus a quarter-full one, 74 us instead of 47)
   long gx = (nwin + NW - 1) / NW;
-  long cap = (256L * 12 / NW) / heads;
+  long cap = (256L * (dt == NMH_DT_BF16 ? 8 : 6) / NW) / heads;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   dim3 grid((unsigned)gx, heads);
