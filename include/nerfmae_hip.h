@@ -48,11 +48,12 @@ NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64
  * per kernel launch (descriptors travel as kernel arguments: graph-capturable), one 96x96 output tile per workgroup, contraction
  * splits only when a launch has too few tiles to fill the chip (partials in ws, summed by one reduce launch per group).
  * Optional geometry (0 = off): stride_k > 0 writes dW[n*ldo + k*stride_k]; up_k/up_v make A the pixel-shuffled view of a fine-grid tensor, so
- * the k^3 tap problems of a ConvTranspose3d(kernel = stride) weight gradient (unetr_block.py:151-158 backward) run as one grouped call that
+ * the tap problems of a ConvTranspose3d(kernel = stride) weight gradient (unetr_block.py:151-158 backward) run as one grouped call that
  * reads the fine gradient once (A = dcat + tap offset, dW = weight + tap, ldo = k^3, stride_k = Cout*k^3, bias_atomic = 1).
  * n_inner > 0: column n of A is the pair (n / n_inner, n % n_inner) and lands at dW[(n % n_inner)*ldo + (n / n_inner)*stride_n2 + k*stride_k],
  * its bias gradient at dbias[n % n_inner] -- the k taps along x of one (tz, ty) tap row are then ONE problem whose A rows are the contiguous
- * k*Cout-element runs of the fine gradient (k^2 problems with full 96-column tiles instead of k^3 with 48). */
+ * k*Cout-element runs of the fine gradient -- with up_k > 0 column n is read at fine row (row + n / n_inner), channel n % n_inner, which is
+ * contiguous when lda == n_inner and k strided pieces otherwise (a skip half in the row) -- k^2 problems with full 96-column tiles instead of k^3 with 48. */
 typedef struct nmh_tn_problem { const void* A; int64_t lda; const void* B; int64_t ldb; float* dW; int64_t ldo; float* dbias; const float* rowscale; int64_t M; int N; int K; int rows_per_sample;
   int64_t stride_k; int up_k; int up_v; int bias_atomic; int n_inner; int64_t stride_n2; } nmh_tn_problem;
 NMH_API int nmh_gemm_tn_grouped(int dt, const nmh_tn_problem* probs, int nprob, float* ws, int64_t ws_floats, void* stream);

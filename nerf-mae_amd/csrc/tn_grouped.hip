@@ -158,7 +158,10 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
             const long Vf = (long)vv * kk;
             arow = (((long)bb * Vf + zq * kk) * Vf + y * kk) * Vf + x * kk;
           }
-          src = (unsigned long long)(A + arow * lda + n);
+          if (up_k && P.ncol2) {   // folded tap row: column n = (tx, co) sits at fine row arow + tx, channel co (contiguous when lda == Cout)
+            const int ni = P.ncol2 & 0xffff, q = n / ni;
+            src = (unsigned long long)(A + (arow + q) * lda + (n - q * ni));
+          } else src = (unsigned long long)(A + arow * lda + n);
         }
       } else {
         const int k = k0 + pcol[i];

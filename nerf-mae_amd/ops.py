@@ -471,17 +471,15 @@ def upconv_dgrad(dcat, Wd, dx, B, v, k, Cin, Cout):
 
 def upconv_wgrad(dcat, x, dW, dbias, B, v, k, Cin, Cout):
     _chk(dcat, x, dW, dbias)
-    if (GROUPED_UPCONV_WGRAD and dcat.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and B * v ** 3 < 2 ** 31
-            and (GROUPED_UPCONV_WGRAD >= 2 or dcat.stride(0) == Cout)):
+    if GROUPED_UPCONV_WGRAD and dcat.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and B * v ** 3 < 2 ** 31 and k * Cout <= 65535:
         return upconv_wgrad_grouped(dcat, x, dW, dbias, B, v, k, Cin, Cout)
     lib().call("nmh_upconv_wgrad", dt_of(dcat), dcat, dcat.stride(0), x, dW, dbias, B, v, k, Cin, Cout, _st())
 
 
-# One grouped call for the whole gradient.  With a contiguous fine gradient (row stride == Cout: decoder1, no skip half) the k taps
-# along x of a (tz, ty) tap row are one problem -- its A rows are the contiguous k*Cout-element runs of dcat, folded back to
-# (tx, co) by the kernel's two-level column map -- i.e. k^2 problems with full tiles, dcat read exactly once (1 grid/GPU, 40^3 -> 160^3:
-# 416 -> ~120 us against the split shuffled-view gemm_tn).  With a skip half (row stride 2*Cout) the per-tap variant (k^3 problems of
-# Cout <= 96 columns) measured slower than the shuffled-view gemm_tn and stays off unless NMH_TNG_UP=2.
+# One grouped call for the whole gradient: the k taps along x of a (tz, ty) tap row are one problem -- its A rows are the k*Cout-element
+# runs of the fine gradient (contiguous without a skip half; with one, k pieces of Cout at the row stride), folded back to (tx, co) by the
+# kernel's two-level column map -- i.e. k^2 problems with full tiles, dcat read exactly once (1 grid/GPU, 40^3 -> 160^3: 416 -> 244 us
+# against the split shuffled-view gemm_tn).  NMH_TNG_UP=0 keeps the shuffled-view kernel (fp32 always uses it).
 GROUPED_UPCONV_WGRAD = int(__import__("os").environ.get("NMH_TNG_UP", "1"))
 
 
@@ -491,22 +489,14 @@ def upconv_wgrad_grouped(dcat, x, dW, dbias, B, v, k, Cin, Cout):
     _chk(dcat, x, dW, dbias)
     k3, ldc, Vf = k ** 3, dcat.stride(0), v * k
     esz = dcat.element_size()
-    fold = ldc == Cout and k * Cout <= 65535
-    n = k * k if fold else k3
-    arr = (_TnProblem * n)()
-    for t in range(n):
-        if fold:     # problem (tz, ty): N = k*Cout columns (tx, co), tap index (tz*k + ty)*k + tx
-            tz, ty = t // k, t % k
-            off = ((tz * Vf + ty) * Vf) * ldc
-            arr[t] = _TnProblem(dcat.data_ptr() + off * esz, ldc, x.data_ptr(), x.stride(0), dW.data_ptr() + (tz * k + ty) * k * 4, k3, dbias.data_ptr(), 0,
-                                B * v ** 3, k * Cout, Cin, v ** 3, Cout * k3, k, v, 1, Cout, 1)
-        else:        # problem tap: N = Cout rows (dY channels), K = Cin: element (n = co, k = ci) -> dW[(ci*Cout + co)*k3 + tap]
-            tz, ty, tx = t // (k * k), (t // k) % k, t % k
-            off = ((tz * Vf + ty) * Vf + tx) * ldc
-            arr[t] = _TnProblem(dcat.data_ptr() + off * esz, ldc, x.data_ptr(), x.stride(0), dW.data_ptr() + t * 4, k3, dbias.data_ptr(), 0,
-                                B * v ** 3, Cout, Cin, v ** 3, Cout * k3, k, v, 1, 0, 0)
+    arr = (_TnProblem * (k * k))()
+    for t in range(k * k):   # problem (tz, ty): N = k*Cout columns (tx, co), tap index (tz*k + ty)*k + tx
+        tz, ty = t // k, t % k
+        off = ((tz * Vf + ty) * Vf) * ldc
+        arr[t] = _TnProblem(dcat.data_ptr() + off * esz, ldc, x.data_ptr(), x.stride(0), dW.data_ptr() + (tz * k + ty) * k * 4, k3, dbias.data_ptr(), 0,
+                            B * v ** 3, k * Cout, Cin, v ** 3, Cout * k3, k, v, 1, Cout, 1)
     ws = _tn_workspace(dcat.device)
-    lib().call("nmh_gemm_tn_grouped", BF16, arr, n, ws, 0 if ws is None else ws.numel(), _st())
+    lib().call("nmh_gemm_tn_grouped", BF16, arr, k * k, ws, 0 if ws is None else ws.numel(), _st())
 
 
 def upconv_shuffle_fwd(upre, bias, skip, out, B, v, k, Cout):

@@ -392,7 +392,7 @@ def test_upconv_block_pieces(dt, k, Cin, Cout, v, skip):
     lib().call("nmh_upconv_wgrad", ops.dt_of(dc), dc, dc.stride(0), xcl, dW4, db4, B, v, k, Cin, Cout, ops._st())
     check(dW4, wr.grad, dt, "shuffled-view upconv dW", 2)
     check(db4, br.grad, dt, "shuffled-view upconv dbias", 2)
-    if dt == torch.bfloat16:   # the grouped-kernel variants: k^2 folded (tx, co) problems without a skip half, one problem per tap with one
+    if dt == torch.bfloat16:   # the grouped kernel: k^2 folded (tx, co) problems (contiguous runs without a skip half, k strided pieces with one)
         dW3, db3 = torch.zeros(Cin, Cout, k, k, k, device="cuda"), torch.zeros(Cout, device="cuda")
         ops.upconv_wgrad_grouped(dc, xcl, dW3, db3, B, v, k, Cin, Cout)
         check(dW3, wr.grad, dt, "grouped upconv dW", 2)
