@@ -391,6 +391,7 @@ class Trainer:
             losses = self.step_fn(None, draw_block_mask((g, g, g), self.model.masking_prob, rng=random))
             self.global_step += 1
             loss_acc += losses[0]
+        self.prefetch_stats = getattr(pf, "stats", None)
         return float(loss_acc) / self.steps_per_epoch
 
     @torch.no_grad()
