@@ -43,6 +43,8 @@ struct C48Args {
   // multi-block variant (MB): Cin = 48 ncib, Cout = 48 ncob; a work item is (tile, output block cob, input block cib), cib innermost:
   // the accumulators persist over cib, the epilogue runs after the last one; Wk holds one fragment-ordered image per (cob, cib)
   int ncib, ncob, ldx, ldy;    // ldx / ldy: channels per voxel of X / Y
+  int cosplit;                 // MB with few tiles: the unit a workgroup walks is (tile, cob) instead of the tile, so that tiles * ncob
+                               // workgroups share the volume (one 40^3 grid has 150 tiles for 256 CUs)
 };
 
 __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b, int& z0, int& y0, int& x0) {
@@ -72,8 +74,10 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 
   // XCD-contiguous tile ranges: block b runs on XCD b%8 (speed only); its tiles are xcd*per + j, j = b/8, stride gridDim/8
   const int nx = 8, xcd = blockIdx.x % nx, jb = blockIdx.x / nx, jstride = gridDim.x / nx;
-  const long per = (a.total + nx - 1) / nx;
-  const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
+  const bool split = MB && a.cosplit;   // units are (tile, cob) pairs, cob fastest
+  const long total = split ? a.total * a.ncob : a.total;
+  const long per = (total + nx - 1) / nx;
+  const long tbeg = (long)xcd * per, tend = (tbeg + per < total) ? tbeg + per : total;
 
   uint4 hreg[HREG];
   const unsigned vox_bytes = MB ? (unsigned)a.ldx * 2u : 96u;
@@ -147,11 +151,13 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   long t = tbeg + jb;
   if (t >= tend) return;
   int cb, cz0, cy0, cx0;  // origin of the current tile; the next tile's origin is computed once (64-bit divisions) and carried over
-  c48_tile_origin(a, t, cb, cz0, cy0, cx0);
+  c48_tile_origin(a, split ? t / a.ncob : t, cb, cz0, cy0, cx0);
+  int cob = split ? (int)(t % a.ncob) : 0, cib = 0;   // MB: output / input channel block of the current work item
+  const bf16_t* const wfirst = MB ? a.Wk + (long)cob * a.ncib * ((long)NSTEP * 3 * 512) : a.Wk;
 #pragma unroll
   for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, cx0, sample_bytes, 0);
-  w_dma(a.Wk, 0, 0);
-  if (DBG & 4) w_dma(a.Wk, 1, 1);
+  w_dma(wfirst, 0, 0);
+  if (DBG & 4) w_dma(wfirst, 1, 1);
   halo_sstore();
   __syncthreads();
   int wb = 0;  // LDS buffer holding chunk 0 of the current tile
@@ -199,21 +205,23 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   };
   if (DBG & 32) tlast = (long long)__builtin_amdgcn_s_memtime();
   const long long tbegin = tlast;
-  int cob = 0, cib = 0;   // MB: output / input channel block of the current work item
   f32x4 acc[4][3];
   for (;;) {
-    // next work item: (t, cob, cib + 1) -> (t, cob + 1, 0) -> (t + jstride, 0, 0)
+    // next work item: (t, cob, cib + 1) -> (t, cob + 1, 0) -> (t + jstride, 0, 0); with split units t = (tile, cob):
+    // (t, cib + 1) -> (t + jstride, 0)
     long tn = t + jstride;
     int nco = 0, nci = 0;
     if (MB) {
       nci = cib + 1; nco = cob; tn = t;
       if (nci == a.ncib) { nci = 0; ++nco; }
-      if (nco == a.ncob) { nco = 0; tn = t + jstride; }
+      if (split) {
+        if (nci == 0) { tn = t + jstride; nco = (int)(tn % a.ncob); }
+      } else if (nco == a.ncob) { nco = 0; tn = t + jstride; }
     }
     const bool has_next = tn < tend;
     const bool pf_next = has_next && !(DBG & 2);
     int nb = cb, nz0 = cz0, ny0 = cy0, nx0 = cx0;
-    if (has_next && (!MB || tn != t)) c48_tile_origin(a, tn, nb, nz0, ny0, nx0);
+    if (has_next && (!MB || tn != t)) c48_tile_origin(a, split ? tn / a.ncob : tn, nb, nz0, ny0, nx0);
     const unsigned nbytes = pf_next ? sample_bytes : 0u;
     const bf16_t* const wcur = MB ? a.Wk + (long)(cob * a.ncib + cib) * WBLK : a.Wk;
     const bf16_t* const wnxt = MB ? a.Wk + (long)(nco * a.ncib + nci) * WBLK : a.Wk;
@@ -405,7 +413,7 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
   a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
   a.accumulate = accumulate;
   a.stats_acc = stats_acc;
-  a.ncib = a.ncob = 1; a.ldx = a.ldy = 48;
+  a.ncib = a.ncob = 1; a.ldx = a.ldy = 48; a.cosplit = 0;
   static const int dbg = getenv("NMH_C48_DBG") ? atoi(getenv("NMH_C48_DBG")) : 0;
   if (stats_acc && !(dbg & 32)) {
     hipError_t e = nmh_zero_async(stats_acc, sizeof(double) * 2 * 48 * B, st);
@@ -451,13 +459,15 @@ int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int
   a.accumulate = accumulate;
   a.stats_acc = nullptr;
   a.ncib = Cin / 48; a.ncob = Cout / 48; a.ldx = Cin; a.ldy = Cout;
+  a.cosplit = (a.total < 256 && a.ncob > 1) ? 1 : 0;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const long nb = a.total < 256 ? ((a.total + 7) / 8 * 8) : 256;
+  const long units = a.cosplit ? a.total * a.ncob : a.total;
+  const long nb = units < 256 ? ((units + 7) / 8 * 8) : 256;
   hipLaunchKernelGGL((conv48_kernel<0, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   return 0;

@@ -528,6 +528,8 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
   const int t16 = (N + 15) / 16;
   if (const char* ov = getenv("NMH_GEMM_CFG")) {  // tuning override "MT,NT"
     int mt = ov[0] - '0', nt = atoi(ov + 2);
+    if (mt == 1 && nt == 2) return launch_nt<T, 1, 2, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+    if (mt == 1 && nt == 3) return launch_nt<T, 1, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (mt == 1 && nt == 4) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (mt == 1 && nt == 6) return launch_nt<T, 1, 6, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
     if (mt == 1 && nt == 8) return launch_nt<T, 1, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
@@ -550,6 +552,22 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
         if (t16 % 8 == 0 && (long)M >= 100000) return launch_nt_k128<8>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
         if (t16 % 6 == 0) return launch_nt_k128<6>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
         if (t16 % 4 == 0) return launch_nt_k128<4>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+      }
+    }
+    // launches of a few dozen workgroups with a long contraction (stage 3 / 4 Linears at 1-2 grids per GPU): one workgroup per CU is
+    // bound by its own LDS fragment reads (a wave reads the whole B tile: 56 KB per 64-deep k-tile with 96 columns, 24 KB with 32), so the
+    // narrowest tile that still gives at most 1.5 workgroups per CU wins (measured, graph replay: 1000x384x1536 13.3 -> 8.0 us,
+    // 125x768x3072 22.7 -> 12.9, 512x768x1536 13.3 -> 8.0, 216x768x768 8.1 -> 5.0; 4000x384x1536 stays at 96 columns: 15.1 vs 17.9 / 23.7)
+    if constexpr (std::is_same<AL, ADirect<bf16_t>>::value) {
+      static const int narrow_on = getenv("NMH_GEMM_NARROW") ? atoi(getenv("NMH_GEMM_NARROW")) : 1;
+      if (narrow_on && K >= 384 && ep.ksplit <= 1) {
+        const long rt = ((long)M + 63) / 64 * batch;
+        auto fits = [&](int nt) { return t16 % nt == 0 && rt * (t16 / nt) <= 384; };
+        if (rt * ((t16 + 5) / 6) <= 192) {   // (252 workgroups of 96 columns -- 4000x384x1536 -- are already one per CU)
+          if (fits(2)) return launch_nt<T, 1, 2, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+          if (fits(3)) return launch_nt<T, 1, 3, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+          if (fits(4)) return launch_nt<T, 1, 4, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
+        }
       }
     }
     if (t16 % 8 == 0 && K <= 128 && (long)M * batch >= 100000) return launch_nt<T, 1, 8, AL>(al, Bw, ldb, M, N, K, batch, ep, st);

@@ -47,7 +47,8 @@ def check(a, b, dt, name="", mult=1.0):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (1000, 384, 96), (517, 288, 96), (2050, 48, 1296), (130, 768, 3072), (64, 64, 256), (4100, 3072, 96)])
+@pytest.mark.parametrize("M,N,K", [(300, 96, 96), (1000, 384, 96), (517, 288, 96), (2050, 48, 1296), (130, 768, 3072), (64, 64, 256), (4100, 3072, 96),
+                                   (1000, 384, 1536), (200, 96, 776)])
 def test_gemm_nt_plain_bias(dt, M, N, K):
     ops = _ops()
     A, W, b = q(rnd(M, K), dt), q(rnd(N, K, seed=1, scale=K ** -0.5), dt), rnd(N, seed=2)
@@ -56,7 +57,8 @@ def test_gemm_nt_plain_bias(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("M,N,K,rps", [(640, 384, 96, 320), (33130, 384, 96, 16565), (32800, 288, 128, 16400)], ids=["small", "33k_rows_k96", "33k_rows_k128"])
+@pytest.mark.parametrize("M,N,K,rps", [(640, 384, 96, 320), (33130, 384, 96, 16565), (32800, 288, 128, 16400), (640, 384, 768, 320), (3200, 288, 512, 1600), (2500, 288, 512, 1250)],
+                         ids=["small", "33k_rows_k96", "33k_rows_k128", "narrow_tiles_32col", "narrow_tiles_48col", "narrow_tiles_32col_ragged"])
 def test_gemm_nt_epilogues(dt, M, N, K, rps):
     """fused epilogues of nmh_gemm_nt; the two large cases are short contractions on many rows (the 40^3-token Linears) with a ragged last
     row tile"""
@@ -681,10 +683,12 @@ def test_conv48_specialised_matches_reference_conv(B, D, H, W):
     check(dW, wr.grad + 0.5, dt, "conv48 wgrad")
 
 
-@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(1, 8, 16, 32, 96, 96), (2, 6, 10, 20, 192, 96), (1, 12, 9, 40, 96, 192), (1, 4, 8, 16, 144, 48)])
+@pytest.mark.parametrize("B,D,H,W,Cin,Cout", [(1, 8, 16, 32, 96, 96), (2, 6, 10, 20, 192, 96), (1, 12, 9, 40, 96, 192), (1, 4, 8, 16, 144, 48),
+                                                (1, 32, 64, 66, 96, 96)])
 def test_conv48_multiblock_matches_reference_conv(B, D, H, W, Cin, Cout):
     """the LDS-halo kernel on 48-channel blocks (Cin, Cout multiples of 48: (tile, output block, input block) work items, one weight image
-    per block pair): forward pack, dgrad pack with accumulate, ragged tiles -- vs F.conv3d"""
+    per block pair): forward pack, dgrad pack with accumulate, ragged tiles -- vs F.conv3d.  Volumes of fewer than 256 tiles spread
+    (tile, output block) units over the workgroups; the last case has more tiles and walks whole tiles"""
     ops = _ops()
     dt = torch.bfloat16
     x = q(rnd(B, Cin, D, H, W), dt)
