@@ -35,7 +35,7 @@ def run(rows, C):
     print(f"ln_bwd rows={rows} C={C}: {(time.perf_counter() - t) / 10 / N * 1e6:.1f} us per call")
 
 
-for rows, C in ((8000, 384), (64000, 192), (512000, 96), (64000, 96), (1000, 384)):
+for rows, C in ((8000, 384), (64000, 192), (512000, 96), (64000, 96), (1000, 384), (2000, 384), (4000, 384)):
     run(rows, C)
 
 
@@ -57,4 +57,4 @@ def run_dyw(B, S, C, shift):
     print(f"ln_bwd + dyw B={B} {S}^3 C={C} shift={shift}: {a.elapsed_time(b) / 10 * 1e3:.1f} us")
 
 
-run_dyw(8, 40, 96, 0); run_dyw(8, 40, 96, 2); run_dyw(8, 10, 384, 2)
+run_dyw(8, 40, 96, 0); run_dyw(8, 40, 96, 2); run_dyw(8, 10, 384, 2); run_dyw(1, 10, 384, 2); run_dyw(2, 10, 384, 2)
