@@ -60,7 +60,10 @@ template <typename T, int RS> __device__ __forceinline__ void stage_tile(char* d
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// NIT: query tiles (16 rows) per wave.  NIT = 4 is one wave per (window, head); with few windows (1-2 grids per GPU: 324 / 648 pairs on
+// 1024 SIMDs) a pair is split over 4 / NIT waves, each with its own copy of K / V and NIT of the four query tiles: the kernel is one
+// dependent chain per wave, and the chain gets shorter
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table, T* __restrict__ out, float* __restrict__ lse,
                                                         int heads, int C, WinMap wm, long npairs) {
   constexpr int RS = OddRS32<32 * (int)sizeof(T)>::v;
@@ -68,7 +71,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   __shared__ float sB[4][344];
   __shared__ int sR[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-  const long pair = (long)blockIdx.x * 4 + wave;
+  constexpr int QS = 4 / NIT;
+  const long unit = (long)blockIdx.x * 4 + wave;
+  const long pair = unit / QS;
+  const int it0 = (int)(unit % QS) * NIT;
   if (pair >= npairs) return;
   const long win = pair / heads;
   const int h = (int)(pair - win * heads);
@@ -81,20 +87,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   stage_tile<T, RS>(sV[wave], vb, ld, lane);
   for (int t = lane; t < 343; t += 64) sB[wave][t] = table[t * heads + h];
   sR[wave][lane] = shifted ? token_region(wm, (int)(win % nW), lane) : 0;
-  Frag<T> kf[4], qf[4];
+  Frag<T> kf[4], qf[NIT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { kf[t] = gfrag<T>(kb, ld, t * 16 + li, g); qf[t] = gfrag<T>(qb, ld, t * 16 + li, g); }
-  f32x4 s[4][4];  // [jt][it]: key j = 16jt+4g+r, query i = 16it+li
+  for (int t = 0; t < 4; ++t) kf[t] = gfrag<T>(kb, ld, t * 16 + li, g);
+#pragma unroll
+  for (int t = 0; t < NIT; ++t) qf[t] = gfrag<T>(qb, ld, (it0 + t) * 16 + li, g);
+  f32x4 s[4][NIT];  // [jt][it - it0]: key j = 16jt+4g+r, query i = 16it+li
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) { s[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(s[jt][it], kf[jt], qf[it]); }
+    for (int it = 0; it < NIT; ++it) { s[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(s[jt][it], kf[jt], qf[it]); }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const float scale = 0.17677669529663689f;  // 32^-0.5
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int i = 16 * it + li;
+  for (int it = 0; it < NIT; ++it) {
+    const int i = 16 * (it0 + it) + li;
     const int ri = sR[wave][i];
     float mx = -3.0e38f;
 #pragma unroll
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   }
   // O = P.V
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[(win * 64 + 16 * it + 4 * g + r) * C + h * 32 + 16 * dt + li] = from_f<T>(o[dt][r]);
+      for (int r = 0; r < 4; ++r) out[(win * 64 + 16 * (it0 + it) + 4 * g + r) * C + h * 32 + 16 * dt + li] = from_f<T>(o[dt][r]);
   }
 }
 
@@ -147,9 +155,16 @@ int k_attn_fwd(int dt, const void* qkv, const float* table, void* out, float* ls
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   const long npairs = nwin * heads;
-  dim3 grid((unsigned)((npairs + 3) / 4));
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qkv, table, (bf16_t*)out, lse, heads, C, wm, npairs);
-  else hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)qkv, table, (float*)out, lse, heads, C, wm, npairs);
+  // waves per pair (NMH_ATTN_QSPLIT=1/2/4 forces; read per call: the tests switch it).  Measured (bf16, 12 heads x 27 windows per grid at
+  // 10^3 tokens): 324 pairs 10.6 / 7.3 / 6.3 us with 1 / 2 / 4 waves, 1296 pairs 12.8 / 10.3 / 14.6, 2592 pairs 16.6 / 18.0 (the chip holds
+  // ~5120 of these waves: 2 x 2592 starts a second round), 6000 pairs 32.9 / 27.9, 24000 pairs 121 / 119
+  const char* qs_s = getenv("NMH_ATTN_QSPLIT");
+  const int qs_env = qs_s ? atoi(qs_s) : 0;
+  const int qs = qs_env ? qs_env : (npairs <= 768 ? 4 : (npairs <= 2560 ? 2 : (npairs <= 4000 ? 1 : 2)));
+#define ATTN_FWD(T, NIT) hipLaunchKernelGGL((attn_fwd_kernel<T, NIT>), dim3((unsigned)((npairs * (4 / NIT) + 3) / 4)), dim3(256), 0, st, (const T*)qkv, table, (T*)out, lse, heads, C, wm, npairs)
+  if (dt == NMH_DT_BF16) { if (qs == 4) ATTN_FWD(bf16_t, 1); else if (qs == 2) ATTN_FWD(bf16_t, 2); else ATTN_FWD(bf16_t, 4); }
+  else { if (qs == 4) ATTN_FWD(float, 1); else if (qs == 2) ATTN_FWD(float, 2); else ATTN_FWD(float, 4); }
+#undef ATTN_FWD
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -266,10 +266,13 @@ def test_patch_merge_layernorm(dt, shape, C):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape,shift,heads", [((2, 8, 8, 8), 0, 3), ((2, 8, 8, 8), 2, 3), ((1, 5, 5, 5), 2, 6), ((1, 10, 10, 10), 2, 3), ((1, 2, 2, 2), 2, 12), ((1, 6, 8, 4), 2, 3)])
-def test_window_attention_core(dt, shape, shift, heads):
-    """attention core on window-ordered qkv vs the oracle's softmax path (bias + mask + pads as keys)."""
+@pytest.mark.parametrize("qsplit", [1, 2, 4])
+def test_window_attention_core(dt, shape, shift, heads, qsplit, monkeypatch):
+    """attention core on window-ordered qkv vs the oracle's softmax path (bias + mask + pads as keys); the forward with a (window, head)
+    pair on one wave or split by query tiles over 2 / 4 waves (NMH_ATTN_QSPLIT; the default picks 4 for <= 768 pairs, else 2)."""
     from oracle import mae3d_oracle as O
     ops = _ops()
+    monkeypatch.setenv("NMH_ATTN_QSPLIT", str(qsplit))
     B, H, W, D = shape
     C = heads * 32
     geom = _geom(ops, B, H, W, D, shift)

@@ -1,2 +1,3 @@
 cd /root/repo
-for w in 0 2048 4096; do echo "--- wide_rows=$w"; NMH_LN_BWD_WIDE_ROWS=$w python tools/bench_ln.py 2>/dev/null | grep -v "64000\|512000"; done
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for g in 1 2 4 8; do python bench.py --batch-per-gpu $g --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-sweep 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print($g, d['ms_per_step'], d['value'])"; done

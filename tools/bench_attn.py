@@ -31,4 +31,4 @@ def run(B, S, C, heads, shift):
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t) / 5 / N * 1e6)
     print(f"attn B={B} {S}^3 C={C} heads={heads} shift={shift}: fwd {res[0]:.1f} us  bwd {res[1]:.1f} us")
-run(4, 10, 384, 12, 2); run(4, 10, 384, 12, 0); run(4, 40, 96, 3, 2); run(4, 20, 192, 6, 0); run(4, 5, 768, 24, 0)
+run(1, 10, 384, 12, 2); run(2, 10, 384, 12, 2); run(1, 5, 768, 24, 0); run(2, 5, 768, 24, 0); run(8, 40, 96, 3, 2); run(8, 20, 192, 6, 2); run(8, 10, 384, 12, 2); run(4, 10, 384, 12, 2); run(4, 10, 384, 12, 0); run(4, 40, 96, 3, 2); run(4, 20, 192, 6, 0); run(4, 5, 768, 24, 0)
