@@ -166,6 +166,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) pm[i][j] = 0.f;
 
+  // gamma of the lane's columns: loop-invariant, but the compiler cannot hoist the loads over the stores to dx.  Only for the narrow rows
+  // (C <= 256: stages 0 / 1, tens of row groups per workgroup; 512000 x 96: 126 -> 118 us) -- a workgroup of the C = 384 launches handles
+  // one row group, and the preloads would only lengthen its chain (1000 x 384: 10.8 -> 12.5 us)
+  constexpr bool HOIST = NCH <= 2;
+  float gam[HOIST ? NCH : 1][8];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = sub + i * LPR;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gam[i][j] = c < nch ? a.gamma[c * 8 + j] : 0.f;
+    }
+  }
   if (MODE == 0 && a.dyw && a.dyw_pads) {   // pad rows of the window-ordered output (they receive no token): zeroed here, not by a launch of their own
     const long wrows = (long)a.wm.B * a.wm.PH * a.wm.PW * a.wm.PD;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < wrows * nch; i += (long)gridDim.x * 256) {
@@ -173,78 +186,105 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
       if (win_to_tok(a.wm, (long)m) < 0) { const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; Vec8<T>::store((T*)a.dyw + (long)m * C + c * 8, z8); }
     }
   }
-  for (long row = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; row < a.rows; row += gstride) {
-    long dyrow = row;
-    if (MODE == 1) dyrow = tok_to_win(a.wm, row);
-    bool masked = false;
-    if (MODE == 0 && a.mask) masked = a.mask[(unsigned)row % (unsigned)a.tokens_per_sample] != 0;
-    float xv[NCH][8], gv[NCH][8];
-    long toks[NCH];
-    float s1 = 0.f, s2 = 0.f;
-    const float mean = a.mean[row], rstd = a.rstd[row];
+  // U consecutive rows per lane group and iteration: all of their loads are issued before the first row is reduced
+  constexpr int U = (!FLUSH && MODE != 2 && NCH == 2) ? 2 : 1;   // measured: 64000 x 192 57 -> 52 us with 2; 512000 x 96 (NCH = 1) 118 -> 154 us with 4 (registers)
+  for (long rowb = ((long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR) * U; rowb < a.rows; rowb += gstride * U) {   // U consecutive rows
+    float dv[U][NCH][8], xr[U][NCH][8], rv[U][NCH][8];
+    long toks[U][NCH];
+    float mean[U], rstd[U];
+    bool ok[U], maskedr[U];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = sub + i * LPR;
-      toks[i] = -1;
+    for (int u = 0; u < U; ++u) {
+      const long row = rowb + u;
+      ok[u] = row < a.rows;
+      maskedr[u] = false;
+      mean[u] = 0.f; rstd[u] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { xv[i][j] = 0.f; gv[i][j] = 0.f; }
-      if (c < nch) {
-        float d[8];
-        Vec8<T>::load(dy + dyrow * C + c * 8, d);
-        if (masked) {
+      for (int i = 0; i < NCH; ++i) {
+        toks[u][i] = -1;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (FLUSH) atomicAdd(&sacc[2 * C + c * 8 + j], d[j]);
-            else pm[MODE == 0 ? i : 0][j] += d[j];
+        for (int j = 0; j < 8; ++j) { dv[u][i][j] = 0.f; xr[u][i][j] = 0.f; rv[u][i][j] = 0.f; }
+      }
+      if (!ok[u]) continue;
+      long dyrow = row;
+      if (MODE == 1) dyrow = tok_to_win(a.wm, row);
+      if (MODE == 0 && a.mask) maskedr[u] = a.mask[(unsigned)row % (unsigned)a.tokens_per_sample] != 0;
+      mean[u] = a.mean[row]; rstd[u] = a.rstd[row];
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = sub + i * LPR;
+        if (c < nch) {
+          Vec8<T>::load(dy + dyrow * C + c * 8, dv[u][i]);
+          if (!maskedr[u]) {
+            const T* p;
+            if (MODE == 2) p = merge_src<T>(x, a.wm, row, c * 8, Cin, &toks[u][i]);
+            else p = x + row * C + c * 8;
+            if (p) Vec8<T>::load(p, xr[u][i]);
           }
-          continue;
-        }
-        const T* p;
-        if (MODE == 2) p = merge_src<T>(x, a.wm, row, c * 8, Cin, &toks[i]);
-        else p = x + row * C + c * 8;
-        float xr[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xr[j] = 0.f;
-        if (p) Vec8<T>::load(p, xr);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = (xr[j] - mean) * rstd;
-          xv[i][j] = xh;
-          if (FLUSH) { atomicAdd(&sacc[c * 8 + j], d[j] * xh); atomicAdd(&sacc[C + c * 8 + j], d[j]); }
-          else { pg[i][j] += d[j] * xh; pb[i][j] += d[j]; }
-          const float g = d[j] * a.gamma[c * 8 + j];
-          gv[i][j] = g;
-          s1 += g;
-          s2 += g * xh;
+          if (MODE != 2 && a.dres) Vec8<T>::load((const T*)a.dres + row * C + c * 8, rv[u][i]);
         }
       }
     }
-    const float m1 = group_sum<LPR>(s1) * invC, m2 = group_sum<LPR>(s2) * invC;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = sub + i * LPR;
-      if (c < nch) {
-        float o[8];
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      const long row = rowb + u;
+      const bool masked = maskedr[u];
+      float xv[NCH][8], gv[NCH][8];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = masked ? 0.f : rstd * (gv[i][j] - m1 - xv[i][j] * m2);
-        if (MODE == 2) {
-          if (toks[i] >= 0) {
-            const int seg = (c * 8) / Cin, off = c * 8 - seg * Cin;
-            Vec8<T>::store(dx + toks[i] * Cin + off, o);
+      for (int i = 0; i < NCH; ++i) {
+        const int c = sub + i * LPR;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[i][j] = 0.f; gv[i][j] = 0.f; }
+        if (c < nch) {
+          if (masked) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              if (FLUSH) atomicAdd(&sacc[2 * C + c * 8 + j], dv[u][i][j]);
+              else pm[MODE == 0 ? i : 0][j] += dv[u][i][j];
+            }
+            continue;
           }
-        } else {
-          if (a.dres) {
-            float r[8];
-            Vec8<T>::load((const T*)a.dres + row * C + c * 8, r);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += r[j];
+          for (int j = 0; j < 8; ++j) {
+            const float d = dv[u][i][j];
+            const float xh = (xr[u][i][j] - mean[u]) * rstd[u];
+            xv[i][j] = xh;
+            if (FLUSH) { atomicAdd(&sacc[c * 8 + j], d * xh); atomicAdd(&sacc[C + c * 8 + j], d); }
+            else { pg[i][j] += d * xh; pb[i][j] += d; }
+            const float g = d * (HOIST ? gam[HOIST ? i : 0][j] : a.gamma[c * 8 + j]);
+            gv[i][j] = g;
+            s1 += g;
+            s2 += g * xh;
           }
-          Vec8<T>::store(dx + row * C + c * 8, o);
-          if (MODE == 0 && a.dyw) {   // adjoint of the window scatter fused here: dyw[win(row)] = s_b * dx[row] (pad rows pre-zeroed)
-            const float sc = a.dyw_scale ? a.dyw_scale[(unsigned)row / (unsigned)a.tokens_per_sample] : 1.0f;
+        }
+      }
+      const float m1 = group_sum<LPR>(s1) * invC, m2 = group_sum<LPR>(s2) * invC;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] *= sc;
-            Vec8<T>::store((T*)a.dyw + tok_to_win(a.wm, row) * C + c * 8, o);
+      for (int i = 0; i < NCH; ++i) {
+        const int c = sub + i * LPR;
+        if (c < nch) {
+          float o[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = masked ? 0.f : rstd[u] * (gv[i][j] - m1 - xv[i][j] * m2);
+          if (MODE == 2) {
+            if (toks[u][i] >= 0) {
+              const int seg = (c * 8) / Cin, off = c * 8 - seg * Cin;
+              Vec8<T>::store(dx + toks[u][i] * Cin + off, o);
+            }
+          } else {
+            if (a.dres) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] += rv[u][i][j];
+            }
+            Vec8<T>::store(dx + row * C + c * 8, o);
+            if (MODE == 0 && a.dyw) {   // adjoint of the window scatter fused here: dyw[win(row)] = s_b * dx[row] (pad rows pre-zeroed)
+              const float sc = a.dyw_scale ? a.dyw_scale[(unsigned)row / (unsigned)a.tokens_per_sample] : 1.0f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] *= sc;
+              Vec8<T>::store((T*)a.dyw + tok_to_win(a.wm, row) * C + c * 8, o);
+            }
           }
         }
       }

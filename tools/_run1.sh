@@ -1,3 +1,2 @@
 cd /root/repo
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-for g in 1 2 4 8; do python bench.py --batch-per-gpu $g --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing --no-sweep 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print($g, d['ms_per_step'], d['value'])"; done
+python tools/bench_ln.py 2>/dev/null | tail -8

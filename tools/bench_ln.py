@@ -58,3 +58,25 @@ def run_dyw(B, S, C, shift):
 
 
 run_dyw(8, 40, 96, 0); run_dyw(8, 40, 96, 2); run_dyw(8, 10, 384, 2); run_dyw(1, 10, 384, 2); run_dyw(2, 10, 384, 2)
+
+
+def run_dyw_cold(B, S, C, shift):
+    """the same launch with every operand cold: 2 GB of other traffic between the timed launches"""
+    rows = B * S ** 3
+    geom = ops.WinGeom(B, S, S, S, (shift,) * 3)
+    x = torch.randn(rows, C, device="cuda").to(dt); dy = torch.randn_like(x); dres = torch.randn_like(x)
+    gamma = torch.randn(C, device="cuda"); mean, rstd = torch.zeros(rows, device="cuda"), torch.ones(rows, device="cuda")
+    dx = torch.empty_like(x); dyw = torch.empty(geom.rows, C, device="cuda", dtype=dt); sc = torch.ones(B, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    junk = torch.empty(1 << 29, device="cuda"); junk2 = torch.empty(1 << 29, device="cuda")
+    fn = lambda: ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db, rows, C, dres=dres, geom=geom, tokens_per_sample=S ** 3, dyw=dyw, dyw_scale=sc)
+    tot = 0.0
+    for i in range(6):
+        junk2.copy_(junk)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        if i: tot += a.elapsed_time(b)
+    print(f"ln_bwd + dyw B={B} {S}^3 C={C} shift={shift} COLD: {tot / 5 * 1e3:.1f} us")
+
+
+run_dyw_cold(8, 40, 96, 2); run_dyw_cold(8, 20, 192, 2); run_dyw_cold(8, 10, 384, 2)
