@@ -58,3 +58,6 @@ t_f0 = timeit(lambda: ops.mae_tail_fwd(y, stats, r, None, Wo, bo, x, ext, tm, B,
 t_f = timeit(lambda: ops.mae_tail_fwd(y, stats, r, out, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred))
 t_u = timeit(lambda: (ops.instnorm_apply(y, stats, out, B, V, Cd, r=r, rmode=1), ops.mae_loss_fwd(out, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred)))
 print(f"fused tail fwd {t_f:.3f} ms (d0 not stored: {t_f0:.3f})   unfused (in_apply + loss fwd) {t_u:.3f} ms")
+bsum = torch.empty(B * Cd * 4 + 4 * Cd, dtype=torch.float64, device=dev)
+t_m = timeit(lambda: ops.mae_tail_fwd(y, stats, r, None, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred, bwd_sums=bsum))
+print(f"fused tail fwd + backward sums (the step's launch; bf16 C=48: matrix-core kernel) {t_m:.3f} ms")
