@@ -136,11 +136,11 @@ def _geom(ops, B, H, W, D, s):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape,shift", [((2, 8, 8, 8), 0), ((2, 8, 8, 8), 2), ((1, 5, 5, 5), 2), ((1, 10, 10, 10), 2), ((1, 2, 2, 2), 2), ((1, 6, 8, 4), 2)])
-def test_layernorm_window_modes(dt, shape, shift):
+@pytest.mark.parametrize("C", [96, 192])
+def test_layernorm_window_modes(dt, shape, shift, C):
     from oracle import mae3d_oracle as O
     ops = _ops()
     B, H, W, D = shape
-    C = 96
     x = q(rnd(B, H, W, D, C), dt)
     gam, bet = 1 + 0.2 * rnd(C, seed=1), 0.1 * rnd(C, seed=2)
     geom = _geom(ops, B, H, W, D, shift)
