@@ -396,17 +396,24 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
 int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, const float* lse, void* dqkv, float* dtable, int heads, int C, const WinMap& wm, hipStream_t st) {
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
-  constexpr int NW = 2;
   // one wave per (window, head); a wave loops over several windows only when there are more waves than the chip holds at once -- 8 per CU in
   // bf16 (248 VGPRs, 28 KB of LDS per 2-wave workgroup), 6 in fp32: the grid is ONE round of resident workgroups (with the former cap of 12
   // per CU, stage 2 at 8 grids was 2592 waves on 2048 slots: a full round plus a quarter-full one, 74 us instead of 47)
-  long gx = (nwin + NW - 1) / NW;
-  long cap = (256L * (dt == NMH_DT_BF16 ? 8 : 6) / NW) / heads;
+  // waves per workgroup: every workgroup ends with 343 global atomics on the head's table gradient; with 4 waves there are half as many
+  // flushes (2592 pairs: 57 -> 50 us, 6000 pairs: 72 -> 70), but fewer, larger workgroups spread worse when the launch is small (324 pairs:
+  // 18.5 -> 21.3 us) or far larger than the chip (24000 pairs: 236 -> 243).  NMH_ATTN_BNW=2/4 forces.
+  const char* nw_s = getenv("NMH_ATTN_BNW");
+  const long npairs = nwin * heads;
+  const int nw = nw_s ? atoi(nw_s) : ((dt == NMH_DT_BF16 && npairs >= 2048 && npairs <= 8000) ? 4 : 2);
+  long gx = (nwin + nw - 1) / nw;
+  long cap = (256L * (dt == NMH_DT_BF16 ? 8 : 6) / nw) / heads;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   dim3 grid((unsigned)gx, heads);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, NW>), grid, dim3(64 * NW), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin);
-  else hipLaunchKernelGGL((attn_bwd_kernel<float, NW>), grid, dim3(64 * NW), 0, st, (const float*)qkv, table, (const float*)dout, lse, (float*)dqkv, dtable, heads, C, wm, nwin);
+  if (dt == NMH_DT_BF16) {
+    if (nw == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin);
+    else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin);
+  } else hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), dim3((unsigned)gx, heads), dim3(128), 0, st, (const float*)qkv, table, (const float*)dout, lse, (float*)dqkv, dtable, heads, C, wm, nwin);
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -273,6 +273,7 @@ def test_window_attention_core(dt, shape, shift, heads, qsplit, monkeypatch):
     from oracle import mae3d_oracle as O
     ops = _ops()
     monkeypatch.setenv("NMH_ATTN_QSPLIT", str(qsplit))
+    monkeypatch.setenv("NMH_ATTN_BNW", "4" if qsplit == 4 else "2")   # backward: 4 / 2 (window, head) pairs per workgroup
     B, H, W, D = shape
     C = heads * 32
     geom = _geom(ops, B, H, W, D, shift)
