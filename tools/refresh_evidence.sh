@@ -1,3 +1,7 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/refresh_evidence.sh <tag>  -- the evidence set of a tree: conv48 / HBM-kernel PMC passes, rocprofv3 step tables at
+# 8 / 4 / 1 grids, the bench line (with --e2e) and the swin_b line, all under gpurun_out/; tools/pmc_to_json.py / pmc_step_to_json.py and a copy of the
+# summaries into profiles/ are run afterwards where the repo is writable
 cd /root/repo
 T=${1:-r2n}
 bash tools/pmc_conv48.sh ${T} 4 > gpurun_out/${T}_pmc_conv48.log 2>&1
