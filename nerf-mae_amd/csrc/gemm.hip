@@ -549,7 +549,8 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
       static const int k128_on = getenv("NMH_GEMM_K128") ? atoi(getenv("NMH_GEMM_K128")) : 1;
       static const long k128_min = getenv("NMH_GEMM_K128_MINM") ? atol(getenv("NMH_GEMM_K128_MINM")) : 16384;
       if (k128_on && batch == 1 && ep.ksplit <= 1 && K <= 128 && M >= k128_min && lda_ok(al.lda, ldb)) {
-        if (t16 % 8 == 0 && (long)M >= 100000) return launch_nt_k128<8>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+        static const long nt8_min = getenv("NMH_GEMM_K128_NT8_MINM") ? atol(getenv("NMH_GEMM_K128_NT8_MINM")) : 16384;   // (1 grid: 64000 rows -- 12.48 -> 12.43 ms with 128-column tiles there too)
+        if (t16 % 8 == 0 && (long)M >= nt8_min) return launch_nt_k128<8>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
         if (t16 % 6 == 0) return launch_nt_k128<6>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
         if (t16 % 4 == 0) return launch_nt_k128<4>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
       }
