@@ -173,6 +173,14 @@ NMH_API int nmh_add_inplace(int dt, void* a, const void* b, int64_t n, void* str
  * skip connection (swin_mae3d.py:1465-1470 + unetr_block.py:196-197: autograd's accumulation, as a HIP kernel). */
 NMH_API int nmh_add(int dt, const void* a, const void* b, void* out, int64_t n, void* stream);
 NMH_API int nmh_fill_f32(float* p, float v, int64_t n, void* stream);
+/* Accumulator arena.  Every entry point that reduces into a caller-provided accumulator (InstanceNorm statistics and backward sums, the
+ * fused conv statistics, loss sums, the gradient norm) clears it first with a launch of its own -- 24 launches of ~5 us on the dependent
+ * chain of a training step.  After nmh_set_prezeroed_arena(base, bytes) the caller guarantees that any accumulator lying wholly inside
+ * [base, base + bytes) is zero on entry (it clears the used part of the arena with ONE launch per step and never hands out a slice twice
+ * between two clears), and those clearing launches are skipped; accumulators outside the range are cleared as before.
+ * bytes = 0 removes the arena.  One arena per process (one process per GPU).  Reference: the reductions are ATen kernels there
+ * (InstanceNorm3d, unetr_block.py:57-71; forward_loss, swin_mae3d.py:1513-1563) and allocate + clear their own workspaces. */
+NMH_API int nmh_set_prezeroed_arena(void* base, int64_t bytes);
 /* ---- dense-prediction heads on the pretrained encoder + decoder (nerf_rpn/model/feature_extractor.py:1898-2244 VoxelSR, 2521-2848
  * VoxelSemantics).  Their convolutions / norms / GEMMs are the entries above; these are the head-specific pieces. ----
  * nmh_grid_to_cl8: (B,4,V) fp32 NCDHW grid -> [B*V][8] channels-last in dt (channels 4..7 zero): input of `encoder1`, whose first

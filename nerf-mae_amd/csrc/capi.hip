@@ -312,6 +312,15 @@ int nmh_grad_from_bf16(const void* bucket, float* g, int64_t n, float scale, voi
   if (!g || !bucket) return -4;
   return k_grad_cast(0, bucket, g, (long)n, scale, ST);
 }
+char* g_nmh_arena_base = nullptr;
+size_t g_nmh_arena_bytes = 0;
+int nmh_set_prezeroed_arena(void* base, int64_t bytes) {
+  CLR();
+  if (bytes < 0 || (bytes > 0 && !base)) return -4;
+  g_nmh_arena_base = (char*)base;
+  g_nmh_arena_bytes = (size_t)bytes;
+  return 0;
+}
 int nmh_fill_f32(float* p, float v, int64_t n, void* stream) {
   CLR(); return k_fill_f32(p, v, (long)n, ST); }
 int nmh_pack_weights(int dt, const void* descs_dev, const int* blk2desc_dev, const int64_t* blkstart_dev, int nblocks, void* stream) {

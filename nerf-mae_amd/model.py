@@ -377,7 +377,8 @@ class _UpBlockFn(torch.autograd.Function):
         if has_skip:
             ops.copy_cols(skip.reshape(B * V, Cout), cat[:, Cout:])
         S = v * k
-        scratch = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
+        new_acc = lambda: ops.acc_zeros((B, Cout, 2), dev)   # noqa: E731  (one slice per reduction: arena slices are single-use)
+        scratch = new_acc()
         ctx.c64 = False
         c48 = (key + "c1.wk") in pk.views and (key + "c2.wk") in pk.views
         c48mb = (not c48 and (key + "c1.wkm") in pk.views and (key + "c2.wkm") in pk.views and S ** 3 >= ops.C48MB_MIN_VOXELS > 0
@@ -404,6 +405,7 @@ class _UpBlockFn(torch.autograd.Function):
         a1 = torch.empty_like(y1)
         ops.instnorm_apply(y1, st1, a1, B, V, Cout)
         st2 = torch.empty((B, Cout, 2), device=dev)
+        scratch = new_acc()
         if halo_stats:
             y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st2, B, V, Cout)
@@ -417,7 +419,7 @@ class _UpBlockFn(torch.autograd.Function):
         if m.has_proj:
             y3 = ops.gemm_nt(cat, pk[key + "c3.w"].view(Cout, Cc))
             st3 = torch.empty((B, Cout, 2), device=dev)
-            ops.instnorm_stats(y3, st3, scratch, B, V, Cout)
+            ops.instnorm_stats(y3, st3, new_acc(), B, V, Cout)
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=y3, stats_r=st3, rmode=2)
         elif not fused_tail:
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=cat, rmode=1)
@@ -450,7 +452,7 @@ class _UpBlockFn(torch.autograd.Function):
         V = S ** 3
         Cc = cat.shape[1]
         dev, dtype = x.device, x.dtype
-        sums2 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
+        sums2 = ops.acc_zeros((B, Cout, 2), dev)
         dy2 = torch.empty_like(y2)
         dcat = torch.empty_like(cat)
         if ctx.tail is not None:   # d(loss)/d(losses[0]) == 1 (the reference calls loss.backward()); d(d0) is never materialised
@@ -459,7 +461,7 @@ class _UpBlockFn(torch.autograd.Function):
                              _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout, r=cat, bwd_sums=bsum)
         elif m.has_proj:
             dout = dout.contiguous()
-            sums3 = torch.empty((B, Cout, 2), dtype=torch.float64, device=dev)
+            sums3 = ops.acc_zeros((B, Cout, 2), dev)
             dy3 = torch.empty_like(y3)
             ops.instnorm_bwd_reduce(dout, out, y2, st2, sums2, B, V, Cout, r=y3, stats_r=st3, sums_r=sums3, rmode=2)
             ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, r=y3, stats_r=st3, sums_r=sums3, rmode=2, dr=dy3)
@@ -485,7 +487,7 @@ class _UpBlockFn(torch.autograd.Function):
                     fn()
         g_c2, g_c1 = _gradbuf(m.conv_block.conv2.weight), _gradbuf(m.conv_block.conv1.weight)
         side(lambda: wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), g_c2))
-        sums1 = torch.empty_like(sums2)
+        sums1 = ops.acc_zeros((B, Cout, 2), dev)
         ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
@@ -871,6 +873,9 @@ class SwinTransformer_MAE3D_New(nn.Module):
 
     def forward_decoder(self, feats: List[Tensor], tail=None) -> Tensor:
         self._packer.join()   # decoder weight layouts are packed on the side stream while the encoder runs
+        arena = ops.AccArena.get(feats[3].device)
+        if arena is not None:
+            arena.begin()     # one clearing launch for every InstanceNorm accumulator of this forward + backward (ops.AccArena)
         f3 = feats[3]
         if self._reducer is not None:
             f3 = self._reducer.trigger(f3, len(self.stages) + 1)  # decoder4 is the last decoder op in backward order

@@ -602,6 +602,54 @@ def grad_from_bf16(bucket, g, scale=1.0):
     return g
 
 
+class AccArena:
+    """Pre-zeroed accumulator arena (include/nerfmae_hip.h: nmh_set_prezeroed_arena).  `take` hands out zeroed fp64 slices that are used
+    ONCE (reduce into, read back) before the next `begin`; `begin` -- called where a step starts to use them -- clears the WHOLE arena
+    with one launch (4 MB: a microsecond of HBM time; clearing only the used part would make the launch depend on the history of
+    previous steps, which a captured graph does not replay).  Slices that do not fit come from `torch.empty` (outside the registered
+    range, so the library clears them itself): the arena is an optimisation, never a correctness dependency.  One per process."""
+
+    BYTES = 4 << 20
+    enabled = __import__("os").environ.get("NMH_ACC_ARENA", "1") != "0"
+    _inst = None
+
+    def __init__(self, device):
+        self.buf = torch.zeros(self.BYTES // 8, dtype=torch.float64, device=device)
+        self.off = 0        # doubles handed out since the last begin()
+        lib().call("nmh_set_prezeroed_arena", self.buf, self.BYTES)
+
+    @classmethod
+    def get(cls, device):
+        if not cls.enabled:
+            return None
+        if cls._inst is None:
+            cls._inst = cls(device)
+        return cls._inst if cls._inst.buf.device == torch.device(device) else None
+
+    def begin(self):
+        lib().call("nmh_fill_f32", self.buf, 0.0, self.BYTES // 4, _st())
+        self.off = 0
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 15) // 16 * 16   # 128-byte slices
+        if self.off + n_al > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n].view(*shape)
+        self.off += n_al
+        return t
+
+
+def acc_zeros(shape, device):
+    """an fp64 accumulator for ONE reduce-and-read use: a zeroed arena slice when the arena is active, else an uninitialised tensor (the
+    entry point it is passed to clears accumulators outside the arena itself)"""
+    ar = AccArena.get(device)
+    t = ar.take(shape) if ar is not None else None
+    return t if t is not None else torch.empty(shape, dtype=torch.float64, device=device)
+
+
 def add(a, b):
     """a + b into a fresh tensor (HIP kernel; used for the two gradients of a feature map with two consumers)"""
     _chk(a, b)

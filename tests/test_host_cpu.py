@@ -156,4 +156,6 @@ def test_capi_rejects_null_required_pointers_without_touching_the_device():
     assert L.nmh_conv3d_k3_c48mb(null, null, null, 1, 8, 8, 8, 96, 96, 0, null) == -4
     assert L.nmh_gemm_tn_grouped(1, null, 3, null, 0, null) == -4
     assert L.nmh_conv3d_k3_c64(null, null, null, 1, 8, 8, 8, 64, 64, 0, null, null, null) == -4
+    assert L.nmh_set_prezeroed_arena(null, 4096) == -4 and L.nmh_set_prezeroed_arena(null, -1) == -4
+    assert L.nmh_set_prezeroed_arena(null, 0) == 0      # bytes = 0 removes the arena
     assert L.nmh_error_string(-4).decode().startswith("nmh:")

@@ -844,3 +844,36 @@ def test_conv64_block_kernel_matches_reference_conv(B, D, H, W, Cin, Cout):
     ws = torch.empty(ops.lib().call("nmh_conv3d_k3_c64_wgrad_ws_floats"), device="cuda")
     ops.lib().call("nmh_conv3d_k3_c64_wgrad", dycl, xcl, dW, ws, B, D, H, W, Cin, Cout, torch.cuda.current_stream().cuda_stream)
     check(dW, wr.grad + 0.5, dt, "conv64 wgrad")
+
+
+def test_prezeroed_accumulator_arena():
+    """nmh_set_prezeroed_arena / ops.AccArena: accumulators inside the registered range are NOT cleared by the entry points (the caller
+    clears the arena once per step), accumulators outside it still are; a slice is handed out once per begin()"""
+    ops = _ops()
+    dt = torch.bfloat16
+    B, V, C = 2, 1000, 48
+    x = q(rnd(B * V, C), dt)
+    xd = dev(x, dt)
+    ref = torch.empty(B, C, 2, device="cuda")
+    ops.instnorm_stats(xd, ref, torch.full((B, C, 2), 7.0, dtype=torch.float64, device="cuda"), B, V, C)   # outside the arena: cleared by the library
+    mu = x.view(B, V, C).float().mean(1)
+    assert torch.allclose(ref[..., 0].cpu(), mu, atol=2e-3)
+    ar = ops.AccArena.get(xd.device)
+    assert ar is not None
+    ar.begin()
+    a1, a2 = ops.acc_zeros((B, C, 2), xd.device), ops.acc_zeros((B, C, 2), xd.device)
+    assert a1.data_ptr() != a2.data_ptr() and float(a1.abs().sum()) == 0.0 and float(a2.abs().sum()) == 0.0
+    st = torch.empty(B, C, 2, device="cuda")
+    ops.instnorm_stats(xd, st, a1, B, V, C)
+    assert torch.allclose(st, ref, rtol=1e-6, atol=1e-7)
+    a2.fill_(3.0)                         # a dirty slice inside the arena is the caller's bug: the library does not clear it ...
+    st2 = torch.empty(B, C, 2, device="cuda")
+    ops.instnorm_stats(xd, st2, a2, B, V, C)
+    assert not torch.allclose(st2, ref)
+    ar.begin()                            # ... the next begin() does
+    a3 = ops.acc_zeros((B, C, 2), xd.device)
+    assert a3.data_ptr() == a1.data_ptr() and float(ar.buf.abs().sum()) == 0.0
+    ops.instnorm_stats(xd, st2, a3, B, V, C)
+    assert torch.allclose(st2, ref, rtol=1e-6, atol=1e-7)
+    big = ops.acc_zeros((ar.buf.numel() + 16,), xd.device)   # does not fit: an ordinary tensor outside the range
+    assert not (ar.buf.data_ptr() <= big.data_ptr() < ar.buf.data_ptr() + ar.BYTES)
