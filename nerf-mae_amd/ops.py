@@ -623,6 +623,8 @@ class AccArena:
         if not cls.enabled:
             return None
         if cls._inst is None:
+            if torch.cuda.is_current_stream_capturing():   # never born inside a graph's private memory pool
+                return None
             cls._inst = cls(device)
         return cls._inst if cls._inst.buf.device == torch.device(device) else None
 
