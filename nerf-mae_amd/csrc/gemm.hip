@@ -561,7 +561,7 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
     // 125x768x3072 22.7 -> 12.9, 512x768x1536 13.3 -> 8.0, 216x768x768 8.1 -> 5.0; 4000x384x1536 stays at 96 columns: 15.1 vs 17.9 / 23.7)
     if constexpr (std::is_same<AL, ADirect<bf16_t>>::value) {
       static const int narrow_on = getenv("NMH_GEMM_NARROW") ? atoi(getenv("NMH_GEMM_NARROW")) : 1;
-      if (narrow_on && K >= 384 && ep.ksplit <= 1) {
+      if (narrow_on && K >= 384 && ep.ksplit <= 1 && lda_ok(al.lda, ldb)) {   // (aligned rows: these launches take the LDS-DMA kernel)
         const long rt = ((long)M + 63) / 64 * batch;
         auto fits = [&](int nt) { return t16 % nt == 0 && rt * (t16 / nt) <= 384; };
         if (rt * ((t16 + 5) / 6) <= 192) {   // (252 workgroups of 96 columns -- 4000x384x1536 -- are already one per CU)

@@ -48,7 +48,7 @@ def check(a, b, dt, name="", mult=1.0):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("M,N,K", [(300, 96, 96), (1000, 384, 96), (517, 288, 96), (2050, 48, 1296), (130, 768, 3072), (64, 64, 256), (4100, 3072, 96),
-                                   (1000, 384, 1536), (200, 96, 776)])
+                                   (1000, 384, 1536), (200, 96, 776), (9000, 64, 384), (9000, 32, 512), (10000, 96, 384)])
 def test_gemm_nt_plain_bias(dt, M, N, K):
     ops = _ops()
     A, W, b = q(rnd(M, K), dt), q(rnd(N, K, seed=1, scale=K ** -0.5), dt), rnd(N, seed=2)
