@@ -192,16 +192,24 @@ class Prefetcher:
     """Asynchronous input pipeline (the reference's DataLoader(num_workers=2, pin_memory=True), run_swin_mae3d.py:578-586): a
     background thread loads the scenes of batch k+1, stages them through the pinned rings and runs the H2D copies and the
     `grid_prepare` kernels on its own copy stream while step k computes; the consumer gets `(xb, extents, event)` and makes its
-    stream wait for the event.  `depth` device batches rotate, guarded by events the consumer records when it is done with one
-    (`done(slot)`), so the producer can run at most depth-1 batches ahead."""
+    stream wait for the event.  `depth` device batches rotate.  A buffer that has been handed out is PENDING until the consumer
+    calls `done(slot)` -- which records the event after which it may be overwritten -- and ONLY `done` frees it: the producer first
+    waits for the hand-back, then for that event (a consumer whose stream still has the device-to-device copy of batch n-2 queued
+    behind a long replay can therefore never have buffer n%depth overwritten underneath it, whatever the thread timing).  The
+    consumer MUST call `done` once per delivered batch.  Augmentation flags come from the prefetcher's OWN `random.Random`
+    (`seed`), never from the global module the training thread draws its block masks from: both streams stay reproducible."""
 
-    def __init__(self, batcher: GridBatcher, batches, batch_size: int, load=None, depth: int = 2, rng=_random):
+    _PENDING = object()
+
+    def __init__(self, batcher: GridBatcher, batches, batch_size: int, load=None, depth: int = 2, rng=None, seed: int = 0):
         import queue
         import threading
-        self.b, self.load, self.rng = batcher, load or (lambda s: s), rng
+        # rng=None: a private generator (the global `random` module belongs to the training thread's mask draws)
+        self.b, self.load, self.rng = batcher, load or (lambda s: s), (rng if rng is not None else _random.Random(seed))
         R, dev = batcher.R, batcher.device
         self.bufs = [torch.empty((batch_size, 4, R, R, R), dtype=torch.float32, device=dev) for _ in range(depth)]
-        self.free = [None] * depth                      # event after which buffer j may be overwritten
+        self.free = [None] * depth                      # None: never handed out; _PENDING: with the consumer; else the event after which buffer j may be overwritten
+        self._handback = threading.Condition()
         self.stream = torch.cuda.Stream(device=dev, priority=-1)   # high priority: its small copy/prepare kernels slot in between the step's kernels
         self.q = queue.Queue(maxsize=depth - 1 if depth > 1 else 1)
         self.batches = batches
@@ -226,14 +234,18 @@ class Prefetcher:
                 scenes = [self.load(s) for s in batch]
                 flags = [draw_augmentation(self.b.flip_prob, self.b.rotate_prob, self.rng) for _ in scenes]
                 t1 = time.perf_counter()
+                with self._handback:                     # handed out before: wait until the consumer has given it back (done(j)) ...
+                    while self.free[j] is Prefetcher._PENDING:
+                        self._handback.wait(0.05)
                 if self.free[j] is not None:
-                    _wait_event(self.free[j])
+                    _wait_event(self.free[j])           # ... and until its last read of the buffer has executed
                 t2 = time.perf_counter()
                 with torch.cuda.stream(self.stream):
                     xb, ext = self.b.prepare(scenes, flags, out=self.bufs[j][:len(scenes)])
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
                 t3 = time.perf_counter()
+                self.free[j] = Prefetcher._PENDING
                 self.q.put((j, xb, ext, ev))
                 t4 = time.perf_counter()
                 st["batches"] += 1; st["load_s"] += t1 - t0; st["wait_free_s"] += t2 - t1; st["prepare_s"] += t3 - t2; st["put_s"] += t4 - t3
@@ -255,4 +267,6 @@ class Prefetcher:
         """the consumer has queued its last read of buffer j on `stream`"""
         ev = torch.cuda.Event()
         ev.record(stream or torch.cuda.current_stream())
-        self.free[j] = ev
+        with self._handback:
+            self.free[j] = ev
+            self._handback.notify_all()

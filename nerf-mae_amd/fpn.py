@@ -163,7 +163,7 @@ class SwinTransformer_FPN_Pretrained_Skip(nn.Module):
                                           compute_dtype=compute_dtype)
         if not is_eval:
             assert checkpoint_path is not None and os.path.exists(checkpoint_path), "The checkpoint does not exist."
-            checkpoint = torch.load(checkpoint_path, map_location="cpu")
+            checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
             model.load_state_dict(checkpoint["state_dict"])
         del model.decoder4
         del model.decoder3

@@ -186,6 +186,7 @@ class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, mod, xb, mask_dev):
         m: "SwinTransformer_MAE3D_New" = mod
+        m._wq.reset()   # first op of every forward pass: drops whatever a failed backward left queued
         B, R = xb.shape[0], xb.shape[2]
         g = R // 4
         T, C, dtype = B * g ** 3, m.embed_dim, m.compute_dtype

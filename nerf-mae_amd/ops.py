@@ -173,6 +173,13 @@ class WgradQueue:
         self.pending, self.inflight, self._cb, self.sync_after_flush = [], [], False, False
         self.deferred = []   # closures (other weight-gradient launches) to issue with the next flush, inside the same fork
 
+    def reset(self):
+        """start of a forward pass: nothing may be queued here -- unless a previous backward pass raised half-way, in which case its
+        operands (whole 160^3 gradients) would stay referenced for good and `_cb` would never re-arm the end-of-backward callback"""
+        if self.pending or self.deferred or self.inflight or self._cb:
+            join_side()
+            self.pending, self.deferred, self.inflight, self._cb = [], [], [], False
+
     def defer(self, fn):
         """queue an arbitrary weight-gradient launch (a closure that keeps its operands alive) for the next flush: the decoder's small-level
         weight gradients then share ONE fork / join with the grouped launch of the first encoder stage instead of a fork each"""

@@ -129,6 +129,8 @@ class GraphedTrainStep:
     With data parallelism the gradient exchange is ONE flat all-reduce between the backward graph and the optimizer graph
     (RCCL collectives are kept out of the captured region)."""
 
+    MAX_EXT_ROWS, MAX_MASK_BITS = 16, 4096   # capacity of one nmh_step_params launch (csrc/misc.hip: ext[48], bits[128])
+
     def __init__(self, model, opt: FusedAdamW, batch: int, reducer=None, warmup: int = 2):
         self.model, self.opt, self.reducer = model, opt, reducer
         dev = model.mask_token.device
@@ -258,10 +260,24 @@ class GraphedTrainStep:
                 if getattr(self, "_pin_mask", None) is None:
                     self._pin_mask = PinnedRing((self.mask.numel(),), torch.uint8)
                 self._pin_mask.upload(torch.as_tensor(block_mask).to(torch.uint8), self.mask)
+            elif bits.shape[0] ** 3 > self.MAX_MASK_BITS:   # more blocks than the launch's argument struct holds (resolution > 256): full mask upload
+                from .model import draw_block_mask  # noqa: F401  (same block fill, done on the host)
+                full = np.zeros((g, g, g), dtype=np.uint8)
+                blk = np.asarray(bits, dtype=np.uint8).repeat(4, 0).repeat(4, 1).repeat(4, 2)
+                full[:blk.shape[0], :blk.shape[1], :blk.shape[2]] = blk
+                if getattr(self, "_pin_mask", None) is None:
+                    self._pin_mask = PinnedRing((self.mask.numel(),), torch.uint8)
+                self._pin_mask.upload(torch.from_numpy(full), self.mask)
+                bits = None
         ext, self._ext_host = self._ext_host, None
-        # mask bits + optimizer hyper-parameters + extents as kernel arguments of one launch: nothing in the step waits on a copy
+        # mask bits + optimizer hyper-parameters + extents as kernel arguments of one launch: nothing in the step waits on a copy.
+        # The argument struct holds 16 samples' extents (nmh_step_params): larger batches send the rest in further launches.
+        first = ext[:self.MAX_EXT_ROWS] if ext is not None else None
         ops.step_params(tokmask=self.mask if bits is not None else None, block_bits=bits, nb=0 if bits is None else bits.shape[0], g=g,
-                        hyper=self.opt.hyper_host, hyper_dev=self.opt.hyper, extents=ext, extents_dev=self.ext if ext is not None else None)
+                        hyper=self.opt.hyper_host, hyper_dev=self.opt.hyper, extents=first, extents_dev=self.ext if ext is not None else None)
+        if ext is not None:
+            for i0 in range(self.MAX_EXT_ROWS, len(ext), self.MAX_EXT_ROWS):
+                ops.step_params(extents=ext[i0:i0 + self.MAX_EXT_ROWS], extents_dev=self.ext[i0:i0 + self.MAX_EXT_ROWS])
         self._g1.replay()
         if self._g2 is not None:
             red, b = self.reducer, self.reducer.bounds
@@ -305,8 +321,16 @@ def save_checkpoint(path: str, model, epoch: int, train_args: dict, opt: "FusedA
     cannot resume its optimizer): AdamW moments over the flat buffer, step count, beta powers, schedule position."""
     ck = {"epoch": epoch, "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "train_args": dict(train_args)}
     if opt is not None:
-        ck["resume"] = {"m": opt.m.detach().cpu(), "v": opt.v.detach().cpu(), "t": opt.t, "lr": opt.lr, "betas": opt.betas, "step": step}
+        # the moments are flat buffers in the model's parameter order: the layout (name -> offset, numel) travels with them, so a file
+        # written under another flat layout (e.g. the 4-element granule of earlier builds) is remapped by name instead of misaligned
+        ck["resume"] = {"m": opt.m.detach().cpu(), "v": opt.v.detach().cpu(), "t": opt.t, "lr": opt.lr, "betas": opt.betas, "step": step,
+                        "layout": flat_layout(model)}
     torch.save(ck, path)
+
+
+def flat_layout(model) -> dict:
+    """{parameter name: [offset, numel]} of the model's flat fp32 parameter / gradient / moment buffers"""
+    return {n: [int(model._offsets[id(p)]), int(p.numel())] for n, p in model.named_parameters() if id(p) in model._offsets}
 
 
 def load_checkpoint(path: str, model, opt: "FusedAdamW" = None, strict: bool = True) -> dict:
@@ -319,7 +343,19 @@ def load_checkpoint(path: str, model, opt: "FusedAdamW" = None, strict: bool = T
         r = ck["resume"]
         if model._flat is None or not model._flat.is_cuda:
             raise RuntimeError("load_checkpoint: move the model to the HIP device before restoring the optimizer")
-        opt.m.copy_(r["m"]); opt.v.copy_(r["v"])
+        lay_now, lay_ck = flat_layout(model), r.get("layout")
+        if lay_ck is None or {k: list(v) for k, v in lay_ck.items()} == lay_now:
+            if r["m"].numel() != opt.m.numel():
+                raise RuntimeError(f"load_checkpoint: the optimizer state has {r['m'].numel()} elements, this build's flat layout {opt.m.numel()} "
+                                   "(a file without a 'layout' section written under another parameter granule cannot be remapped)")
+            opt.m.copy_(r["m"]); opt.v.copy_(r["v"])
+        else:   # another flat layout: remap every parameter's moments by name
+            if set(lay_ck) != set(lay_now) or any(lay_ck[k][1] != lay_now[k][1] for k in lay_now):
+                raise RuntimeError("load_checkpoint: the optimizer state belongs to a different parameter set")
+            opt.m.zero_(); opt.v.zero_()
+            for k, (off, n) in lay_now.items():
+                o2 = lay_ck[k][0]
+                opt.m[off:off + n].copy_(r["m"][o2:o2 + n]); opt.v[off:off + n].copy_(r["v"][o2:o2 + n])
         opt.t, opt.lr, opt.betas = r["t"], r["lr"], tuple(r["betas"])
     return ck
 
@@ -371,7 +407,7 @@ class Trainer:
         # keeps queueing replays ahead of the device
         if self.step_fn._g1 is None:
             self.step_fn._capture()    # before the producer thread exists: its allocations / copies would invalidate a global-mode capture
-        pf = data.Prefetcher(self.batcher, batches, self.batch, load=self._scene, rng=random)
+        pf = data.Prefetcher(self.batcher, batches, self.batch, load=self._scene, seed=1000003 * self.seed + 7919 * epoch + self.rank)
         main = torch.cuda.current_stream()
         loss_acc = torch.zeros((), device=self.step_fn.x.device)
         for j, xb, ext, ev in pf:

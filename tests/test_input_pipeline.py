@@ -126,3 +126,55 @@ def test_prefetcher_delivers_batches_in_order_with_a_slow_and_a_fast_consumer():
             time.sleep(delay)
             n += 1
         assert n == len(batches)
+
+
+@pytest.mark.gpu
+def test_prefetcher_never_overwrites_a_buffer_before_done_with_a_device_backlog():
+    """the consumer's stream has a long backlog in front of its device-to-device copy (the previous step's graph replay) and it calls
+    `done` late: a buffer must stay untouched from hand-out until the event `done` records has completed.  (Round 2's prefetcher let
+    the producer proceed when `done` had not been called yet -- it saw `None` or the stale event of batch n-4 -- and `grid_prepare` on
+    the high-priority copy stream then overwrote the batch the training step was about to read.)"""
+    import time
+    import numpy as np
+    from nerf_mae_amd import data
+    R = 32
+    scenes = [data.synthetic_scene((32, 31 - (i % 2), 30), seed=50 + i, dtype=np.uint8) for i in range(12)]
+    batches = [scenes[2 * b:2 * b + 2] for b in range(6)]
+    ref = data.GridBatcher(R, "cuda", normalize_density=True)
+    want = [ref.prepare(b, flags=[0, 0])[0].clone() for b in batches]
+    torch.cuda.synchronize()
+    bt = data.GridBatcher(R, "cuda", normalize_density=True)
+    pf = data.Prefetcher(bt, batches, 2, depth=2)
+    main = torch.cuda.current_stream()
+    got = []
+    for j, xb, ext, ev in pf:
+        main.wait_event(ev)
+        torch.cuda._sleep(60_000_000)      # ~30 ms of device time queued in front of the read of this batch
+        got.append(xb.clone())             # the read (queued behind the sleep)
+        time.sleep(0.03)                   # the window in which the old producer started the next-but-one batch into the same buffer
+        pf.done(j, main)
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for n, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"batch {n} was overwritten before its read executed"
+
+
+def test_prefetcher_uses_a_private_rng():
+    """augmentation flags come from the prefetcher's own generator: drawing them leaves the global `random` stream (the training
+    thread's block masks) untouched, and equal seeds give equal flags whatever else runs"""
+    import random
+    from nerf_mae_amd import data
+
+    class _B:   # batcher stand-in: records the flags, no device
+        flip_prob, rotate_prob, R, device = 0.5, 0.5, 8, "cpu"
+
+    def flags_for(seed):
+        rng = random.Random(seed)
+        return [data.draw_augmentation(0.5, 0.5, rng) for _ in range(16)]
+    random.seed(5)
+    before = random.getstate()
+    a, b = flags_for(3), flags_for(3)
+    assert a == b and random.getstate() == before and flags_for(4) != a
+    import inspect
+    sig = inspect.signature(data.Prefetcher.__init__)
+    assert sig.parameters["rng"].default is None and "seed" in sig.parameters

@@ -9,14 +9,38 @@ TINY = dict(patch_size=[4] * 3, window_size=[4] * 3, embed_dim=32, depths=[2, 2,
             masking_prob=0.75, stochastic_depth_prob=0.1)
 
 
-def test_metrics_match_reference_formulas():
-    from nerf_mae_amd.trainer import mse, psnr
-    torch.manual_seed(0)
-    p, t = torch.rand(2, 3, 3, 3, 64, 3), torch.rand(2, 3, 3, 3, 64, 3)
-    m = torch.rand(2, 3, 3, 3, 64, 1) > 0.4
-    ref = ((p - t) ** 2)[m.expand_as(p)].mean()            # nerf_rpn/model/metrics.py:69-75
-    assert torch.allclose(mse(p, t, m), ref)
-    assert torch.allclose(psnr(p, t, m), -10 * torch.log10(ref))
+def _g16_cases():
+    from oracle.gen_golden_metrics import CASES, case_inputs
+    for i, (name, shape, rule) in enumerate(CASES):
+        yield name, case_inputs(name, shape, rule, 1600 + i)
+
+
+def _check_g16(golden, device):
+    """trainer.mse / psnr / eval_metrics against golden g16 = outputs of the reference's own nerf_rpn/model/metrics.py:69-79
+    (oracle/gen_golden_metrics.py), incl. the empty-mask (NaN), single-voxel and pred == target (+inf) edge cases"""
+    from nerf_mae_amd.trainer import eval_metrics, mse, psnr
+    g = golden("g16_metrics.npz")
+    for name, (p, t, m) in _g16_cases():
+        assert abs((p.double().sum() + 2 * t.double().sum()).item() - float(g[f"{name}_checksum"])) < 1e-6, "input regeneration drifted"
+        assert int(m.sum()) == int(g[f"{name}_nsel"])
+        p, t, m = p.to(device), t.to(device), m.to(device)
+        got_m, got_p = float(mse(p, t, m)), float(psnr(p, t, m))
+        np.testing.assert_allclose(got_m, float(g[f"{name}_mse"]), rtol=2e-6, equal_nan=True)
+        np.testing.assert_allclose(got_p, float(g[f"{name}_psnr"]), rtol=2e-6, equal_nan=True)
+        # the eval tuple path (run_swin_mae3d.py:747-760): pred / target carry 4 channels, the metric takes [..., :3]
+        pad = torch.zeros(p.shape[:-1] + (1,), device=device)
+        ev_p, ev_m = eval_metrics((None, None, None, torch.cat([p, pad], -1), m, torch.cat([t, pad + 0.5], -1)))
+        np.testing.assert_allclose(float(ev_m), float(g[f"{name}_mse"]), rtol=2e-6, equal_nan=True)
+        np.testing.assert_allclose(float(ev_p), float(g[f"{name}_psnr"]), rtol=2e-6, equal_nan=True)
+
+
+def test_metrics_match_reference_golden(golden):
+    _check_g16(golden, "cpu")
+
+
+@pytest.mark.gpu
+def test_metrics_match_reference_golden_on_device(golden):
+    _check_g16(golden, "cuda")
 
 
 def test_checkpoint_format_is_the_references(tmp_path):
