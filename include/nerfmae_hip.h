@@ -116,6 +116,22 @@ NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW
  * (the adjoint of the attention branch's window reverse; replaces nmh_window_gather_scale). */
 NMH_API int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C, const int* wm, const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, void* stream);
 NMH_API int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* dyw, const float* dyw_scale, void* stream);
+/* Fused MLP branch of a Swin block, bf16 (swin_mae3d.py:352-358 torchvision MLP + :368 `x + stochastic_depth(mlp(norm2(x)))`):
+ *   x2[row] = x1[row] + rowscale[row / rows_per_scale] * (gelu(LN(x1[row]) . W1^T + b1) . W2^T + b2)
+ * in ONE launch: LayerNorm in the MFMA operand registers, the hidden dimension walked in chunks whose GELU output feeds the second
+ * GEMM from registers -- neither the pre-activation nor the activation is written.  W1 = fc1 weight [4C][C] (bf16, row-major),
+ * W2T = fc2 weight TRANSPOSED [4C][C] (bf16; pack mode 1 of nmh_pack_weights), gamma/beta/b1/b2 fp32.  mean/rstd (optional, [M])
+ * receive the LayerNorm statistics.  nmh_mlp_fused_supported(C) != 0 for C in {96,128,192,256,384}; other widths return -1 (callers
+ * use nmh_layernorm_fwd + 2 x nmh_gemm_nt).  Replaces nmh_layernorm_fwd + nmh_gemm_nt(act=1) + nmh_gemm_nt(resid, rowscale).
+ * backward: from dx2 = dL/dx2 recomputes LN and the hidden activations and writes
+ *   dx1 = dx2 + LN_backward(dh . W1)       [M][C]      hact = gelu(pre-activation)          [M][4C]  (B operand of dW2 = (s dx2)^T hact)
+ *   x1n = LN(x1)                           [M][C]      dh = s (dx2 . W2) * gelu'(pre-act.)  [M][4C]  (A operand of dW1 = dh^T x1n)
+ * accumulates dgamma / dbeta (fp32 atomics) and, when dyw != NULL, also stores dx1 in window order scaled by dyw_scale[row /
+ * rows_per_scale] (pad rows zeroed; wm as for nmh_layernorm_bwd) -- the attention branch's incoming gradient.  The two weight /
+ * bias gradients stay nmh_gemm_tn(_grouped) calls on (dx2, hact, rowscale) and (dh, x1n). */
+NMH_API int nmh_mlp_fused_supported(int C);
+NMH_API int nmh_mlp_fused_fwd(const void* x1, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* b2, const float* rowscale, int rows_per_scale, void* x2, float* mean, float* rstd, int64_t M, int C, float eps, void* stream);
+NMH_API int nmh_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* rowscale, int rows_per_scale, void* dx1, void* x1n, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm, int64_t M, int C, float eps, void* stream);
 /* out[tok] = x[tok] + rowscale[b]*yw[window_row(tok)]: window reverse + un-roll + un-pad (:176-196) + residual + stochastic depth */
 NMH_API int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream);
 /* dyw[window_row] = rowscale[b]*dx[tok] (0 for pad rows): adjoint of the above */

@@ -95,7 +95,7 @@ class _Lib:
             prof.setdefault(key, []).append((e0, e1))
         else:
             rc = getattr(self.cdll, name)(*conv)
-        if ret == "int" and name != "nmh_version" and rc != 0:  # int64_t/char* returns are values, not status codes
+        if ret == "int" and name != "nmh_version" and not name.endswith("_supported") and rc != 0:  # int64_t/char* returns and capability queries are values, not status codes
             raise NmhError(f"{name} failed with code {rc}: {self.cdll.nmh_error_string(rc).decode()}")
         return rc
 

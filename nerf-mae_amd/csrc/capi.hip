@@ -164,6 +164,24 @@ int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const
               dyw, dyw_scale};
   return k_ln_bwd(a, ST);
 }
+int nmh_mlp_fused_supported(int C) { return k_mlp_fused_supported(C); }
+int nmh_mlp_fused_fwd(const void* x1, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* b2, const float* rowscale,
+                      int rows_per_scale, void* x2, float* mean, float* rstd, int64_t M, int C, float eps, void* stream) {
+  CLR();
+  REQ(x1, gamma, beta, W1, b1, W2T, b2, x2);
+  if (M <= 0) return 0;
+  return k_mlp_fused_fwd(x1, gamma, beta, W1, b1, W2T, b2, rowscale, rows_per_scale, x2, mean, rstd, (long)M, C, eps, ST);
+}
+int nmh_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* rowscale,
+                      int rows_per_scale, void* dx1, void* x1n, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm,
+                      int64_t M, int C, float eps, void* stream) {
+  CLR();
+  REQ(x1, dx2, gamma, beta, W1, b1, W2T, dx1, x1n, hact, dh, dgamma, dbeta);
+  if (M <= 0) return 0;
+  if (dyw && !wm) return -4;
+  const WinMap w = to_wm(wm);
+  return k_mlp_fused_bwd(x1, dx2, gamma, beta, W1, b1, W2T, rowscale, rows_per_scale, dx1, x1n, hact, dh, dgamma, dbeta, dyw, dyw_scale, wm ? &w : nullptr, (long)M, C, eps, ST);
+}
 int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream) {
   CLR();
   return k_window_scatter_residual(dt, yw, x, out, rowscale, C, to_wm(wm), ST);

@@ -156,6 +156,14 @@ int k_ln_bwd(const LnBwdArgs& a, hipStream_t st);
 int k_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
 int k_window_gather_scale(int dt, const void* dx, void* dyw, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
 
+// ---- mlp_fused.hip: LN -> fc1 -> GELU -> fc2 -> row-scale -> + residual in one launch (bf16), and its backward ----
+int k_mlp_fused_supported(int C);
+int k_mlp_fused_fwd(const void* x1, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* b2, const float* rowscale,
+                    int rows_per_scale, void* x2, float* mean, float* rstd, long M, int C, float eps, hipStream_t st);
+int k_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* rowscale,
+                    int rows_per_scale, void* dx1, void* x1n, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const WinMap* wm,
+                    long M, int C, float eps, hipStream_t st);
+
 // instance norm over channels-last [B, V, C]; stats[b][c] = {mean, rstd}
 int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st);
 // out = lrelu( IN(x) [+ r | + IN(r)] ); rmode 0 none, 1 plain residual, 2 normalized residual (stats_r)

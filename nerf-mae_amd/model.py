@@ -240,12 +240,19 @@ class _BlockFn(torch.autograd.Function):
         ops.window_attn_fwd(qkv, b.attn.relative_position_bias_table, o, lse, heads, C, geom)
         x1 = torch.empty_like(x)   # x1 = x + sd1 * window_reverse(proj(o)): the reverse + residual are the GEMM's store
         ops.gemm_nt_window_scatter(o, pk[key + "proj.w"].view(C, C), x1, x, b.attn.proj.bias, sd1, tps, geom)
-        x1n = torch.empty_like(x)
-        mean2, rstd2 = torch.empty(T, device=dev), torch.empty(T, device=dev)
-        ops.layernorm_fwd(x1, b.norm2.weight, b.norm2.bias, x1n, mean2, rstd2, T, C)
-        h_pre = torch.empty((T, 4 * C), dtype=dtype, device=dev)
-        h_act = ops.gemm_nt(x1n, pk[key + "fc1.w"].view(4 * C, C), bias=b.mlp[0].bias, act=1, C2=h_pre)
-        x2 = ops.gemm_nt(h_act, pk[key + "fc2.w"].view(C, 4 * C), bias=b.mlp[3].bias, resid=x1, rowscale=sd2, rows_per_scale=tps)
+        ctx.mlp_fused = ops.mlp_fused_ok(x, C, T)
+        if ctx.mlp_fused:
+            # LN2 -> fc1 -> GELU -> fc2 -> row scale -> + residual in one launch; nothing but x1 is kept for the backward (csrc/mlp_fused.hip)
+            x2 = ops.mlp_fused_fwd(x1, b.norm2.weight, b.norm2.bias, pk[key + "fc1.w"].view(4 * C, C), b.mlp[0].bias, pk[key + "fc2.wT"].view(4 * C, C),
+                                   b.mlp[3].bias, rowscale=sd2, rows_per_scale=tps)
+            x1n = mean2 = rstd2 = h_pre = h_act = None
+        else:
+            x1n = torch.empty_like(x)
+            mean2, rstd2 = torch.empty(T, device=dev), torch.empty(T, device=dev)
+            ops.layernorm_fwd(x1, b.norm2.weight, b.norm2.bias, x1n, mean2, rstd2, T, C)
+            h_pre = torch.empty((T, 4 * C), dtype=dtype, device=dev)
+            h_act = ops.gemm_nt(x1n, pk[key + "fc1.w"].view(4 * C, C), bias=b.mlp[0].bias, act=1, C2=h_pre)
+            x2 = ops.gemm_nt(h_act, pk[key + "fc2.w"].view(C, 4 * C), bias=b.mlp[3].bias, resid=x1, rowscale=sd2, rows_per_scale=tps)
         ctx.b, ctx.geom = b, geom
         ctx.saved = (x, xnw, mean1, rstd1, qkv, o, lse, x1, x1n, mean2, rstd2, h_pre, h_act, sd1, sd2)
         return x2
@@ -269,14 +276,22 @@ class _BlockFn(torch.autograd.Function):
                 with ops.side_stream(enable=T >= ops.side_stream.min_rows):
                     ops.gemm_tn(A, Bm, _gradbuf(lin.weight), rowscale=rowscale, rows_per_scale=rps, dbias=_gradbuf(lin.bias))
         # ---- MLP branch
-        dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
-        wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
-        dx1n = ops.gemm_nt(dh, pk[key + "fc1.wT"].view(C, 4 * C))
-        wgrad(dh, x1n, b.mlp[0])
-        dx1 = torch.empty_like(x)
         dyw = torch.empty_like(xnw)   # = sd1 * dx1 in window order (adjoint of the window reverse), second output of the LN backward
-        ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
-                          geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1)
+        if ctx.mlp_fused:
+            # one launch: recomputes LN2 / the hidden activations, writes the operands of the two weight gradients and dx1 (+ its window-ordered copy)
+            dx1, x1n, h_act, dh = ops.mlp_fused_bwd(x1, dx2, b.norm2.weight, b.norm2.bias, pk[key + "fc1.w"].view(4 * C, C), b.mlp[0].bias,
+                                                    pk[key + "fc2.wT"].view(4 * C, C), _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias),
+                                                    rowscale=sd2, rows_per_scale=tps, dyw=dyw, dyw_scale=sd1, geom=geom)
+            wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
+            wgrad(dh, x1n, b.mlp[0])
+        else:
+            dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
+            wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
+            dx1n = ops.gemm_nt(dh, pk[key + "fc1.wT"].view(C, 4 * C))
+            wgrad(dh, x1n, b.mlp[0])
+            dx1 = torch.empty_like(x)
+            ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
+                              geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1)
         # ---- attention branch
         do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
         wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)

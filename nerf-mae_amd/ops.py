@@ -393,6 +393,51 @@ def gemm_nt_window_scatter(A, W, out, resid, bias, rowscale, tokens_per_sample, 
     return out
 
 
+MLP_FUSED = __import__("os").environ.get("NMH_MLP_FUSED", "1") != "0"
+MLP_FUSED_MIN_ROWS = int(__import__("os").environ.get("NMH_MLP_FUSED_MIN_ROWS", "4096"))   # fewer rows: too few 64-row workgroups to fill the chip, the unfused chain wins
+
+
+# widths that take the fused kernels by default.  Measured (tools/bench_mlp_fused.py, 8 grids per GPU, forward + backward): C = 96 (persistent
+# kernels, both weight matrices resident in LDS) 187 + 478 us against 457 + 555 us for the unfused chain; the chunk-ring kernels win the
+# forward at C = 192 (77 vs 136 us) but lose it back in the backward (249 vs 204 us) and lose both at C = 384 (8000 rows = 125 workgroups,
+# each a serial chain of 48 weight chunks) -- those widths stay on the unfused chain unless listed here
+MLP_FUSED_WIDTHS = tuple(int(v) for v in __import__("os").environ.get("NMH_MLP_FUSED_WIDTHS", "96").split(",") if v)
+
+
+def mlp_fused_ok(x, C: int, rows: int) -> bool:
+    """dispatch rule of the fused MLP kernels: bf16, a width that profits (MLP_FUSED_WIDTHS) and enough rows to give every CU work"""
+    return (MLP_FUSED and x.dtype == torch.bfloat16 and C in MLP_FUSED_WIDTHS and rows >= MLP_FUSED_MIN_ROWS
+            and bool(lib().call("nmh_mlp_fused_supported", C)))
+
+
+def mlp_fused_fwd(x1, gamma, beta, W1, b1, W2T, b2, rowscale=None, rows_per_scale=1, out=None, mean=None, rstd=None, eps=1e-5):
+    """x2 = x1 + rowscale[row / rows_per_scale] * (gelu(LN(x1) @ W1^T + b1) @ W2 + b2) in one launch (bf16); W1 [4C,C], W2T = fc2.weight^T [4C,C]"""
+    _chk(x1, gamma, beta, W1, b1, W2T, b2, rowscale, out, mean, rstd)
+    M, C = x1.shape
+    if out is None:
+        out = torch.empty_like(x1)
+    ev = _prof(("mlp_fused_fwd", M, C))
+    lib().call("nmh_mlp_fused_fwd", x1, gamma, beta, W1, b1, W2T, b2, rowscale, rows_per_scale, out, mean, rstd, M, C, eps, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
+def mlp_fused_bwd(x1, dx2, gamma, beta, W1, b1, W2T, dgamma, dbeta, rowscale=None, rows_per_scale=1, dyw=None, dyw_scale=None, geom: Optional[WinGeom] = None, eps=1e-5):
+    """-> (dx1, x1n, hact, dh); dgamma / dbeta accumulated; dyw (optional, with geom): dx1 in window order times dyw_scale[sample]"""
+    _chk(x1, dx2, gamma, beta, W1, b1, W2T, dgamma, dbeta, rowscale, dyw, dyw_scale)
+    M, C = x1.shape
+    dx1, x1n = torch.empty_like(x1), torch.empty_like(x1)
+    hact = torch.empty((M, 4 * C), dtype=x1.dtype, device=x1.device)
+    dh = torch.empty_like(hact)
+    ev = _prof(("mlp_fused_bwd", M, C))
+    lib().call("nmh_mlp_fused_bwd", x1, dx2, gamma, beta, W1, b1, W2T, rowscale, rows_per_scale, dx1, x1n, hact, dh, dgamma, dbeta, dyw, dyw_scale,
+               geom.carr if geom is not None else None, M, C, eps, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return dx1, x1n, hact, dh
+
+
 def window_scatter_residual(yw, x, out, rowscale, C, geom: WinGeom):
     _chk(yw, x, out, rowscale)
     lib().call("nmh_window_scatter_residual", dt_of(x), yw, x, out, rowscale, C, geom.carr, _st())

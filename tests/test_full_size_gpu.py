@@ -1,28 +1,35 @@
-"""GPU, BASELINE.json's full sizes (swin_s = configs[2], swin_b* = configs[3], 4x160^3): the hot path against the CPU oracle on one
-grid (the oracle needs ~20-40 s for forward + backward on the GPU box's host), and size-independent properties of the 160^3 kernels that an oracle at a toy size cannot
-exercise (every tile / halo boundary of the persistent LDS-halo convolutions)."""
+"""GPU, BASELINE.json's full sizes (swin_t = configs[1] at its batch of 4, swin_s = configs[2], swin_b* = configs[3], all 160^3): the hot
+path against the CPU oracle (the oracle needs ~20-40 s per grid for forward + backward on the GPU box's host), INCLUDING batches > 1
+of ragged grids -- the shape `bench.py` times (batch-indexed logic that only exists at 160^3: the XCD-contiguous tile ranges of the
+persistent convs over B*tiles, per-sample fp64 InstanceNorm accumulators, `rows_per_sample` in the grouped weight gradients, per-sample
+extents in the decoder tail) -- and size-independent properties of the 160^3 kernels that an oracle at a toy size cannot exercise
+(every tile / halo boundary of the persistent LDS-halo convolutions)."""
 import random
 
 import pytest
 import torch
 
+from tests._metrics import assert_close, rel_l2, relerr
+
 pytestmark = pytest.mark.gpu
+SWIN_T = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24])
 SWIN_S = dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24])
 # BASELINE configs[3]; the defined deviation of SURVEY 8(c): canonical Swin-B heads, 3 x 42-channel sincos pos-embed zero-padded to 128
 SWIN_B = dict(embed_dim=128, depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32])
-BACKBONES = {"swin_s": SWIN_S, "swin_b": SWIN_B}
+EXTENTS = [(160, 160, 160), (160, 132, 96), (120, 160, 144)]     # the three extents of bench.py / SURVEY 8(d)
+# case -> (backbone, extents of the batch): one ragged grid per backbone (round 1-2), the benched batch shape for swin_s (three ragged
+# grids: every extent bench.py uses) and BASELINE configs[1] (swin_t, batch 4)
+CASES = {
+    "swin_s": (SWIN_S, [EXTENTS[1]]),
+    "swin_b": (SWIN_B, [EXTENTS[1]]),
+    "swin_s_b3": (SWIN_S, [EXTENTS[0], EXTENTS[1], EXTENTS[2]]),
+    "swin_t_b4": (SWIN_T, [EXTENTS[2], EXTENTS[0], EXTENTS[1], EXTENTS[2]]),
+}
 
 
-def relerr(a, b):
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
-
-
-@pytest.fixture(scope="module", params=["swin_s", "swin_b"])
-def oracle_run(request):
-    """one oracle forward + backward at full size per backbone, shared by the fp32 and the bf16 comparison"""
-    cfg = BACKBONES[request.param]
-    extra = dict(pad_pos_embed=True) if request.param == "swin_b" else {}
+def _run_oracle(name):
+    cfg, exts = CASES[name]
+    extra = dict(pad_pos_embed=True) if name == "swin_b" else {}
     import time
     import psutil
     from oracle import mae3d_oracle as O
@@ -34,18 +41,26 @@ def oracle_run(request):
         for n, p in ora.named_parameters():
             if p.requires_grad and (n.endswith("bias") or "relative_position_bias_table" in n):
                 p.add_(0.02 * torch.randn_like(p))
-    xs = [O.synthetic_grid((160, 132, 96), 5)]        # ragged extents: pad_tensor + the analytic valid mask at full size
+    xs = [O.synthetic_grid(e, 5 + i) for i, e in enumerate(exts)]    # ragged extents: pad_tensor + the analytic valid mask at full size
     bm = O.draw_block_mask((40, 40, 40), 0.75, rng=random.Random(123))
     out = ora(xs, block_mask=bm, return_pred=True)
     out[0].backward()
-    print(f"[full size {request.param}] oracle forward+backward: {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
+    print(f"[full size {name}] oracle forward+backward of {len(xs)} grid(s): {time.perf_counter() - t0:.1f} s on {torch.get_num_threads()} threads")
     return ora, xs, bm, [o.detach() for o in out], cfg
 
 
-@pytest.mark.parametrize("dtype,ltol,ptol,gcos", [(torch.float32, 1e-4, 1e-3, 0.9999), (torch.bfloat16, 2e-2, 6e-2, 0.99)], ids=["fp32", "bf16"])
-def test_full_size_matches_oracle(oracle_run, dtype, ltol, ptol, gcos):
+@pytest.fixture(scope="module", params=["swin_s", "swin_b", "swin_s_b3"])
+def oracle_run(request):
+    """one oracle forward + backward at full size per case, shared by the fp32 and the bf16 comparison"""
+    return _run_oracle(request.param)
+
+
+def _compare(run, dtype, ltol, ptol, gcos, gnorm):
+    # bf16: max-norm / relative L2 at ptol = 3e-2 (measured 1.2-1.6e-2 on all four cases); elementwise |a-b| <= 0.2 (|b| + rms): the absolute
+    # error of a bf16 network output is uniform over the tensor (tests/test_model_gpu.py), measured worst 0.10-0.12
+    elem_mult = 1.0 if dtype == torch.float32 else 0.2 / ptol
     from nerf_mae_amd.model import SwinTransformer_MAE3D
-    ora, xs, bm, lo, cfg = oracle_run
+    ora, xs, bm, lo, cfg = run
     hip = SwinTransformer_MAE3D(patch_size=[4] * 3, window_size=[4] * 3, resolution=160, masking_prob=0.75, stochastic_depth_prob=0.0,
                                 compute_dtype=dtype, **cfg)
     hip.load_state_dict(ora.state_dict(), strict=True)
@@ -56,7 +71,10 @@ def test_full_size_matches_oracle(oracle_run, dtype, ltol, ptol, gcos):
     torch.cuda.synchronize()
     for a, b, n in zip(lh[:3], lo[:3], ("loss", "loss_rgb", "loss_alpha")):
         assert abs(a.item() - b.item()) / abs(b.item()) < ltol, (n, a.item(), b.item())
-    assert relerr(lh[3], lo[3]) < ptol, "reconstructed grid"   # north star: within 1e-3 relative in fp32
+    # north star: reconstructed grids within 1e-3 relative in fp32 -- per SAMPLE (a sample whose grid were wrong would hide behind the
+    # others in a whole-batch norm), max-norm + relative L2 + elementwise with atol = rtol * rms (tests/_metrics.py)
+    for i in range(len(xs)):
+        assert_close(lh[3][i], lo[3][i], ptol, f"reconstructed grid of sample {i}", elem_mult=elem_mult)
     po = dict(ora.named_parameters())
     fa, fb = [], []
     for n, p in hip.named_parameters():
@@ -65,7 +83,19 @@ def test_full_size_matches_oracle(oracle_run, dtype, ltol, ptol, gcos):
             fb.append(po[n].grad.flatten())
     fa, fb = torch.cat(fa), torch.cat(fb)
     assert (torch.dot(fa, fb) / (fa.norm() * fb.norm())).item() > gcos
-    assert abs(fa.norm().item() - fb.norm().item()) / fb.norm().item() < (1e-3 if dtype == torch.float32 else 5e-2)
+    assert abs(fa.norm().item() - fb.norm().item()) / fb.norm().item() < gnorm
+
+
+@pytest.mark.parametrize("dtype,ltol,ptol,gcos", [(torch.float32, 1e-4, 1e-3, 0.9999), (torch.bfloat16, 2e-2, 3e-2, 0.99)], ids=["fp32", "bf16"])
+def test_full_size_matches_oracle(oracle_run, dtype, ltol, ptol, gcos):
+    _compare(oracle_run, dtype, ltol, ptol, gcos, 1e-3 if dtype == torch.float32 else 5e-2)
+
+
+def test_swin_t_batch4_full_size_bf16_matches_oracle():
+    """BASELINE configs[1] as stated: swin_t, batch 4 x 160^3, bf16 (and the fp32 parity mode on the same oracle run)"""
+    run = _run_oracle("swin_t_b4")
+    _compare(run, torch.bfloat16, 2e-2, 3e-2, 0.99, 5e-2)
+    _compare(run, torch.float32, 1e-4, 1e-3, 0.9999, 1e-3)
 
 
 def _pack(w, mode, n):

@@ -33,16 +33,12 @@ def dev(t, dt=None):
     return (t if dt is None else t.to(dt)).cuda().contiguous()
 
 
-def relerr(a, b):
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+from tests._metrics import assert_close, relerr  # noqa: E402
 
 
-def check(a, b, dt, name="", mult=1.0):
-    e = relerr(a, b)
-    if __import__("os").environ.get("NMH_PRINT_ERR"):
-        print(f"  [{name}] {dt} relerr {e:.2e}")
-    assert e < TOL[dt] * mult, f"{name}: rel err {e:.3e} (dtype {dt})"
+def check(a, b, dt, name="", mult=1.0, elem_mult=1.0):
+    """max-norm, relative-L2 and elementwise (atol = rtol * rms(ref)) against the same tolerance (tests/_metrics.py)"""
+    assert_close(a, b, TOL[dt] * mult, f"{name} {dt}", elem_mult=elem_mult)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -877,3 +873,88 @@ def test_prezeroed_accumulator_arena():
     assert torch.allclose(st2, ref, rtol=1e-6, atol=1e-7)
     big = ops.acc_zeros((ar.buf.numel() + 16,), xd.device)   # does not fit: an ordinary tensor outside the range
     assert not (ar.buf.data_ptr() <= big.data_ptr() < ar.buf.data_ptr() + ar.BYTES)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused MLP branch (csrc/mlp_fused.hip): LN2 -> fc1 -> GELU -> fc2 -> stochastic-depth row scale -> + residual, forward and backward,
+# against plain fp32 math on the bf16-rounded inputs (the torchvision MLP + LayerNorm of swin_mae3d.py:351-358,368) and against the
+# unfused HIP chain it replaces; every rows-per-wave variant, ragged row counts (partial 64-row tiles), per-sample scales, and the
+# window-ordered second output of the backward (shifted + padded geometry)
+# ------------------------------------------------------------------------------------------------
+def _mlp_ref(x, gam, bet, W1, b1, W2, b2, rs, tps):
+    xn = F.layer_norm(x, (x.shape[1],), gam, bet, 1e-5)
+    hp = xn @ W1.T + b1
+    h = F.gelu(hp)
+    y = h @ W2.T + b2
+    scale = rs.repeat_interleave(tps)[: x.shape[0], None]
+    return x + scale * y, xn, h
+
+
+@pytest.mark.parametrize("C,M,tps", [(96, 200, 100), (96, 4133, 4133), (96, 70000, 35000), (128, 1000, 500), (192, 777, 259), (192, 2048, 1024), (256, 300, 150), (384, 130, 65), (384, 1000, 500)])
+@pytest.mark.parametrize("mt", [1, 2, 4, "p1", "p2"])
+def test_mlp_fused_forward_backward(C, M, tps, mt, monkeypatch):
+    """mt = 1/2/4: the chunk-ring kernels with 16*mt rows per wave; "p1"/"p2": the persistent LDS-resident-weight kernels (C = 96)"""
+    ops = _ops()
+    dt = torch.bfloat16
+    if mt in (4, "p1", "p2") and C != 96:
+        pytest.skip("variant exists for C = 96 only")
+    if isinstance(mt, str):
+        monkeypatch.delenv("NMH_MLP_FWD_MT", raising=False)
+        monkeypatch.delenv("NMH_MLP_BWD_MT", raising=False)
+        monkeypatch.setenv("NMH_MLP96_FWD_MT", mt[1])
+        monkeypatch.setenv("NMH_MLP96_BWD_MT", mt[1])
+    else:
+        monkeypatch.setenv("NMH_MLP_FWD_MT", str(mt))
+        monkeypatch.setenv("NMH_MLP_BWD_MT", str(min(mt, 2)))
+    B = (M + tps - 1) // tps
+    x = q(rnd(M, C, seed=1) * 1.5 + 0.3, dt)
+    gam, bet = 1 + 0.2 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    W1, b1 = q(rnd(4 * C, C, seed=4, scale=C ** -0.5), dt), 0.2 * rnd(4 * C, seed=5)
+    W2, b2 = q(rnd(C, 4 * C, seed=6, scale=(4 * C) ** -0.5), dt), 0.2 * rnd(C, seed=7)
+    rs = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.8, 1.0][:B] + [1.0] * max(0, B - 4))
+    dy = q(rnd(M, C, seed=8), dt)
+    xr, gr, br, W1r, b1r, W2r, b2r = [t.clone().requires_grad_(True) for t in (x, gam, bet, W1, b1, W2, b2)]
+    ref, xn_ref, h_ref = _mlp_ref(xr, gr, br, W1r, b1r, W2r, b2r, rs, tps)
+    (ref * dy).sum().backward()
+    # ---- forward
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    W1d, W2Td = dev(W1, dt), dev(W2.T.contiguous(), dt)
+    out = ops.mlp_fused_fwd(dev(x, dt), dev(gam), dev(bet), W1d, dev(b1), W2Td, dev(b2), rowscale=dev(rs), rows_per_scale=tps, mean=mean, rstd=rstd)
+    check(out, ref, dt, "mlp fused fwd")
+    mu = x.mean(1)
+    check(mean, mu, torch.float32, "mlp fused mean", 10)
+    check(rstd, (x.var(1, unbiased=False) + 1e-5).rsqrt(), torch.float32, "mlp fused rstd", 10)
+    # the unfused chain on the same inputs: LN -> gemm(+GELU) -> gemm(+scale, +residual)
+    xn_u = torch.empty(M, C, dtype=dt, device="cuda")
+    m_u, r_u = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    ops.layernorm_fwd(dev(x, dt), dev(gam), dev(bet), xn_u, m_u, r_u, M, C)
+    hpre_u = torch.empty(M, 4 * C, dtype=dt, device="cuda")
+    hact_u = ops.gemm_nt(xn_u, W1d, bias=dev(b1), act=1, C2=hpre_u)
+    out_u = ops.gemm_nt(hact_u, dev(W2, dt), bias=dev(b2), resid=dev(x, dt), rowscale=dev(rs), rows_per_scale=tps)
+    assert_close(out, out_u.float().cpu(), 1e-2, "mlp fused fwd vs unfused chain")   # two bf16 roundings of the same fp32 arithmetic
+    # ---- backward (with the window-ordered second output when the rows form a token grid)
+    geom = dyw = None
+    dyw_scale = torch.tensor([0.5, 2.0, 1.0, 1.0][:B] + [1.0] * max(0, B - 4))
+    if M == B * tps and tps in (100, 500, 150, 65):
+        shape = {100: (5, 5, 4), 500: (10, 10, 5), 150: (6, 5, 5), 65: (13, 5, 1)}[tps]
+        geom = ops.WinGeom(B, *shape, [2, 2, 2])
+        dyw = torch.full((geom.rows, C), 3.0, dtype=dt, device="cuda")
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx1, x1n, hact, dh = ops.mlp_fused_bwd(dev(x, dt), dev(dy, dt), dev(gam), dev(bet), W1d, dev(b1), W2Td, dg, db, rowscale=dev(rs), rows_per_scale=tps,
+                                           dyw=dyw, dyw_scale=dev(dyw_scale) if dyw is not None else None, geom=geom)
+    check(dx1, xr.grad, dt, "mlp fused dx1", 2)
+    check(x1n, xn_ref.detach(), dt, "mlp fused x1n")
+    check(hact, h_ref.detach(), dt, "mlp fused hact")
+    check(dg, gr.grad, dt, "mlp fused dgamma", 2)
+    check(db, br.grad, dt, "mlp fused dbeta", 2)
+    # dh is the A operand of dW1 = dh^T x1n (and db1 = column sums): check it through those products in fp32
+    dW1 = dh.float().T @ x1n.float()
+    check(dW1, W1r.grad, dt, "mlp fused dW1 via dh", 2)
+    check(dh.float().sum(0), b1r.grad, dt, "mlp fused db1 via dh", 2)
+    scale_rows = rs.repeat_interleave(tps)[:M, None].cuda()
+    dW2 = (dev(dy, dt).float() * scale_rows).T @ hact.float()
+    check(dW2, W2r.grad, dt, "mlp fused dW2 via hact", 2)
+    if dyw is not None:
+        g_ref = torch.empty(geom.rows, C, dtype=dt, device="cuda")
+        ops.window_gather_scale(dx1, g_ref, dev(dyw_scale), C, geom)
+        assert torch.equal(dyw, g_ref), "window-ordered second output (incl. zeroed pad rows)"

@@ -9,9 +9,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def relerr(a, b):
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+from tests._metrics import assert_close, relerr  # noqa: E402
+
+# bf16 whole-model outputs: max-norm and relative L2 within 3e-2 (measured 1.0-1.6e-2); the elementwise bound |a-b| <= t (|b| + rms(b)) holds
+# at t = 0.2 (measured worst 0.11-0.12): the absolute error of a bf16 network output is set by the magnitude of the 48-term dot products
+# and 160^3-voxel InstanceNorms that feed it -- uniform over the tensor -- not by the element's own magnitude
+BF16_ELEM_MULT = 0.2 / 3e-2
 
 
 def _pair(cfg, dtype, res=32, sd=0.0, mask_p=0.75, init="formula"):
@@ -87,7 +90,10 @@ def test_fp32_formula_weights_forward_matches_oracle():
         lo, lh = _run_both(ora, hip, xs, 42)
         for a, b, n in zip(lh[:3], lo[:3], ("loss", "loss_rgb", "loss_alpha")):
             assert abs(a.item() - b.item()) / abs(b.item()) < 1e-4, (n, a.item(), b.item())
-        assert relerr(lh[3], lo[3]) < 1e-3, "reconstructed grid"
+        # formula-filled weights (the golden fixtures' tensors) put the 2^3-voxel InstanceNorms of the coarsest decoder level into a regime where
+        # two correct fp32 implementations differ far more than with the reference's initialisation (the next test: 2e-6 there): max-norm and
+        # relative L2 hold the north-star 1e-3; the elementwise bound (atol = rtol * rms) is met at 2e-3 (measured 1.12e-3)
+        assert_close(lh[3], lo[3], 1e-3, "reconstructed grid", elem_mult=2.0)
 
 
 @pytest.mark.parametrize("cfg,name,res", [(SWIN_T, "swin_t", 32), (TINY, "tiny", 96)])
@@ -100,7 +106,7 @@ def test_fp32_forward_backward_matches_oracle(cfg, name, res):
     lo, lh, l64, rows = _grads_vs_fp64(ora, hip, xs, 42)
     for a, b in zip(lh[:3], lo[:3]):
         assert abs(a.item() - b.item()) / abs(b.item()) < 1e-5
-    assert relerr(lh[3], lo[3]) < 1e-4, "reconstructed grid"
+    assert_close(lh[3], lo[3], 1e-4, "reconstructed grid")
     worst = max(rows.items(), key=lambda kv: kv[1][0])
     print(f"[{name}] worst grad err vs fp64: hip {worst[1][0]:.2e} (reference fp32 {worst[1][1]:.2e}) at {worst[0]}")
     ref_noise = max(r[1] for r in rows.values())
@@ -117,7 +123,7 @@ def test_swin_b_width_trains_in_bf16():
     xs = [O.synthetic_grid((32, 32, 32), 5), O.synthetic_grid((32, 28, 30), 6)]
     lo, lh = _run_both(ora, hip, xs, 11)
     assert abs(lh[0].item() - lo[0].item()) / abs(lo[0].item()) < 2e-2
-    assert relerr(lh[3], lo[3]) < 5e-2
+    assert_close(lh[3], lo[3], 3e-2, "reconstructed grid", elem_mult=BF16_ELEM_MULT)
     fa = torch.cat([p.grad.float().cpu().flatten() for n, p in hip.named_parameters() if p.grad is not None and p.requires_grad])
     fb = torch.cat([dict(ora.named_parameters())[n].grad.flatten() for n, p in hip.named_parameters() if p.grad is not None and p.requires_grad])
     assert (torch.dot(fa, fb) / (fa.norm() * fb.norm())).item() > 0.995
@@ -149,7 +155,7 @@ def test_bf16_close_to_oracle_and_eval_contract():
     lo, lh, l64, rows = _grads_vs_fp64(ora, hip, xs, 7)
     for a, b in zip(lh[:3], lo[:3]):
         assert abs(a.item() - b.item()) / abs(b.item()) < 1e-2
-    assert relerr(lh[3], lo[3]) < 5e-2
+    assert_close(lh[3], lo[3], 3e-2, "reconstructed grid", elem_mult=BF16_ELEM_MULT)
     assert min(r[2] for r in rows.values()) > 0.95, min(rows.items(), key=lambda kv: kv[1][2])
     po, ph = dict(ora.named_parameters()), dict(hip.named_parameters())
     fa = torch.cat([ph[n].grad.float().cpu().flatten() for n in rows])
