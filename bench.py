@@ -135,7 +135,9 @@ def main():
 
     # synthetic inputs: valid extents cycle through {160^3, 160x132x96, 120x160x144}, resident in HBM
     exts = [(R, R, R), (R, int(R * 0.825), int(R * 0.6)), (int(R * 0.75), R, int(R * 0.9))]
-    sweep_sizes = [] if (args.no_sweep or args.eager or world > 1) else [b for b in (1, 4, 8) if b != Bg]
+    # N = 1: the 1 / 4 / 8 grids-per-GPU figures of this GPU.  N > 1: BOTH scaling legs in the one line -- `value` is the strong leg (global batch 8
+    # split over the ranks); config.sweep adds the weak legs at 8 and 1 grids per GPU, each with its own comm_ms_exposed
+    sweep_sizes = [] if (args.no_sweep or args.eager) else [b for b in ((1, 4, 8) if world == 1 else (8, 1)) if b != Bg]
     nmax = max([Bg] + sweep_sizes)
     # stored-format scenes (W,L,H,4 with raw density) go through the product input pipeline (density->alpha, layout, padding on the GPU)
     scenes = [data.synthetic_scene(exts[(rank * nmax + i) % 3], seed=rank * 131 + i) for i in range(nmax)]
@@ -217,8 +219,14 @@ def main():
         d2, _ = run_leg(nb, ks, 3)
         gps = ks * nb * world / d2
         sweep["%d_grids_per_gpu" % nb] = {"grids_per_s": round(gps, 3), "ms_per_step": round(1e3 * d2 / ks, 3), "whole_step_mfma_frac": frac(gps / world)}
+        if world > 1:   # weak-scaling leg: global batch nb * N; its exposed communication as for the headline leg
+            d3, _ = run_leg(nb, ks, 3, use_reducer=False)
+            broadcast_parameters(model)
+            sweep["%d_grids_per_gpu" % nb].update({"scaling": "weak", "global_batch": nb * world, "comm_ms_exposed": round(1e3 * (d2 - d3) / ks, 3)})
     sweep["%d_grids_per_gpu" % Bg] = {"grids_per_s": round(grids_per_s, 3), "ms_per_step": round(1e3 * dt / args.steps, 3),
                                       "whole_step_mfma_frac": frac(grids_per_s / world)}
+    if world > 1:
+        sweep["%d_grids_per_gpu" % Bg].update({"scaling": scaling, "global_batch": Bg * world, "comm_ms_exposed": comm_exposed})
 
     # per-kernel durations with HIP events on the launch stream: a few extra eager steps on the same model/data right after
     # the timed region (graph replays cannot carry per-launch events; the kernels, shapes and data are identical).  The side stream
@@ -308,6 +316,25 @@ def main():
                                "frac_back_to_back": None if sustained is None else round(fl / (sustained * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                "traffic": None,
                                "algorithmic_flop_per_launch": fl, "algorithmic_bytes_per_launch": 2.0 * Bg * R ** 3 * E2 * 2}
+            # the contract figure: the same kernel INSIDE the replayed graph (a second short run under rocprofv3 --kernel-trace); the eager-step
+            # event figure stays in the line as `frac_eager_events`
+            trace = replay_trace_kernels(args, Bg) if world == 1 else None
+            if trace is not None:
+                rx = "conv48_kernel<0, false>" if key[0] == "conv3d_k3_c48" else ("conv64_kernel" if key[0] == "conv3d_k3_halo" else None)
+                hits = [(ns, cnt) for (nm, gx, gy, gz), (ns, cnt) in trace["kernels"].items() if rx and rx in nm and ns / max(cnt, 1e-9) > 1.0e6]
+                if hits:
+                    ns_tot, cnt_tot = sum(h[0] for h in hits), sum(h[1] for h in hits)
+                    avg_r = ns_tot / cnt_tot / 1e6
+                    rl = out["roofline"]
+                    rl["frac_eager_events"], rl["avg_launch_ms_eager_events"] = rl["frac"], rl["avg_launch_ms"]
+                    rl["avg_launch_ms"] = round(avg_r, 4)
+                    rl["achieved"] = round(fl / (avg_r * 1e-3) / 1e12, 2)
+                    rl["frac"] = round(fl / (avg_r * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                    rl["launches_timed"] = round(cnt_tot * trace["steps"])
+                    rl["timing"] = ("rocprofv3 --kernel-trace of %d replayed steps of the SAME command at %d grids/GPU (a second short run spawned by bench.py; "
+                                    "per-launch average of this kernel inside the HIP graph)" % (trace["steps"], Bg))
+                out["roofline"]["kernels"] = roofline_families(trace, cfg, R, Bg)
+                out["roofline"]["replayed_step_ms_in_trace"] = round(trace["step_ns"] / 1e6, 3)
             # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes (counters cannot be read in-process): the committed
             # summary is quoted only when it was taken on THIS kernel source (sha256 of conv48.hip) at the same shape
             try:
@@ -385,6 +412,118 @@ def main():
     if world > 1:
         dist.destroy_process_group()
 
+
+
+def replay_trace_kernels(args, Bg):
+    """Per-kernel durations INSIDE the replayed HIP graph -- the timed region itself: a short second run of this script under
+    `rocprofv3 --kernel-trace` (same model, batch and launch path; no sweep / CPU baseline / event timing), whose kernel trace is cut into
+    steps at the weight-pack launches.  Returns {(kernel name, grid): [total ns per step, launches per step]} averaged over the replayed
+    steps well inside the run, or None when rocprofv3 is not available (the line then keeps the eager-step event figures)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("NMH_BENCH_INNER") == "1" or os.environ.get("NMH_BENCH_NO_TRACE") == "1":
+        return None
+    out_dir = tempfile.mkdtemp(prefix="nmh_trace_", dir="/tmp")
+    env = dict(os.environ, NMH_BENCH_INNER="1", TMPDIR="/tmp")
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
+           "--batch-per-gpu", str(Bg), "--backbone", args.backbone, "--resolution", str(args.resolution), "--dtype", args.dtype,
+           "--no-cpu-baseline", "--no-kernel-timing", "--no-sweep", "--steps", "8", "--warmup", "2"]
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+        f = glob.glob(out_dir + "/**/*kernel_trace.csv", recursive=True)[0]
+        rows = list(csv.DictReader(open(f)))
+    except Exception:  # noqa: BLE001
+        shutil.rmtree(out_dir, ignore_errors=True)
+        return None
+    shutil.rmtree(out_dir, ignore_errors=True)
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "pack_kernel" in r["Kernel_Name"]]
+    idx = [i for j, i in enumerate(idx) if j == 0 or int(rows[i]["Start_Timestamp"]) - int(rows[idx[j - 1]]["Start_Timestamp"]) > 5_000_000]
+    if len(idx) < 7:
+        return None
+    steps = [(idx[k], idx[k + 1]) for k in range(len(idx) - 6, len(idx) - 2)]   # four replayed steps well inside the timed region
+    agg = collections.defaultdict(lambda: [0.0, 0.0])
+    for a, b in steps:
+        for r in rows[a:b]:
+            name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("unsigned short", "bf16")
+            key = (name[:90], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+            agg[key][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / len(steps)
+            agg[key][1] += 1.0 / len(steps)
+    wall = sum(int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"]) for a, b in steps) / len(steps)
+    return {"kernels": dict(agg), "step_ns": wall, "steps": len(steps)}
+
+
+def roofline_families(trace, cfg, R, Bg):
+    """the replayed step by kernel family: time per step from the kernel trace, algorithmic FLOPs per step from SURVEY 8(d)'s model, against the
+    2.5 PFLOP/s dense bf16 MFMA peak (the HBM-bound families carry no FLOP figure)"""
+    import re
+    C, depths = cfg["embed_dim"], cfg["depths"]
+    E2 = C // 2
+    g = R // 4
+    lin = attn = merge = 0.0
+    s_ = g
+    for i, d in enumerate(depths):
+        c = C * 2 ** i
+        if i > 0:
+            s_ = (s_ + 1) // 2
+            merge += 2.0 * s_ ** 3 * (4 * c) * c
+        T = s_ ** 3
+        lin += d * (2.0 * T * c * 3 * c + 2.0 * T * c * c + 16.0 * T * c * c)
+        attn += d * 4.0 * T * 64 * c
+    embed = 2.0 * g ** 3 * 256 * C
+    conv_small = up = c3 = 0.0
+    v = s_
+    for cin, cout, k, skip in ((8 * C, 4 * C, 2, True), (4 * C, 2 * C, 2, True), (2 * C, C, 2, True), (C, C // 2, 4, False)):
+        V = (v * k) ** 3
+        up += 2.0 * V * cin * cout
+        cc = 2 * cout if skip else cout
+        if skip:
+            conv_small += 2.0 * V * 27 * cc * cout + 2.0 * V * 27 * cout * cout
+            c3 += 2.0 * V * cc * cout
+        v *= k
+    conv1 = 2.0 * 27 * E2 * E2 * R ** 3
+    fam = [
+        ("conv %d->%d 3x3x3 @%d^3 fwd+dgrad (conv48_kernel<0,false> / conv64_kernel)" % (E2, E2, R), r"conv48_kernel<0, false>|conv64_kernel", 4 * conv1),
+        ("conv %d->%d 3x3x3 @%d^3 weight gradient (conv48_wgrad_kernel, persistent launches)" % (E2, E2, R), r"conv48_wgrad_kernel|conv64_wgrad_kernel", 2 * conv1),
+        ("decoder convs at the 10^3..40^3 levels, fwd+dgrad+wgrad (conv48_kernel<0,true>, AConv3, BConv3TN, small conv48_wgrad launches)",
+         r"conv48_kernel<0, true>|AConv3|BConv3TN|conv48_wgrad_reduce", 3 * conv_small),
+        ("encoder Linear / patch-embed / merge / transpose-conv / 1x1 GEMMs fwd+dgrad (gemm_nt*, fused MLP)", r"gemm_nt|mlp96_|mlp_fwd_kernel|mlp_bwd_kernel|nt_ksplit",
+         2 * (lin + merge + up + c3) + embed),
+        ("encoder + transpose-conv weight gradients (gemm_tn_grouped, gemm_tn)", r"gemm_tn", lin + merge + embed + up + c3),
+        ("window attention core fwd+bwd (attn_fwd / attn_bwd)", r"attn_", 3.5 * attn),
+        ("LayerNorm fwd+bwd", r"ln_fwd|ln_bwd", None),
+        ("decoder-1 elementwise passes @%d^3 (tail fwd/bwd, InstanceNorm apply / reduce / backward)" % R, r"tail_|in_apply|in_bwd_apply|in_reduce|in_finalize", None),
+        ("weight pack + grad norm + AdamW", r"pack_kernel|adamw|sqnorm|clip_coef", None),
+    ]
+    used, out = set(), []
+    ks = trace["kernels"]
+    for name, rx, fl in fam:
+        t = n = 0.0
+        for key, (ns, cnt) in ks.items():
+            if key in used or not re.search(rx, key[0]):
+                continue
+            big = ns / max(cnt, 1e-9) > 1.5e6      # the persistent 160^3 launches of the conv families
+            if "weight gradient (conv48_wgrad_kernel" in name and not big:
+                continue
+            used.add(key)
+            t += ns
+            n += cnt
+        row = {"family": name, "ms_per_step": round(t / 1e6, 3), "launches_per_step": round(n, 1)}
+        if fl is not None and t > 0:
+            fl_step = fl * Bg
+            row["algorithmic_tflop_per_step"] = round(fl_step / 1e12, 4)
+            row["achieved_tflops"] = round(fl_step / (t * 1e-9) / 1e12, 1)
+            row["frac_of_mfma_peak"] = round(fl_step / (t * 1e-9) / 1e12 / PEAK_BF16_TFLOPS, 4)
+        out.append(row)
+    rest = sum(ns for key, (ns, cnt) in ks.items() if key not in used)
+    out.append({"family": "everything else", "ms_per_step": round(rest / 1e6, 3), "launches_per_step": round(sum(c for k, (ns, c) in ks.items() if k not in used), 1)})
+    return out
 
 def e2e_leg(model, args, R, sweep):
     """Trainer.fit on HOST-resident synthetic scenes (stored format, through the pinned ring / copy stream / grid_prepare kernel):

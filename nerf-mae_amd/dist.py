@@ -29,28 +29,74 @@ class _Trigger(torch.autograd.Function):
         return g, None, None
 
 
+def stage_chunk_groups(model, si: int, n: int):
+    """the modules of encoder stage `si` in (at most) n consecutive groups of whole Swin blocks, the stage's patch merging with the first"""
+    mods = list(model.stages[si])
+    lead = [m for m in mods if not hasattr(m, "attn")]
+    blocks = [m for m in mods if hasattr(m, "attn")]
+    n = max(1, min(n, len(blocks)))
+    per = -(-len(blocks) // n)
+    groups = [blocks[i * per:(i + 1) * per] for i in range(n) if blocks[i * per:(i + 1) * per]]
+    groups[0] = lead + groups[0]
+    return groups
+
+
 class GradReducer:
-    def __init__(self, model, process_group=None, comm_dtype: Optional[torch.dtype] = None):
+    """Gradient ranges ("segments") of the flat buffer in forward order:
+        0 embed(+mask token) | 1 stage 0 | 2 stage 1 | 3 .. 3+nc-1 the nc block groups of stage 2 | 3+nc stage 3 | 4+nc decoders + head
+    Stage 2 carries 70 % of the encoder's parameters (swin_s: 18 of 24 blocks): it is exchanged in `stage_chunks` pieces (default 3, i.e. 6
+    blocks each) so that the first all-reduce of the big range is in flight while two thirds of the stage are still in backward."""
+    CHUNK_STAGE = 2
+
+    def __init__(self, model, process_group=None, comm_dtype: Optional[torch.dtype] = None, stage_chunks: Optional[int] = None):
+        import os
         self.model, self.group = model, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # NMH_DP_FORCE=1: run the whole exchange machinery also over a one-rank group (single-GPU measurements of its cost)
+        self.active = self.world > 1 or os.environ.get("NMH_DP_FORCE") == "1"
         if model._flat is None:
             model.flatten_parameters()
         off = model._offsets
         first = lambda mod: min(off[id(p)] for p in mod.parameters() if p.requires_grad)  # noqa: E731
         n = model._flat_grad.numel()
-        # forward-order boundaries: [embed | stage0 | stage1 | stage2 | stage3 | decoders+head(+mask_token)]
-        b = [0] + [first(st) for st in model.stages] + [first(model.decoder4), n]
+        if stage_chunks is None:
+            stage_chunks = int(os.environ.get("NMH_DP_STAGE2_CHUNKS", "3"))
+        self.chunk_stage = self.CHUNK_STAGE if len(model.stages) > self.CHUNK_STAGE else -1
+        self.chunk_groups = stage_chunk_groups(model, self.chunk_stage, stage_chunks) if self.chunk_stage >= 0 else []
+        nc = max(1, len(self.chunk_groups))
+        self.nchunks = nc
+        # coarse forward-order boundaries: [embed | stage0 | stage1 | stage2 | stage3 | decoders+head]
+        sb = [0] + [first(st) for st in model.stages] + [first(model.decoder4), n]
+        self.stage_bounds = sb
+        b = []
+        for si in range(len(model.stages) + 1):       # entry si = start of segment "stage si-1" (entry 0: embed)
+            b.append(sb[si])
+            if si - 1 == self.chunk_stage and nc > 1:
+                b.extend(first(grp[0]) for grp in self.chunk_groups[1:])
+        b += sb[len(model.stages) + 1:]
         self.bounds = b
         self.nseg = len(b) - 1
         self.on_gpu = model._flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self.world > 1 and self.on_gpu) else None
+        self.comm_stream = torch.cuda.Stream() if (self.active and self.on_gpu) else None
         self.pending: List = []
         self.comm_dtype = comm_dtype
-        self.staging = torch.empty(n, dtype=comm_dtype, device=model._flat_grad.device) if (comm_dtype and self.world > 1) else None
+        self.staging = torch.empty(n, dtype=comm_dtype, device=model._flat_grad.device) if (comm_dtype and self.active) else None
+
+    def seg_stage(self, si: int, chunk: int = 0) -> int:
+        """segment id of encoder stage si (of its block group `chunk` for the chunked stage)"""
+        extra = self.nchunks - 1 if self.chunk_stage >= 0 else 0
+        if si < self.chunk_stage or self.chunk_stage < 0:
+            return 1 + si
+        if si == self.chunk_stage:
+            return 1 + si + chunk
+        return 1 + si + extra
+
+    def seg_decoder(self) -> int:
+        return self.nseg - 1
 
     def trigger(self, x, seg: int):
         """insert after the forward op whose *inputs* bound segment `seg` from below (see model.forward)"""
-        if self.world == 1 or not torch.is_grad_enabled():
+        if not self.active or not torch.is_grad_enabled():
             return x
         return _Trigger.apply(x, self, seg)
 
@@ -75,7 +121,7 @@ class GradReducer:
         """gradient mean of flat_grad[lo:hi] (element offsets, multiples of 8).  RCCL + overlap: issued on the comm stream after everything
         queued on the current stream so far (the producers of that range), so the caller can go on launching backward work; `wait()`
         joins.  Otherwise (gloo dry runs, overlap off): on the current stream."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         if overlap and self.comm_stream is not None and dist.get_backend(self.group) == "nccl":
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -89,7 +135,7 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def launch(self, seg: int):
-        if self.world == 1:
+        if not self.active:
             return
         lo, hi = self.bounds[seg], self.bounds[seg + 1]
         if not self.on_gpu:  # CPU/gloo (tests): synchronous
@@ -105,13 +151,13 @@ class GradReducer:
 
     def allreduce_flat(self):
         """the whole flat gradient buffer in one message on the current stream"""
-        if self.world == 1:
+        if not self.active:
             return
         self._exchange(0, self.model._flat_grad.numel())
 
     def finish(self):
         """call after backward: reduce any segment whose trigger did not fire, then join the comm stream"""
-        if self.world == 1:
+        if not self.active:
             return
         if self.on_gpu and dist.get_backend(self.group) != "nccl":
             self.allreduce_flat()

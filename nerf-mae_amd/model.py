@@ -857,17 +857,24 @@ class SwinTransformer_MAE3D_New(nn.Module):
         noise = torch.bernoulli(keep).div_(keep)
         return [(noise[2 * i], noise[2 * i + 1]) for i in range(len(blocks))]
 
-    def _run_stage(self, si: int, x: Tensor, sd_noise, bi: int):
-        """stage `si` on channels-last x; `bi` = index of the stage's first block in `sd_noise`.  Returns (output, next block index)."""
+    def _run_stage(self, si: int, x: Tensor, sd_noise, bi: int, red=None):
+        """stage `si` on channels-last x; `bi` = index of the stage's first block in `sd_noise`.  Returns (output, next block index).
+        With a data-parallel reducer the stage (each block group of the chunked stage, dist.GradReducer) is preceded by the trigger that
+        launches its gradient range's all-reduce -- backward order: blocks of the group, the flush that issues (and joins) their queued weight
+        gradients, then the trigger."""
         grouped = ops.GROUPED_WGRAD and self.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad
-        if grouped:
-            x = _StageFlushFn.apply(x, self._wq)   # backward order: blocks of the stage, this flush (, then the reducer trigger)
-        for mod in self.stages[si]:
-            if isinstance(mod, SwinBlock3D):
-                x = mod(x, None if sd_noise is None else sd_noise[bi])
-                bi += 1
-            else:
-                x = mod(x)
+        groups = red.chunk_groups if (red is not None and si == getattr(red, "chunk_stage", -1) and red.chunk_groups) else [list(self.stages[si])]
+        for k, grp in enumerate(groups):
+            if red is not None:
+                x = red.trigger(x, red.seg_stage(si, k))  # backward reaching here => this range's gradients are complete
+            if grouped:
+                x = _StageFlushFn.apply(x, self._wq)
+            for mod in grp:
+                if isinstance(mod, SwinBlock3D):
+                    x = mod(x, None if sd_noise is None else sd_noise[bi])
+                    bi += 1
+                else:
+                    x = mod(x)
         return x, bi
 
     def forward_encoder(self, tok: Tensor, sd_noise=None):
@@ -875,11 +882,9 @@ class SwinTransformer_MAE3D_New(nn.Module):
         red = self._reducer
         if sd_noise is None:
             sd_noise = self._draw_sd_noise(tok.shape[0], tok.device)
-        self._wq.sync_after_flush = red is not None   # a gradient all-reduce of the stage follows the flush: join before it
+        self._wq.sync_after_flush = red is not None   # a gradient all-reduce of the range follows the flush: join before it
         for si in range(len(self.stages)):
-            if red is not None:
-                x = red.trigger(x, si + 1)  # backward reaching here => stage si gradients are complete
-            x, bi = self._run_stage(si, x, sd_noise, bi)
+            x, bi = self._run_stage(si, x, sd_noise, bi, red)
             if si + 1 < len(self.stages) and torch.is_grad_enabled() and x.requires_grad:
                 x, skip = _Fork2Fn.apply(x)     # consumed by the next stage and by a decoder / neck
                 feats.append(skip)
@@ -894,7 +899,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
             arena.begin()     # one clearing launch for every InstanceNorm accumulator of this forward + backward (ops.AccArena)
         f3 = feats[3]
         if self._reducer is not None:
-            f3 = self._reducer.trigger(f3, len(self.stages) + 1)  # decoder4 is the last decoder op in backward order
+            f3 = self._reducer.trigger(f3, self._reducer.seg_decoder())  # decoder4 is the last decoder op in backward order
             if torch.is_grad_enabled() and f3.requires_grad:
                 # backward order: decoder4, THIS flush (the decoder's queued small-level weight gradients are issued and joined), then the
                 # trigger that starts the decoder segment's all-reduce

@@ -141,10 +141,12 @@ class GraphedTrainStep:
         self.losses = None
         self._ext_host = None
         self._g1 = self._g2 = self._gb1 = self._gb2 = None
+        self._gb, self._ranges = [], []
         self._warm = warmup
         self.overlap = True    # False: every collective on the main stream (A/B measurement of what the overlap hides)
-        if reducer is not None and reducer.world > 1 and len(reducer.bounds) != 7:
-            raise ValueError("GraphedTrainStep: the split data-parallel step expects the 6 gradient segments of a 4-stage encoder + decoder")
+        if reducer is not None and reducer.world > 1 and len(reducer.stage_bounds) != 7:
+            raise ValueError("GraphedTrainStep: the data-parallel step expects the gradient segments of a 4-stage encoder + decoder")
+        self.comm_captured = False
 
     def set_extents(self, ext):
         """valid extents [B][3] of the batch now in `self.x` (host list / tensor) -> static device buffer, through a pinned ring"""
@@ -158,11 +160,21 @@ class GraphedTrainStep:
         return out
 
     def _capture(self):
-        # the eager path's autograd triggers would issue collectives on the comm stream inside the capture: graph mode owns the
-        # exchange (see __call__), so they are switched off for good on this model
-        self.model._reducer = None
+        import os
+        import torch.distributed as tdist
         ops.side_stream.auto(self.x.shape[0])
-        split = self.reducer is not None and self.reducer.world > 1
+        # NMH_DP_FORCE_SPLIT=1 / NMH_DP_FORCE=1: the data-parallel step also with a one-rank group (tools/bench_dp_overhead.py: what the machinery costs)
+        dp = self.reducer is not None and (self.reducer.active or os.environ.get("NMH_DP_FORCE_SPLIT") == "1")
+        # RCCL collectives CAN be captured into a HIP graph on this stack (tools/probe_rccl_capture.py: replay == eager): the whole step --
+        # forward, backward with the segment all-reduces launched by the autograd triggers on the comm stream, join, clip + AdamW -- is then
+        # ONE graph and the exchange overlaps the backward without any host-side replay boundary.  NMH_DP_CAPTURE_COMM=0 (or a backend other
+        # than RCCL, e.g. the gloo dry runs) keeps the collectives outside: the step is cut into pieces at the gradient-range boundaries.
+        self.comm_captured = (dp and self.reducer.active and self.reducer.on_gpu and tdist.is_initialized() and tdist.get_backend(self.reducer.group) == "nccl"
+                              and os.environ.get("NMH_DP_CAPTURE_COMM", "1") != "0" and os.environ.get("NMH_DP_FORCE_SPLIT") != "1")
+        split = dp and not self.comm_captured
+        # split mode: the eager path's autograd triggers would issue collectives on the comm stream inside the capture, graph mode owns the
+        # exchange (see __call__); captured mode: the triggers ARE the exchange
+        self.model._reducer = self.reducer if self.comm_captured else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -172,6 +184,8 @@ class GraphedTrainStep:
                     self._split_a(zero=True); self._split_b1(); self._split_b2()
                 else:
                     self._fwd_bwd()
+                    if self.comm_captured:
+                        self.reducer.finish()
         torch.cuda.current_stream().wait_stream(s)
         # inside the replayed step the gradient buffer is cleared by the optimizer kernel of the previous step (hyper[7]); only the
         # first replay needs it cleared here
@@ -182,32 +196,47 @@ class GraphedTrainStep:
         if not split:
             with torch.cuda.graph(self._g1, capture_error_mode=_CAPTURE_MODE):
                 out = self._fwd_bwd(zero=False)
+                if self.comm_captured:
+                    self.reducer.finish()      # ranges whose trigger did not fire (the embed tail) + join of the comm stream
                 self.losses = torch.stack([o.detach() for o in out[:3]])
                 self.opt.launch()
             return
-        # data parallel: the step is cut where gradient segments complete, and the collectives run BETWEEN the replays on the comm
+        # data parallel, collectives outside the graphs: the step is cut where gradient ranges complete, and the collectives run BETWEEN the replays on the comm
         # stream (RCCL stays outside the captured regions), overlapping the next piece of the backward:
-        #   g1 = forward + decoder backward          -> all-reduce [decoders, head]
-        #   gb1 = backward of stages 3 and 2         -> all-reduce [stage 2, stage 3]
-        #   gb2 = backward of stages 1, 0, the embed -> all-reduce [mask token, embed, stage 0, stage 1]
+        #   g1  = forward + decoder backward                              -> all-reduce [decoders, head]
+        #   gb[0] = backward of stage 3 and the LAST third of stage 2     -> all-reduce [stage 2 blocks 12.., stage 3]
+        #   gb[1], gb[2] = backward of the middle / first third of stage 2 -> all-reduce of that third (the first exchange of the 48.9 M
+        #                  stage-2/3 parameters is in flight while two thirds of stage 2 are still in backward)
+        #   gb[3] = backward of stages 1, 0, the embed                    -> all-reduce [mask token, embed, stage 0, stage 1]
         #   g2 = clip + AdamW
         with torch.cuda.graph(self._g1, capture_error_mode=_CAPTURE_MODE):
             out = self._split_a(zero=False)
             self.losses = torch.stack([o.detach() for o in out[:3]])
         pool = self._g1.pool()
-        self._gb1, self._gb2, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._gb1, pool=pool, capture_error_mode=_CAPTURE_MODE):
-            self._split_b1()
-        with torch.cuda.graph(self._gb2, pool=pool, capture_error_mode=_CAPTURE_MODE):
-            self._split_b2()
+        self._gb = []
+        for k in range(len(self._pieces["back"])):
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                self._split_back(k)
+            self._gb.append(gk)
+        self._g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g2, pool=pool, capture_error_mode=_CAPTURE_MODE):
             self.opt.launch()
+        self._gb1 = self._gb[0]            # (kept for callers that test for the split mode)
+        self._pieces = None
 
-    # ---- the step in three autograd pieces (data-parallel graph mode) ----------------------------------------------------------------
+    # ---- the step in autograd pieces (data-parallel graph mode) ----------------------------------------------------------------------
+    def _stage2_chunks(self):
+        """block groups of the chunked encoder stage (dist.GradReducer.chunk_groups: stage 2 in three groups of six blocks for swin_s)"""
+        from .dist import stage_chunk_groups
+        if self.reducer is not None and self.reducer.chunk_groups:
+            return self.reducer.chunk_groups
+        return stage_chunk_groups(self.model, 2, 3)
+
     def _split_a(self, zero=True):
-        """forward + decoder backward.  The encoder features enter the decoder (and stage 1's output enters stage 2) through detached
-        leaves, so each later piece is its own autograd graph whose incoming gradients are the `.grad` of those leaves."""
-        from .model import _EmbedFn
+        """forward + decoder backward.  The encoder features enter the decoder (and every later piece enters the next) through detached
+        leaves, so each piece is its own autograd graph whose incoming gradients are the `.grad` of those leaves."""
+        from .model import _EmbedFn, _StageFlushFn, SwinBlock3D
         m = self.model
         if zero:
             m.zero_grad()
@@ -220,22 +249,66 @@ class GraphedTrainStep:
         f0, bi = m._run_stage(0, tok, sd, 0)
         f1, bi = m._run_stage(1, f0, sd, bi)
         e1 = f1.detach().requires_grad_()
-        f2, bi = m._run_stage(2, e1, sd, bi)
+        groups = self._stage2_chunks()
+        grouped = ops.GROUPED_WGRAD and m.compute_dtype == torch.bfloat16
+        x, ins, outs = e1, [], []
+        for k, grp in enumerate(groups):
+            ins.append(x)
+            y = _StageFlushFn.apply(x, m._wq) if grouped else x     # backward of the group ends by issuing its queued weight gradients
+            for mod in grp:
+                if isinstance(mod, SwinBlock3D):
+                    y = mod(y.contiguous(), None if sd is None else sd[bi])
+                    bi += 1
+                else:
+                    y = mod(y.contiguous())
+            outs.append(y)
+            x = y.detach().requires_grad_() if k + 1 < len(groups) else y
+        f2 = outs[-1]
         f3, bi = m._run_stage(3, f2, sd, bi)
         d = [f.detach().requires_grad_() for f in (f0, f1, f2, f3)]
         losses = m._decode_and_loss(d, self.x, self.ext, self.mask, None)
         losses[0].backward()
-        self._pieces = ((f0, f1, f2, f3), e1, d)
+        # gradient ranges of the pieces (element offsets into the flat buffers; parameters lie in module order)
+        off = m._offsets
+        first = lambda mod: min(off[id(p)] for p in mod.parameters() if p.requires_grad)  # noqa: E731
+        b = self.reducer.stage_bounds if self.reducer is not None else None
+        s2_lo, s3_hi = (b[3], b[5]) if b is not None else (first(m.stages[2]), first(m.decoder4))
+        starts = [s2_lo] + [first(grp[0]) for grp in groups[1:]]
+        back = []
+        n = len(groups)
+        for k in range(n - 1, -1, -1):       # backward order: last group (together with stage 3) first
+            hi = s3_hi if k == n - 1 else starts[k + 1]
+            back.append({"kind": "s2", "k": k, "lo": starts[k], "hi": hi})
+        back.append({"kind": "s01", "lo": 0, "hi": s2_lo})
+        self._pieces = {"f": (f0, f1, f2, f3), "e1": e1, "d": d, "ins": ins, "outs": outs, "back": back}
+        self._ranges = [(p["lo"], p["hi"]) for p in back]
         return losses[0], losses[1], losses[2]
 
+    def _split_back(self, j: int):
+        """piece j of the encoder backward (see _capture)"""
+        P = self._pieces
+        pc = P["back"][j]
+        f0, f1, f2, f3 = P["f"]
+        d, ins, outs = P["d"], P["ins"], P["outs"]
+        if pc["kind"] == "s2":
+            k = pc["k"]
+            if k == len(outs) - 1:
+                torch.autograd.backward([f3, f2], [d[3].grad, d[2].grad])
+            else:
+                torch.autograd.backward([outs[k]], [ins[k + 1].grad])
+        else:
+            e1 = P["e1"]
+            ops.add_inplace(e1.grad, d[1].grad)     # stage 1's output feeds stage 2 and decoder3's skip connection
+            torch.autograd.backward([f1, f0], [e1.grad, d[0].grad])
+
+    # (compatibility with the three-piece step of round 2: the two encoder pieces by name)
     def _split_b1(self):
-        (f0, f1, f2, f3), e1, d = self._pieces
-        torch.autograd.backward([f3, f2], [d[3].grad, d[2].grad])
+        for j, pc in enumerate(self._pieces["back"]):
+            if pc["kind"] == "s2":
+                self._split_back(j)
 
     def _split_b2(self):
-        (f0, f1, f2, f3), e1, d = self._pieces
-        ops.add_inplace(e1.grad, d[1].grad)     # stage 1's output feeds stage 2 and decoder3's skip connection
-        torch.autograd.backward([f1, f0], [e1.grad, d[0].grad])
+        self._split_back(len(self._pieces["back"]) - 1)
         self._pieces = None
 
     def __call__(self, grids=None, block_mask=None):
@@ -280,12 +353,11 @@ class GraphedTrainStep:
                 ops.step_params(extents=ext[i0:i0 + self.MAX_EXT_ROWS], extents_dev=self.ext[i0:i0 + self.MAX_EXT_ROWS])
         self._g1.replay()
         if self._g2 is not None:
-            red, b = self.reducer, self.reducer.bounds
+            red, b = self.reducer, self.reducer.stage_bounds
             red.allreduce_range(b[5], b[6], overlap=self.overlap)
-            self._gb1.replay()
-            red.allreduce_range(b[3], b[5], overlap=self.overlap)
-            self._gb2.replay()
-            red.allreduce_range(b[0], b[3], overlap=self.overlap)
+            for gk, (lo, hi) in zip(self._gb, self._ranges):
+                gk.replay()
+                red.allreduce_range(lo, hi, overlap=self.overlap)
             red.wait()
             self._g2.replay()
         return self.losses

@@ -26,7 +26,12 @@ def _worker(rank, world, port, q):
         dist.broadcast(ref, src=0)
         assert torch.equal(ref, m._flat)
         red = GradReducer(m)
-        assert red.nseg == 6 and red.bounds[0] == 0 and red.bounds[-1] == m._flat_grad.numel()
+        # swin_t: stage 2 has 6 blocks -> three groups of two; segments embed | stage0 | stage1 | 3 x stage-2 groups | stage3 | decoders
+        assert red.nseg == 8 and red.nchunks == 3 and red.bounds[0] == 0 and red.bounds[-1] == m._flat_grad.numel()
+        assert red.bounds == sorted(red.bounds) and len(set(red.bounds)) == len(red.bounds)
+        assert [red.seg_stage(0), red.seg_stage(1), red.seg_stage(2, 0), red.seg_stage(2, 2), red.seg_stage(3), red.seg_decoder()] == [1, 2, 3, 5, 6, 7]
+        assert red.bounds[red.seg_stage(2, 1)] == m._offsets[id(next(red.chunk_groups[1][0].parameters()))]
+        assert red.stage_bounds[3] == red.bounds[3] and red.stage_bounds[4] == red.bounds[6] and len(red.stage_bounds) == 7
         # segment 0 holds mask_token + patch embed; last segment starts at decoder4
         assert red.bounds[1] == m._offsets[id(next(m.stages[0].parameters()))]
         # fake backward: rank-specific gradients, triggers fire in backward order (decoder, stage3..0), finish() does the rest
@@ -38,11 +43,11 @@ def _worker(rank, world, port, q):
         order = []
         orig = red.launch
         red.launch = lambda seg: (order.append(seg), orig(seg))[1]
-        for seg in (1, 2, 3, 4, 5):       # forward order: stage0..3 inputs, then decoder input
+        for seg in (1, 2, 3, 4, 5, 6, 7):       # forward order: stage0, stage1, the three stage-2 groups, stage3 inputs, then decoder input
             y = red.trigger(y * 1.0, seg)
         y.sum().backward()
         red.finish()
-        assert order == [5, 4, 3, 2, 1, 0], order
+        assert order == [7, 6, 5, 4, 3, 2, 1, 0], order
         assert torch.allclose(g, expect, rtol=1e-6), (g - expect).abs().max()
         assert torch.allclose(x.grad, torch.ones(3))
         q.put((rank, "ok"))

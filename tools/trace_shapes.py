@@ -16,7 +16,7 @@ a, b = idx[-8], idx[-7]          # a replayed step well inside the timed region
 seg = rows[a:b]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in seg:
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))
     name = re.sub(r"unsigned short", "bf16", name).replace("void ", "")
     key = (name[:70], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
     agg[key][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
