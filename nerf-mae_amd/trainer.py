@@ -165,12 +165,15 @@ class GraphedTrainStep:
         ops.side_stream.auto(self.x.shape[0])
         # NMH_DP_FORCE_SPLIT=1 / NMH_DP_FORCE=1: the data-parallel step also with a one-rank group (tools/bench_dp_overhead.py: what the machinery costs)
         dp = self.reducer is not None and (self.reducer.active or os.environ.get("NMH_DP_FORCE_SPLIT") == "1")
-        # RCCL collectives CAN be captured into a HIP graph on this stack (tools/probe_rccl_capture.py: replay == eager): the whole step --
-        # forward, backward with the segment all-reduces launched by the autograd triggers on the comm stream, join, clip + AdamW -- is then
-        # ONE graph and the exchange overlaps the backward without any host-side replay boundary.  NMH_DP_CAPTURE_COMM=0 (or a backend other
-        # than RCCL, e.g. the gloo dry runs) keeps the collectives outside: the step is cut into pieces at the gradient-range boundaries.
+        # RCCL collectives CAN be captured into a HIP graph on this stack (tools/probe_rccl_capture.py: replay == eager).  With
+        # NMH_DP_CAPTURE_COMM=1 the whole step -- forward, backward with the range all-reduces launched by the autograd triggers on the comm
+        # stream, join, clip + AdamW -- is ONE graph without host-side replay boundaries.  Measured over a one-rank RCCL group
+        # (tools/bench_dp_overhead.py, ms/step at 1 / 8 grids): single process 12.38 / 58.93, split graphs 13.07 / 60.20, one graph with the
+        # collectives inside 13.41 / 60.67 -- no gain on one GPU (what both pay is the bf16 bucket casts and the joins of the weight-gradient
+        # side stream in front of every exchange), and plain collectives between graph replays are the more conservative use of RCCL for a
+        # first multi-GPU run, so the DEFAULT keeps the collectives outside: the step is cut into pieces at the gradient-range boundaries.
         self.comm_captured = (dp and self.reducer.active and self.reducer.on_gpu and tdist.is_initialized() and tdist.get_backend(self.reducer.group) == "nccl"
-                              and os.environ.get("NMH_DP_CAPTURE_COMM", "1") != "0" and os.environ.get("NMH_DP_FORCE_SPLIT") != "1")
+                              and os.environ.get("NMH_DP_CAPTURE_COMM", "0") == "1" and os.environ.get("NMH_DP_FORCE_SPLIT") != "1")
         split = dp and not self.comm_captured
         # split mode: the eager path's autograd triggers would issue collectives on the comm stream inside the capture, graph mode owns the
         # exchange (see __call__); captured mode: the triggers ARE the exchange

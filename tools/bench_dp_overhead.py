@@ -24,13 +24,13 @@ rng = random.Random(1)
 # modes over a ONE-rank RCCL group: the collectives degenerate to copies, everything around them is real
 MODES = (("single process (one graph, no exchange)", {}, False),
          ("split graphs, collectives between the replays", {"NMH_DP_FORCE_SPLIT": "1", "NMH_DP_FORCE": "1"}, True),
-         ("ONE graph with the RCCL all-reduces captured inside", {"NMH_DP_FORCE": "1"}, True))
+         ("ONE graph with the RCCL all-reduces captured inside", {"NMH_DP_FORCE": "1", "NMH_DP_CAPTURE_COMM": "1"}, True))
 for nb in [int(a) for a in sys.argv[1:]] or [1, 2]:
     scenes = [data.synthetic_scene((R, R, R), seed=i) for i in range(nb)]
     xb, ext = data.GridBatcher(R, dev, normalize_density=True)(scenes, flags=[0] * nb)
     grids = [xb[i].contiguous() for i in range(nb)]
     for name, env, use_red in MODES:
-        for k in ("NMH_DP_FORCE_SPLIT", "NMH_DP_FORCE"):
+        for k in ("NMH_DP_FORCE_SPLIT", "NMH_DP_FORCE", "NMH_DP_CAPTURE_COMM"):
             os.environ.pop(k, None)
         os.environ.update(env)
         red = GradReducer(model, comm_dtype=torch.bfloat16) if use_red else None
