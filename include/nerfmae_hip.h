@@ -116,6 +116,21 @@ NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW
  * (the adjoint of the attention branch's window reverse; replaces nmh_window_gather_scale). */
 NMH_API int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C, const int* wm, const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, void* stream);
 NMH_API int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* dyw, const float* dyw_scale, void* stream);
+/* decoder1, forward, bf16: ConvTranspose3d(96 -> 48, kernel = stride = 4) (unetr_block.py:151-158) COMPOSED with the first 3x3x3 conv of the
+ * residual block that follows it (unetr_block.py:35-44; swin_mae3d.py:1246-1257): the conv of the up-sampled map at fine voxel 4j + a only
+ * touches 1..8 coarse cells j + n, so y1[4j + a] = sum_n x[j + n] . Wc[a][n] with 216 composed 96 x 48 blocks -- 31 instead of 133 kFLOP per
+ * voxel; the up-sampled map itself is not read.  nmh_cconv_pack builds the composed weights (fragment order, nmh_cconv_pack_numel() bf16
+ * elements) and the [27][48] fp32 border table from the fp32 master parameters: Wt = transp_conv.weight [96][48][4][4][4], W1 =
+ * conv_block.conv1.weight [48][48][3][3][3], bt = transp_conv.bias [48]; ws = nmh_cconv_pack_ws_floats() floats of scratch (the two
+ * weights transposed to contiguous rows).  nmh_cconv_fwd: x [B][v^3][96] -> y1 [B][(4v)^3][48] (v a multiple
+ * of 8); y1 lacks the per-channel constant that the transpose conv's bias contributes in the interior (the affine-free InstanceNorm that
+ * follows removes any such constant, like conv1's own bias) but carries its border variation; stats_acc (optional fp64 [B][48][2]) receives
+ * sum / sum of squares of the outputs (fused InstanceNorm statistics, as nmh_conv3d_k3_c48).  The residual path still needs the up-sampled
+ * map (nmh_upconv_fwd); the backward keeps the two-step kernels. */
+NMH_API int64_t nmh_cconv_pack_numel(void);
+NMH_API int64_t nmh_cconv_pack_ws_floats(void);
+NMH_API int nmh_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, void* stream);
+NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, int B, int v, double* stats_acc, void* stream);
 /* Fused MLP branch of a Swin block, bf16 (swin_mae3d.py:352-358 torchvision MLP + :368 `x + stochastic_depth(mlp(norm2(x)))`):
  *   x2[row] = x1[row] + rowscale[row / rows_per_scale] * (gelu(LN(x1[row]) . W1^T + b1) . W2^T + b2)
  * in ONE launch: LayerNorm in the MFMA operand registers, the hidden dimension walked in chunks whose GELU output feeds the second

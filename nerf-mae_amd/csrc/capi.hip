@@ -164,6 +164,19 @@ int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const
               dyw, dyw_scale};
   return k_ln_bwd(a, ST);
 }
+int64_t nmh_cconv_pack_numel(void) { return (int64_t)k_cconv_pack_numel(); }
+int64_t nmh_cconv_pack_ws_floats(void) { return (int64_t)k_cconv_pack_ws_floats(); }
+int nmh_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, void* stream) {
+  CLR();
+  REQ(Wt, W1, bt, Wcp, delta, ws);
+  return k_cconv_pack(Wt, W1, bt, Wcp, delta, ws, ST);
+}
+int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, int B, int v, double* stats_acc, void* stream) {
+  CLR();
+  REQ(x, Wcp, delta, y1);
+  if (B <= 0 || v <= 0) return 0;
+  return k_cconv_fwd(x, Wcp, delta, y1, B, v, stats_acc, ST);
+}
 int nmh_mlp_fused_supported(int C) { return k_mlp_fused_supported(C); }
 int nmh_mlp_fused_fwd(const void* x1, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* b2, const float* rowscale,
                       int rows_per_scale, void* x2, float* mean, float* rstd, int64_t M, int C, float eps, void* stream) {

@@ -1,0 +1,445 @@
+// Composed forward of decoder1's first two linear ops (reference: unetr_block.py:151-158 ConvTranspose3d(96 -> 48, kernel = stride = 4)
+// followed by unetr_block.py:35-44 Conv3d(48 -> 48, 3x3x3, pad 1), swin_mae3d.py:1246-1257), bf16, gfx950.
+//
+// u = ConvT(x) is piecewise linear in the coarse grid: u[4j + a] = Wt[a]^T x[j] + bt for phase a in {0..3}^3.  The 3x3x3 convolution
+// of u at fine voxel 4j + a only touches the coarse cells j + n, n in N(a) = Nz x Ny x Nx with N(0) = {-1, 0}, N(1) = N(2) = {0},
+// N(3) = {0, +1} per axis (3.375 cells on average instead of 27 fine taps):
+//     y1[4j + a][c] = sum_{n in N(a)} sum_ci x[j + n][ci] Wc[a][n][ci][c]  +  border term,
+//     Wc[a][n][ci][c] = sum_{d in {-1,0,1}^3 : floor((a + d) / 4) = n} sum_co Wt[ci][co][(a + d) mod 4] W1[c][co][d].
+// 216 (a, n) blocks of 96 x 48 weights (2 MB) replace 27 x 48 x 48 per fine voxel: 31 instead of 133 kFLOP per voxel.  The transpose
+// conv's bias enters as sum_{d inside the volume} sum_co bt[co] W1[c][co][d]: constant per channel in the interior -- removed by the
+// affine-free InstanceNorm that follows, like conv1's own bias -- and different only on the border shell of the volume,
+// where a (class, channel) table of DIFFERENCES to the interior value is added.  Zero padding of u = zero coarse cells outside the grid.
+//
+// Kernel: a persistent 512-thread workgroup per CU walks blocks of 4x8x8 coarse cells (16x32x32 fine voxels):
+//   * the 6x10x10x96 coarse halo sits in LDS (117 KB; 192-byte cells, line stride 1952 B: conflict-free ds_read_b128 for the 2x8-cell MFMA
+//     column tiles under the b128 service groups of the part);
+//   * wave w owns 32 cells (z = w / 2, four y-lines) = two 16-cell column tiles; products are formed transposed (weights as the A
+//     operand, rows permuted) so that a lane leaves with 12 consecutive channels of one fine voxel: a 16-byte + an 8-byte store;
+//   * the 64 phases are walked as 16 (a_z, a_y) groups with the four a_x phases in flight together (96 accumulators): one x fragment
+//     then feeds up to four phases;
+//   * the 2 MB of composed weights stream through a 2 x 18 KB LDS ring by LDS-DMA in 108 chunks of 18 fragments (one (group, n_z, n_y,
+//     k-step): the six (a_x, n_x) blocks x three channel tiles), fragment-ordered by the pack kernel below;
+//   * InstanceNorm statistics of the (bf16-rounded) outputs are folded per group (DPP row sums -> LDS -> fp64 atomics per sample), as in
+//     conv48.hip.
+#include "common.hpp"
+#include "kernels.hpp"
+#include <cstdlib>
+
+namespace cc {
+constexpr int BZ = 4, BY = 8, BX = 8, HZ = BZ + 2, HY = BY + 2, HX = BX + 2;
+constexpr int CELL = 192, LINE = HX * CELL + 32, PLANE = HY * LINE, HALO = HZ * PLANE;
+constexpr int WCHUNK = 18 * 1024, NCHUNK = 108, WHALF = 9 * 1024, NHALF = 2 * NCHUNK;   // ring: 4 slots of half a chunk (9 fragments)
+constexpr int OFF_RING = HALO, OFF_SACC = OFF_RING + 2 * WCHUNK, OFF_DELTA = OFF_SACC + 2 * 96 * 4, LDS_BYTES = OFF_DELTA + 27 * 48 * 4;
+static_assert(LDS_BYTES <= 163840, "LDS budget");
+constexpr int HCH = HZ * HY * HX * 12;          // 16-byte chunks of the halo (7200)
+constexpr int HREG = (HCH + 511) / 512;         // 15
+// the six (a_x, n_x) blocks of a chunk
+__device__ constexpr int BLK_AX[6] = {0, 0, 1, 2, 3, 3};
+__device__ constexpr int BLK_NX[6] = {0, 1, 1, 1, 1, 2};   // index into xf[]: n_x + 1
+}  // namespace cc
+
+struct CConvArgs {
+  const bf16_t* X; const bf16_t* Wcp; const float* delta; bf16_t* Y; double* stats_acc;
+  int B, v, nbz, nby, nbx; long total;
+};
+
+// neighbour offsets of phase component a: count and first offset
+__host__ __device__ __forceinline__ int cc_ncnt(int a) { return (a == 0 || a == 3) ? 2 : 1; }
+__host__ __device__ __forceinline__ int cc_nfirst(int a) { return a == 0 ? -1 : 0; }
+
+// DBG (diagnostic builds, NMH_CCONV_DBG): 1 = no output stores, 2 = no weight DMA / waits (stale weights), 4 = no MFMAs, 8 = no epilogue at all.  0 = product.
+template <int DBG>
+__global__ __launch_bounds__(512) void cconv_fwd_kernel(CConvArgs a) {
+  using namespace cc;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + OFF_RING;
+  float* const sacc = reinterpret_cast<float*>(smem + OFF_SACC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int V = a.v, F = 4 * a.v;
+
+  if (tid < 192) sacc[tid] = 0.f;
+  for (int i = tid; i < 27 * 48; i += 512) reinterpret_cast<float*>(smem + OFF_DELTA)[i] = a.delta[i];
+  // the line pads are never read (a fragment read stays inside its cell); nothing to clear
+
+  // XCD-contiguous block ranges (as conv48.hip): workgroup w runs on XCD w % 8
+  const int nx8 = 8, xcd = blockIdx.x % nx8, jb = blockIdx.x / nx8, jstride = gridDim.x / nx8;
+  const long per = (a.total + nx8 - 1) / nx8;
+  const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
+
+  // half-chunk h (9 lane-linear 1-KB images: blocks 3 (h & 1) .. +2 of chunk h / 2) -> ring slot: wave w takes image w, wave 0 also image 8
+  auto w_dma = [&](int h, int slot) {
+    if (DBG & 2) return;
+    const char* src = reinterpret_cast<const char*>(a.Wcp) + (long)h * WHALF;
+    char* dst = wbuf + slot * WHALF;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wave * 1024 + lv * 16),
+                                     (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * 1024 + lv * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + 8 * 1024), 16, 0, 0);
+  };
+  auto row_sum = [](float v) -> float {  // inclusive scan over the 16-lane row: lane 15 ends up with the row total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    return v;
+  };
+  int st_b = -1, scur = 0;
+  auto stats_flush = [&]() {
+    if (st_b >= 0 && tid < 96) {
+      const float v = sacc[scur * 96 + tid];
+      sacc[scur * 96 + tid] = 0.f;
+      atomicAdd(a.stats_acc + (long)st_b * 96 + tid, (double)v);
+    }
+  };
+
+  // per-lane geometry inside the block: wave = (z_l, y half), column tile i = two y-lines, lane li = (y line, x)
+  const int z_l = wave >> 1, y_l = (wave & 1) * 4, ly = li >> 3, lx = li & 7;
+  const int xbase = (z_l + 1) * PLANE + (y_l + 1 + ly) * LINE + (lx + 1) * CELL + g * 16;   // halo offset of this lane's cell, column tile 0, k-group g
+
+  long t = tbeg + jb;
+  if (t >= tend) return;
+  w_dma(0, 0); w_dma(1, 1); w_dma(2, 2);   // three half-chunks ahead
+  for (; t < tend; t += jstride) {
+    // ---- block origin
+    const unsigned tu = (unsigned)t;
+    unsigned r1 = tu / (unsigned)a.nbx; const int xb = (int)(tu - r1 * (unsigned)a.nbx);
+    unsigned r2 = r1 / (unsigned)a.nby; const int yb = (int)(r1 - r2 * (unsigned)a.nby);
+    unsigned r3 = r2 / (unsigned)a.nbz; const int zb = (int)(r2 - r3 * (unsigned)a.nbz);
+    const int b = __builtin_amdgcn_readfirstlane((int)r3);
+    const int z0 = __builtin_amdgcn_readfirstlane(zb * BZ), y0 = __builtin_amdgcn_readfirstlane(yb * BY), x0 = __builtin_amdgcn_readfirstlane(xb * BX);
+    // ---- coarse halo -> LDS (cells outside the grid are zero: the zero padding of the fine convolution)
+    {
+      // all requests first, then all LDS stores: in front of an LDS store the backend waits for every outstanding vector-memory operation
+      // (it cannot tell the store from the LDS-DMA weight prefetch in flight) -- one drain for the 15 loads instead of one per load
+      const bf16_t* Xb = a.X + (long)b * V * V * V * 96;
+      uint4 hv[HREG];
+#pragma unroll
+      for (int i = 0; i < HREG; ++i) {
+        const int cid = tid + 512 * i;
+        const int cell = cid / 12, c12 = cid - cell * 12;
+        const int hz = cell / (HY * HX), rem = cell - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+        const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
+        hv[i] = make_uint4(0, 0, 0, 0);
+        if (cid < HCH && (unsigned)z < (unsigned)V && (unsigned)y < (unsigned)V && (unsigned)x < (unsigned)V)
+          hv[i] = *reinterpret_cast<const uint4*>(Xb + ((long)(z * V + y) * V + x) * 96 + c12 * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < HREG; ++i) {
+        const int cid = tid + 512 * i;
+        if (cid < HCH) {
+          const int cell = cid / 12, c12 = cid - cell * 12;
+          const int hz = cell / (HY * HX), rem = cell - hz * (HY * HX), hy = rem / HX, hx = rem - hy * HX;
+          *reinterpret_cast<uint4*>(halo + hz * PLANE + hy * LINE + hx * CELL + c12 * 16) = hv[i];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // the halo is complete before anyone reads it (the x fragments of a chunk are requested in front of its weight barrier)
+    if (a.stats_acc && b != st_b) {
+      stats_flush();
+      if (st_b >= 0) scur ^= 1;
+      st_b = b;
+    }
+    int ck = 0;
+#pragma unroll 1
+    for (int gi = 0; gi < 16; ++gi) {
+      const int az = gi >> 2, ay = gi & 3;
+      f32x4 acc[4][3][2];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[p][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int cz = cc_ncnt(az), cy = cc_ncnt(ay), fz = cc_nfirst(az), fy = cc_nfirst(ay);
+#pragma unroll 1
+      for (int iz = 0; iz < cz; ++iz)
+#pragma unroll 1
+        for (int iy = 0; iy < cy; ++iy) {
+          const int noff = xbase + (fz + iz) * PLANE + (fy + iy) * LINE;
+#pragma unroll 1
+          for (int s = 0; s < 3; ++s, ++ck) {
+            Frag<bf16_t> xf[3][2];
+#pragma unroll
+            for (int nx = 0; nx < 3; ++nx)
+#pragma unroll
+              for (int m = 0; m < 2; ++m) xf[nx][m].v = *reinterpret_cast<const bf16x8*>(halo + noff + (nx - 1) * CELL + m * 2 * LINE + s * 64);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int h = 2 * ck + half;
+              // half-chunk h has landed once at most the pieces of the two younger half-chunks (and, in front of a group's first one, the 16
+              // output stores of the previous group, which are younger still) are outstanding: vector-memory operations retire in order
+              const bool after_epi = half == 0 && gi > 0 && iz == 0 && iy == 0 && s == 0;
+              if (DBG & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              else if (wave == 0) {
+                if (after_epi) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+              } else {
+                if (after_epi) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+              }
+              __builtin_amdgcn_s_barrier();     // everyone's pieces of h are visible; everyone is done with half-chunk h - 1, whose slot is refilled
+              {
+                const int hn = h + 3 >= NHALF ? h + 3 - NHALF : h + 3;
+                w_dma(hn, (h + 3) & 3);
+              }
+              // all nine weight fragments of the half-chunk are requested before the first MFMA: left to itself the compiler reuses ONE fragment
+              // register and serialises read -> wait -> 2 MFMAs (an LDS round trip per 34 MFMA cycles: measured 3x the MFMA time)
+              const char* wsrc = wbuf + (h & 3) * WHALF + lane * 16;
+              Frag<bf16_t> wf[9];
+#pragma unroll
+              for (int i = 0; i < 9; ++i) wf[i].v = *reinterpret_cast<const bf16x8*>(wsrc + i * 1024);
+#pragma unroll
+              for (int kk = 0; kk < 3; ++kk) {
+                const int k = 3 * half + kk;
+#pragma unroll
+                for (int n = 0; n < 3; ++n)
+#pragma unroll
+                  for (int m = 0; m < 2; ++m) {
+                    if (DBG & 4) { asm volatile("" ::"v"(wf[kk * 3 + n].v), "v"(xf[BLK_NX[k]][m].v)); }
+                    else mma(acc[BLK_AX[k]][n][m], wf[kk * 3 + n], xf[BLK_NX[k]][m]);
+                  }
+              }
+            }
+          }
+        }
+      if (DBG & 8) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(acc[p][n][m]));
+        continue;
+      }
+      // ---- epilogue of the group: lane (li, g) owns channels 12 g .. 12 g + 11 (rows 4 g + r of channel tile n <-> channel 12 g + 4 n + r)
+      const int zf = 4 * (z0 + z_l) + az;
+      const int kz = zf == 0 ? 0 : (zf == F - 1 ? 2 : 1);
+      // InstanceNorm statistics: per-lane partial sums of the group's fp32 outputs (the bf16 rounding of the stored values moves mean and
+      // variance over 4 M voxels by ~1e-6 relative), folded over the 16 voxel columns by DPP row sums
+      float st1[3][4], st2[3][4];
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st1[n][r] = 0.f; st2[n][r] = 0.f; }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int yf = 4 * (y0 + y_l + 2 * m + ly) + ay;
+        const int ky = yf == 0 ? 0 : (yf == F - 1 ? 2 : 1);
+        bf16_t* const drow = a.Y + ((((long)b * F + zf) * F + yf) * F + 4 * (x0 + lx)) * 48 + 12 * g;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int xf_ = 4 * (x0 + lx) + p;
+          const int kx = xf_ == 0 ? 0 : (xf_ == F - 1 ? 2 : 1);
+          float vv[3][4];
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[n][r] = acc[p][n][m][r];
+          const int cls = (kz * 3 + ky) * 3 + kx;
+          if (cls != 13) {   // border shell: the transpose conv's bias reaches fewer taps than in the interior
+            // raw ds_read + own wait: a compiler-visible LDS (or global) load here is preceded by `s_waitcnt vmcnt(0)` -- the weight prefetch is an
+            // LDS-DMA in flight -- which drains the output stores of the previous voxel every time (measured: the epilogue then dominates the kernel)
+            f32x4 d0, d1, d2;
+            const unsigned daddr = (unsigned)(OFF_DELTA + (cls * 48 + 12 * g) * 4);
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(d0), "=&v"(d1), "=&v"(d2) : "v"(daddr) : "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { vv[0][r] += d0[r]; vv[1][r] += d1[r]; vv[2][r] += d2[r]; }
+          }
+          unsigned w6[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w6[q] = pk_bf16(vv[q >> 1][(q & 1) * 2], vv[q >> 1][(q & 1) * 2 + 1]);
+          bf16_t* dst = drow + p * 48;
+          // (non-temporal stores measured slower: 1.95 vs 1.48 ms at 8 grids -- the 24-byte pieces of a voxel row no longer merge in L2)
+          if (!(DBG & 1)) {
+            *reinterpret_cast<uint4*>(dst) = make_uint4(w6[0], w6[1], w6[2], w6[3]);
+            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(w6[4], w6[5]);
+          } else asm volatile("" ::"v"(w6[0]), "v"(w6[1]), "v"(w6[2]), "v"(w6[3]), "v"(w6[4]), "v"(w6[5]));
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st1[n][r] += vv[n][r]; st2[n][r] += vv[n][r] * vv[n][r]; }
+        }
+      }
+      if (a.stats_acc) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a1 = row_sum(st1[n][r]), a2 = row_sum(st2[n][r]);
+            if (li == 15) {
+              // raw ds_add_f32: behind a compiler-visible LDS atomic the backend puts `s_waitcnt vmcnt(0)` (an LDS-DMA weight prefetch is in flight and
+              // it cannot prove the two LDS regions apart) -- which would drain the 16 output stores just issued, once per group
+              const unsigned addr = (unsigned)(OFF_SACC + (scur * 96 + (12 * g + 4 * n + r) * 2) * 4);
+              asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:4" ::"v"(addr), "v"(a1), "v"(a2) : "memory");
+            }
+          }
+      }
+    }
+    __syncthreads();   // everyone is done with the halo (and the statistics slot) before the next block overwrites it
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing weight prefetch
+  __syncthreads();
+  if (a.stats_acc) stats_flush();
+}
+
+// ------------------------------------------------------------------------------------------------
+// composed weights in fragment order + the border-bias difference table, from the fp32 master parameters:
+//   Wt [96][48][4][4][4] (ConvTranspose3d weight), W1 [48][48][3][3][3] (Conv3d weight), bt [48] (ConvTranspose3d bias)
+//   -> Wcp bf16 [108 chunks][18 fragments][64 lanes][8], delta fp32 [27][48]
+// Two launches (on the side stream under the encoder): (1) both weights transposed to co-contiguous rows WtT [64 ph][96 ci][48 co],
+// W1T [27 d][48 c][48 co] (+ the border table); (2) one thread per packed element: up to 27 taps x 48-term dot products of contiguous rows.
+// ------------------------------------------------------------------------------------------------
+constexpr long CC_WTT = 64L * 96 * 48, CC_W1T = 27L * 48 * 48;
+
+__global__ __launch_bounds__(256) void cconv_tr_kernel(const float* __restrict__ Wt, const float* __restrict__ W1, float* __restrict__ ws) {
+  // one workgroup per source row block: contiguous reads, 192-byte contiguous writes (an LDS tile in between)
+  __shared__ float tile[64 * 49];
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk < 96) {                          // WtT[ph][ci][co] = Wt[ci][co][ph], ci = blk: 48 x 64 source floats
+    const float* src = Wt + (long)blk * 48 * 64;
+    for (int i = tid; i < 48 * 64; i += 256) { const int co = i >> 6, ph = i & 63; tile[ph * 49 + co] = src[i]; }
+    __syncthreads();
+    for (int i = tid; i < 64 * 48; i += 256) { const int ph = i / 48, co = i - ph * 48; ws[((long)ph * 96 + blk) * 48 + co] = tile[ph * 49 + co]; }
+  } else if (blk < 96 + 48) {              // W1T[d][c][co] = W1[c][co][d], c = blk - 96: 48 x 27 source floats
+    const int c = blk - 96;
+    const float* src = W1 + (long)c * 48 * 27;
+    for (int i = tid; i < 48 * 27; i += 256) { const int co = i / 27, d = i - co * 27; tile[d * 49 + co] = src[i]; }
+    __syncthreads();
+    for (int i = tid; i < 27 * 48; i += 256) { const int d = i / 48, co = i - d * 48; ws[CC_WTT + ((long)d * 48 + c) * 48 + co] = tile[d * 49 + co]; }
+  }
+}
+
+// one workgroup per fragment (16 channels x 32 input channels = 512 elements, one per thread); per contributing tap the 32 WtT rows and the
+// 16 W1T rows are staged in LDS (coalesced 16-byte loads) and every thread forms its 48-term dot product from there
+__global__ __launch_bounds__(512) void cconv_pack_kernel(const float* __restrict__ ws, const float* __restrict__ bt, bf16_t* __restrict__ Wcp, float* __restrict__ delta) {
+  constexpr int RSF = 52;                                  // padded row (floats)
+  __shared__ __attribute__((aligned(16))) float swt[32 * RSF];
+  __shared__ __attribute__((aligned(16))) float sw1[16 * RSF];
+  const float* WtT = ws;
+  const float* W1T = ws + CC_WTT;
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  if (blk >= 108 * 18) {   // border table, one workgroup per class: delta[class][c] = -(sum over the taps that fall outside the volume for the class)
+    const int cls = blk - 108 * 18, kz = cls / 9, ky = (cls / 3) % 3, kx = cls % 3;
+    const int c = tid % 48, part = tid / 48;               // 10 tap groups x 48 channels (32 threads idle)
+    float acc = 0.f;
+    if (part < 10)
+      for (int d = part; d < 27; d += 10) {
+        const int dz = d / 9 - 1, dy = (d / 3) % 3 - 1, dx = d % 3 - 1;
+        const bool valid = !((kz == 0 && dz < 0) || (kz == 2 && dz > 0) || (ky == 0 && dy < 0) || (ky == 2 && dy > 0) || (kx == 0 && dx < 0) || (kx == 2 && dx > 0));
+        if (valid) continue;
+        const float* w1 = W1T + ((long)d * 48 + c) * 48;
+        for (int co = 0; co < 48; ++co) acc -= bt[co] * w1[co];
+      }
+    swt[tid] = acc;
+    __syncthreads();
+    if (tid < 48) {
+      float v = 0.f;
+      for (int p = 0; p < 10; ++p) v += swt[p * 48 + tid];
+      delta[cls * 48 + tid] = v;
+    }
+    return;
+  }
+  const int ck = blk / 18, fr = blk - ck * 18;
+  int gi = 0, iz = 0, iy = 0, s = 0, run = 0;
+  for (gi = 0; gi < 16; ++gi) {
+    const int cnt = cc_ncnt(gi >> 2) * cc_ncnt(gi & 3) * 3;
+    if (ck < run + cnt) break;
+    run += cnt;
+  }
+  {
+    const int loc = ck - run, cy = cc_ncnt(gi & 3);
+    s = loc % 3;
+    const int zy = loc / 3;
+    iz = zy / cy; iy = zy - iz * cy;
+  }
+  const int az = gi >> 2, ay = gi & 3, nz = cc_nfirst(az) + iz, ny = cc_nfirst(ay) + iy;
+  const int k6 = fr / 3, nt = fr - k6 * 3;
+  const int ax = cc::BLK_AX[k6], nx = cc::BLK_NX[k6] - 1;
+  const int lane = tid >> 3, j = tid & 7, li = lane & 15, g = lane >> 4;
+  const int cil = 8 * g + j;                               // input channel 32 s + cil
+  float acc = 0.f;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int tz = az + dz, qz = tz < 0 ? -1 : (tz > 3 ? 1 : 0);
+    if (qz != nz) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int ty = ay + dy, qy = ty < 0 ? -1 : (ty > 3 ? 1 : 0);
+      if (qy != ny) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int tx = ax + dx, qx = tx < 0 ? -1 : (tx > 3 ? 1 : 0);
+        if (qx != nx) continue;                            // (block-uniform branches)
+        const int ph = ((tz & 3) * 4 + (ty & 3)) * 4 + (tx & 3), d = ((dz + 1) * 3 + (dy + 1)) * 3 + (dx + 1);
+        __syncthreads();
+        if (tid < 384) {                                   // 32 contiguous rows of 48 floats
+          const int r = tid / 12, q = tid - r * 12;
+          *reinterpret_cast<float4*>(swt + r * RSF + q * 4) = *reinterpret_cast<const float4*>(WtT + ((long)ph * 96 + 32 * s + r) * 48 + q * 4);
+        } else if (tid < 384 + 128) {                      // 16 rows: channel of accumulator row r = 12 (r >> 2) + 4 nt + (r & 3); 128 threads x 1.5 float4
+          for (int i = tid - 384; i < 192; i += 128) {
+            const int r = i / 12, q = i - r * 12, c = 12 * (r >> 2) + 4 * nt + (r & 3);
+            *reinterpret_cast<float4*>(sw1 + r * RSF + q * 4) = *reinterpret_cast<const float4*>(W1T + ((long)d * 48 + c) * 48 + q * 4);
+          }
+        }
+        __syncthreads();
+        float s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          const float4 u = *reinterpret_cast<const float4*>(swt + cil * RSF + q * 4), w = *reinterpret_cast<const float4*>(sw1 + li * RSF + q * 4);
+          s2 += u.x * w.x + u.y * w.y + u.z * w.z + u.w * w.w;
+        }
+        acc += s2;
+      }
+    }
+  }
+  Wcp[((long)blk * 64 + lane) * 8 + j] = f2bf(acc);
+}
+
+long k_cconv_pack_ws_floats() { return CC_WTT + CC_W1T; }
+
+int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, hipStream_t st) {
+  hipLaunchKernelGGL(cconv_tr_kernel, dim3(96 + 48), dim3(256), 0, st, Wt, W1, ws);
+  NMH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cconv_pack_kernel, dim3(108 * 18 + 27), dim3(512), 0, st, (const float*)ws, bt, (bf16_t*)Wcp, delta);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+long k_cconv_pack_numel() { return 108L * 18 * 512; }
+
+int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st) {
+  using namespace cc;
+  if (v % BY || v % BX || v % BZ) return -2;
+  CConvArgs a;
+  a.X = (const bf16_t*)X; a.Wcp = (const bf16_t*)Wcp; a.delta = delta; a.Y = (bf16_t*)Y; a.stats_acc = stats_acc;
+  a.B = B; a.v = v; a.nbz = v / BZ; a.nby = v / BY; a.nbx = v / BX;
+  a.total = (long)B * a.nbz * a.nby * a.nbx;
+  if (a.total >= (1L << 31) || (long)B * 64 * v * v * v * 48 >= (1L << 40)) return -2;
+  if (stats_acc) {
+    hipError_t e = nmh_zero_async(stats_acc, sizeof(double) * 2 * 48 * B, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  long nb = a.total < 256 ? a.total : 256;
+  nb = nb / 8 * 8;          // the XCD-contiguous ranges need a multiple of 8 workgroups
+  if (nb < 8) nb = 8;
+  static const int dbg = getenv("NMH_CCONV_DBG") ? atoi(getenv("NMH_CCONV_DBG")) : 0;
+#define CC_LAUNCH(D)                                                                                                              \
+  {                                                                                                                               \
+    static bool attr = false;                                                                                                     \
+    if (!attr) {                                                                                                                  \
+      hipError_t e = hipFuncSetAttribute((const void*)cconv_fwd_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      if (e != hipSuccess) return (int)e;                                                                                         \
+      attr = true;                                                                                                                \
+    }                                                                                                                             \
+    hipLaunchKernelGGL(cconv_fwd_kernel<D>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);                                     \
+  }
+  if (dbg == 1) CC_LAUNCH(1) else if (dbg == 2) CC_LAUNCH(2) else if (dbg == 4) CC_LAUNCH(4) else if (dbg == 8) CC_LAUNCH(8) else if (dbg == 6) CC_LAUNCH(6)
+  else if (dbg == 10) CC_LAUNCH(10) else if (dbg == 12) CC_LAUNCH(12) else if (dbg == 14) CC_LAUNCH(14) else CC_LAUNCH(0)
+#undef CC_LAUNCH
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

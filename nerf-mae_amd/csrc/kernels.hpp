@@ -156,6 +156,12 @@ int k_ln_bwd(const LnBwdArgs& a, hipStream_t st);
 int k_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
 int k_window_gather_scale(int dt, const void* dx, void* dyw, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
 
+// ---- cconv.hip: ConvTranspose3d(96 -> 48, k = s = 4) composed with the 3x3x3 conv that follows it (decoder1, forward) ----
+int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, hipStream_t st);
+long k_cconv_pack_numel();
+long k_cconv_pack_ws_floats();
+int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st);
+
 // ---- mlp_fused.hip: LN -> fc1 -> GELU -> fc2 -> row-scale -> + residual in one launch (bf16), and its backward ----
 int k_mlp_fused_supported(int C);
 int k_mlp_fused_fwd(const void* x1, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* b2, const float* rowscale,

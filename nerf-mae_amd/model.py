@@ -104,6 +104,7 @@ class _Packer:
     def __init__(self):
         self.items = []  # (key, param, mode, dims, numel)
         self.views = {}
+        self.cconv = None   # (decoder1 UpBlock3D, composed weight buffer, border table) when the composed forward applies
 
     def add(self, key: str, p: nn.Parameter, mode: int):
         sh = tuple(p.shape)
@@ -159,9 +160,12 @@ class _Packer:
         sp = self.split if (self.split and ops.side_stream.enabled and os.environ.get("NMH_PACK_SPLIT", "1") != "0") else n
         if sp > 0:
             ops.pack_weights(self.dt, self.descs, self.blk2desc[:sp], self.blkstart[:sp], sp)
-        if sp < n:
-            with ops.side_stream():
+        with ops.side_stream(enable=sp < n):
+            if sp < n:
                 ops.pack_weights(self.dt, self.descs, self.blk2desc[sp:], self.blkstart[sp:], n - sp)
+            if self.cconv is not None:    # decoder1: ConvTranspose o conv1 composed weights (csrc/cconv.hip), from the fp32 masters
+                up, Wcp, delta, ws = self.cconv
+                ops.cconv_pack(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws)
 
     @staticmethod
     def join():
@@ -412,7 +416,11 @@ class _UpBlockFn(torch.autograd.Function):
         ctx.c64 = c64
         halo_stats = c48 or c64    # InstanceNorm statistics come out of the conv epilogue
         st1 = torch.empty((B, Cout, 2), device=dev)
-        if halo_stats:   # InstanceNorm statistics come out of the conv epilogue (no extra pass over the 160^3 tensor)
+        cc = pk.cconv if (c48 and pk.cconv is not None and pk.cconv[0] is m and v % 8 == 0) else None
+        if cc is not None:   # decoder1: y1 straight from the coarse map with the composed weights (4x fewer FLOPs; cat is only the residual)
+            y1 = ops.cconv_fwd(x.view(B, v, v, v, Cin), cc[1], cc[2], B, v, stats_acc=scratch).view(B * V, Cout)
+            ops.instnorm_finalize(scratch, st1, B, V, Cout)
+        elif halo_stats:   # InstanceNorm statistics come out of the conv epilogue (no extra pass over the 160^3 tensor)
             y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st1, B, V, Cout)
         else:
@@ -806,6 +814,11 @@ class SwinTransformer_MAE3D_New(nn.Module):
                 P.add(key + "c3.w", d.conv_block.conv3.weight, P.CAST)
                 P.add(key + "c3.wT", d.conv_block.conv3.weight, P.TRANS)
         P.build(self.compute_dtype, device)
+        d1 = getattr(self, "decoder1", None)
+        if (ops.CCONV and d1 is not None and self.compute_dtype == torch.bfloat16 and (d1.cin, d1.cout, d1.k) == (96, 48, 4) and not d1.has_proj
+                and (self.resolution // 4) % 8 == 0):
+            P.cconv = (d1, torch.empty(ops.cconv_pack_numel(), dtype=torch.bfloat16, device=device), torch.empty((27, 48), device=device),
+                       torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device=device))
         self._packer = P
         self._pk = P
         self._wq = ops.WgradQueue()   # deferred encoder weight gradients (grouped launches, issued per stage)

@@ -267,6 +267,42 @@ def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None):
     return out
 
 
+CCONV = __import__("os").environ.get("NMH_CCONV", "1") != "0"   # decoder1 forward: ConvTranspose(k = s = 4) composed with conv1 (csrc/cconv.hip)
+
+
+def cconv_pack(Wt, W1, bt, Wcp, delta, ws=None):
+    """composed decoder1 weights (fragment order, bf16) + [27,48] border table from transp_conv.weight [96,48,4,4,4], conv1.weight [48,48,3,3,3],
+    transp_conv.bias; ws: cconv_pack_ws_floats() floats of scratch (allocated here when not given)"""
+    _chk(Wt, W1, bt, Wcp, delta, ws)
+    if tuple(Wt.shape) != (96, 48, 4, 4, 4) or tuple(W1.shape) != (48, 48, 3, 3, 3) or Wcp.numel() < cconv_pack_numel() or delta.numel() < 27 * 48:
+        raise ValueError("cconv_pack: shapes")
+    if ws is None:
+        ws = torch.empty(cconv_pack_ws_floats(), dtype=torch.float32, device=Wcp.device)
+    lib().call("nmh_cconv_pack", Wt, W1, bt, Wcp, delta, ws, _st())
+
+
+def cconv_pack_ws_floats() -> int:
+    return int(lib().call("nmh_cconv_pack_ws_floats"))
+
+
+def cconv_pack_numel() -> int:
+    return int(lib().call("nmh_cconv_pack_numel"))
+
+
+def cconv_fwd(x, Wcp, delta, B, v, out=None, stats_acc=None):
+    """y1 [B,(4v)^3,48] = conv3x3x3(ConvTranspose_{k=s=4}(x [B,v^3,96])) minus the interior bias constant (see include/nerfmae_hip.h)"""
+    _chk(x, Wcp, delta, out, stats_acc)
+    if x.dtype != torch.bfloat16 or x.shape[-1] != 96 or v % 8:
+        raise RuntimeError("cconv_fwd needs bf16 activations with 96 channels on a coarse grid whose edge is a multiple of 8")
+    if out is None:
+        out = torch.empty((B, 4 * v, 4 * v, 4 * v, 48), dtype=x.dtype, device=x.device)
+    ev = _prof(("cconv_fwd", B, 4 * v, 96, 48))
+    lib().call("nmh_cconv_fwd", x, Wcp, delta, out, B, v, stats_acc, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 C48MB_MIN_VOXELS = int(__import__("os").environ.get("NMH_C48MB_MIN_VOXELS", "32768"))   # 0 disables the 48-channel-block multi-block kernel
 
 

@@ -958,3 +958,44 @@ def test_mlp_fused_forward_backward(C, M, tps, mt, monkeypatch):
         g_ref = torch.empty(geom.rows, C, dtype=dt, device="cuda")
         ops.window_gather_scale(dx1, g_ref, dev(dyw_scale), C, geom)
         assert torch.equal(dyw, g_ref), "window-ordered second output (incl. zeroed pad rows)"
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder1 forward: ConvTranspose3d(96 -> 48, k = s = 4) composed with the 3x3x3 conv that follows (csrc/cconv.hip) against the two
+# reference ops in fp32 on the bf16-rounded inputs (unetr_block.py:151-158 + :35-44), incl. the border shell (bias reaches fewer taps
+# there), the fused InstanceNorm statistics, several blocks per sample and per workgroup, and the two-step HIP path it replaces
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,v", [(1, 8), (2, 8), (1, 16), (3, 24)])
+def test_cconv_forward_matches_convtranspose_then_conv(B, v):
+    ops = _ops()
+    dt = torch.bfloat16
+    x = q(rnd(B, v, v, v, 96, seed=1), dt)
+    Wt = rnd(96, 48, 4, 4, 4, seed=2, scale=96 ** -0.5)
+    W1 = rnd(48, 48, 3, 3, 3, seed=3, scale=(27 * 48) ** -0.5)
+    bt = rnd(48, seed=4, scale=0.5)
+    Wcp = torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda")
+    delta = torch.empty(27, 48, device="cuda")
+    ops.cconv_pack(dev(Wt), dev(W1), dev(bt), Wcp, delta)
+    acc = torch.full((B, 48, 2), 7.0, dtype=torch.float64, device="cuda")
+    y = ops.cconv_fwd(dev(x, dt), Wcp, delta, B, v, stats_acc=acc)
+    torch.cuda.synchronize()
+    u = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), Wt, bt, stride=4)
+    ref = F.conv3d(u, W1, None, padding=1)
+    ref = ref - torch.einsum("o,codhw->c", bt, W1)[None, :, None, None, None]     # the interior bias constant (removed by the InstanceNorm that follows)
+    ref = ref.permute(0, 2, 3, 4, 1)
+    check(y, ref, dt, f"cconv fwd B={B} v={v}")
+    # the border shell on its own (where the bias table matters): faces of the volume
+    Fv = 4 * v
+    for sl in ((slice(None), 0), (slice(None), Fv - 1), (slice(None), slice(None), 0), (slice(None), slice(None), slice(None), Fv - 1)):
+        check(y[sl], ref[sl], dt, "cconv fwd border face")
+    yq = y.float().cpu().double()
+    check(acc[:, :, 0].float(), yq.sum(dim=(1, 2, 3)).float(), torch.float32, "cconv fused IN sum", 5)
+    check(acc[:, :, 1].float(), (yq * yq).sum(dim=(1, 2, 3)).float(), torch.float32, "cconv fused IN sumsq", 5)
+    # against the two-step HIP path (bf16 u, then the 48 -> 48 LDS-halo conv): same function, different rounding points
+    wt_p = _pack_via_kernel(Wt, 4, dt, Wt.numel())
+    cat = torch.empty(B * Fv ** 3, 48, dtype=dt, device="cuda")
+    ops.upconv_fwd(dev(x, dt).view(-1, 96), wt_p.view(64 * 48, 96), dev(bt), cat, B, v, 4, 96, 48)
+    wk = _pack_via_kernel(W1, 6, dt, 41 * 3 * 64 * 8)
+    y2 = ops.conv3d_k3_c48(cat.view(B, Fv, Fv, Fv, 48), wk)
+    const = torch.einsum("o,codhw->c", bt, W1)
+    assert_close(y.float().cpu(), y2.float().cpu() - const, 2e-2, "cconv vs two-step HIP path (interior + border)", elem_mult=2.0)

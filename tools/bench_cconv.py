@@ -1,0 +1,39 @@
+"""composed ConvTranspose(k=s=4) o conv3x3x3 forward (csrc/cconv.hip) against the 48 -> 48 LDS-halo conv it replaces, 160^3, graph replay of 5 calls"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nerf_mae_amd import ops
+
+def bench(fn, n=5, reps=4):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn(); torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for _ in range(n): fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) / n)
+    return best
+
+for B in [int(v) for v in sys.argv[1:]] or [8, 1]:
+    v = 40
+    x = torch.randn(B, v, v, v, 96, device="cuda").to(torch.bfloat16)
+    Wt = torch.randn(96, 48, 4, 4, 4, device="cuda") * 96 ** -0.5
+    W1 = torch.randn(48, 48, 3, 3, 3, device="cuda") * (27 * 48) ** -0.5
+    bt = torch.randn(48, device="cuda")
+    Wcp = torch.empty(ops.cconv_pack_numel(), dtype=torch.bfloat16, device="cuda"); delta = torch.empty(27, 48, device="cuda")
+    t_pack = bench(lambda: ops.cconv_pack(Wt, W1, bt, Wcp, delta))
+    y = torch.empty(B, 160, 160, 160, 48, dtype=torch.bfloat16, device="cuda")
+    acc = torch.zeros(B, 48, 2, dtype=torch.float64, device="cuda")
+    t_cc = bench(lambda: ops.cconv_fwd(x, Wcp, delta, B, v, out=y, stats_acc=acc))
+    u = torch.randn(B, 160, 160, 160, 48, device="cuda").to(torch.bfloat16)
+    from tests.test_kernels_gpu import _pack_via_kernel
+    wk = _pack_via_kernel(W1.cpu(), 6, torch.bfloat16, 41 * 3 * 64 * 8)
+    t_c48 = bench(lambda: ops.conv3d_k3_c48(u, wk, out=y, stats_acc=acc))
+    fl = 2.0 * 216 * 96 * 48 * v ** 3 * B
+    print(f"B={B}: cconv_fwd {t_cc:.3f} ms ({fl / t_cc / 1e9:.0f} TFLOP/s of composed work, {2.0 * 27 * 48 * 48 * 160 ** 3 * B / t_cc / 1e9:.0f} of the two-step FLOPs)   "
+          f"conv48 {t_c48:.3f} ms   pack {t_pack * 1e3:.0f} us", flush=True)
