@@ -451,26 +451,32 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdArgs a) {
 // ================================================================================================
 constexpr int W96_BYTES = 24 * 3 * 1024;
 
+// byte offset of lane (li, g)'s 16 bytes inside a fragment's KB: [g >> 1][li][g & 1] -- row reads stay lane-distinct (every bank once per
+// b128 service group), and the eight rows x 32 bytes of a transpose read are one contiguous 256-byte run (the plain lane order g*16 + li puts
+// them into two 128-byte runs 256 bytes apart = the same 32 banks twice: PMC showed 31 % of the LDS cycles as conflicts)
+__device__ __forceinline__ int w96_lane_off(int li, int g) { return (g >> 1) * 512 + li * 32 + (g & 1) * 16; }
+
 __device__ __forceinline__ void w96_stage(char* dst, const bf16_t* __restrict__ W, int wave, int nwaves, int lane) {
   const int g = lane >> 4, li = lane & 15;
   for (int f = wave; f < 72; f += nwaves) {
     const int b = f / 3, s = f - 3 * b;
-    *reinterpret_cast<uint4*>(dst + (f * 64 + lane) * 16) = *reinterpret_cast<const uint4*>(W + (16 * b + li) * 96 + 32 * s + 8 * g);
+    *reinterpret_cast<uint4*>(dst + f * 1024 + w96_lane_off(li, g)) = *reinterpret_cast<const uint4*>(W + (16 * b + li) * 96 + 32 * s + 8 * g);
   }
 }
 __device__ __forceinline__ Frag<bf16_t> w96_row(const char* W, int b, int s, int lane) {
   Frag<bf16_t> f;
-  f.v = *reinterpret_cast<const bf16x8*>(W + ((b * 3 + s) * 64 + lane) * 16);
+  f.v = *reinterpret_cast<const bf16x8*>(W + (b * 3 + s) * 1024 + w96_lane_off(lane & 15, lane >> 4));
   return f;
 }
-// lane-dependent part of a transposed fragment address (see above): rows m0 + 4 g + (p >> 2), columns 16 ct + 4 (p & 3) .. +3
+// lane-dependent part of a transposed fragment address: rows m0 + 4 g + (p >> 2), columns 16 ct + 4 (p & 3) .. +3, i.e. element W[n][c] of
+// fragment (n >> 4, c >> 5) at [(c >> 4) & 1][n & 15][(c >> 3) & 1][c & 7]
 __device__ __forceinline__ int w96_tr_lane(int lane) {
   const int g = lane >> 4, p = lane & 15;
-  return ((((p & 3) >> 1) * 16 + 4 * g + (p >> 2)) * 16) + (p & 1) * 8;
+  return (4 * g + (p >> 2)) * 32 + ((p & 3) >> 1) * 16 + (p & 1) * 8;
 }
 // k-step over hidden rows [32 kq, 32 kq + 32), operand rows = channels 16 ct .. +15
 __device__ __forceinline__ Frag<bf16_t> w96_tr(const char* W, int kq, int ct, int trl) {
-  const char* a = W + ((2 * kq) * 3 + (ct >> 1)) * 1024 + ((2 * ct) & 3) * 256 + trl;
+  const char* a = W + ((2 * kq) * 3 + (ct >> 1)) * 1024 + (ct & 1) * 512 + trl;
   const bf16x4 lo = ds_read_tr16(a), hi = ds_read_tr16(a + 3 * 1024);
   Frag<bf16_t> f;
   f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
