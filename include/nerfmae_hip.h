@@ -131,6 +131,14 @@ NMH_API int64_t nmh_cconv_pack_numel(void);
 NMH_API int64_t nmh_cconv_pack_ws_floats(void);
 NMH_API int nmh_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, void* stream);
 NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, int B, int v, double* stats_acc, void* stream);
+/* Weight gradient of decoder1's conv1 THROUGH the composition above (backward of unetr_block.py:35-44 with respect to conv1.weight; replaces the
+ * 48 -> 48 nmh_conv3d_k3_c48_wgrad launch on the up-sampled map): dW1[c][co][d] += sum_a sum_ci Wt[ci][co][(a+d) mod 4] . G[a][n(a,d)][ci][c] with
+ * G[a][n] = sum_j x[j+n]^T dy1[4j+a] -- the same 216 blocks as the forward, a quarter of the FLOPs, contraction over the coarse cells.
+ * x [B][v^3][96], dy1 [B][(4v)^3][48] (bf16), pack_ws = the scratch nmh_cconv_pack filled in this step (holds the transposed Wt), bt = transp_conv.bias,
+ * ws = nmh_cconv_wgrad_ws_floats() floats.  Exact for a dy1 whose per-sample, per-channel sums vanish -- the input gradient of the affine-free
+ * InstanceNorm that conv1 feeds (the term bt[co] * sum_p dy1[p][c] is then carried by the border voxels alone, which the entry sums). */
+NMH_API int64_t nmh_cconv_wgrad_ws_floats(void);
+NMH_API int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* ws, int B, int v, void* stream);
 /* Fused MLP branch of a Swin block, bf16 (swin_mae3d.py:352-358 torchvision MLP + :368 `x + stochastic_depth(mlp(norm2(x)))`):
  *   x2[row] = x1[row] + rowscale[row / rows_per_scale] * (gelu(LN(x1[row]) . W1^T + b1) . W2^T + b2)
  * in ONE launch: LayerNorm in the MFMA operand registers, the hidden dimension walked in chunks whose GELU output feeds the second

@@ -177,6 +177,13 @@ int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, 
   if (B <= 0 || v <= 0) return 0;
   return k_cconv_fwd(x, Wcp, delta, y1, B, v, stats_acc, ST);
 }
+int64_t nmh_cconv_wgrad_ws_floats(void) { return (int64_t)k_cconv_wgrad_ws_floats(); }
+int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* ws, int B, int v, void* stream) {
+  CLR();
+  REQ(x, dy1, pack_ws, bt, dW1, ws);
+  if (B <= 0 || v <= 0) return 0;
+  return k_cconv_wgrad(x, dy1, pack_ws, bt, dW1, ws, B, v, ST);
+}
 int nmh_mlp_fused_supported(int C) { return k_mlp_fused_supported(C); }
 int nmh_mlp_fused_fwd(const void* x1, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* b2, const float* rowscale,
                       int rows_per_scale, void* x2, float* mean, float* rstd, int64_t M, int C, float eps, void* stream) {

@@ -443,3 +443,356 @@ int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int
   NMH_CHECK_LAUNCH();
   return 0;
 }
+
+// ================================================================================================
+// Weight gradient of decoder1's conv1 THROUGH the composition (backward of the op above with respect to conv1.weight):
+//     dW1[c][co][d] = sum_p dy1[p][c] u[p + d][co]      with u = ConvT(x)   (unetr_block.py:35-44 backward; the 4 TFLOP/step launch of conv48_wgrad)
+//  =  sum_a sum_ci Wt[ci][co][(a + d) mod 4] . G[a][n(a, d)][ci][c],         G[a][n][ci][c] = sum_j x[j + n][ci] dy1[4j + a][c]
+// (the transpose conv's bias drops out: its term sum_p dy1[p][c] is the sum of an InstanceNorm input gradient = 0).  G are the same 216
+// (phase, neighbour) blocks as the forward's composed weights: a quarter of the FLOPs, contraction over the coarse cells.
+// Kernel: workgroup = (unit, slab).  A unit is one (a_z, a_y) phase group with at most two of its (n_z, n_y) neighbour lines (corner groups,
+// which have four, are two units) = 6 or 12 blocks of 96 x 48; a slab is every S-th PAIR of coarse lines (b, z, y..y+1).  Per pair the two
+// fine gradient lines (4z + a_z, 4y + a_y: 2 x 160 x 48, stored phase-major [a_x][cell][48] in LDS) and the x lines (z + n_z, y + n_y, with a
+// zero cell at both ends, stored as two 48-channel halves) go through a double-buffered LDS stage (register prefetch of the next pair); both
+// MFMA operands are contraction-major and come out of the tiles by ds_read_b64_tr_b16 at computed addresses (96-byte rows: every bank once).
+// 12 waves: wave = ((a_x, n_x) block, ci half) keeps 9 accumulator tiles per neighbour line.  Partials per workgroup -> workspace; the
+// reduce + chain-rule kernels below fold them into dW1.
+// ================================================================================================
+namespace ccw {
+constexpr int VMAX = 40;
+constexpr int XHALF = (VMAX + 2) * 96, XLINE = 2 * XHALF, XCOMB = 2 * XLINE;      // x: [comb][line][ci half][cell + 1][48 ch]
+constexpr int DPH = VMAX * 96, DLINE = 4 * DPH;                                   // dy: [line][a_x][cell][48 ch]
+constexpr int OFF_X = 0, OFF_DY = 2 * XCOMB, STAGE = OFF_DY + 2 * DLINE, OFF_ZERO = 2 * STAGE, LDS_BYTES = OFF_ZERO + 256;
+constexpr int MAXU = 24;
+static_assert(LDS_BYTES <= 163840, "LDS budget");
+}  // namespace ccw
+
+struct CCWUnit { signed char az, ay, ncomb, nz0, ny0, nz1, ny1, pad; int wg0, nslab; int blk0, blk1; };   // blk: index of the comb's first G block (x 6 + k6)
+struct CCWArgs {
+  const bf16_t* X; const bf16_t* dY; float* part;
+  int B, v, nunit; long npair;
+  CCWUnit u[ccw::MAXU];
+};
+
+__global__ __launch_bounds__(768) void cconv_wgrad_kernel(CCWArgs a) {
+  using namespace ccw;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, p = lane & 15;
+  // unit / slab of this workgroup
+  int ui = 0;
+  for (int i = 0; i < a.nunit; ++i)
+    if ((int)blockIdx.x >= a.u[i].wg0) ui = i;
+  const CCWUnit U = a.u[ui];
+  const int slab = blockIdx.x - U.wg0, nslab = U.nslab, ncomb = U.ncomb;
+  const int v = a.v, F = 4 * v, hv = v >> 1;
+  const int b6 = wave >> 1, half = wave & 1, ax = cc::BLK_AX[b6], nx = cc::BLK_NX[b6] - 1;
+
+  // zero cells at both ends of every x line (never overwritten) and the zero rows
+  for (int i = tid; i < 2 * STAGE / 16; i += 768) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 16) reinterpret_cast<uint4*>(smem + OFF_ZERO)[tid] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  // chunk assignment of the stage loads: dy 2 * 4v * 6 chunks, then ncomb * 2 * v * 12 chunks of x.  Everything about a thread's chunks except
+  // the pair's base addresses is invariant: global element offset, LDS byte offset and (for x) the line / plane shift are computed ONCE
+  // (recomputing them per pair -- a dozen divisions by the runtime edge per chunk -- was most of the kernel's time: 3.9 ms at 8 grids)
+  const int ndy = 2 * 4 * v * 6, nxc = 2 * v * 12, ntot = ndy + ncomb * nxc;
+  constexpr int NLD = 5;   // 768 * 5 >= 1920 + 2 * 960
+  uint4 hreg[NLD];
+  int goff[NLD], loff[NLD], meta[NLD];      // meta: -1 none, 0 dy, else 1 + (dz + 1) * 8 + (dyl + 1) for x (dz in -1..1, dyl = line + n_y in -1..2)
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + 768 * i;
+    goff[i] = 0; loff[i] = 0; meta[i] = -1;
+    if (idx < ndy) {
+      const int line = idx / (24 * v), rem = idx - line * (24 * v), vox = rem / 6, c6 = rem - vox * 6;
+      goff[i] = line * 4 * F * 48 + vox * 48 + c6 * 8;
+      loff[i] = OFF_DY + line * DLINE + (vox & 3) * DPH + (vox >> 2) * 96 + c6 * 16;
+      meta[i] = 0;
+    } else if (idx < ntot) {
+      const int k = idx - ndy, comb = k / nxc, r0 = k - comb * nxc, line = r0 / (12 * v), rem = r0 - line * (12 * v), cell = rem / 12, c12 = rem - cell * 12;
+      const int dz = comb ? U.nz1 : U.nz0, dyl = line + (comb ? U.ny1 : U.ny0);
+      const int hf = c12 >= 6, c6 = c12 - 6 * hf;
+      goff[i] = ((dz * v + dyl) * v + cell) * 96 + c12 * 8;
+      loff[i] = OFF_X + comb * XCOMB + line * XLINE + hf * XHALF + (cell + 1) * 96 + c6 * 16;
+      meta[i] = 1 + (dz + 1) * 8 + (dyl + 1);
+    }
+  }
+  auto gload = [&](long pair) {
+    const unsigned pu = (unsigned)pair;
+    const unsigned q1 = pu / (unsigned)hv, y2 = pu - q1 * (unsigned)hv, b = q1 / (unsigned)v, z = q1 - b * (unsigned)v;
+    const bf16_t* dyb = a.dY + ((((long)b * F + 4 * (long)z + U.az) * F + 4 * (long)(2 * y2) + U.ay) * F) * 48;
+    const bf16_t* xb = a.X + ((((long)b * v + z) * v + 2 * y2) * v) * 96;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      hreg[i] = make_uint4(0, 0, 0, 0);
+      if (meta[i] == 0) hreg[i] = *reinterpret_cast<const uint4*>(dyb + goff[i]);
+      else if (meta[i] > 0) {
+        const int m = meta[i] - 1, zz = (int)z + (m >> 3) - 1, yy = (int)(2 * y2) + (m & 7) - 1;
+        if ((unsigned)zz < (unsigned)v && (unsigned)yy < (unsigned)v) hreg[i] = *reinterpret_cast<const uint4*>(xb + goff[i]);
+      }
+    }
+  };
+  auto sstore = [&](int st) {
+    char* base = smem + st * STAGE;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (meta[i] >= 0) *reinterpret_cast<uint4*>(base + loff[i]) = hreg[i];
+  };
+
+  f32x4 acc[2][3][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ksteps = (2 * v + 31) / 32;
+  long pair = slab;
+  int st = 0;
+  if (pair < a.npair) { gload(pair); sstore(0); }
+  __syncthreads();
+  for (; pair < a.npair; pair += nslab, st ^= 1) {
+    const long nxt = pair + nslab;
+    if (nxt < a.npair) gload(nxt);
+    const char* xs = smem + st * STAGE + OFF_X + half * XHALF;
+    const char* ds = smem + st * STAGE + OFF_DY + ax * DPH;
+    for (int t = 0; t < ksteps; ++t) {
+      // rows of this lane in the k-step: cell i -> (line, x); rows past the pair read zeros
+      int offx[2], offd[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = 32 * t + 16 * h + 4 * g + (p >> 2);
+        const int line = i >= v, xi = i - line * v;
+        const bool ok = i < 2 * v;
+        offx[h] = ok ? line * XLINE + (xi + 1 + nx) * 96 + (p & 3) * 8 : -1;
+        offd[h] = ok ? line * DLINE + xi * 96 + (p & 3) * 8 : -1;
+      }
+      const char* zr = smem + OFF_ZERO + (p & 3) * 8;
+      Frag<bf16_t> df[3];
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) {
+        const bf16x4 lo = ds_read_tr16(offd[0] >= 0 ? ds + offd[0] + ct * 32 : zr), hi = ds_read_tr16(offd[1] >= 0 ? ds + offd[1] + ct * 32 : zr);
+        df[ct].v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (c < ncomb) {
+#pragma unroll
+          for (int it = 0; it < 3; ++it) {
+            const bf16x4 lo = ds_read_tr16(offx[0] >= 0 ? xs + c * XCOMB + offx[0] + it * 32 : zr), hi = ds_read_tr16(offx[1] >= 0 ? xs + c * XCOMB + offx[1] + it * 32 : zr);
+            Frag<bf16_t> xf;
+            xf.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) mma(acc[c][it][ct], xf, df[ct]);     // rows ci = 48 half + 16 it + 4 g + r, column c = 16 ct + p
+          }
+        }
+      }
+    }
+    if (nxt < a.npair) sstore(st ^ 1);
+    __syncthreads();
+  }
+  // partial blocks of this workgroup: part[wg][comb][b6][ci][c]
+  float* out = a.part + (long)blockIdx.x * (2 * 6 * 96 * 48);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (c < ncomb)
+#pragma unroll
+      for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[((c * 6 + b6) * 96 + 48 * half + 16 * it + 4 * g + r) * 48 + 16 * ct + p] = acc[c][it][ct][r];
+}
+
+// G[block][ci][c] = sum over the slabs of the unit that owns the block (block = (group, neighbour line, (a_x, n_x)): the forward's order)
+__global__ void cconv_wgrad_reduce_kernel(CCWArgs a, float* __restrict__ G) {
+  // grid = (unit, neighbour line of the unit, (a_x, n_x) block, 18 pieces of 256 elements)
+  const int piece = blockIdx.x % 18, r1 = blockIdx.x / 18, k6 = r1 % 6, r2 = r1 / 6, comb = r2 & 1, ui = r2 >> 1;
+  const CCWUnit U = a.u[ui];
+  if (comb >= U.ncomb) return;
+  const int blk = (comb ? U.blk1 : U.blk0) * 6 + k6;
+  const int e = piece * 256 + threadIdx.x;
+  float s = 0.f;
+  for (int w = 0; w < U.nslab; ++w) s += a.part[(long)(U.wg0 + w) * (2 * 6 * 96 * 48) + (comb * 6 + k6) * 4608 + e];
+  G[(long)blk * 4608 + e] = s;
+}
+
+// The transpose conv's bias: dW1[c][co][d] contains bt[co] * sum_{p : p + d inside the volume} dy1[p][c].  dy1 is the input gradient of an
+// affine-free InstanceNorm, so its sum over a whole sample is zero (the same fact that makes conv1's own bias gradient vanish) and the sum over
+// the valid voxels is MINUS the sum over the border voxels that tap d excludes.  This kernel takes the sums of dy1 over the 26 border classes
+// (k_z, k_y, k_x in {first, interior, last}^3) -- one workgroup per (sample, fine z plane), only the border lines are read in full.
+__global__ __launch_bounds__(256) void cconv_dy_border_kernel(const bf16_t* __restrict__ dY, float* __restrict__ C, int F, int planes_per_block) {
+  __shared__ float red[27 * 48];
+  const int nblk = (F + planes_per_block - 1) / planes_per_block;
+  const int b = blockIdx.x / nblk, z0 = (blockIdx.x - b * nblk) * planes_per_block, tid = threadIdx.x;
+  const int vl = tid / 6, c8 = tid - vl * 6;          // 42 voxel lanes x 6 groups of 8 channels (threads 252..255 idle)
+  for (int i = tid; i < 27 * 48; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float acc[3][8];
+  auto flush = [&](int kz, int ky) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (acc[kx][j] != 0.f) atomicAdd(&red[((kz * 3 + ky) * 3 + kx) * 48 + c8 * 8 + j], acc[kx][j]);
+        acc[kx][j] = 0.f;
+      }
+  };
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[kx][j] = 0.f;
+  if (vl < 42) {
+    for (int fz = z0; fz < z0 + planes_per_block && fz < F; ++fz) {
+      const int kz = fz == 0 ? 0 : (fz == F - 1 ? 2 : 1);
+      const int ly0 = (int)blockIdx.y * ((F + (int)gridDim.y - 1) / (int)gridDim.y), ly1 = ly0 + (F + (int)gridDim.y - 1) / (int)gridDim.y;
+      for (int fy = ly0; fy < ly1 && fy < F; ++fy) {
+        const int ky = fy == 0 ? 0 : (fy == F - 1 ? 2 : 1);
+        const bf16_t* base = dY + ((((long)b * F + fz) * F + fy) * F) * 48 + c8 * 8;
+        if (kz != 1 || ky != 1) {            // a border line: every voxel of it is a border voxel
+          for (int fx = vl; fx < F; fx += 42) {
+            float v8[8];
+            Vec8<bf16_t>::load(base + (long)fx * 48, v8);
+            const int kx = fx == 0 ? 0 : (fx == F - 1 ? 2 : 1);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+              if (q == kx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[q][j] += v8[j];
+          }
+        } else if (vl < 2) {                 // an interior line: its two end voxels
+          float v8[8];
+          Vec8<bf16_t>::load(base + (long)(vl ? F - 1 : 0) * 48, v8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[vl ? 2 : 0][j] += v8[j];
+        }
+        if (ky != 1 || fy == F - 2 || fy == ly1 - 1) flush(kz, ky);      // class changes after line 0, after the interior run and after the last line
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 27 * 48; e += 256)
+    if (red[e] != 0.f) atomicAdd(C + e, red[e]);
+}
+
+// dW1[c][co][d] += sum over the 8 phases of the group: sum_ci WtT[(a + d) mod 4][ci][co] . G[a][n(a, d)][ci][c]
+// (- bt[co] * sum of dy1 over the border classes that tap d excludes: added by the first phase group)
+__global__ __launch_bounds__(256) void cconv_wgrad_chain_kernel(const float* __restrict__ G, const float* __restrict__ WtT, const float* __restrict__ bt,
+                                                                const float* __restrict__ Cb, float* __restrict__ dW1) {
+  __shared__ float sg[96 * 49], sw[96 * 49];
+  const int d = blockIdx.x / 8, agrp = blockIdx.x - d * 8, tid = threadIdx.x;
+  const int dz = d / 9 - 1, dy = (d / 3) % 3 - 1, dx = d % 3 - 1;
+  float acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+  for (int ai = 0; ai < 8; ++ai) {
+    const int aa = agrp * 8 + ai, az = aa >> 4, ay = (aa >> 2) & 3, ax = aa & 3;
+    const int tz = az + dz, ty = ay + dy, tx = ax + dx;
+    const int nz = tz < 0 ? -1 : (tz > 3 ? 1 : 0), ny = ty < 0 ? -1 : (ty > 3 ? 1 : 0), nxx = tx < 0 ? -1 : (tx > 3 ? 1 : 0);
+    const int ph = ((tz & 3) * 4 + (ty & 3)) * 4 + (tx & 3);
+    // block index of (a, n) in the forward's order
+    int base = 0;
+    const int gi = az * 4 + ay;
+    for (int q = 0; q < gi; ++q) base += cc_ncnt(q >> 2) * cc_ncnt(q & 3);
+    const int izy = (nz - cc_nfirst(az)) * cc_ncnt(ay) + (ny - cc_nfirst(ay));
+    const int k6 = ax == 0 ? (nxx < 0 ? 0 : 1) : (ax == 3 ? (nxx > 0 ? 5 : 4) : ax + 1);
+    const float* gsrc = G + (long)((base + izy) * 6 + k6) * 4608;
+    const float* wsrc = WtT + (long)ph * 4608;
+    __syncthreads();
+    for (int i = tid; i < 4608; i += 256) { const int r = i / 48, c = i - r * 48; sg[r * 49 + c] = gsrc[i]; sw[r * 49 + c] = wsrc[i]; }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      const int e = tid + 256 * o, c = e / 48, co = e - c * 48;
+      float s = 0.f;
+      for (int ci = 0; ci < 96; ++ci) s += sg[ci * 49 + c] * sw[ci * 49 + co];
+      acc[o] += s;
+    }
+  }
+  if (agrp == 0) {
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      const int e = tid + 256 * o, c = e / 48, co = e - c * 48;
+      float sb = 0.f;
+      for (int cls = 0; cls < 27; ++cls) {
+        const int kz = cls / 9, ky = (cls / 3) % 3, kx = cls % 3;
+        const bool excluded = (kz == 0 && dz < 0) || (kz == 2 && dz > 0) || (ky == 0 && dy < 0) || (ky == 2 && dy > 0) || (kx == 0 && dx < 0) || (kx == 2 && dx > 0);
+        if (excluded) sb += Cb[cls * 48 + c];
+      }
+      acc[o] -= bt[co] * sb;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 9; ++o) {
+    const int e = tid + 256 * o, c = e / 48, co = e - c * 48;
+    atomicAdd(dW1 + ((long)c * 48 + co) * 27 + d, acc[o]);
+  }
+}
+
+long k_cconv_wgrad_ws_floats() { return 256L * (2 * 6 * 96 * 48) + 216L * 4608 + 27 * 48; }
+
+// dW1 [48][48][3][3][3] += conv1 weight gradient from x [B][v^3][96] and dy1 [B][(4v)^3][48]; WtT = first part of the pack workspace of
+// nmh_cconv_pack (the transpose-conv weight as [64 phases][96][48]); ws: k_cconv_wgrad_ws_floats() floats
+// (valid for a dy1 whose per-sample sums vanish: the gradient of an affine-free InstanceNorm's input, which is what conv1 feeds)
+int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* ws, int B, int v, hipStream_t st) {
+  using namespace ccw;
+  if (v % 8 || v > VMAX) return -2;
+  CCWArgs a{};
+  a.X = (const bf16_t*)X; a.dY = (const bf16_t*)dY; a.part = ws; a.B = B; a.v = v;
+  a.npair = (long)B * v * (v / 2);
+  // units: every (a_z, a_y) group with at most two of its neighbour lines; slabs in proportion to the bytes a unit streams per pair
+  int nu = 0, base = 0;
+  double wsum = 0.0, wgt[MAXU];
+  for (int gi = 0; gi < 16; ++gi) {
+    const int az = gi >> 2, ay = gi & 3, cz = cc_ncnt(az), cy = cc_ncnt(ay), fz = cc_nfirst(az), fy = cc_nfirst(ay);
+    const int ncombs = cz * cy;
+    for (int first = 0; first < ncombs; first += 2) {
+      CCWUnit& u = a.u[nu];
+      u.az = (signed char)az; u.ay = (signed char)ay;
+      u.ncomb = (signed char)(ncombs - first >= 2 ? 2 : 1);
+      const int c0 = first, c1 = first + 1;
+      u.nz0 = (signed char)(fz + c0 / cy); u.ny0 = (signed char)(fy + c0 % cy);
+      u.nz1 = (signed char)(fz + c1 / cy); u.ny1 = (signed char)(fy + c1 % cy);
+      u.blk0 = base + c0; u.blk1 = base + c1;
+      wgt[nu] = 30.7 + 16.1 * u.ncomb;
+      wsum += wgt[nu];
+      ++nu;
+    }
+    base += ncombs;
+  }
+  a.nunit = nu;
+  int wg = 0;
+  for (int i = 0; i < nu; ++i) {
+    int s = (int)(248.0 * wgt[i] / wsum);
+    if (s < 1) s = 1;
+    if ((long)s > a.npair) s = (int)a.npair;
+    a.u[i].wg0 = wg; a.u[i].nslab = s;
+    wg += s;
+  }
+  if (wg > 256) return -2;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)cconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)wg), dim3(768), LDS_BYTES, st, a);
+  NMH_CHECK_LAUNCH();
+  float* G = ws + 256L * (2 * 6 * 96 * 48);
+  float* Cb = G + 216L * 4608;
+  hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)(nu * 2 * 6 * 18)), dim3(256), 0, st, a, G);
+  NMH_CHECK_LAUNCH();
+  {
+    hipError_t e = nmh_zero_async(Cb, sizeof(float) * 27 * 48, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  {
+    const int F = 4 * v, ppb = 5;
+    hipLaunchKernelGGL(cconv_dy_border_kernel, dim3((unsigned)(B * ((F + ppb - 1) / ppb)), 8), dim3(256), 0, st, (const bf16_t*)dY, Cb, F, ppb);
+  }
+  NMH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cconv_wgrad_chain_kernel, dim3(27 * 8), dim3(256), 0, st, (const float*)G, WtT, bt, (const float*)Cb, dW1);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}

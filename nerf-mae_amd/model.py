@@ -448,6 +448,7 @@ class _UpBlockFn(torch.autograd.Function):
         elif not fused_tail:
             ops.instnorm_apply(y2, st2, out, B, V, Cout, r=cat, rmode=1)
         ctx.m, ctx.dims, ctx.conv, ctx.c48 = m, (B, v, has_skip), conv, c48
+        ctx.cc = cc is not None and ops.CCONV_WGRAD and v <= 40
         ctx.saved = (x, cat, y1, st1, a1, y2, st2, y3, st3, out)
         ctx.tail = None
         if tail is not None:
@@ -516,7 +517,10 @@ class _UpBlockFn(torch.autograd.Function):
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
-        side(lambda: wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), g_c1))
+        if ctx.cc:   # decoder1: conv1's weight gradient through the composition (a quarter of the FLOPs, contraction over the coarse cells; csrc/cconv.hip)
+            ops.cconv_wgrad(x.view(B, v, v, v, Cin), dy1.view(B, S, S, S, Cout), pk.cconv[3], m.transp_conv.bias, g_c1, B, v)
+        else:
+            side(lambda: wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), g_c1))
         if m.has_proj:
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
             g_c3 = _gradbuf(m.conv_block.conv3.weight)

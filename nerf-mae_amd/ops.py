@@ -303,6 +303,26 @@ def cconv_fwd(x, Wcp, delta, B, v, out=None, stats_acc=None):
     return out
 
 
+CCONV_WGRAD = __import__("os").environ.get("NMH_CCONV_WGRAD", "1") != "0"   # conv1's weight gradient through the composition (with NMH_CCONV)
+_CCW_WS = {}
+
+
+def cconv_wgrad(x, dy1, pack_ws, bt, dW1, B, v):
+    """conv1.weight gradient [48,48,3,3,3] += through the composed ConvTranspose o conv (include/nerfmae_hip.h: nmh_cconv_wgrad); dy1 must be the
+    input gradient of the affine-free InstanceNorm behind conv1 (zero per-sample sums)"""
+    _chk(x, dy1, pack_ws, bt, dW1)
+    if x.dtype != torch.bfloat16 or dy1.dtype != torch.bfloat16 or v % 8 or v > 40:
+        raise RuntimeError("cconv_wgrad needs bf16 operands on a coarse grid whose edge is a multiple of 8 (<= 40)")
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _CCW_WS:
+        _CCW_WS[key] = torch.empty(int(lib().call("nmh_cconv_wgrad_ws_floats")), dtype=torch.float32, device=x.device)
+    ev = _prof(("cconv_wgrad", B, 4 * v, 96, 48))
+    lib().call("nmh_cconv_wgrad", x, dy1, pack_ws, bt, dW1, _CCW_WS[key], B, v, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return dW1
+
+
 C48MB_MIN_VOXELS = int(__import__("os").environ.get("NMH_C48MB_MIN_VOXELS", "32768"))   # 0 disables the 48-channel-block multi-block kernel
 
 

@@ -999,3 +999,44 @@ def test_cconv_forward_matches_convtranspose_then_conv(B, v):
     y2 = ops.conv3d_k3_c48(cat.view(B, Fv, Fv, Fv, 48), wk)
     const = torch.einsum("o,codhw->c", bt, W1)
     assert_close(y.float().cpu(), y2.float().cpu() - const, 2e-2, "cconv vs two-step HIP path (interior + border)", elem_mult=2.0)
+
+
+@pytest.mark.parametrize("B,v", [(1, 8), (2, 16), (1, 24), (2, 40)])
+def test_cconv_wgrad_matches_autograd_of_the_two_ops(B, v):
+    """conv1.weight gradient through the composed ConvTranspose o conv (csrc/cconv.hip: G blocks + chain rule + the bias term carried by the
+    border voxels) against autograd of conv3d(conv_transpose3d(x)) in fp32 on the bf16-rounded operands, and against the two-step HIP weight
+    gradient (48 -> 48 LDS-halo kernel on the bf16 up-sampled map).  dy1 is the input gradient of an InstanceNorm (zero sums per sample and
+    channel), which is what conv1 feeds in the model and what the entry's bias term relies on."""
+    ops = _ops()
+    dt = torch.bfloat16
+    Fv = 4 * v
+    x = q(rnd(B, v, v, v, 96, seed=1), dt)
+    Wt = rnd(96, 48, 4, 4, 4, seed=2, scale=96 ** -0.5)
+    W1 = rnd(48, 48, 3, 3, 3, seed=3, scale=(27 * 48) ** -0.5)
+    bt = rnd(48, seed=4, scale=0.5)
+    gup = rnd(B, 48, Fv, Fv, Fv, seed=5)
+    # an InstanceNorm backward makes dy1 zero-sum per (sample, channel); round to bf16 the way the pipeline stores it
+    y_lin = F.conv3d(F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), Wt, bt, stride=4), W1, None, padding=1).requires_grad_(True)
+    (F.instance_norm(y_lin) * gup).sum().backward()
+    dy = q(y_lin.grad, dt)                                    # (B,48,F,F,F)
+    W1r = W1.clone().requires_grad_(True)
+    u = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), Wt, bt, stride=4)
+    (F.conv3d(u, W1r, None, padding=1) * dy).sum().backward()
+    # HIP: pack (fills the workspace with the transposed Wt), then the composed weight gradient
+    Wcp = torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda")
+    delta = torch.empty(27, 48, device="cuda")
+    pws = torch.empty(ops.cconv_pack_ws_floats(), device="cuda")
+    ops.cconv_pack(dev(Wt), dev(W1), dev(bt), Wcp, delta, pws)
+    dW = torch.zeros(48, 48, 3, 3, 3, device="cuda")
+    dy_cl = dev(dy.permute(0, 2, 3, 4, 1).contiguous(), dt)
+    ops.cconv_wgrad(dev(x, dt), dy_cl, pws, dev(bt), dW, B, v)
+    check(dW, W1r.grad, dt, f"cconv wgrad B={B} v={v}", 2)
+    # accumulation contract (+=) and the two-step HIP kernel on the bf16 up-sampled map
+    ops.cconv_wgrad(dev(x, dt), dy_cl, pws, dev(bt), dW, B, v)
+    check(dW, 2 * W1r.grad, dt, "cconv wgrad accumulates", 2)
+    wt_p = _pack_via_kernel(Wt, 4, dt, Wt.numel())
+    cat = torch.empty(B * Fv ** 3, 48, dtype=dt, device="cuda")
+    ops.upconv_fwd(dev(x, dt).view(-1, 96), wt_p.view(64 * 48, 96), dev(bt), cat, B, v, 4, 96, 48)
+    dW2 = torch.zeros(48, 48, 3, 3, 3, device="cuda")
+    ops.conv3d_k3_c48_wgrad(dy_cl, cat.view(B, Fv, Fv, Fv, 48), dW2)
+    assert_close(dW.float().cpu() / 2, dW2.float().cpu(), 2e-2, "cconv wgrad vs two-step HIP weight gradient")

@@ -34,6 +34,13 @@ for B in [int(v) for v in sys.argv[1:]] or [8, 1]:
     from tests.test_kernels_gpu import _pack_via_kernel
     wk = _pack_via_kernel(W1.cpu(), 6, torch.bfloat16, 41 * 3 * 64 * 8)
     t_c48 = bench(lambda: ops.conv3d_k3_c48(u, wk, out=y, stats_acc=acc))
+    dy = torch.randn(B, 160, 160, 160, 48, device="cuda").to(torch.bfloat16)
+    pws = torch.empty(ops.cconv_pack_ws_floats(), device="cuda")
+    ops.cconv_pack(Wt, W1, bt, Wcp, delta, pws)
+    dW = torch.zeros(48, 48, 3, 3, 3, device="cuda")
+    t_cw = bench(lambda: ops.cconv_wgrad(x, dy, pws, bt, dW, B, v))
+    t_w48 = bench(lambda: ops.conv3d_k3_c48_wgrad(dy, u, dW))
+    print(f"B={B}: cconv_wgrad {t_cw:.3f} ms   conv48_wgrad {t_w48:.3f} ms", flush=True)
     fl = 2.0 * 216 * 96 * 48 * v ** 3 * B
     print(f"B={B}: cconv_fwd {t_cc:.3f} ms ({fl / t_cc / 1e9:.0f} TFLOP/s of composed work, {2.0 * 27 * 48 * 48 * 160 ** 3 * B / t_cc / 1e9:.0f} of the two-step FLOPs)   "
           f"conv48 {t_c48:.3f} ms   pack {t_pack * 1e3:.0f} us", flush=True)
