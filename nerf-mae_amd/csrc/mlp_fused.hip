@@ -778,7 +778,8 @@ template <int MT> int launch96_fwd(const MlpFwdArgs& a, hipStream_t st) {
     attr = true;
   }
   long nb = (a.M + 8 * 16 * MT - 1) / (8 * 16 * MT);
-  if (nb > 256) nb = 256;
+  static const long cap = getenv("NMH_MLP96_WGS") ? atol(getenv("NMH_MLP96_WGS")) : 256;   // persistent workgroups (one per CU: 144 KB of LDS each)
+  if (nb > cap) nb = cap;
   hipLaunchKernelGGL((mlp96_fwd_kernel<MT>), dim3((unsigned)nb), dim3(512), lds, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
@@ -792,7 +793,8 @@ template <int MT> int launch96_bwd(const MlpBwdArgs& a, hipStream_t st) {
     attr = true;
   }
   long nb = (a.M + 4 * 16 * MT - 1) / (4 * 16 * MT);
-  if (nb > 256) nb = 256;
+  static const long cap = getenv("NMH_MLP96_WGS") ? atol(getenv("NMH_MLP96_WGS")) : 256;
+  if (nb > cap) nb = cap;
   hipLaunchKernelGGL((mlp96_bwd_kernel<MT>), dim3((unsigned)nb), dim3(256), lds, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
