@@ -139,6 +139,13 @@ NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, vo
  * InstanceNorm that conv1 feeds (the term bt[co] * sum_p dy1[p][c] is then carried by the border voxels alone, which the entry sums). */
 NMH_API int64_t nmh_cconv_wgrad_ws_floats(void);
 NMH_API int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* ws, int B, int v, void* stream);
+/* The residual branch of the same block, bf16: u = ConvTranspose3d(96 -> 48, kernel = stride = 4)(x) + bias (unetr_block.py:151-158, 193-200), as a
+ * persistent kernel with the coarse fragments in registers and the 64 phase weights streamed through LDS (replaces nmh_upconv_fwd at this shape).
+ * nmh_upconv4_pack: fragment-ordered bf16 weights (nmh_upconv4_pack_numel() elements) from pack_ws = the scratch nmh_cconv_pack filled in this step
+ * (holds the transposed Wt).  nmh_upconv4_fwd: x [B][v^3][96] -> u [B][(4v)^3][48], v a multiple of 8. */
+NMH_API int64_t nmh_upconv4_pack_numel(void);
+NMH_API int nmh_upconv4_pack(const float* pack_ws, void* Wup, void* stream);
+NMH_API int nmh_upconv4_fwd(const void* x, const void* Wup, const float* bt, void* u, int B, int v, void* stream);
 /* Fused MLP branch of a Swin block, bf16 (swin_mae3d.py:352-358 torchvision MLP + :368 `x + stochastic_depth(mlp(norm2(x)))`):
  *   x2[row] = x1[row] + rowscale[row / rows_per_scale] * (gelu(LN(x1[row]) . W1^T + b1) . W2^T + b2)
  * in ONE launch: LayerNorm in the MFMA operand registers, the hidden dimension walked in chunks whose GELU output feeds the second

@@ -184,6 +184,18 @@ int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const 
   if (B <= 0 || v <= 0) return 0;
   return k_cconv_wgrad(x, dy1, pack_ws, bt, dW1, ws, B, v, ST);
 }
+int64_t nmh_upconv4_pack_numel(void) { return (int64_t)k_upconv4_pack_numel(); }
+int nmh_upconv4_pack(const float* pack_ws, void* Wup, void* stream) {
+  CLR();
+  REQ(pack_ws, Wup);
+  return k_upconv4_pack(pack_ws, Wup, ST);
+}
+int nmh_upconv4_fwd(const void* x, const void* Wup, const float* bt, void* u, int B, int v, void* stream) {
+  CLR();
+  REQ(x, Wup, bt, u);
+  if (B <= 0 || v <= 0) return 0;
+  return k_upconv4_fwd(x, Wup, bt, u, B, v, ST);
+}
 int nmh_mlp_fused_supported(int C) { return k_mlp_fused_supported(C); }
 int nmh_mlp_fused_fwd(const void* x1, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* b2, const float* rowscale,
                       int rows_per_scale, void* x2, float* mean, float* rstd, int64_t M, int C, float eps, void* stream) {

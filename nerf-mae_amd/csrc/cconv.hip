@@ -445,6 +445,158 @@ int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int
 }
 
 // ================================================================================================
+// The transpose convolution itself (the residual branch u = ConvT(x) of decoder1: unetr_block.py:151-158, 193-200), same skeleton without
+// the halo: u[4j + a] = Wt[a]^T x[j] + bt.  A wave keeps the x fragments of its 32 cells in REGISTERS for the whole block (no neighbours),
+// the 64 x (96 x 48) phase weights stream through a 3-slot LDS ring in 48 chunks of 12 fragments ((a_z, a_y) group x k-step: four a_x
+// phases x three channel tiles), and a lane leaves with the same 4 voxels x 12 channels as above: 384 contiguous bytes per (lane, line).
+// ================================================================================================
+namespace up4 {
+constexpr int NCHUNK = 48, WCH = 12 * 1024, RING = 3, LDS_BYTES = RING * WCH;
+}
+struct Up4Args { const bf16_t* X; const bf16_t* W; const float* bt; bf16_t* Y; int B, v, nbz, nby, nbx; long total; };
+
+__global__ __launch_bounds__(512) void upconv4_fwd_kernel(Up4Args a) {
+  using namespace up4;
+  using cc::BZ; using cc::BY; using cc::BX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int V = a.v, F = 4 * a.v;
+  const int nx8 = 8, xcd = blockIdx.x % nx8, jb = blockIdx.x / nx8, jstride = gridDim.x / nx8;
+  const long per = (a.total + nx8 - 1) / nx8;
+  const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
+  // chunk c (12 lane-linear 1-KB images) -> ring slot: wave w takes image w, waves 0..3 also image 8 + w
+  auto w_dma = [&](int c, int slot) {
+    const char* src = reinterpret_cast<const char*>(a.W) + (long)c * WCH;
+    char* dst = smem + slot * WCH;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wave * 1024 + lv * 16),
+                                     (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, 0, 0);
+    if (wave < 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (8 + wave) * 1024 + lv * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + (8 + wave) * 1024), 16, 0, 0);
+  };
+  float bb[3][4];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bb[n][r] = a.bt[12 * g + 4 * n + r];
+  const int z_l = wave >> 1, y_l = (wave & 1) * 4, ly = li >> 3, lx = li & 7;
+  long t = tbeg + jb;
+  if (t >= tend) return;
+  w_dma(0, 0); w_dma(1, 1);
+  int slot = 0;
+  for (; t < tend; t += jstride) {
+    const unsigned tu = (unsigned)t;
+    unsigned r1 = tu / (unsigned)a.nbx; const int xb = (int)(tu - r1 * (unsigned)a.nbx);
+    unsigned r2 = r1 / (unsigned)a.nby; const int yb = (int)(r1 - r2 * (unsigned)a.nby);
+    unsigned r3 = r2 / (unsigned)a.nbz; const int zb = (int)(r2 - r3 * (unsigned)a.nbz);
+    const int b = __builtin_amdgcn_readfirstlane((int)r3);
+    const int z0 = __builtin_amdgcn_readfirstlane(zb * BZ), y0 = __builtin_amdgcn_readfirstlane(yb * BY), x0 = __builtin_amdgcn_readfirstlane(xb * BX);
+    Frag<bf16_t> xf[3][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const bf16_t* xc = a.X + ((((long)b * V + z0 + z_l) * V + y0 + y_l + 2 * m + ly) * V + x0 + lx) * 96 + 8 * g;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) xf[s][m].v = *reinterpret_cast<const bf16x8*>(xc + 32 * s);
+    }
+    int ck = 0;
+#pragma unroll 1
+    for (int gi = 0; gi < 16; ++gi) {
+      const int az = gi >> 2, ay = gi & 3;
+      f32x4 acc[4][3][2];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) acc[p][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 3; ++s, ++ck) {
+        // chunk ck has landed once at most the pieces of the next chunk (and, in front of a group's first chunk, the 16 output stores of the
+        // previous group, younger still) are outstanding: vector-memory operations retire in order
+        const bool after_epi = s == 0 && gi > 0;
+        if (wave < 4) {
+          if (after_epi) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        } else {
+          if (after_epi) asm volatile("s_waitcnt vmcnt(17) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        {
+          const int cn = ck + 2 >= NCHUNK ? ck + 2 - NCHUNK : ck + 2;
+          const int sn = slot == 0 ? 2 : slot - 1;          // (slot + 2) % 3
+          w_dma(cn, sn);
+        }
+        const char* wsrc = smem + slot * WCH + lane * 16;
+        slot = slot == 2 ? 0 : slot + 1;
+        Frag<bf16_t> wf[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) wf[i].v = *reinterpret_cast<const bf16x8*>(wsrc + i * 1024);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) mma(acc[p][n][m], wf[p * 3 + n], xf[s][m]);
+      }
+      const int zf = 4 * (z0 + z_l) + az;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int yf = 4 * (y0 + y_l + 2 * m + ly) + ay;
+        bf16_t* const drow = a.Y + ((((long)b * F + zf) * F + yf) * F + 4 * (x0 + lx)) * 48 + 12 * g;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          unsigned w6[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+            w6[q] = pk_bf16(acc[p][q >> 1][m][(q & 1) * 2] + bb[q >> 1][(q & 1) * 2], acc[p][q >> 1][m][(q & 1) * 2 + 1] + bb[q >> 1][(q & 1) * 2 + 1]);
+          bf16_t* dst = drow + p * 48;
+          *reinterpret_cast<uint4*>(dst) = make_uint4(w6[0], w6[1], w6[2], w6[3]);
+          *reinterpret_cast<uint2*>(dst + 8) = make_uint2(w6[4], w6[5]);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing weight prefetch
+  __syncthreads();
+}
+
+// Wup bf16 [48 chunks = (a_z, a_y) group x k-step][12 fragments = a_x x channel tile][64 lanes][8] from WtT (workspace of the pack above)
+__global__ __launch_bounds__(512) void upconv4_pack_kernel(const float* __restrict__ WtT, bf16_t* __restrict__ Wup) {
+  const int blk = blockIdx.x, tid = threadIdx.x;          // one workgroup per fragment
+  const int ck = blk / 12, fr = blk - ck * 12, gi = ck / 3, s = ck - gi * 3, ax = fr / 3, n = fr - ax * 3;
+  const int lane = tid >> 3, j = tid & 7, li = lane & 15, g = lane >> 4;
+  const int ph = gi * 4 + ax, ci = 32 * s + 8 * g + j, c = 12 * (li >> 2) + 4 * n + (li & 3);
+  Wup[((long)blk * 64 + lane) * 8 + j] = f2bf(WtT[((long)ph * 96 + ci) * 48 + c]);
+}
+
+long k_upconv4_pack_numel() { return 48L * 12 * 512; }
+
+int k_upconv4_pack(const float* ws, void* Wup, hipStream_t st) {
+  hipLaunchKernelGGL(upconv4_pack_kernel, dim3(48 * 12), dim3(512), 0, st, ws, (bf16_t*)Wup);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+int k_upconv4_fwd(const void* X, const void* Wup, const float* bt, void* Y, int B, int v, hipStream_t st) {
+  using namespace cc;
+  if (v % BY || v % BX || v % BZ) return -2;
+  Up4Args a;
+  a.X = (const bf16_t*)X; a.W = (const bf16_t*)Wup; a.bt = bt; a.Y = (bf16_t*)Y;
+  a.B = B; a.v = v; a.nbz = v / BZ; a.nby = v / BY; a.nbx = v / BX;
+  a.total = (long)B * a.nbz * a.nby * a.nbx;
+  if (a.total >= (1L << 31) || (long)B * 64 * v * v * v * 48 >= (1L << 40)) return -2;
+  long nb = a.total < 256 ? a.total : 256;
+  nb = nb / 8 * 8;
+  if (nb < 8) nb = 8;
+  hipLaunchKernelGGL(upconv4_fwd_kernel, dim3((unsigned)nb), dim3(512), up4::LDS_BYTES, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ================================================================================================
 // Weight gradient of decoder1's conv1 THROUGH the composition (backward of the op above with respect to conv1.weight):
 //     dW1[c][co][d] = sum_p dy1[p][c] u[p + d][co]      with u = ConvT(x)   (unetr_block.py:35-44 backward; the 4 TFLOP/step launch of conv48_wgrad)
 //  =  sum_a sum_ci Wt[ci][co][(a + d) mod 4] . G[a][n(a, d)][ci][c],         G[a][n][ci][c] = sum_j x[j + n][ci] dy1[4j + a][c]

@@ -163,6 +163,9 @@ long k_cconv_pack_ws_floats();
 int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st);
 int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* ws, int B, int v, hipStream_t st);
 long k_cconv_wgrad_ws_floats();
+long k_upconv4_pack_numel();
+int k_upconv4_pack(const float* ws, void* Wup, hipStream_t st);
+int k_upconv4_fwd(const void* X, const void* Wup, const float* bt, void* Y, int B, int v, hipStream_t st);
 
 // ---- mlp_fused.hip: LN -> fc1 -> GELU -> fc2 -> row-scale -> + residual in one launch (bf16), and its backward ----
 int k_mlp_fused_supported(int C);

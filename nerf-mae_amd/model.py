@@ -164,8 +164,10 @@ class _Packer:
             if sp < n:
                 ops.pack_weights(self.dt, self.descs, self.blk2desc[sp:], self.blkstart[sp:], n - sp)
             if self.cconv is not None:    # decoder1: ConvTranspose o conv1 composed weights (csrc/cconv.hip), from the fp32 masters
-                up, Wcp, delta, ws = self.cconv
+                up, Wcp, delta, ws, Wup = self.cconv
                 ops.cconv_pack(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws)
+                if Wup is not None:
+                    ops.upconv4_pack(ws, Wup)
 
     @staticmethod
     def join():
@@ -393,7 +395,11 @@ class _UpBlockFn(torch.autograd.Function):
         has_skip = skip is not None
         Cc = 2 * Cout if has_skip else Cout
         cat = torch.empty((B * V, Cc), dtype=dtype, device=dev)
-        ops.upconv_fwd(x, pk[key + "t.w"].view(k3 * Cout, Cin), m.transp_conv.bias, cat, B, v, k, Cin, Cout)   # pixel shuffle in the epilogue
+        cc = pk.cconv if ((key + "c1.wk") in pk.views and pk.cconv is not None and pk.cconv[0] is m and v % 8 == 0 and not has_skip) else None
+        if cc is not None and cc[4] is not None:   # decoder1: persistent kernel, coarse fragments in registers (csrc/cconv.hip)
+            ops.upconv4_fwd(x.view(B, v, v, v, Cin), cc[4], m.transp_conv.bias, cat, B, v)
+        else:
+            ops.upconv_fwd(x, pk[key + "t.w"].view(k3 * Cout, Cin), m.transp_conv.bias, cat, B, v, k, Cin, Cout)   # pixel shuffle in the epilogue
         if has_skip:
             ops.copy_cols(skip.reshape(B * V, Cout), cat[:, Cout:])
         S = v * k
@@ -416,7 +422,7 @@ class _UpBlockFn(torch.autograd.Function):
         ctx.c64 = c64
         halo_stats = c48 or c64    # InstanceNorm statistics come out of the conv epilogue
         st1 = torch.empty((B, Cout, 2), device=dev)
-        cc = pk.cconv if (c48 and pk.cconv is not None and pk.cconv[0] is m and v % 8 == 0) else None
+        cc = cc if c48 else None
         if cc is not None:   # decoder1: y1 straight from the coarse map with the composed weights (4x fewer FLOPs; cat is only the residual)
             y1 = ops.cconv_fwd(x.view(B, v, v, v, Cin), cc[1], cc[2], B, v, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st1, B, V, Cout)
@@ -822,7 +828,8 @@ class SwinTransformer_MAE3D_New(nn.Module):
         if (ops.CCONV and d1 is not None and self.compute_dtype == torch.bfloat16 and (d1.cin, d1.cout, d1.k) == (96, 48, 4) and not d1.has_proj
                 and (self.resolution // 4) % 8 == 0):
             P.cconv = (d1, torch.empty(ops.cconv_pack_numel(), dtype=torch.bfloat16, device=device), torch.empty((27, 48), device=device),
-                       torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device=device))
+                       torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device=device),
+                       torch.empty(ops.upconv4_pack_numel(), dtype=torch.bfloat16, device=device) if ops.UPCONV4 else None)
         self._packer = P
         self._pk = P
         self._wq = ops.WgradQueue()   # deferred encoder weight gradients (grouped launches, issued per stage)

@@ -303,6 +303,33 @@ def cconv_fwd(x, Wcp, delta, B, v, out=None, stats_acc=None):
     return out
 
 
+UPCONV4 = __import__("os").environ.get("NMH_UPCONV4", "1") != "0"   # decoder1's transpose conv as the persistent kernel of csrc/cconv.hip (with NMH_CCONV)
+
+
+def upconv4_pack_numel() -> int:
+    return int(lib().call("nmh_upconv4_pack_numel"))
+
+
+def upconv4_pack(pack_ws, Wup):
+    """fragment-ordered bf16 weights of the k = s = 4 transpose conv from the scratch cconv_pack filled in this step"""
+    _chk(pack_ws, Wup)
+    if Wup.numel() < upconv4_pack_numel() or Wup.dtype != torch.bfloat16:
+        raise ValueError("upconv4_pack: shapes")
+    lib().call("nmh_upconv4_pack", pack_ws, Wup, _st())
+
+
+def upconv4_fwd(x, Wup, bt, out, B, v):
+    """u [B,(4v)^3,48] = ConvTranspose3d_{k=s=4}(x [B,v^3,96]) + bt (include/nerfmae_hip.h: nmh_upconv4_fwd)"""
+    _chk(x, Wup, bt, out)
+    if x.dtype != torch.bfloat16 or out.dtype != torch.bfloat16 or x.shape[-1] != 96 or v % 8 or out.numel() != B * (4 * v) ** 3 * 48:
+        raise RuntimeError("upconv4_fwd needs bf16 activations with 96 channels on a coarse grid whose edge is a multiple of 8")
+    ev = _prof(("upconv4_fwd", B, 4 * v, 96, 48))
+    lib().call("nmh_upconv4_fwd", x, Wup, bt, out, B, v, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 CCONV_WGRAD = __import__("os").environ.get("NMH_CCONV_WGRAD", "1") != "0"   # conv1's weight gradient through the composition (with NMH_CCONV)
 _CCW_WS = {}
 

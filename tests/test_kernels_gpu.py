@@ -1001,6 +1001,34 @@ def test_cconv_forward_matches_convtranspose_then_conv(B, v):
     assert_close(y.float().cpu(), y2.float().cpu() - const, 2e-2, "cconv vs two-step HIP path (interior + border)", elem_mult=2.0)
 
 
+@pytest.mark.parametrize("B,v", [(1, 8), (2, 8), (1, 16), (3, 24), (2, 40)])
+def test_upconv4_forward_matches_conv_transpose(B, v):
+    """decoder1's transpose conv as the persistent register-fragment kernel (csrc/cconv.hip upconv4): against F.conv_transpose3d in fp32 on the
+    bf16-rounded operands, and BIT-exact against the GEMM + pixel-shuffle kernel it replaces (same bf16 weights, fp32 accumulation over the same
+    96 products... in a different order: so within one bf16 ulp, not equal)"""
+    ops = _ops()
+    dt = torch.bfloat16
+    Fv = 4 * v
+    x = q(rnd(B, v, v, v, 96, seed=11), dt)
+    Wt = rnd(96, 48, 4, 4, 4, seed=12, scale=96 ** -0.5)
+    bt = rnd(48, seed=13, scale=0.5)
+    ws = torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device="cuda")
+    Wcp = torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda")
+    delta = torch.empty(27, 48, device="cuda")
+    ops.cconv_pack(dev(Wt), dev(rnd(48, 48, 3, 3, 3, seed=3)), dev(bt), Wcp, delta, ws)
+    Wup = torch.empty(ops.upconv4_pack_numel(), dtype=dt, device="cuda")
+    ops.upconv4_pack(ws, Wup)
+    u = torch.full((B * Fv ** 3, 48), 3.0, dtype=dt, device="cuda")
+    ops.upconv4_fwd(dev(x, dt), Wup, dev(bt), u, B, v)
+    torch.cuda.synchronize()
+    ref = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), q(Wt, dt), bt, stride=4).permute(0, 2, 3, 4, 1)
+    check(u.view(B, Fv, Fv, Fv, 48), ref, dt, f"upconv4 fwd B={B} v={v}")
+    wt_p = _pack_via_kernel(Wt, 4, dt, Wt.numel())
+    cat = torch.empty(B * Fv ** 3, 48, dtype=dt, device="cuda")
+    ops.upconv_fwd(dev(x, dt).view(-1, 96), wt_p.view(64 * 48, 96), dev(bt), cat, B, v, 4, 96, 48)
+    assert_close(u.float().cpu(), cat.float().cpu(), 8e-3, "upconv4 vs GEMM + pixel shuffle")
+
+
 @pytest.mark.parametrize("B,v", [(1, 8), (2, 16), (1, 24), (2, 40)])
 def test_cconv_wgrad_matches_autograd_of_the_two_ops(B, v):
     """conv1.weight gradient through the composed ConvTranspose o conv (csrc/cconv.hip: G blocks + chain rule + the bias term carried by the

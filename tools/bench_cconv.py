@@ -41,6 +41,13 @@ for B in [int(v) for v in sys.argv[1:]] or [8, 1]:
     t_cw = bench(lambda: ops.cconv_wgrad(x, dy, pws, bt, dW, B, v))
     t_w48 = bench(lambda: ops.conv3d_k3_c48_wgrad(dy, u, dW))
     print(f"B={B}: cconv_wgrad {t_cw:.3f} ms   conv48_wgrad {t_w48:.3f} ms", flush=True)
+    Wup = torch.empty(ops.upconv4_pack_numel(), dtype=torch.bfloat16, device="cuda")
+    ops.upconv4_pack(pws, Wup)
+    cat = torch.empty(B * 160 ** 3, 48, dtype=torch.bfloat16, device="cuda")
+    t_u4 = bench(lambda: ops.upconv4_fwd(x, Wup, bt, cat, B, v))
+    wt_p = _pack_via_kernel(Wt.cpu(), 4, torch.bfloat16, Wt.numel())
+    t_u = bench(lambda: ops.upconv_fwd(x.view(-1, 96), wt_p.view(64 * 48, 96), bt, cat, B, v, 4, 96, 48))
+    print(f"B={B}: upconv4_fwd {t_u4:.3f} ms ({B * 160 ** 3 * 96 / t_u4 / 1e6:.0f} GB/s of output)   GEMM + pixel shuffle {t_u:.3f} ms", flush=True)
     fl = 2.0 * 216 * 96 * 48 * v ** 3 * B
     print(f"B={B}: cconv_fwd {t_cc:.3f} ms ({fl / t_cc / 1e9:.0f} TFLOP/s of composed work, {2.0 * 27 * 48 * 48 * 160 ** 3 * B / t_cc / 1e9:.0f} of the two-step FLOPs)   "
           f"conv48 {t_c48:.3f} ms   pack {t_pack * 1e3:.0f} us", flush=True)
