@@ -138,7 +138,17 @@ NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, vo
  * ws = nmh_cconv_wgrad_ws_floats() floats.  Exact for a dy1 whose per-sample, per-channel sums vanish -- the input gradient of the affine-free
  * InstanceNorm that conv1 feeds (the term bt[co] * sum_p dy1[p][c] is then carried by the border voxels alone, which the entry sums). */
 NMH_API int64_t nmh_cconv_wgrad_ws_floats(void);
-NMH_API int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* ws, int B, int v, void* stream);
+NMH_API int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, void* stream);
+/* Input gradient THROUGH the composition: dx = ConvT^T(conv1^T(dy1)) (backward of unetr_block.py:151-158 after unetr_block.py:35-44) is a stride-4
+ * convolution of the fine gradient with a 6x6x6 kernel of 48 -> 96 matrices (the transposes of the same 216 blocks): conv1's input gradient on the fine
+ * grid -- a full 48 -> 48 conv pass that only fed the transpose conv's backward -- is never formed.  nmh_cconv_dgrad_pack gathers the forward's
+ * fragment-ordered weights into this kernel's order (nmh_cconv_dgrad_pack_numel() bf16 elements).  nmh_cconv_dgrad: dy1 [B][(4v)^3][48] ->
+ * dx [B][v^3][96] = (add ? add : 0) + gradient (add may alias dx: the part of dx that comes through the residual branch).  With this entry the
+ * transpose conv's own parameter gradients through conv1 come from nmh_cconv_wgrad's G blocks: pass dWt [96][48][4][4][4] / dbt [48] (fp32, accumulated;
+ * NULL = not wanted) there; the part through the residual branch stays with nmh_upconv_wgrad on the residual gradient alone. */
+NMH_API int64_t nmh_cconv_dgrad_pack_numel(void);
+NMH_API int nmh_cconv_dgrad_pack(const void* Wcp, void* Wdp, void* stream);
+NMH_API int nmh_cconv_dgrad(const void* dy1, const void* Wdp, const void* add, void* dx, int B, int v, void* stream);
 /* The residual branch of the same block, bf16: u = ConvTranspose3d(96 -> 48, kernel = stride = 4)(x) + bias (unetr_block.py:151-158, 193-200), as a
  * persistent kernel with the coarse fragments in registers and the 64 phase weights streamed through LDS (replaces nmh_upconv_fwd at this shape).
  * nmh_upconv4_pack: fragment-ordered bf16 weights (nmh_upconv4_pack_numel() elements) from pack_ws = the scratch nmh_cconv_pack filled in this step

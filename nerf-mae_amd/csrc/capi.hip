@@ -178,11 +178,23 @@ int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, 
   return k_cconv_fwd(x, Wcp, delta, y1, B, v, stats_acc, ST);
 }
 int64_t nmh_cconv_wgrad_ws_floats(void) { return (int64_t)k_cconv_wgrad_ws_floats(); }
-int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* ws, int B, int v, void* stream) {
+int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, void* stream) {
   CLR();
   REQ(x, dy1, pack_ws, bt, dW1, ws);
   if (B <= 0 || v <= 0) return 0;
-  return k_cconv_wgrad(x, dy1, pack_ws, bt, dW1, ws, B, v, ST);
+  return k_cconv_wgrad(x, dy1, pack_ws, bt, dW1, dWt, dbt, ws, B, v, ST);
+}
+int64_t nmh_cconv_dgrad_pack_numel(void) { return (int64_t)k_cconv_dpack_numel(); }
+int nmh_cconv_dgrad_pack(const void* Wcp, void* Wdp, void* stream) {
+  CLR();
+  REQ(Wcp, Wdp);
+  return k_cconv_dpack(Wcp, Wdp, ST);
+}
+int nmh_cconv_dgrad(const void* dy1, const void* Wdp, const void* add, void* dx, int B, int v, void* stream) {
+  CLR();
+  REQ(dy1, Wdp, dx);
+  if (B <= 0 || v <= 0) return 0;
+  return k_cconv_dgrad(dy1, Wdp, add, dx, B, v, ST);
 }
 int64_t nmh_upconv4_pack_numel(void) { return (int64_t)k_upconv4_pack_numel(); }
 int nmh_upconv4_pack(const float* pack_ws, void* Wup, void* stream) {

@@ -882,12 +882,83 @@ __global__ __launch_bounds__(256) void cconv_wgrad_chain_kernel(const float* __r
   }
 }
 
+// The transpose conv's OWN parameters through the composition (their gradient via u = ConvT(x) -> conv1, the part that used to need conv1's input
+// gradient on the fine grid):  dWt[ci][co][ph] += sum_{(a, d) : (a + d) mod 4 = ph} sum_c G[a][n(a, d)][ci][c] W1[c][co][d]   (27 pairs per phase),
+// dbt[co] += sum_p (conv1^T dy1)[p][co] = - sum_d sum_c W1[c][co][d] . (sum of dy1 over the border classes that tap d excludes)   (zero total sums, as above).
+// grid = 64 phases x 3 (d_z): 9 pairs each, the G block and W1T[d] staged in LDS.
+__global__ __launch_bounds__(256) void cconv_wgrad_chain_t_kernel(const float* __restrict__ G, const float* __restrict__ W1T, const float* __restrict__ Cb,
+                                                                  float* __restrict__ part, float* __restrict__ dbt) {
+  __shared__ float sg[96 * 49], sw[48 * 49], scb[27 * 48];
+  const int ph = blockIdx.x / 3, dz = (int)(blockIdx.x % 3) - 1, tid = threadIdx.x;
+  const int pz = ph >> 4, py = (ph >> 2) & 3, px = ph & 3;
+  if (ph == 0)
+    for (int i = tid; i < 27 * 48; i += 256) scb[i] = Cb[i];
+  float acc[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) acc[i] = 0.f;
+  float bacc = 0.f;
+  for (int dyx = 0; dyx < 9; ++dyx) {
+    const int dy = dyx / 3 - 1, dx = dyx % 3 - 1, d = ((dz + 1) * 3 + (dy + 1)) * 3 + (dx + 1);
+    const int az = (pz - dz) & 3, ay = (py - dy) & 3, ax = (px - dx) & 3;
+    const int tz = az + dz, ty = ay + dy, tx = ax + dx;
+    const int nz = tz < 0 ? -1 : (tz > 3 ? 1 : 0), ny = ty < 0 ? -1 : (ty > 3 ? 1 : 0), nxx = tx < 0 ? -1 : (tx > 3 ? 1 : 0);
+    int base = 0;
+    const int gi = az * 4 + ay;
+    for (int q = 0; q < gi; ++q) base += cc_ncnt(q >> 2) * cc_ncnt(q & 3);
+    const int izy = (nz - cc_nfirst(az)) * cc_ncnt(ay) + (ny - cc_nfirst(ay));
+    const int k6 = ax == 0 ? (nxx < 0 ? 0 : 1) : (ax == 3 ? (nxx > 0 ? 5 : 4) : ax + 1);
+    const float* gsrc = G + (long)((base + izy) * 6 + k6) * 4608;
+    const float* wsrc = W1T + (long)d * 2304;
+    __syncthreads();
+    for (int i = tid; i < 4608; i += 256) { const int r = i / 48, c = i - r * 48; sg[r * 49 + c] = gsrc[i]; }
+    for (int i = tid; i < 2304; i += 256) { const int r = i / 48, c = i - r * 48; sw[r * 49 + c] = wsrc[i]; }
+    __syncthreads();
+    // (c outermost, two at a time: fully unrolled the other way round the 18 x 48 products are all hoisted and spill -- measured 2.4 ms)
+#pragma unroll 2
+    for (int c = 0; c < 48; ++c) {
+#pragma unroll
+      for (int o = 0; o < 18; ++o) {
+        const int e = tid + 256 * o, ci = e / 48, co = e - ci * 48;
+        acc[o] += sg[ci * 49 + c] * sw[c * 49 + co];
+      }
+    }
+    if (ph == 0) {     // the bias (once per tap d: the phase-0 workgroups); the class sums sit in LDS
+      __syncthreads();
+      if (tid < 48) {    // sb[c] = sum of dy1 over the border classes that tap d excludes
+        float sb = 0.f;
+        for (int cls = 0; cls < 27; ++cls) {
+          const int kz = cls / 9, ky = (cls / 3) % 3, kx = cls % 3;
+          const bool excluded = (kz == 0 && dz < 0) || (kz == 2 && dz > 0) || (ky == 0 && dy < 0) || (ky == 2 && dy > 0) || (kx == 0 && dx < 0) || (kx == 2 && dx > 0);
+          if (excluded) sb += scb[cls * 48 + tid];
+        }
+        sg[tid] = sb;    // (the G block is done with)
+      }
+      __syncthreads();
+      if (tid < 48)
+        for (int c = 0; c < 48; ++c) bacc -= sw[c * 49 + tid] * sg[c];
+    }
+  }
+  // partial [workgroup][ci][co] (contiguous): the 192 workgroups walk the SAME elements in the same order -- atomics on dWt[e][ph] would all land on
+  // one 256-byte line at a time (measured 2.4 ms); the kernel below folds the three d_z parts into dWt
+#pragma unroll
+  for (int o = 0; o < 18; ++o) part[(long)blockIdx.x * 4608 + tid + 256 * o] = acc[o];
+  if (ph == 0 && tid < 48 && dbt) atomicAdd(dbt + tid, bacc);
+}
+
+__global__ __launch_bounds__(256) void cconv_wgrad_chain_t_reduce_kernel(const float* __restrict__ part, float* __restrict__ dWt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;      // dWt element (e, ph), ph fastest
+  if (i >= 4608 * 64) return;
+  const int e = i >> 6, ph = i & 63;
+  const float* p = part + (long)ph * 3 * 4608 + e;
+  dWt[i] += p[0] + p[4608] + p[2 * 4608];
+}
+
 long k_cconv_wgrad_ws_floats() { return 256L * (2 * 6 * 96 * 48) + 216L * 4608 + 27 * 48; }
 
 // dW1 [48][48][3][3][3] += conv1 weight gradient from x [B][v^3][96] and dy1 [B][(4v)^3][48]; WtT = first part of the pack workspace of
 // nmh_cconv_pack (the transpose-conv weight as [64 phases][96][48]); ws: k_cconv_wgrad_ws_floats() floats
 // (valid for a dy1 whose per-sample sums vanish: the gradient of an affine-free InstanceNorm's input, which is what conv1 feeds)
-int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* ws, int B, int v, hipStream_t st) {
+int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, hipStream_t st) {
   using namespace ccw;
   if (v % 8 || v > VMAX) return -2;
   CCWArgs a{};
@@ -945,6 +1016,230 @@ int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* 
   }
   NMH_CHECK_LAUNCH();
   hipLaunchKernelGGL(cconv_wgrad_chain_kernel, dim3(27 * 8), dim3(256), 0, st, (const float*)G, WtT, bt, (const float*)Cb, dW1);
+  NMH_CHECK_LAUNCH();
+  if (dWt) {   // the transpose conv's own weight / bias gradient through conv1 (W1T sits behind WtT in the pack workspace)
+    // (the per-slab partials at the head of ws are consumed: their space takes the 192 x 4608 partial sums)
+    hipLaunchKernelGGL(cconv_wgrad_chain_t_kernel, dim3(64 * 3), dim3(256), 0, st, (const float*)G, WtT + CC_WTT, (const float*)Cb, ws, dbt);
+    NMH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cconv_wgrad_chain_t_reduce_kernel, dim3(4608 * 64 / 256), dim3(256), 0, st, (const float*)ws, dWt);
+    NMH_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ================================================================================================
+// Input gradient THROUGH the composition: dx = ConvT^T(conv1^T(dy1)) is a stride-4 convolution of the fine gradient with a 6x6x6 kernel of 48 -> 96
+// matrices,   dx[j][ci] = sum_{p in [0,6)^3} sum_c dy1[4j - 1 + p][c] Wd[p][c][ci],   Wd[p] = Wc[a(p)][n(p)]^T  (p = 0: (a, n) = (3, +1); 1..4: (p - 1, 0);
+// 5: (0, -1) per axis): the same 216 blocks as the forward, the same 31 kFLOP per fine voxel instead of 133 -- and conv1's input gradient on the
+// fine grid (a full 48 -> 48 conv48 pass that only fed the transpose conv's backward) is never formed.
+// Kernel = the forward mirrored: persistent 512-thread workgroup per block of 4x8x8 coarse cells, wave = 32 cells with 6 x 2 accumulator tiles
+// (96 channels), the 2 MB of weights through the same 4-slot LDS-DMA ring (108 chunks of 18 fragments = (fine line offset p_z, p_y; three
+// k-steps)); the contraction operand of a cell is 576 CONTIGUOUS bytes of a fine line (voxels 4x - 1 .. 4x + 4, 9 k-steps) and is read straight
+// from global memory into a 4-chunk register ring, three chunks ahead of the MFMAs.
+// ================================================================================================
+constexpr long CD_NUMEL = 36L * 54 * 512;     // + 64 zero elements behind them
+struct CDArgs { const bf16_t* dY; const bf16_t* Wdp; const bf16_t* add; bf16_t* DX; int B, v, nbz, nby, nbx; long total; };
+
+__global__ __launch_bounds__(512) void cconv_dgrad_kernel(CDArgs a) {
+  using namespace cc;
+  constexpr int NSLOT = 8, LEAD = 7;     // weight ring: 8 slots of half a chunk, seven half-chunks (3.5 chunks) ahead -- further than the operand ring below,
+                                         // because vector-memory operations retire in order: waiting for a weight piece waits for every older operand load
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wbuf = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int V = a.v, F = 4 * a.v;
+  const int nx8 = 8, xcd = blockIdx.x % nx8, jb = blockIdx.x / nx8, jstride = gridDim.x / nx8;
+  const long per = (a.total + nx8 - 1) / nx8;
+  const long tbeg = (long)xcd * per, tend = (tbeg + per < a.total) ? tbeg + per : a.total;
+  auto w_dma = [&](int h, int slot) {
+    const char* src = reinterpret_cast<const char*>(a.Wdp) + (long)h * WHALF;
+    char* dst = wbuf + slot * WHALF;
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wave * 1024 + lv * 16),
+                                     (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, 0, 0);
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * 1024 + lv * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + 8 * 1024), 16, 0, 0);
+  };
+  const int z_l = wave >> 1, y_l = (wave & 1) * 4, ly = li >> 3, lx = li & 7;
+  const long zoff = (a.Wdp + CD_NUMEL + 8 * g) - a.dY;      // the zero line, as an element offset from dY
+  long t = tbeg + jb;
+  if (t >= tend) return;
+#pragma unroll
+  for (int h0 = 0; h0 < LEAD; ++h0) w_dma(h0, h0);
+  // block origin -> this lane's cell (z, y of column tile 0, x) and sample
+  struct Org { int b, zc, yc0, xc; };
+  auto origin = [&](long tt) {
+    const unsigned tu = (unsigned)tt;
+    unsigned r1 = tu / (unsigned)a.nbx; const int xb = (int)(tu - r1 * (unsigned)a.nbx);
+    unsigned r2 = r1 / (unsigned)a.nby; const int yb = (int)(r1 - r2 * (unsigned)a.nby);
+    unsigned r3 = r2 / (unsigned)a.nbz; const int zb = (int)(r2 - r3 * (unsigned)a.nbz);
+    Org o;
+    o.b = __builtin_amdgcn_readfirstlane((int)r3);
+    o.zc = __builtin_amdgcn_readfirstlane(zb * BZ) + z_l;
+    o.yc0 = yb * BY + y_l + ly;
+    o.xc = xb * BX + lx;
+    return o;
+  };
+  // the operand stream runs three chunks ahead of the MFMAs and straight on into the next block of this workgroup (when there is none: into the
+  // same block again -- valid addresses, values unused), so that every half-iteration issues exactly three operand loads: the counted waits rely on it
+  long tp = t;
+  Org po = origin(tp);
+  int ppz = 0, ppy = 0, ps = 0;
+  Frag<bf16_t> xr[4][3][2];
+  // chunk (p_z, p_y, s) of column tile m -> ring slot: the lane's three 16-byte pieces (k-steps 3 s .. 3 s + 2, k-group g) of the 576-byte window
+  auto ld = [&](Frag<bf16_t> (&dst)[3][2], int m) {
+    const int fz = 4 * po.zc - 1 + ppz, fy = 4 * (po.yc0 + 2 * m) - 1 + ppy, vx0 = 4 * po.xc - 1;
+    const bool line_ok = (unsigned)fz < (unsigned)F && (unsigned)fy < (unsigned)F;
+    const long lo = (long)po.b * F * F * F * 48 + (((long)fz * F + fy) * F + vx0) * 48 + 8 * g;
+#pragma unroll
+    for (int kl = 0; kl < 3; ++kl) {
+      const int kk = 3 * ps + kl, px = ((4 * kk + g) * 43) >> 8;      // (4 kk + g) / 6: the window voxel this piece lies in
+      const bool ok = line_ok && (unsigned)(vx0 + px) < (unsigned)F;
+      // always ONE load per piece: pieces outside the volume read the zero line behind the packed weights
+      // raw loads: the waits are the counted ones in the main loop (left to the compiler, two of the eight half-iterations get `s_waitcnt vmcnt(0)`
+      // in front of their first MFMA -- a full memory round trip -- and the address select becomes branches around merged loads)
+      const bf16_t* src = a.dY + (ok ? lo + 32 * kk : zoff);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[kl][m].v) : "v"(src));
+    }
+  };
+  auto advance = [&]() {
+    if (++ps == 3) {
+      ps = 0;
+      if (++ppy == 6) {
+        ppy = 0;
+        if (++ppz == 6) {
+          ppz = 0;
+          tp = tp + jstride < tend ? tp + jstride : tp;
+          po = origin(tp);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    ld(xr[u], 0); ld(xr[u], 1);
+    advance();
+  }
+  for (; t < tend; t += jstride) {
+    const Org o = origin(t);
+    f32x4 acc[6][2];
+#pragma unroll
+    for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[tt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int h = 0;
+#pragma unroll 1
+    for (int it = 0; it < 27; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          // In-order retirement: half-chunk h of the weights has landed once at most the operations issued behind it are outstanding -- six younger
+          // half-chunks (6 P pieces, P = 2 for wave 0) and the three operand loads of each of the last seven half-iterations: 6 P + 21; the operand
+          // pieces of this chunk (issued three chunks ago, the last of them five half-iterations back) once at most 4 (P + 3) are: the stricter
+          // count in front of a chunk's first half
+          if (half == 0) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+          } else {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(33) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(27) lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_s_barrier();
+          {
+            const int hn = h + LEAD >= NHALF ? h + LEAD - NHALF : h + LEAD;
+            w_dma(hn, (2 * u + half + LEAD) & (NSLOT - 1));
+          }
+          ld(xr[(u + 3) & 3], half);
+          const char* wsrc = wbuf + ((2 * u + half) & (NSLOT - 1)) * WHALF + lane * 16;
+          Frag<bf16_t> wf[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) wf[i].v = *reinterpret_cast<const bf16x8*>(wsrc + i * 1024);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const int f = 9 * half + i, kl = f / 6, tt = f - kl * 6;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) mma(acc[tt][m], wf[i], xr[u][kl][m]);
+          }
+          ++h;
+        }
+        advance();
+      }
+    }
+    // ---- dx of the block: lane (cell li, g) holds channels 24 g .. 24 g + 23 (row 4 g + r of tile tt <-> channel 24 g + 4 tt + r)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const long cell = (((long)o.b * V + o.zc) * V + o.yc0 + 2 * m) * V + o.xc;
+      float vv[24];
+#pragma unroll
+      for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[4 * tt + r] = acc[tt][m][r];
+      if (a.add) {
+        const bf16_t* ap = a.add + cell * 96 + 24 * g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          float v8[8];
+          Vec8<bf16_t>::load(ap + 8 * q, v8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vv[8 * q + j] += v8[j];
+        }
+      }
+      bf16_t* dp = a.DX + cell * 96 + 24 * g;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        *reinterpret_cast<uint4*>(dp + 8 * q) = make_uint4(pk_bf16(vv[8 * q], vv[8 * q + 1]), pk_bf16(vv[8 * q + 2], vv[8 * q + 3]),
+                                                           pk_bf16(vv[8 * q + 4], vv[8 * q + 5]), pk_bf16(vv[8 * q + 6], vv[8 * q + 7]));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// Wdp bf16 [36 (p_z, p_y)][9 k-steps][6 channel tiles][64 lanes][8] from the forward's fragment-ordered composed weights (a gather: the two passes
+// use the same bf16 values)
+__global__ __launch_bounds__(512) void cconv_dpack_kernel(const bf16_t* __restrict__ Wcp, bf16_t* __restrict__ Wdp) {
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const int combo = blk / 54, f = blk - combo * 54, kk = f / 6, tt = f - kk * 6, pz = combo / 6, py = combo - pz * 6;
+  const int lane = tid >> 3, j = tid & 7, li = lane & 15, g = lane >> 4;
+  const int ci = 24 * (li >> 2) + 4 * tt + (li & 3), kap = 32 * kk + 8 * g + j, px = kap / 48, c = kap - px * 48;
+  auto an = [](int p, int& aa, int& nn) { if (p == 0) { aa = 3; nn = 1; } else if (p == 5) { aa = 0; nn = -1; } else { aa = p - 1; nn = 0; } };
+  int az, nz, ay, ny, ax, nx;
+  an(pz, az, nz); an(py, ay, ny); an(px, ax, nx);
+  int base = 0;
+  const int gi = az * 4 + ay;
+  for (int q = 0; q < gi; ++q) base += cc_ncnt(q >> 2) * cc_ncnt(q & 3);
+  const int izy = (nz - cc_nfirst(az)) * cc_ncnt(ay) + (ny - cc_nfirst(ay));
+  const int k6 = ax == 0 ? (nx < 0 ? 0 : 1) : (ax == 3 ? (nx > 0 ? 5 : 4) : ax + 1);
+  const int s = ci >> 5, gf = (ci & 31) >> 3, jf = ci & 7, nt = (c % 12) >> 2, lif = 4 * (c / 12) + (c & 3);
+  const long src = ((((long)(base + izy) * 3 + s) * 18 + k6 * 3 + nt) * 64 + 16 * gf + lif) * 8 + jf;
+  Wdp[((long)blk * 64 + lane) * 8 + j] = Wcp[src];
+  if (blk == 0 && tid < 64) Wdp[CD_NUMEL + tid] = f2bf(0.f);
+}
+
+long k_cconv_dpack_numel() { return CD_NUMEL + 64; }
+
+int k_cconv_dpack(const void* Wcp, void* Wdp, hipStream_t st) {
+  hipLaunchKernelGGL(cconv_dpack_kernel, dim3(36 * 54), dim3(512), 0, st, (const bf16_t*)Wcp, (bf16_t*)Wdp);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// dx [B][v^3][96] = (add ? add : 0) + the composed input gradient of dy1 [B][(4v)^3][48]; add may alias dx
+int k_cconv_dgrad(const void* dY, const void* Wdp, const void* add, void* DX, int B, int v, hipStream_t st) {
+  using namespace cc;
+  if (v % BY || v % BX || v % BZ) return -2;
+  CDArgs a;
+  a.dY = (const bf16_t*)dY; a.Wdp = (const bf16_t*)Wdp; a.add = (const bf16_t*)add; a.DX = (bf16_t*)DX;
+  a.B = B; a.v = v; a.nbz = v / BZ; a.nby = v / BY; a.nbx = v / BX;
+  a.total = (long)B * a.nbz * a.nby * a.nbx;
+  if (a.total >= (1L << 31) || (long)B * 64 * v * v * v * 48 >= (1L << 40)) return -2;
+  long nb = a.total < 256 ? a.total : 256;
+  nb = nb / 8 * 8;
+  if (nb < 8) nb = 8;
+  hipLaunchKernelGGL(cconv_dgrad_kernel, dim3((unsigned)nb), dim3(512), 8 * WHALF, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -164,10 +164,12 @@ class _Packer:
             if sp < n:
                 ops.pack_weights(self.dt, self.descs, self.blk2desc[sp:], self.blkstart[sp:], n - sp)
             if self.cconv is not None:    # decoder1: ConvTranspose o conv1 composed weights (csrc/cconv.hip), from the fp32 masters
-                up, Wcp, delta, ws, Wup = self.cconv
+                up, Wcp, delta, ws, Wup, Wdp = self.cconv
                 ops.cconv_pack(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws)
                 if Wup is not None:
                     ops.upconv4_pack(ws, Wup)
+                if Wdp is not None:
+                    ops.cconv_dgrad_pack(Wcp, Wdp)
 
     @staticmethod
     def join():
@@ -522,9 +524,14 @@ class _UpBlockFn(torch.autograd.Function):
         ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
-        conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
+        # decoder1 with the composed kernels: conv1's input gradient on the fine grid is never formed -- dx and the transpose conv's parameter gradients
+        # take their conv1 part through the composition (cconv_dgrad below, cconv_wgrad's G blocks), dcat keeps the residual branch's gradient alone
+        cdg = ctx.cc and pk.cconv[5] is not None
+        if not cdg:
+            conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
         if ctx.cc:   # decoder1: conv1's weight gradient through the composition (a quarter of the FLOPs, contraction over the coarse cells; csrc/cconv.hip)
-            ops.cconv_wgrad(x.view(B, v, v, v, Cin), dy1.view(B, S, S, S, Cout), pk.cconv[3], m.transp_conv.bias, g_c1, B, v)
+            ops.cconv_wgrad(x.view(B, v, v, v, Cin), dy1.view(B, S, S, S, Cout), pk.cconv[3], m.transp_conv.bias, g_c1, B, v,
+                            dWt=_gradbuf(m.transp_conv.weight) if cdg else None, dbt=_gradbuf(m.transp_conv.bias) if cdg else None)
         else:
             side(lambda: wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), g_c1))
         if m.has_proj:
@@ -541,6 +548,8 @@ class _UpBlockFn(torch.autograd.Function):
             ops.copy_cols(dcat[:, Cout:], dskip)
         dx = torch.empty((B * v ** 3, Cin), dtype=dtype, device=dev)
         ops.upconv_dgrad(dcat, pk[key + "t.wd"].view(Cin, k3 * Cout), dx, B, v, k, Cin, Cout)   # reads dcat through the pixel shuffle
+        if cdg:
+            ops.cconv_dgrad(dy1, pk.cconv[5], B, v, add=dx, out=dx)
         g_tw, g_tb = _gradbuf(m.transp_conv.weight), _gradbuf(m.transp_conv.bias)
         if defer or (ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None):
             m._wq.defer(lambda: ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout))
@@ -829,7 +838,8 @@ class SwinTransformer_MAE3D_New(nn.Module):
                 and (self.resolution // 4) % 8 == 0):
             P.cconv = (d1, torch.empty(ops.cconv_pack_numel(), dtype=torch.bfloat16, device=device), torch.empty((27, 48), device=device),
                        torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device=device),
-                       torch.empty(ops.upconv4_pack_numel(), dtype=torch.bfloat16, device=device) if ops.UPCONV4 else None)
+                       torch.empty(ops.upconv4_pack_numel(), dtype=torch.bfloat16, device=device) if ops.UPCONV4 else None,
+                       torch.empty(ops.cconv_dgrad_pack_numel(), dtype=torch.bfloat16, device=device) if (ops.CCONV_DGRAD and ops.CCONV_WGRAD) else None)
         self._packer = P
         self._pk = P
         self._wq = ops.WgradQueue()   # deferred encoder weight gradients (grouped launches, issued per stage)

@@ -303,6 +303,37 @@ def cconv_fwd(x, Wcp, delta, B, v, out=None, stats_acc=None):
     return out
 
 
+CCONV_DGRAD = __import__("os").environ.get("NMH_CCONV_DGRAD", "1") != "0"   # decoder1: input gradient through the composition (with NMH_CCONV_WGRAD)
+
+
+def cconv_dgrad_pack_numel() -> int:
+    return int(lib().call("nmh_cconv_dgrad_pack_numel"))
+
+
+def cconv_dgrad_pack(Wcp, Wdp):
+    """the composed weights in the input-gradient kernel's fragment order, gathered from the forward's (include/nerfmae_hip.h: nmh_cconv_dgrad_pack)"""
+    _chk(Wcp, Wdp)
+    if Wdp.numel() < cconv_dgrad_pack_numel() or Wdp.dtype != torch.bfloat16 or Wcp.numel() < cconv_pack_numel():
+        raise ValueError("cconv_dgrad_pack: shapes")
+    lib().call("nmh_cconv_dgrad_pack", Wcp, Wdp, _st())
+
+
+def cconv_dgrad(dy1, Wdp, B, v, add=None, out=None):
+    """dx [B,v^3,96] = (add or 0) + ConvT^T(conv1^T(dy1 [B,(4v)^3,48])) (include/nerfmae_hip.h: nmh_cconv_dgrad); add may be out"""
+    _chk(dy1, Wdp, add, out)
+    if dy1.dtype != torch.bfloat16 or v % 8 or dy1.numel() != B * (4 * v) ** 3 * 48:
+        raise RuntimeError("cconv_dgrad needs a bf16 gradient with 48 channels on a fine grid whose edge is a multiple of 32")
+    if out is None:
+        out = torch.empty((B * v ** 3, 96), dtype=dy1.dtype, device=dy1.device)
+    if out.numel() != B * v ** 3 * 96 or (add is not None and (add.numel() != out.numel() or add.dtype != out.dtype)):
+        raise ValueError("cconv_dgrad: shapes")
+    ev = _prof(("cconv_dgrad", B, 4 * v, 48, 96))
+    lib().call("nmh_cconv_dgrad", dy1, Wdp, add, out, B, v, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 UPCONV4 = __import__("os").environ.get("NMH_UPCONV4", "1") != "0"   # decoder1's transpose conv as the persistent kernel of csrc/cconv.hip (with NMH_CCONV)
 
 
@@ -334,17 +365,20 @@ CCONV_WGRAD = __import__("os").environ.get("NMH_CCONV_WGRAD", "1") != "0"   # co
 _CCW_WS = {}
 
 
-def cconv_wgrad(x, dy1, pack_ws, bt, dW1, B, v):
+def cconv_wgrad(x, dy1, pack_ws, bt, dW1, B, v, dWt=None, dbt=None):
     """conv1.weight gradient [48,48,3,3,3] += through the composed ConvTranspose o conv (include/nerfmae_hip.h: nmh_cconv_wgrad); dy1 must be the
-    input gradient of the affine-free InstanceNorm behind conv1 (zero per-sample sums)"""
-    _chk(x, dy1, pack_ws, bt, dW1)
+    input gradient of the affine-free InstanceNorm behind conv1 (zero per-sample sums).  dWt [96,48,4,4,4] / dbt [48] (fp32, optional): += the
+    transpose conv's own parameter gradients through conv1 (used with cconv_dgrad, when conv1's input gradient on the fine grid is not formed)"""
+    _chk(x, dy1, pack_ws, bt, dW1, dWt, dbt)
+    if (dWt is None) != (dbt is None) or (dWt is not None and (dWt.numel() != 96 * 48 * 64 or dbt.numel() != 48)):
+        raise ValueError("cconv_wgrad: dWt / dbt")
     if x.dtype != torch.bfloat16 or dy1.dtype != torch.bfloat16 or v % 8 or v > 40:
         raise RuntimeError("cconv_wgrad needs bf16 operands on a coarse grid whose edge is a multiple of 8 (<= 40)")
     key = (x.device.index, torch.cuda.current_stream().cuda_stream)
     if key not in _CCW_WS:
         _CCW_WS[key] = torch.empty(int(lib().call("nmh_cconv_wgrad_ws_floats")), dtype=torch.float32, device=x.device)
     ev = _prof(("cconv_wgrad", B, 4 * v, 96, 48))
-    lib().call("nmh_cconv_wgrad", x, dy1, pack_ws, bt, dW1, _CCW_WS[key], B, v, _st())
+    lib().call("nmh_cconv_wgrad", x, dy1, pack_ws, bt, dW1, dWt, dbt, _CCW_WS[key], B, v, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return dW1

@@ -1048,7 +1048,8 @@ def test_cconv_wgrad_matches_autograd_of_the_two_ops(B, v):
     (F.instance_norm(y_lin) * gup).sum().backward()
     dy = q(y_lin.grad, dt)                                    # (B,48,F,F,F)
     W1r = W1.clone().requires_grad_(True)
-    u = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), Wt, bt, stride=4)
+    Wtr, btr = Wt.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    u = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), Wtr, btr, stride=4)
     (F.conv3d(u, W1r, None, padding=1) * dy).sum().backward()
     # HIP: pack (fills the workspace with the transposed Wt), then the composed weight gradient
     Wcp = torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda")
@@ -1068,3 +1069,53 @@ def test_cconv_wgrad_matches_autograd_of_the_two_ops(B, v):
     dW2 = torch.zeros(48, 48, 3, 3, 3, device="cuda")
     ops.conv3d_k3_c48_wgrad(dy_cl, cat.view(B, Fv, Fv, Fv, 48), dW2)
     assert_close(dW.float().cpu() / 2, dW2.float().cpu(), 2e-2, "cconv wgrad vs two-step HIP weight gradient")
+    # the transpose conv's own parameter gradients through conv1, from the same G blocks (what cconv_dgrad's callers need: conv1's input
+    # gradient on the fine grid is not formed there); += contract checked by the pre-filled buffers
+    dW3 = torch.zeros(48, 48, 3, 3, 3, device="cuda")
+    dWt = torch.full((96, 48, 4, 4, 4), 0.25, device="cuda")
+    dbt = torch.full((48,), -0.5, device="cuda")
+    ops.cconv_wgrad(dev(x, dt), dy_cl, pws, dev(bt), dW3, B, v, dWt=dWt, dbt=dbt)
+    check(dW3, W1r.grad, dt, "cconv wgrad (with dWt)", 2)
+    check(dWt - 0.25, Wtr.grad, dt, f"transpose conv weight gradient through the composition B={B} v={v}", 2)
+    check(dbt + 0.5, btr.grad, dt, "transpose conv bias gradient through the composition (border classes)", 3)
+
+
+@pytest.mark.parametrize("B,v", [(1, 8), (2, 8), (1, 16), (3, 24), (2, 40)])
+def test_cconv_dgrad_matches_autograd_of_the_two_ops(B, v):
+    """input gradient through the composition (csrc/cconv.hip cconv_dgrad: a stride-4 convolution of dy1 with the 6^3 kernel of transposed composed
+    blocks) against autograd of conv3d(conv_transpose3d(x)) in fp32, with and without the pre-existing dx of the residual branch, and against the
+    two-step HIP path (48 -> 48 LDS-halo input gradient on the fine grid, then the transpose conv's)"""
+    ops = _ops()
+    dt = torch.bfloat16
+    Fv = 4 * v
+    Wt = rnd(96, 48, 4, 4, 4, seed=2, scale=96 ** -0.5)
+    W1 = rnd(48, 48, 3, 3, 3, seed=3, scale=(27 * 48) ** -0.5)
+    bt = rnd(48, seed=4, scale=0.5)
+    dy = q(rnd(B, Fv, Fv, Fv, 48, seed=6), dt)
+    xr = torch.zeros(B, 96, v, v, v, requires_grad=True)
+    (F.conv3d(F.conv_transpose3d(xr, Wt, bt, stride=4), W1, None, padding=1) * dy.permute(0, 4, 1, 2, 3)).sum().backward()
+    ref = xr.grad.permute(0, 2, 3, 4, 1).reshape(-1, 96)
+    Wcp = torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda")
+    delta = torch.empty(27, 48, device="cuda")
+    ops.cconv_pack(dev(Wt), dev(W1), dev(bt), Wcp, delta)
+    Wdp = torch.empty(ops.cconv_dgrad_pack_numel(), dtype=dt, device="cuda")
+    ops.cconv_dgrad_pack(Wcp, Wdp)
+    dy_d = dev(dy, dt)
+    dx = ops.cconv_dgrad(dy_d, Wdp, B, v)
+    torch.cuda.synchronize()
+    check(dx, ref, dt, f"cconv dgrad B={B} v={v}")
+    # border cells on their own (zero padding of the fine grid = missing window voxels)
+    d5, r5 = dx.view(B, v, v, v, 96), ref.view(B, v, v, v, 96)
+    for sl in ((slice(None), 0), (slice(None), v - 1), (slice(None), slice(None), 0), (slice(None), slice(None), slice(None), v - 1)):
+        check(d5[sl], r5[sl], dt, "cconv dgrad border face")
+    add = q(rnd(B * v ** 3, 96, seed=7), dt)
+    buf = dev(add, dt).clone()
+    ops.cconv_dgrad(dy_d, Wdp, B, v, add=buf, out=buf)           # in place: the residual branch's dx is already there
+    check(buf, ref + add, dt, "cconv dgrad added to an existing dx")
+    # two-step HIP path
+    wkd = _pack_via_kernel(W1, 7, dt, 41 * 3 * 64 * 8)
+    dcat = ops.conv3d_k3_c48(dy_d.view(B, Fv, Fv, Fv, 48), wkd)
+    wtd = _pack_via_kernel(Wt, 5, dt, Wt.numel())
+    dx2 = torch.empty(B * v ** 3, 96, dtype=dt, device="cuda")
+    ops.upconv_dgrad(dcat.view(-1, 48), wtd.view(96, 64 * 48), dx2, B, v, 4, 96, 48)
+    assert_close(dx.float().cpu(), dx2.float().cpu(), 2e-2, "cconv dgrad vs two-step HIP input gradient", elem_mult=2.0)

@@ -41,6 +41,13 @@ for B in [int(v) for v in sys.argv[1:]] or [8, 1]:
     t_cw = bench(lambda: ops.cconv_wgrad(x, dy, pws, bt, dW, B, v))
     t_w48 = bench(lambda: ops.conv3d_k3_c48_wgrad(dy, u, dW))
     print(f"B={B}: cconv_wgrad {t_cw:.3f} ms   conv48_wgrad {t_w48:.3f} ms", flush=True)
+    Wdp = torch.empty(ops.cconv_dgrad_pack_numel(), dtype=torch.bfloat16, device="cuda")
+    t_dp = bench(lambda: ops.cconv_dgrad_pack(Wcp, Wdp))
+    dxb = torch.empty(B * v ** 3, 96, dtype=torch.bfloat16, device="cuda")
+    t_dg = bench(lambda: ops.cconv_dgrad(dy.view(-1, 48), Wdp, B, v, out=dxb))
+    wkd = _pack_via_kernel(W1.cpu(), 7, torch.bfloat16, 41 * 3 * 64 * 8)
+    t_d48 = bench(lambda: ops.conv3d_k3_c48(dy, wkd, out=y))
+    print(f"B={B}: cconv_dgrad {t_dg:.3f} ms ({2.0 * 216 * 96 * 48 * v ** 3 * B / t_dg / 1e9:.0f} TFLOP/s of composed work)   conv48 input gradient {t_d48:.3f} ms   dgrad pack {t_dp * 1e3:.0f} us", flush=True)
     Wup = torch.empty(ops.upconv4_pack_numel(), dtype=torch.bfloat16, device="cuda")
     ops.upconv4_pack(pws, Wup)
     cat = torch.empty(B * 160 ** 3, 48, dtype=torch.bfloat16, device="cuda")
