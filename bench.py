@@ -489,20 +489,27 @@ def roofline_families(trace, cfg, R, Bg):
         v *= k
     conv1 = 2.0 * 27 * E2 * E2 * R ** 3
     has_cc = any("cconv_fwd_kernel" in k[0] for k in trace["kernels"])
+    has_cw = any("cconv_wgrad_kernel" in k[0] for k in trace["kernels"])
+    has_cd = any("cconv_dgrad_kernel" in k[0] for k in trace["kernels"])
+    composed = "(executes 216*96*48*2 FLOP per coarse cell -- a quarter of the reference's algorithmic FLOPs, which are what is counted here)"
     fam = [
-        ("decoder1 conv1 forward as ConvTranspose o conv composed on the coarse grid (cconv_fwd_kernel: executes 216*96*48*2 FLOP per coarse cell, "
-         "a quarter of the reference's algorithmic FLOPs counted here)", r"cconv_fwd_kernel", conv1 if has_cc else None),
-        ("conv %d->%d 3x3x3 @%d^3 fwd+dgrad (conv48_kernel<0,false> / conv64_kernel)" % (E2, E2, R), r"conv48_kernel<0, false>|conv64_kernel", (3 if has_cc else 4) * conv1),
-        ("conv %d->%d 3x3x3 @%d^3 weight gradient (conv48_wgrad_kernel, persistent launches)" % (E2, E2, R), r"conv48_wgrad_kernel|conv64_wgrad_kernel", 2 * conv1),
+        ("decoder1 conv1 forward as ConvTranspose o conv composed on the coarse grid: cconv_fwd_kernel " + composed, r"cconv_fwd_kernel", conv1 if has_cc else None),
+        ("decoder1 conv1 input gradient through the composition: cconv_dgrad_kernel " + composed, r"cconv_dgrad_kernel", conv1 if has_cd else None),
+        ("decoder1 conv1 weight gradient through the composition: cconv_wgrad_kernel + reduce / border sums / chain rule to conv1 and the transpose conv "
+         + composed, r"cconv_wgrad|cconv_dy_border", conv1 if has_cw else None),
+        ("conv %d->%d 3x3x3 @%d^3 fwd+dgrad (conv48_kernel<0,false> / conv64_kernel)" % (E2, E2, R), r"conv48_kernel<0, false>|conv64_kernel",
+         (4 - int(has_cc) - int(has_cd)) * conv1),
+        ("conv %d->%d 3x3x3 @%d^3 weight gradient (conv48_wgrad_kernel, persistent launches)" % (E2, E2, R), r"conv48_wgrad_kernel|conv64_wgrad_kernel",
+         (1 if has_cw else 2) * conv1),
         ("decoder convs at the 10^3..40^3 levels, fwd+dgrad+wgrad (conv48_kernel<0,true>, AConv3, BConv3TN, small conv48_wgrad launches)",
          r"conv48_kernel<0, true>|AConv3|BConv3TN|conv48_wgrad_reduce", 3 * conv_small),
-        ("encoder Linear / patch-embed / merge / transpose-conv / 1x1 GEMMs fwd+dgrad (gemm_nt*, fused MLP)", r"gemm_nt|mlp96_|mlp_fwd_kernel|mlp_bwd_kernel|nt_ksplit",
+        ("encoder Linear / patch-embed / merge / transpose-conv / 1x1 GEMMs fwd+dgrad (gemm_nt*, fused MLP)", r"gemm_nt|mlp96_|mlp_fwd_kernel|mlp_bwd_kernel|nt_ksplit|upconv4_fwd",
          2 * (lin + merge + up + c3) + embed),
         ("encoder + transpose-conv weight gradients (gemm_tn_grouped, gemm_tn)", r"gemm_tn", lin + merge + embed + up + c3),
         ("window attention core fwd+bwd (attn_fwd / attn_bwd)", r"attn_", 3.5 * attn),
         ("LayerNorm fwd+bwd", r"ln_fwd|ln_bwd", None),
         ("decoder-1 elementwise passes @%d^3 (tail fwd/bwd, InstanceNorm apply / reduce / backward)" % R, r"tail_|in_apply|in_bwd_apply|in_reduce|in_finalize", None),
-        ("weight pack (incl. the composed decoder1 weights) + grad norm + AdamW", r"pack_kernel|cconv_tr_kernel|adamw|sqnorm|clip_coef", None),
+        ("weight pack (incl. the composed decoder1 weights) + grad norm + AdamW", r"pack_kernel|cconv_tr_kernel|cconv_dpack|upconv4_pack|adamw|sqnorm|clip_coef", None),
     ]
     used, out = set(), []
     ks = trace["kernels"]

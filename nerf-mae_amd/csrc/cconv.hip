@@ -1037,13 +1037,27 @@ int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* 
 // k-steps)); the contraction operand of a cell is 576 CONTIGUOUS bytes of a fine line (voxels 4x - 1 .. 4x + 4, 9 k-steps) and is read straight
 // from global memory into a 4-chunk register ring, three chunks ahead of the MFMAs.
 // ================================================================================================
+#ifndef CD_RING
+#define CD_RING 4
+#endif
 constexpr long CD_NUMEL = 36L * 54 * 512;     // + 64 zero elements behind them
+// Order of the 36 fine-line offsets (p_z, p_y): a fine line 4z + 3 is offset 4 of cell z and offset 0 of cell z + 1 (4z + 4: offsets 5 and 1), likewise in
+// y -- both readers sit in neighbouring waves / lanes of the same workgroup.  Walking the offsets as {0,4},{1,5},{2},{3} x {0,4},{1,5},{2},{3} puts the
+// two reads of such a line at most three steps apart (they hit in L2 / the memory-side cache) instead of two thirds of a block apart (HBM twice).
+__device__ constexpr unsigned char CD_ORDER[36] = {
+    0 * 6 + 0, 0 * 6 + 4, 4 * 6 + 0, 4 * 6 + 4, 0 * 6 + 1, 0 * 6 + 5, 4 * 6 + 1, 4 * 6 + 5, 0 * 6 + 2, 4 * 6 + 2, 0 * 6 + 3, 4 * 6 + 3,
+    1 * 6 + 0, 1 * 6 + 4, 5 * 6 + 0, 5 * 6 + 4, 1 * 6 + 1, 1 * 6 + 5, 5 * 6 + 1, 5 * 6 + 5, 1 * 6 + 2, 5 * 6 + 2, 1 * 6 + 3, 5 * 6 + 3,
+    2 * 6 + 0, 2 * 6 + 4, 2 * 6 + 1, 2 * 6 + 5, 2 * 6 + 2, 2 * 6 + 3,
+    3 * 6 + 0, 3 * 6 + 4, 3 * 6 + 1, 3 * 6 + 5, 3 * 6 + 2, 3 * 6 + 3};
 struct CDArgs { const bf16_t* dY; const bf16_t* Wdp; const bf16_t* add; bf16_t* DX; int B, v, nbz, nby, nbx; long total; };
 
 __global__ __launch_bounds__(512) void cconv_dgrad_kernel(CDArgs a) {
   using namespace cc;
-  constexpr int NSLOT = 8, LEAD = 7;     // weight ring: 8 slots of half a chunk, seven half-chunks (3.5 chunks) ahead -- further than the operand ring below,
-                                         // because vector-memory operations retire in order: waiting for a weight piece waits for every older operand load
+  // operand ring: RING chunks of registers, RING - 1 chunks (2 RING - 2 half-iterations) ahead of the MFMAs; weight ring: NSLOT slots of half a chunk,
+  // LEAD half-chunks ahead -- further than the operand ring, because vector-memory operations retire in order: waiting for a weight piece waits for
+  // every older operand load.  The eight waves run in lockstep (a barrier per half-chunk): every operand load of every wave has to be on time.
+  constexpr int RING = CD_RING, NSLOT = 2 * RING, LEAD = 2 * RING - 1;
+  static_assert(108 % RING == 0 && NSLOT * cc::WHALF <= 160 * 1024 && 5 * LEAD - 2 <= 63, "ring geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
@@ -1058,12 +1072,13 @@ __global__ __launch_bounds__(512) void cconv_dgrad_kernel(CDArgs a) {
     asm volatile("" : "+v"(lv));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + wave * 1024 + lv * 16),
                                      (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, 0, 0);
-    if (wave == 0)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * 1024 + lv * 16),
-                                       (__attribute__((address_space(3))) void*)(dst + 8 * 1024), 16, 0, 0);
+    // the ninth image in eight 128-byte slices, one per wave (8 active lanes): every wave issues exactly two pieces per half-chunk, so the counted
+    // waits below need no per-wave branch (with one, the register operands tied to the wait are copied around it -- before their data has landed)
+    if (lane < 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 8 * 1024 + wave * 128 + lv * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + 8 * 1024 + wave * 128), 16, 0, 0);
   };
   const int z_l = wave >> 1, y_l = (wave & 1) * 4, ly = li >> 3, lx = li & 7;
-  const long zoff = (a.Wdp + CD_NUMEL + 8 * g) - a.dY;      // the zero line, as an element offset from dY
   long t = tbeg + jb;
   if (t >= tend) return;
 #pragma unroll
@@ -1086,42 +1101,78 @@ __global__ __launch_bounds__(512) void cconv_dgrad_kernel(CDArgs a) {
   // same block again -- valid addresses, values unused), so that every half-iteration issues exactly three operand loads: the counted waits rely on it
   long tp = t;
   Org po = origin(tp);
-  int ppz = 0, ppy = 0, ps = 0;
-  Frag<bf16_t> xr[4][3][2];
+  int gz = 0, gy = 0, iz = 0, iy = 0, ppz = 0, ppy = 0, ps = 0;     // CD_ORDER, generated: offset = group + 4 * index, groups {0,4} {1,5} {2} {3}
+  Frag<bf16_t> xr[RING][3][2];
+  // Operand addressing, cheap enough for the 648 loads a wave issues per block (64-bit per-lane address arithmetic with its quarter-rate multiplies
+  // made the kernel VALU-bound: 1.64 ms): raw buffer loads.  The descriptor's base (scalar, per block and wave) is the first voxel of the window of
+  // cell (z, y = 0, x = 0): line (4 z - 1, -1), voxel -1; the lane's offset inside it (per block) is 4 y lines + 4 x voxels + its k-group; the piece's
+  // line / k-step offset is a scalar.  Pieces outside the volume get an out-of-range offset: the buffer load returns zeros.
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  struct PState { i32x4 rsrc; unsigned voff0, voff1, ymask, xbad; };
+  auto pstate = [&](const Org& q) {
+    PState r;
+    const long base = (long)(size_t)a.dY + 2 * ((long)q.b * F * F * F * 48 + (((long)(4 * q.zc - 1) * F - 1) * F - 1) * 48);
+    r.rsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(base & 0xffffffffL));
+    r.rsrc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((base >> 32) & 0xffff));
+    r.rsrc[2] = 0x7fffffff;
+    r.rsrc[3] = 0x00020000;
+    r.voff0 = (unsigned)((4 * q.yc0 * F + 4 * q.xc) * 96 + 16 * g);
+    r.voff1 = r.voff0 + (unsigned)(8 * F * 96);
+    // bits 0 / 1: column tile 0 sits in the first / last cell line of the volume, bits 2 / 3: column tile 1
+    r.ymask = (q.yc0 == 0 ? 1u : 0u) | (q.yc0 == V - 1 ? 2u : 0u) | (q.yc0 + 2 == V - 1 ? 8u : 0u);
+    // bit kk set: piece kk of this lane lies in a window voxel outside the line (voxel -1 of the first cell: 4 kk + g < 6; voxel F of the last: >= 30)
+    r.xbad = (q.xc == 0 ? (g < 2 ? 0x3u : 0x1u) : 0u) | (q.xc == V - 1 ? (g >= 2 ? 0x180u : 0x100u) : 0u);
+    return r;
+  };
+  PState pq = pstate(po);
   // chunk (p_z, p_y, s) of column tile m -> ring slot: the lane's three 16-byte pieces (k-steps 3 s .. 3 s + 2, k-group g) of the 576-byte window
   auto ld = [&](Frag<bf16_t> (&dst)[3][2], int m) {
-    const int fz = 4 * po.zc - 1 + ppz, fy = 4 * (po.yc0 + 2 * m) - 1 + ppy, vx0 = 4 * po.xc - 1;
-    const bool line_ok = (unsigned)fz < (unsigned)F && (unsigned)fy < (unsigned)F;
-    const long lo = (long)po.b * F * F * F * 48 + (((long)fz * F + fy) * F + vx0) * 48 + 8 * g;
+    const bool zbad = (unsigned)(4 * po.zc - 1 + ppz) >= (unsigned)F;                    // (scalar)
+    const unsigned ysel = (ppy == 0 ? 1u : (ppy == 5 ? 2u : 0u)) << (2 * m);            // (scalar)
+    const bool lbad = zbad || (pq.ymask & ysel) != 0u;
+    const int soff = (ppz * F + ppy) * F * 96 + 192 * ps;                                // (scalar)
+    const unsigned xb = pq.xbad >> (3 * ps);
 #pragma unroll
     for (int kl = 0; kl < 3; ++kl) {
-      const int kk = 3 * ps + kl, px = ((4 * kk + g) * 43) >> 8;      // (4 kk + g) / 6: the window voxel this piece lies in
-      const bool ok = line_ok && (unsigned)(vx0 + px) < (unsigned)F;
-      // always ONE load per piece: pieces outside the volume read the zero line behind the packed weights
-      // raw loads: the waits are the counted ones in the main loop (left to the compiler, two of the eight half-iterations get `s_waitcnt vmcnt(0)`
-      // in front of their first MFMA -- a full memory round trip -- and the address select becomes branches around merged loads)
-      const bf16_t* src = a.dY + (ok ? lo + 32 * kk : zoff);
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[kl][m].v) : "v"(src));
+      const unsigned vo = (lbad || ((xb >> kl) & 1u)) ? 0xfffffff0u : (m ? pq.voff1 : pq.voff0);
+      // always ONE load per piece; raw: the waits are the counted ones in the main loop
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst[kl][m].v) : "v"(vo), "s"(pq.rsrc), "s"(soff + 64 * kl));
     }
   };
   auto advance = [&]() {
     if (++ps == 3) {
       ps = 0;
-      if (++ppy == 6) {
-        ppy = 0;
-        if (++ppz == 6) {
-          ppz = 0;
-          tp = tp + jstride < tend ? tp + jstride : tp;
-          po = origin(tp);
+      if (++iy == (gy < 2 ? 2 : 1)) {
+        iy = 0;
+        if (++iz == (gz < 2 ? 2 : 1)) {
+          iz = 0;
+          if (++gy == 4) {
+            gy = 0;
+            if (++gz == 4) {
+              gz = 0;
+              tp = tp + jstride < tend ? tp + jstride : tp;
+              po = origin(tp);
+              pq = pstate(po);
+            }
+          }
         }
       }
+      ppz = gz + 4 * iz; ppy = gy + 4 * iy;
     }
   };
 #pragma unroll
-  for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < RING - 1; ++u) {
     ld(xr[u], 0); ld(xr[u], 1);
     advance();
   }
+  // the counted waits of the main loop assume its steady-state issue order; the start-up order is different (all weight pieces, then all operand
+  // pieces): drain it once
+#pragma unroll
+  for (int u = 0; u < RING - 1; ++u)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(xr[u][0][0].v), "+v"(xr[u][1][0].v), "+v"(xr[u][2][0].v), "+v"(xr[u][0][1].v), "+v"(xr[u][1][1].v), "+v"(xr[u][2][1].v)
+                 :
+                 : "memory");
   for (; t < tend; t += jstride) {
     const Org o = origin(t);
     f32x4 acc[6][2];
@@ -1131,29 +1182,30 @@ __global__ __launch_bounds__(512) void cconv_dgrad_kernel(CDArgs a) {
       for (int m = 0; m < 2; ++m) acc[tt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     int h = 0;
 #pragma unroll 1
-    for (int it = 0; it < 27; ++it) {
+    for (int it = 0; it < 108 / RING; ++it) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RING; ++u) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          // In-order retirement: half-chunk h of the weights has landed once at most the operations issued behind it are outstanding -- six younger
-          // half-chunks (6 P pieces, P = 2 for wave 0) and the three operand loads of each of the last seven half-iterations: 6 P + 21; the operand
-          // pieces of this chunk (issued three chunks ago, the last of them five half-iterations back) once at most 4 (P + 3) are: the stricter
-          // count in front of a chunk's first half
-          if (half == 0) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-          } else {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(33) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(27) lgkmcnt(0)" ::: "memory");
-          }
-          __builtin_amdgcn_s_barrier();
+          // In-order retirement, 5 operations per wave and half-iteration (2 weight pieces, 3 operand loads): half-chunk h of the weights (issued LEAD
+          // half-iterations ago, in front of that half-iteration's operand loads) has landed once at most 5 LEAD - 2 operations are outstanding; the
+          // operand pieces of this chunk (the last of them issued 2 RING - 3 half-iterations back) once at most 5 (2 RING - 4) are: the stricter
+          // count in front of a chunk's first half.  The registers the raw loads fill pass through the wait as read-write operands: nothing that
+          // uses them can be scheduled in front of it (no per-wave branch around the wait: tied operands would be copied around it -- before
+          // their data has landed).
+#define CD_WAIT(N)                                                                                                                                      \
+  asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)"                                                                                                        \
+               : "+v"(xr[u][0][0].v), "+v"(xr[u][1][0].v), "+v"(xr[u][2][0].v), "+v"(xr[u][0][1].v), "+v"(xr[u][1][1].v), "+v"(xr[u][2][1].v) : "i"(N) \
+               : "memory")
+          if (half == 0) CD_WAIT(5 * (2 * RING - 4) < 5 * LEAD - 2 ? 5 * (2 * RING - 4) : 5 * LEAD - 2); else CD_WAIT(5 * LEAD - 2);
+#undef CD_WAIT
+          __builtin_amdgcn_s_barrier();     // everyone's pieces of half-chunk h are visible; everyone is done with half-chunk h - 1, whose slot is refilled
           {
             const int hn = h + LEAD >= NHALF ? h + LEAD - NHALF : h + LEAD;
-            w_dma(hn, (2 * u + half + LEAD) & (NSLOT - 1));
+            w_dma(hn, (2 * u + half + LEAD) % NSLOT);
           }
-          ld(xr[(u + 3) & 3], half);
-          const char* wsrc = wbuf + ((2 * u + half) & (NSLOT - 1)) * WHALF + lane * 16;
+          ld(xr[(u + RING - 1) % RING], half);
+          const char* wsrc = wbuf + ((2 * u + half) % NSLOT) * WHALF + lane * 16;
           Frag<bf16_t> wf[9];
 #pragma unroll
           for (int i = 0; i < 9; ++i) wf[i].v = *reinterpret_cast<const bf16x8*>(wsrc + i * 1024);
@@ -1202,7 +1254,7 @@ __global__ __launch_bounds__(512) void cconv_dgrad_kernel(CDArgs a) {
 // use the same bf16 values)
 __global__ __launch_bounds__(512) void cconv_dpack_kernel(const bf16_t* __restrict__ Wcp, bf16_t* __restrict__ Wdp) {
   const int blk = blockIdx.x, tid = threadIdx.x;
-  const int combo = blk / 54, f = blk - combo * 54, kk = f / 6, tt = f - kk * 6, pz = combo / 6, py = combo - pz * 6;
+  const int pos = blk / 54, f = blk - pos * 54, kk = f / 6, tt = f - kk * 6, combo = CD_ORDER[pos], pz = combo / 6, py = combo - pz * 6;
   const int lane = tid >> 3, j = tid & 7, li = lane & 15, g = lane >> 4;
   const int ci = 24 * (li >> 2) + 4 * tt + (li & 3), kap = 32 * kk + 8 * g + j, px = kap / 48, c = kap - px * 48;
   auto an = [](int p, int& aa, int& nn) { if (p == 0) { aa = 3; nn = 1; } else if (p == 5) { aa = 0; nn = -1; } else { aa = p - 1; nn = 0; } };
@@ -1239,7 +1291,13 @@ int k_cconv_dgrad(const void* dY, const void* Wdp, const void* add, void* DX, in
   long nb = a.total < 256 ? a.total : 256;
   nb = nb / 8 * 8;
   if (nb < 8) nb = 8;
-  hipLaunchKernelGGL(cconv_dgrad_kernel, dim3((unsigned)nb), dim3(512), 8 * WHALF, st, a);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)cconv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CD_RING * WHALF);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(cconv_dgrad_kernel, dim3((unsigned)nb), dim3(512), 2 * CD_RING * WHALF, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
 }
