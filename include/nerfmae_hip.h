@@ -126,7 +126,7 @@ NMH_API int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* 
  * of 8); y1 lacks the per-channel constant that the transpose conv's bias contributes in the interior (the affine-free InstanceNorm that
  * follows removes any such constant, like conv1's own bias) but carries its border variation; stats_acc (optional fp64 [B][48][2]) receives
  * sum / sum of squares of the outputs (fused InstanceNorm statistics, as nmh_conv3d_k3_c48).  The residual path still needs the up-sampled
- * map (nmh_upconv_fwd); the backward keeps the two-step kernels. */
+ * map (nmh_upconv4_fwd below); backward: nmh_cconv_wgrad / nmh_cconv_dgrad. */
 NMH_API int64_t nmh_cconv_pack_numel(void);
 NMH_API int64_t nmh_cconv_pack_ws_floats(void);
 NMH_API int nmh_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, void* stream);
@@ -136,7 +136,9 @@ NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, vo
  * G[a][n] = sum_j x[j+n]^T dy1[4j+a] -- the same 216 blocks as the forward, a quarter of the FLOPs, contraction over the coarse cells.
  * x [B][v^3][96], dy1 [B][(4v)^3][48] (bf16), pack_ws = the scratch nmh_cconv_pack filled in this step (holds the transposed Wt), bt = transp_conv.bias,
  * ws = nmh_cconv_wgrad_ws_floats() floats.  Exact for a dy1 whose per-sample, per-channel sums vanish -- the input gradient of the affine-free
- * InstanceNorm that conv1 feeds (the term bt[co] * sum_p dy1[p][c] is then carried by the border voxels alone, which the entry sums). */
+ * InstanceNorm that conv1 feeds (the term bt[co] * sum_p dy1[p][c] is then carried by the border voxels alone, which the entry sums).
+ * dWt [96][48][4][4][4] / dbt [48] (fp32, both or neither; NULL = not wanted): += the gradient of the transpose conv's own weight / bias THROUGH conv1, from
+ * the same G blocks and border sums (see nmh_cconv_dgrad: with it conv1's input gradient on the fine grid, which nmh_upconv_wgrad would need, does not exist). */
 NMH_API int64_t nmh_cconv_wgrad_ws_floats(void);
 NMH_API int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, void* stream);
 /* Input gradient THROUGH the composition: dx = ConvT^T(conv1^T(dy1)) (backward of unetr_block.py:151-158 after unetr_block.py:35-44) is a stride-4
