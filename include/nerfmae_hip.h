@@ -80,6 +80,11 @@ NMH_API int nmh_ncdhw_to_ndhwc(int dt, const float* src, void* dst, int B, int64
 /* The same convolution specialised for Cin = Cout = 48, bf16 (decoder1.conv_block at 160^3 -- 75 % of the model's FLOPs): persistent
  * LDS-halo implicit GEMM; Wk = fragment-ordered pack [41 steps][3][64 lanes][8] (pack modes 6 fwd / 7 dgrad). */
 NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, void* stream);
+/* The input-gradient launch of that kernel when the conv's INPUT was LeakyReLU(InstanceNorm3d(Y1)) (decoder1's conv2, unetr_block.py:60-63 backward):
+ * dX = conv^T(dY) as nmh_conv3d_k3_c48 with the dgrad pack, and in the same epilogue the two per-(sample, channel) sums the InstanceNorm backward needs,
+ * sums [B][48][2] fp64 (zeroed here) = (sum g, sum g * yhat) with g = dX * lrelu'(Y1 - mean), yhat = (Y1 - mean) * rstd, stats1 = (mean, rstd) pairs
+ * [B][48][2] -- what nmh_instnorm_bwd_reduce(dX, Y1, rmode 0) would produce in a separate pass over both tensors. */
+NMH_API int nmh_conv3d_k3_c48_bwd_reduce(const void* dY, const void* Wkd, void* dX, int B, int D, int H, int W, const void* Y1, const float* stats1, float slope, double* sums, void* stream);
 /* The LDS-halo kernel on 48-channel blocks: Cin, Cout multiples of 48 (the 40^3 decoder level of swin_t/s: 96 / 192 channels;
  * UnetResBlock convs, unetr_block.py:35-44); Wk = one fragment-ordered image per (output block, input block), output-block-major
  * (pack modes 6 / 7 on a [Cout][Cin][27] weight).  No fused statistics. */

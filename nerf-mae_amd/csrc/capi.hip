@@ -126,6 +126,12 @@ int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int D, int 
   CLR();
   return k_conv48(X, Wk, Y, B, D, H, W, accumulate, stats_acc, ST);
 }
+int nmh_conv3d_k3_c48_bwd_reduce(const void* dY, const void* Wkd, void* dX, int B, int D, int H, int W, const void* Y1, const float* stats1, float slope,
+                                 double* sums, void* stream) {
+  CLR();
+  REQ(dY, Wkd, dX, Y1, stats1, sums);
+  return k_conv48(dY, Wkd, dX, B, D, H, W, 0, sums, ST, Y1, stats1, slope);
+}
 int nmh_conv3d_k3_c48mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
   CLR();
   if (!X || !Wk || !Y) return -4;

@@ -40,6 +40,9 @@ struct C48Args {
   FDiv dtx, dty, dtz;
   int accumulate;
   double* stats_acc;           // optional [B][48][2] fp64 accumulators: per-channel sum / sum of squares of the (bf16-rounded) outputs
+  // backward-reduce variant (RB: the launch is the input gradient of a conv whose INPUT was lrelu(InstanceNorm(Y1))): stats_acc receives the two
+  // sums the InstanceNorm backward needs, sum g and sum g * yhat with g = out * lrelu'(Y1 - mean), yhat = (Y1 - mean) * rstd (nmh_instnorm_bwd_reduce)
+  const bf16_t* Y1; const float* stats1; float slope;
   // multi-block variant (MB): Cin = 48 ncib, Cout = 48 ncob; a work item is (tile, output block cob, input block cib), cib innermost:
   // the accumulators persist over cib, the epilogue runs after the last one; Wk holds one fragment-ordered image per (cob, cib)
   int ncib, ncob, ldx, ldy;    // ldx / ldy: channels per voxel of X / Y
@@ -63,7 +66,7 @@ __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b
 
 // DBG (diagnostic builds only, NMH_C48_DBG): 1 = no output stores, 2 = no halo prefetch / LDS refill, 4 = no weight DMA and no
 // chunk barriers, 8 = no MFMAs (operand traffic only), 16 = no operand reads in the k-loop (MFMAs only).  DBG = 0 is the product.
-template <int DBG, bool MB = false>
+template <int DBG, bool MB = false, bool RB = false>
 __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   using namespace c48;
   constexpr long WBLK = (long)NSTEP * 3 * 512;   // elements of one (cob, cib) weight image
@@ -179,8 +182,9 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   int st_b = -1, scur = 0;
   auto stats_flush = [&]() {
     if (st_b >= 0 && tid < 96) {
-      const float v = sacc[scur * 96 + tid];
+      float v = sacc[scur * 96 + tid];
       sacc[scur * 96 + tid] = 0.f;
+      if (RB && (tid & 1)) v *= a.stats1[(long)st_b * 96 + tid];      // sum g (y - mean) -> sum g yhat: rstd of (sample, channel tid / 2)
       atomicAdd(a.stats_acc + (long)st_b * 96 + tid, (double)v);
     }
   };
@@ -327,6 +331,26 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       const bool zx_ok = z < a.D && x < a.W && (!(DBG & 1) || a.accumulate == 77);
       auto epilogue = [&](auto with_stats) {
         constexpr bool ST = decltype(with_stats)::value;
+        // RB: the matching values of Y1 (24 bytes per line) and the lane's 12 channel means are requested first -- the halo registers are free by now --
+        // and used after the four lines have been converted and stored
+        uint4 yA[RB ? 4 : 1]; uint2 yB[RB ? 4 : 1]; float4 mu4[RB ? 3 : 1];
+        unsigned wk[RB ? 4 : 1][6];
+        if constexpr (RB) {
+          const bf16_t* const y1p = a.Y1 + (dst0 - a.Y);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (zx_ok && y0 + y_l + i < a.H) {
+              yA[i] = *reinterpret_cast<const uint4*>(y1p + i * rowstride);
+              yB[i] = *reinterpret_cast<const uint2*>(y1p + i * rowstride + 8);
+            }
+          // (mean, rstd) pairs of channels 12 g .. 12 g + 11: 24 floats, the means are the even ones
+          const float4* sp = reinterpret_cast<const float4*>(a.stats1 + ((long)b * 48 + 12 * g) * 2);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const float4 p0 = sp[2 * q], p1 = sp[2 * q + 1];
+            mu4[q] = make_float4(p0.x, p0.z, p1.x, p1.z);
+          }
+        }
         float st1[ST ? 3 : 1][4], st2[ST ? 3 : 1][4];
         if (ST) {
 #pragma unroll
@@ -355,7 +379,11 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
             for (int q = 0; q < 6; ++q) w6[q] = pk_bf16(v[q >> 1][(q & 1) * 2], v[q >> 1][(q & 1) * 2 + 1]);
             *reinterpret_cast<uint4*>(dst) = make_uint4(w6[0], w6[1], w6[2], w6[3]);   // (8-byte aligned 16-byte store: dword alignment suffices)
             *reinterpret_cast<uint2*>(dst + 8) = make_uint2(w6[4], w6[5]);
-            if (ST) {  // statistics of exactly what the normalisation pass will read back
+            if constexpr (RB) {
+#pragma unroll
+              for (int q = 0; q < 6; ++q) wk[i][q] = w6[q];
+            }
+            if (ST && !RB) {  // statistics of exactly what the normalisation pass will read back
 #pragma unroll
               for (int q = 0; q < 6; ++q) {
                 const float q0 = __uint_as_float(w6[q] << 16), q1 = __uint_as_float(w6[q] & 0xffff0000u);
@@ -364,6 +392,22 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
               }
             }
           }
+        }
+        if constexpr (RB) {   // sums of the InstanceNorm backward over the (bf16-rounded) outputs just stored
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (zx_ok && y0 + y_l + i < a.H) {
+              const unsigned yw[6] = {yA[i].x, yA[i].y, yA[i].z, yA[i].w, yB[i].x, yB[i].y};
+#pragma unroll
+              for (int q = 0; q < 6; ++q) {
+                const float d0 = __uint_as_float(wk[i][q] << 16), d1 = __uint_as_float(wk[i][q] & 0xffff0000u);
+                const float m0 = (q & 1) ? mu4[q >> 1].z : mu4[q >> 1].x, m1 = (q & 1) ? mu4[q >> 1].w : mu4[q >> 1].y;
+                const float t0 = __uint_as_float(yw[q] << 16) - m0, t1 = __uint_as_float(yw[q] & 0xffff0000u) - m1;
+                const float g0 = d0 * (t0 > 0.f ? 1.0f : a.slope), g1 = d1 * (t1 > 0.f ? 1.0f : a.slope);
+                st1[q >> 1][(q & 1) * 2] += g0; st1[q >> 1][(q & 1) * 2 + 1] += g1;
+                st2[q >> 1][(q & 1) * 2] += g0 * t0; st2[q >> 1][(q & 1) * 2 + 1] += g1 * t1;
+              }
+            }
         }
         if (ST) {
 #pragma unroll
@@ -379,7 +423,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
             }
         }
       };
-      if (stats) epilogue(std::true_type{});
+      if (stats || RB) epilogue(std::true_type{});
       else epilogue(std::false_type{});
     }
     stamp(6);
@@ -402,9 +446,12 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 }
 
 
-int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st) {
+int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st,
+             const void* Y1, const float* stats1, float slope) {
   using namespace c48;
   C48Args a;
+  a.Y1 = (const bf16_t*)Y1; a.stats1 = stats1; a.slope = slope;
+  if (Y1 && (!stats1 || !stats_acc || accumulate)) return -1;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
@@ -437,6 +484,17 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
     NMH_CHECK_LAUNCH();
     return 0;
   }
+  if (Y1) {
+    static bool attr_rb = false;
+    if (!attr_rb) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+      attr_rb = true;
+    }
+    hipLaunchKernelGGL((conv48_kernel<0, false, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(conv48_kernel<0>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
@@ -450,6 +508,7 @@ int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int
   if (Cin % 48 || Cout % 48 || Cin <= 0 || Cout <= 0) return -2;
   if ((long)D * H * W * Cin * 2 >= (1L << 32)) return -2;   // 32-bit buffer offsets inside one sample
   C48Args a;
+  a.Y1 = nullptr; a.stats1 = nullptr; a.slope = 0.f;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;

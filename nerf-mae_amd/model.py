@@ -504,7 +504,12 @@ class _UpBlockFn(torch.autograd.Function):
             ops.instnorm_bwd_apply(dout, out, y2, st2, sums2, dy2, B, V, Cout, rmode=1, dr=dcat)  # dcat <- g (plain residual)
         conv = ctx.conv
         wgrad = ops.conv3d_k3_c48_wgrad if ctx.c48 else ops.conv3d_k3_wgrad
-        da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
+        sums1 = ops.acc_zeros((B, Cout, 2), dev)
+        fused_red = ctx.c48 and ops.C48_BWD_REDUCE and S % 16 == 0
+        if fused_red:   # the InstanceNorm-backward sums of (da1, y1) come out of the conv epilogue (no separate pass over both 160^3 tensors)
+            da1 = ops.conv3d_k3_c48_bwd_reduce(dy2.view(B, S, S, S, Cout), pk[key + "c2.wkd"], y1, st1, sums1).view(B * V, Cout)
+        else:
+            da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
         # Weight gradients run on the forked side stream -- except the persistent 160^3 kernels, which own every CU: overlapping
         # them with the next MFMA kernel OR with the HBM-bound InstanceNorm passes measured slower (51.2 vs 50.4 ms at 4 grids,
         # 34.8 vs 30.8 ms at 1), so they stay on the main stream.
@@ -520,8 +525,8 @@ class _UpBlockFn(torch.autograd.Function):
                     fn()
         g_c2, g_c1 = _gradbuf(m.conv_block.conv2.weight), _gradbuf(m.conv_block.conv1.weight)
         side(lambda: wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), g_c2))
-        sums1 = ops.acc_zeros((B, Cout, 2), dev)
-        ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
+        if not fused_red:
+            ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
         ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         # decoder1 with the composed kernels: conv1's input gradient on the fine grid is never formed -- dx and the transpose conv's parameter gradients

@@ -267,6 +267,25 @@ def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None):
     return out
 
 
+C48_BWD_REDUCE = __import__("os").environ.get("NMH_C48_BWD_REDUCE", "1") != "0"   # decoder1 conv2 input gradient: InstanceNorm-backward sums in the conv epilogue
+
+
+def conv3d_k3_c48_bwd_reduce(dY, Wkd, y1, stats1, sums, out=None, slope=0.01):
+    """dX = conv^T(dY) (48 -> 48, dgrad pack) + the InstanceNorm-backward sums of (dX, y1) in the epilogue (include/nerfmae_hip.h:
+    nmh_conv3d_k3_c48_bwd_reduce); sums: fp64 [B,48,2]"""
+    _chk(dY, Wkd, y1, stats1, sums, out)
+    B, D, H, W, Cin = dY.shape
+    if Cin != 48 or dY.dtype != torch.bfloat16 or y1.dtype != torch.bfloat16 or y1.numel() != dY.numel() or sums.dtype != torch.float64:
+        raise RuntimeError("conv3d_k3_c48_bwd_reduce needs bf16 tensors with 48 channels and fp64 sums")
+    if out is None:
+        out = torch.empty((B, D, H, W, 48), dtype=dY.dtype, device=dY.device)
+    ev = _prof(("conv3d_k3_c48", B, D, 48, 48))
+    lib().call("nmh_conv3d_k3_c48_bwd_reduce", dY, Wkd, out, B, D, H, W, y1, stats1, float(slope), sums, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 CCONV = __import__("os").environ.get("NMH_CCONV", "1") != "0"   # decoder1 forward: ConvTranspose(k = s = 4) composed with conv1 (csrc/cconv.hip)
 
 

@@ -1001,6 +1001,41 @@ def test_cconv_forward_matches_convtranspose_then_conv(B, v):
     assert_close(y.float().cpu(), y2.float().cpu() - const, 2e-2, "cconv vs two-step HIP path (interior + border)", elem_mult=2.0)
 
 
+@pytest.mark.parametrize("B,D,H,W", [(1, 16, 16, 16), (2, 20, 24, 40), (3, 32, 32, 32), (1, 7, 9, 19)])
+def test_conv48_input_gradient_with_fused_instnorm_backward_sums(B, D, H, W):
+    """nmh_conv3d_k3_c48_bwd_reduce (decoder1 conv2's input gradient, unetr_block.py:60-63 backward): the same dX as the plain launch, bit for bit, and
+    the InstanceNorm-backward sums (sum g, sum g * yhat) of the separate reduce pass over (dX, y1) -- including partial tiles and several samples
+    per workgroup (the per-sample flush of the LDS accumulators)"""
+    ops = _ops()
+    dt = torch.bfloat16
+    w = rnd(48, 48, 3, 3, 3, seed=1, scale=(27 * 48) ** -0.5)
+    wkd = _pack_via_kernel(w, 7, dt, 41 * 3 * 64 * 8)
+    dy = dev(q(rnd(B, D, H, W, 48, seed=2), dt), dt)
+    y1 = dev(q(rnd(B, D, H, W, 48, seed=3) * 1.5 + 0.3, dt), dt)
+    V = D * H * W
+    st = torch.empty(B, 48, 2, device="cuda")
+    ops.instnorm_stats(y1.view(B * V, 48), st, ops.acc_zeros((B, 48, 2), "cuda"), B, V, 48)
+    ref_dx = ops.conv3d_k3_c48(dy, wkd)
+    ref_sums = torch.zeros(B, 48, 2, dtype=torch.float64, device="cuda")
+    ops.instnorm_bwd_reduce(ref_dx.view(B * V, 48), None, y1.view(B * V, 48), st, ref_sums, B, V, 48, rmode=0)
+    sums = torch.full((B, 48, 2), 5.0, dtype=torch.float64, device="cuda")          # zeroed by the entry
+    dx = ops.conv3d_k3_c48_bwd_reduce(dy, wkd, y1, st, sums)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, ref_dx)
+    # fp32 partial sums in a different order: relative to the size of the summands
+    scale = (ref_dx.float().abs().sum(dim=(1, 2, 3)) / V).clamp_min(1e-6).cpu()      # [B,48]
+    for k in range(2):
+        err = ((sums[:, :, k] - ref_sums[:, :, k]).abs().cpu() / (scale * V)).max().item()
+        assert err < 2e-5, (k, err)
+    # against the definition, fp64 on the host
+    yd, dd = y1.double().cpu(), dx.double().cpu()
+    mean, rstd = st[:, :, 0].double().cpu(), st[:, :, 1].double().cpu()
+    t = yd - mean[:, None, None, None, :]
+    g = dd * torch.where(t > 0, 1.0, 0.01)
+    check(sums[:, :, 0].float(), g.sum(dim=(1, 2, 3)).float(), torch.float32, "fused IN-backward sum g", 20)
+    check(sums[:, :, 1].float(), (g * t * rstd[:, None, None, None, :]).sum(dim=(1, 2, 3)).float(), torch.float32, "fused IN-backward sum g yhat", 20)
+
+
 @pytest.mark.parametrize("B,v", [(1, 8), (2, 8), (1, 16), (3, 24), (2, 40)])
 def test_upconv4_forward_matches_conv_transpose(B, v):
     """decoder1's transpose conv as the persistent register-fragment kernel (csrc/cconv.hip upconv4): against F.conv_transpose3d in fp32 on the
