@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(AL al, const T* __restrict
 // X[m][32 s + 8 g ..]: a plain 16-byte global load -- so the row tile never touches LDS, only the weight tile does (both k-tiles at once, one
 // barrier), and the workgroup needs 25-34 KB instead of 40-48 KB: four to six workgroups per CU instead of three.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+// KS = k-steps of 32 held in registers: 4 (K <= 128) or 6 (K <= 192: the 20^3-token Linears of stage 1 -- three k-tiles of weights in LDS at once).
+template <int NT, int KS = 4>
 __global__ __launch_bounds__(256) void gemm_nt_k128_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bw, long ldb, int M, int N, int K, EpiParams ep) {
   constexpr int BN = 16 * NT, BR = (BN + 31) / 32;
   using T = bf16_t;
@@ -310,14 +311,14 @@ __global__ __launch_bounds__(256) void gemm_nt_k128_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * BN, lc = tid & 7, lr = tid >> 3;
   const int row = m0 + wave * 16 + li;
-  Frag<T> af[4];
+  Frag<T> af[KS];
   {
     const bf16_t* ar = A + (long)(row < M ? row : M - 1) * lda + 8 * g;   // clamped rows are computed but never stored
 #pragma unroll
-    for (int s = 0; s < 4; ++s) af[s].v = 32 * s + 8 * g < K ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ar + 32 * s)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < KS; ++s) af[s].v = 32 * s + 8 * g < K ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ar + 32 * s)) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
+  for (int kt = 0; kt < KS / 2; ++kt) {
     const int k = kt * 64 + lc * 8;
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void gemm_nt_k128_kernel(const bf16_t* __restr
 #pragma unroll
   for (int b = 0; b < NT; ++b) acc[0][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
+  for (int s = 0; s < KS; ++s) {
     if (32 * s < K) {
       const char* Bs = smem + (s >> 1) * BN * 128;
 #pragma unroll
@@ -346,11 +347,11 @@ __global__ __launch_bounds__(256) void gemm_nt_k128_kernel(const bf16_t* __restr
   __syncthreads();   // the epilogue slabs alias the weight tile
   nt_epilogue<T, 1, NT>(acc, smem, ep, m0, n0, M, N, wave, lane, 0);
 }
-template <int NT>
+template <int NT, int KS = 4>
 static int launch_nt_k128(const bf16_t* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st) {
-  constexpr int BN = 16 * NT, lds_main = 2 * BN * 128, lds_epi = 4 * 16 * (BN + 4) * 4, lds = lds_main > lds_epi ? lds_main : lds_epi;
+  constexpr int BN = 16 * NT, lds_main = (KS / 2) * BN * 128, lds_epi = 4 * 16 * (BN + 4) * 4, lds = lds_main > lds_epi ? lds_main : lds_epi;
   dim3 grid((M + 63) / 64, (N + BN - 1) / BN, 1);
-  hipLaunchKernelGGL(gemm_nt_k128_kernel<NT>, grid, dim3(256), lds, st, A, lda, (const bf16_t*)Bw, ldb, M, N, K, ep);
+  hipLaunchKernelGGL((gemm_nt_k128_kernel<NT, KS>), grid, dim3(256), lds, st, A, lda, (const bf16_t*)Bw, ldb, M, N, K, ep);
   NMH_CHECK_LAUNCH();
   return 0;
 }
@@ -553,6 +554,13 @@ static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int
         if (t16 % 8 == 0 && (long)M >= nt8_min) return launch_nt_k128<8>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
         if (t16 % 6 == 0) return launch_nt_k128<6>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
         if (t16 % 4 == 0) return launch_nt_k128<4>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+      }
+      // (measured at 8 grids, 64000 rows x 768 / 576 / 192 x 192: step 51.75 ms with it, 51.59 without, 52.0 with 128-column tiles: off by default)
+      static const int k192_on = getenv("NMH_GEMM_K192") ? atoi(getenv("NMH_GEMM_K192")) : 0;
+      if (k192_on && k128_on && batch == 1 && ep.ksplit <= 1 && K > 128 && K <= 192 && M >= k128_min && lda_ok(al.lda, ldb)) {
+        if (k192_on == 8 && t16 % 8 == 0) return launch_nt_k128<8, 6>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+        if (t16 % 6 == 0) return launch_nt_k128<6, 6>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+        if (t16 % 4 == 0) return launch_nt_k128<4, 6>(al.A, al.lda, Bw, ldb, M, N, K, ep, st);
       }
     }
     // launches of a few dozen workgroups with a long contraction (stage 3 / 4 Linears at 1-2 grids per GPU): one workgroup per CU is
