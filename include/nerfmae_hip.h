@@ -143,9 +143,10 @@ NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, vo
  * ws = nmh_cconv_wgrad_ws_floats() floats.  Exact for a dy1 whose per-sample, per-channel sums vanish -- the input gradient of the affine-free
  * InstanceNorm that conv1 feeds (the term bt[co] * sum_p dy1[p][c] is then carried by the border voxels alone, which the entry sums).
  * dWt [96][48][4][4][4] / dbt [48] (fp32, both or neither; NULL = not wanted): += the gradient of the transpose conv's own weight / bias THROUGH conv1, from
- * the same G blocks and border sums (see nmh_cconv_dgrad: with it conv1's input gradient on the fine grid, which nmh_upconv_wgrad would need, does not exist). */
+ * the same G blocks and border sums; phase: 0 = everything, 1 = the partial G blocks only (the persistent launch), 2 = the small launches behind it (reduce,
+ * border sums, chain rules: they only feed weight gradients and may go to a side stream; same ws) (see nmh_cconv_dgrad: with it conv1's input gradient on the fine grid, which nmh_upconv_wgrad would need, does not exist). */
 NMH_API int64_t nmh_cconv_wgrad_ws_floats(void);
-NMH_API int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, void* stream);
+NMH_API int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, int phase, void* stream);
 /* Input gradient THROUGH the composition: dx = ConvT^T(conv1^T(dy1)) (backward of unetr_block.py:151-158 after unetr_block.py:35-44) is a stride-4
  * convolution of the fine gradient with a 6x6x6 kernel of 48 -> 96 matrices (the transposes of the same 216 blocks): conv1's input gradient on the fine
  * grid -- a full 48 -> 48 conv pass that only fed the transpose conv's backward -- is never formed.  nmh_cconv_dgrad_pack gathers the forward's

@@ -184,11 +184,12 @@ int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, 
   return k_cconv_fwd(x, Wcp, delta, y1, B, v, stats_acc, ST);
 }
 int64_t nmh_cconv_wgrad_ws_floats(void) { return (int64_t)k_cconv_wgrad_ws_floats(); }
-int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, void* stream) {
+int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, int phase, void* stream) {
   CLR();
   REQ(x, dy1, pack_ws, bt, dW1, ws);
   if (B <= 0 || v <= 0) return 0;
-  return k_cconv_wgrad(x, dy1, pack_ws, bt, dW1, dWt, dbt, ws, B, v, ST);
+  if (phase < 0 || phase > 2) return -1;
+  return k_cconv_wgrad(x, dy1, pack_ws, bt, dW1, dWt, dbt, ws, B, v, phase, ST);
 }
 int64_t nmh_cconv_dgrad_pack_numel(void) { return (int64_t)k_cconv_dpack_numel(); }
 int nmh_cconv_dgrad_pack(const void* Wcp, void* Wdp, void* stream) {

@@ -958,8 +958,10 @@ long k_cconv_wgrad_ws_floats() { return 256L * (2 * 6 * 96 * 48) + 216L * 4608 +
 // dW1 [48][48][3][3][3] += conv1 weight gradient from x [B][v^3][96] and dy1 [B][(4v)^3][48]; WtT = first part of the pack workspace of
 // nmh_cconv_pack (the transpose-conv weight as [64 phases][96][48]); ws: k_cconv_wgrad_ws_floats() floats
 // (valid for a dy1 whose per-sample sums vanish: the gradient of an affine-free InstanceNorm's input, which is what conv1 feeds)
-int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, hipStream_t st) {
+int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, int phase, hipStream_t st) {
   using namespace ccw;
+  // phase 0: everything; 1: the G partials only (the persistent kernel: main stream); 2: reduce, border sums and the chain rules (small launches that
+  // only feed weight gradients: the caller may issue them on a side stream behind phase 1)
   if (v % 8 || v > VMAX) return -2;
   CCWArgs a{};
   a.X = (const bf16_t*)X; a.dY = (const bf16_t*)dY; a.part = ws; a.B = B; a.v = v;
@@ -1000,8 +1002,11 @@ int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* 
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)wg), dim3(768), LDS_BYTES, st, a);
-  NMH_CHECK_LAUNCH();
+  if (phase != 2) {
+    hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)wg), dim3(768), LDS_BYTES, st, a);
+    NMH_CHECK_LAUNCH();
+  }
+  if (phase == 1) return 0;
   float* G = ws + 256L * (2 * 6 * 96 * 48);
   float* Cb = G + 216L * 4608;
   hipLaunchKernelGGL(cconv_wgrad_reduce_kernel, dim3((unsigned)(nu * 2 * 6 * 18)), dim3(256), 0, st, a, G);

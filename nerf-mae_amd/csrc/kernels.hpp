@@ -162,7 +162,7 @@ int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, f
 long k_cconv_pack_numel();
 long k_cconv_pack_ws_floats();
 int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st);
-int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, hipStream_t st);
+int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, int phase, hipStream_t st);
 long k_cconv_dpack_numel();
 int k_cconv_dpack(const void* Wcp, void* Wdp, hipStream_t st);
 int k_cconv_dgrad(const void* dY, const void* Wdp, const void* add, void* DX, int B, int v, hipStream_t st);

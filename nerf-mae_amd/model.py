@@ -535,8 +535,19 @@ class _UpBlockFn(torch.autograd.Function):
         if not cdg:
             conv(dy1.view(B, S, S, S, Cout), "c1.wd", Cc, out=dcat.view(B, S, S, S, Cc), accumulate=not m.has_proj)
         if ctx.cc:   # decoder1: conv1's weight gradient through the composition (a quarter of the FLOPs, contraction over the coarse cells; csrc/cconv.hip)
-            ops.cconv_wgrad(x.view(B, v, v, v, Cin), dy1.view(B, S, S, S, Cout), pk.cconv[3], m.transp_conv.bias, g_c1, B, v,
-                            dWt=_gradbuf(m.transp_conv.weight) if cdg else None, dbt=_gradbuf(m.transp_conv.bias) if cdg else None)
+            # the persistent G kernel on the main stream; reduce / border sums / chain rules (0.5 ms of small launches that only feed weight gradients) behind
+            # it on the side stream, or with the encoder's next weight-gradient flush
+            cw = lambda ph: ops.cconv_wgrad(x.view(B, v, v, v, Cin), dy1.view(B, S, S, S, Cout), pk.cconv[3], m.transp_conv.bias, g_c1, B, v,  # noqa: E731
+                                            dWt=_gradbuf(m.transp_conv.weight) if cdg else None, dbt=_gradbuf(m.transp_conv.bias) if cdg else None, phase=ph)
+            if not ops.side_stream.enabled or not ops.CCONV_WGRAD_SPLIT:
+                cw(0)
+            else:
+                cw(1)
+                if ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None:
+                    m._wq.defer(lambda: cw(2))
+                else:
+                    with ops.side_stream():
+                        cw(2)
         else:
             side(lambda: wgrad(dy1.view(B, S, S, S, Cout), cat.view(B, S, S, S, Cc), g_c1))
         if m.has_proj:

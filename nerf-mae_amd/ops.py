@@ -381,10 +381,11 @@ def upconv4_fwd(x, Wup, bt, out, B, v):
 
 
 CCONV_WGRAD = __import__("os").environ.get("NMH_CCONV_WGRAD", "1") != "0"   # conv1's weight gradient through the composition (with NMH_CCONV)
+CCONV_WGRAD_SPLIT = __import__("os").environ.get("NMH_CCONV_WGRAD_SPLIT", "0") != "0"   # its small launches on the side stream (measured: 52.36 vs 52.34 ms at 8 grids, 29.70 vs 29.64 at 4 -- off)
 _CCW_WS = {}
 
 
-def cconv_wgrad(x, dy1, pack_ws, bt, dW1, B, v, dWt=None, dbt=None):
+def cconv_wgrad(x, dy1, pack_ws, bt, dW1, B, v, dWt=None, dbt=None, phase=0):
     """conv1.weight gradient [48,48,3,3,3] += through the composed ConvTranspose o conv (include/nerfmae_hip.h: nmh_cconv_wgrad); dy1 must be the
     input gradient of the affine-free InstanceNorm behind conv1 (zero per-sample sums).  dWt [96,48,4,4,4] / dbt [48] (fp32, optional): += the
     transpose conv's own parameter gradients through conv1 (used with cconv_dgrad, when conv1's input gradient on the fine grid is not formed)"""
@@ -393,11 +394,11 @@ def cconv_wgrad(x, dy1, pack_ws, bt, dW1, B, v, dWt=None, dbt=None):
         raise ValueError("cconv_wgrad: dWt / dbt")
     if x.dtype != torch.bfloat16 or dy1.dtype != torch.bfloat16 or v % 8 or v > 40:
         raise RuntimeError("cconv_wgrad needs bf16 operands on a coarse grid whose edge is a multiple of 8 (<= 40)")
-    key = (x.device.index, torch.cuda.current_stream().cuda_stream)
+    key = x.device.index          # (one workspace per device: phase 2 may run on a side stream behind phase 1)
     if key not in _CCW_WS:
         _CCW_WS[key] = torch.empty(int(lib().call("nmh_cconv_wgrad_ws_floats")), dtype=torch.float32, device=x.device)
     ev = _prof(("cconv_wgrad", B, 4 * v, 96, 48))
-    lib().call("nmh_cconv_wgrad", x, dy1, pack_ws, bt, dW1, dWt, dbt, _CCW_WS[key], B, v, _st())
+    lib().call("nmh_cconv_wgrad", x, dy1, pack_ws, bt, dW1, dWt, dbt, _CCW_WS[key], B, v, int(phase), _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return dW1
