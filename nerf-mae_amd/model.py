@@ -914,6 +914,10 @@ class SwinTransformer_MAE3D_New(nn.Module):
         gradients, then the trigger."""
         grouped = ops.GROUPED_WGRAD and self.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad
         groups = red.chunk_groups if (red is not None and si == getattr(red, "chunk_stage", -1) and red.chunk_groups) else [list(self.stages[si])]
+        if red is None and si == 0 and grouped and ops.STAGE0_BLOCK_FLUSH and len(groups) == 1 and len(groups[0]) > 1:
+            # stage 0 is the END of the backward pass: flushed as a whole, all of its weight gradients run exposed after the last input-gradient
+            # kernel; per block, the second block's run under the first block's chain
+            groups = [[mod] for mod in groups[0]]
         for k, grp in enumerate(groups):
             if red is not None:
                 x = red.trigger(x, red.seg_stage(si, k))  # backward reaching here => this range's gradients are complete
