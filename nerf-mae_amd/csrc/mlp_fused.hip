@@ -81,6 +81,35 @@ __device__ __forceinline__ void ln_rows(const bf16_t* __restrict__ x, long row, 
   }
 }
 
+// the same from rows and affine parameters already in registers (the lane's C / 32 16-byte pieces, requested a tile earlier; gamma / beta of its k-groups)
+template <int C>
+__device__ __forceinline__ void ln_rows_raw(const uint4 (&raw)[C / 32], const float (&gm)[C / 32][8], const float (&bt)[C / 32][8], float eps,
+                                            Frag<bf16_t> (&af)[C / 32], float& mean, float& rstd) {
+  constexpr int KS = C / 32;
+  float xv[KS][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    unpack8(raw[k], xv[k]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += xv[k][j];
+  }
+  mean = quad_row_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < KS; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = xv[k][j] - mean; q += d * d; }
+  rstd = rsqrtf(quad_row_sum(q) * (1.0f / C) + eps);
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (xv[k][j] - mean) * rstd * gm[k][j] + bt[k][j];
+    af[k].v = pack8(o);
+  }
+}
+
 // register-staged copy of chunk j of two [4C][C] row-major weight matrices into the LDS ring (rows padded to RS bytes)
 template <int C, int HC> struct WStage {
   static constexpr int RS = MlpCfg<C>::RS, CPR = C / 8, PER = HC * CPR, TOTAL = 2 * PER, NI = (TOTAL + 255) / 256;
@@ -594,19 +623,60 @@ __global__ __launch_bounds__(256) void mlp96_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pg[c][r] = 0.f; pb[c][r] = 0.f; }
   const long ntile = (a.M + 16 * MT - 1) / (16 * MT);
-  for (long t = (long)blockIdx.x * NW + wave; t < ntile; t += (long)gridDim.x * NW) {
+  // One wave per SIMD (the two weight matrices fill the LDS): nothing hides a load's latency but the wave's own instruction stream (PMC: waves waiting
+  // 46-56 %).  So nothing is loaded where it is used: the affine parameters of both layouts sit in registers for the whole kernel (the wave has 512 to
+  // itself), every row a tile reads -- x1 and dx2 in the operand layout (k-group pieces) and in the accumulator layout (4-channel pieces), the row
+  // scales -- is requested one tile ahead, the fc1 bias of hidden block hb + 1 during block hb.
+  float gmo[KS][8], bto[KS][8], gmc[CT][4];
+#pragma unroll
+  for (int k = 0; k < KS; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gmo[k][j] = a.gamma[32 * k + 8 * g + j]; bto[k][j] = a.beta[32 * k + 8 * g + j]; }
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gmc[c][r] = a.gamma[16 * c + 4 * g + r];
+  struct Pre { uint4 nx[MT][KS], nd[MT][KS]; uint2 xc[MT][CT], dc[MT][CT]; float sc[MT], dsc[MT]; };
+  auto fetch = [&](long t, Pre& q) {
+    const long rb = t * (16 * MT);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const long row = rb + 16 * m + li;
+      const long rc = row < a.M ? row : a.M - 1;          // (rows behind the end, a tile behind the last one: valid addresses, values unused)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        q.nx[m][s] = *reinterpret_cast<const uint4*>(a.x1 + rc * C + 32 * s + 8 * g);
+        q.nd[m][s] = *reinterpret_cast<const uint4*>(a.dx2 + rc * C + 32 * s + 8 * g);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        q.xc[m][c] = *reinterpret_cast<const uint2*>(a.x1 + rc * C + 16 * c + 4 * g);
+        q.dc[m][c] = *reinterpret_cast<const uint2*>(a.dx2 + rc * C + 16 * c + 4 * g);
+      }
+      q.sc[m] = a.rowscale ? a.rowscale[rc / a.rows_per_scale] : 1.0f;
+      q.dsc[m] = (a.dyw && a.dyw_scale) ? a.dyw_scale[rc / a.rows_per_scale] : 1.0f;
+    }
+  };
+  Pre cur;
+  const long tstride = (long)gridDim.x * NW;
+  fetch((long)blockIdx.x * NW + wave, cur);
+  float4 bnext[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) bnext[b] = *reinterpret_cast<const float4*>(a.b1 + 16 * b + 4 * g);
+  for (long t = (long)blockIdx.x * NW + wave; t < ntile; t += tstride) {
     const long rbase = t * (16 * MT);
+    Pre nxt;
+    fetch(t + tstride, nxt);
     Frag<bf16_t> xf[MT][KS], df[MT][KS];
     float mean[MT], rstd[MT], sc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const long row = rbase + 16 * m + li;
-      const long rc = row < a.M ? row : a.M - 1;
-      ln_rows<C>(a.x1, rc, g, a.gamma, a.beta, a.eps, xf[m], mean[m], rstd[m]);
-      sc[m] = a.rowscale ? a.rowscale[rc / a.rows_per_scale] : 1.0f;
+      ln_rows_raw<C>(cur.nx[m], gmo, bto, a.eps, xf[m], mean[m], rstd[m]);
+      sc[m] = cur.sc[m];
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        df[m][s].v = *reinterpret_cast<const bf16x8*>(a.dx2 + rc * C + 32 * s + 8 * g);
+        df[m][s].v = __builtin_bit_cast(bf16x8, cur.nd[m][s]);
         if (row < a.M) *reinterpret_cast<bf16x8*>(a.x1n + row * C + 32 * s + 8 * g) = xf[m][s].v;
       }
     }
@@ -630,10 +700,17 @@ __global__ __launch_bounds__(256) void mlp96_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) { mma(hp[m][b], wf1, xf[m][s]); mma(dh[m][b], wf2, df[m][s]); }
         }
+      float4 bcur[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bcur[b] = bnext[b];
+      {
+        const int hn = hb == 5 ? 0 : hb + 1;       // (block 0 of the next tile behind the last one)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bnext[b] = *reinterpret_cast<const float4*>(a.b1 + 64 * hn + 16 * b + 4 * g);
+      }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const float4 bb = *reinterpret_cast<const float4*>(a.b1 + 64 * hb + 16 * b + 4 * g);
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+        const float bv[4] = {bcur[b].x, bcur[b].y, bcur[b].z, bcur[b].w};
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -693,10 +770,9 @@ __global__ __launch_bounds__(256) void mlp96_bwd_kernel(MlpBwdArgs a) {
       float xh[CT][4];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const uint2 xr = *reinterpret_cast<const uint2*>(a.x1 + rc * C + 16 * c + 4 * g);
+        const uint2 xr = cur.xc[m][c];
         const float xv[4] = {__uint_as_float(xr.x << 16), __uint_as_float(xr.x & 0xffff0000u), __uint_as_float(xr.y << 16), __uint_as_float(xr.y & 0xffff0000u)};
-        const float4 gm4 = *reinterpret_cast<const float4*>(a.gamma + 16 * c + 4 * g);
-        const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+        const float gm[4] = {gmc[c][0], gmc[c][1], gmc[c][2], gmc[c][3]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float d = ok ? acc[m][c][r] : 0.f;
@@ -711,11 +787,11 @@ __global__ __launch_bounds__(256) void mlp96_bwd_kernel(MlpBwdArgs a) {
         }
       }
       const float m1 = quad_row_sum(s1) * (1.0f / C), m2 = quad_row_sum(s2) * (1.0f / C);
-      const float dsc = (a.dyw && a.dyw_scale) ? a.dyw_scale[rc / a.rows_per_scale] : 1.0f;
+      const float dsc = cur.dsc[m];
       float v[CT][4];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const uint2 rr2 = *reinterpret_cast<const uint2*>(a.dx2 + rc * C + 16 * c + 4 * g);
+        const uint2 rr2 = cur.dc[m][c];
         const float rv[4] = {__uint_as_float(rr2.x << 16), __uint_as_float(rr2.x & 0xffff0000u), __uint_as_float(rr2.y << 16), __uint_as_float(rr2.y & 0xffff0000u)};
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[c][r] = rstd[m] * (acc[m][c][r] - m1 - xh[c][r] * m2) + rv[r];
@@ -746,6 +822,7 @@ __global__ __launch_bounds__(256) void mlp96_bwd_kernel(MlpBwdArgs a) {
         __builtin_amdgcn_wave_barrier();
       }
     }
+    cur = nxt;
   }
   // dgamma / dbeta: butterfly over the 16 token lanes, per-wave partials through LDS (the slabs), one set of atomics per workgroup
   __syncthreads();
