@@ -214,8 +214,10 @@ NMH_API int nmh_upconv_shuffle_bwd(int dt, const void* dcat, void* dupre, void* 
 NMH_API int nmh_mae_loss_fwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, double* sums, float* losses, float* pred, float* dpred, void* stream);
 NMH_API int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int Cd, const double* sums, void* dd0, void* dpred8, float* dWout, float* dbout, void* stream);
 /* Forward of the decoder tail in one pass: d0 = lrelu(IN(y) + r) (unetr_block.py:62-71) -> 1x1 head -> loss terms
- * (swin_mae3d.py:1496-1549); arguments as nmh_instnorm_apply (rmode 1) + nmh_mae_loss_fwd. */
-NMH_API int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, double* bwd_sums, void* stream);
+ * (swin_mae3d.py:1496-1549); arguments as nmh_instnorm_apply (rmode 1) + nmh_mae_loss_fwd.  sign_mask (optional, with bwd_sums, bf16 / 48 channels):
+ * [B*R^3][8] bytes (6 used), bit j of byte c = [d0[voxel][8c + j] > 0] -- with the backward's sums taken here, the sign is all nmh_mae_tail_bwd still needs of d0:
+ * given the mask it reads 8 bytes per voxel instead of the residual row (r and d0 may then both be NULL there). */
+NMH_API int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, double* bwd_sums, unsigned char* sign_mask, void* stream);
 /* Backward of the decoder tail d0 = lrelu(IN(y) + r) -> 1x1 head -> loss in two elementwise passes that never materialise d(d0)
  * (swin_mae3d.py:1496-1549 + unetr_block.py:62-71 backward): d(d0) = Wout^T dpred is recomputed per element from dpred/loss_sums
  * (both from nmh_mae_loss_fwd).  in_sums[b][c] = {sum g, sum g*yhat}, dy = IN-backward, dr = g; dWout/dbout accumulate the head
@@ -224,7 +226,7 @@ NMH_API int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const vo
  * bwd_sums (optional, fp64 [B*C*4 + 4*C], zeroed by nmh_mae_tail_fwd): the forward pass also takes the reductions of this backward
  * ({sum g, sum g*yhat} per (sample, channel) and the head weight gradient, RGB and alpha parts of the loss kept apart until their
  * normalisers are known); passed on to nmh_mae_tail_bwd it makes the backward a single apply pass (one 3-tensor read pass less). */
-NMH_API int nmh_mae_tail_bwd(int dt, const void* d0, const void* r, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums, void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, const double* bwd_sums, void* stream);
+NMH_API int nmh_mae_tail_bwd(int dt, const void* d0, const void* r, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums, void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, const double* bwd_sums, const unsigned char* sign_mask, void* stream);
 /* Input pipeline in one pass (nerf_rpn/datasets.py:88-101,198-233,247-248 + torch_utils.py:56-90): one stored scene
  * rgbsigma (W,L,H,4), fp32 or uint8, already in device memory -> the (4,R,R,R) fp32 slot of the padded batch: uint8/255, optional
  * density->alpha = clip(1-exp(-exp(sigma)/100),0,1) (fp32 scenes), (W,L,H,C)->(C,W,L,H), the z-up augmentations (flags: 1 = 90-degree

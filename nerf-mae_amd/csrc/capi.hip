@@ -294,17 +294,19 @@ int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const float* bou
   return k_loss_bwd(a, dd0, dWout, dbout, ST);
 }
 int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, void* d0, const float* Wout, const float* bout, const float* target, const int* extents,
-                     const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, double* bwd_sums, void* stream) {
+                     const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, double* bwd_sums,
+                     unsigned char* sign_mask, void* stream) {
   CLR();
-  LossArgs a{dt, nullptr, Wout, bout, target, extents, tokmask, B, R, C, sums, pred, dpred, bwd_sums};
+  LossArgs a{dt, nullptr, Wout, bout, target, extents, tokmask, B, R, C, sums, pred, dpred, bwd_sums, sign_mask};
   int rc = k_tail_fwd(a, y, stats, r, d0, slope, ST);
   if (rc) return rc;
   return k_loss_finalize(sums, losses, ST);
 }
 int nmh_mae_tail_bwd(int dt, const void* d0, const void* r, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums,
-                     void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, const double* bwd_sums, void* stream) {
+                     void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, const double* bwd_sums, const unsigned char* sign_mask,
+                     void* stream) {
   CLR();
-  return k_tail_bwd(dt, d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, (long)V, C, bwd_sums, ST);
+  return k_tail_bwd(dt, d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, (long)V, C, bwd_sums, ST, sign_mask);
 }
 int nmh_grid_prepare(int src_u8, const void* src, int W, int L, int H, float* dst, int R, int flags, void* stream) {
   CLR();

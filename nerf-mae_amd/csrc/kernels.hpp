@@ -208,6 +208,8 @@ struct LossArgs {
   float* dp;                             // optional fp32 [B*R^3][4]: un-normalised d(loss)/d(pred) (forward only)
   double* bwd_sums;                      // optional (k_tail_fwd): [B][C][4] {sum g_rgb, sum g_rgb*xhat, sum g_a, sum g_a*xhat} + [4][C] head weight-gradient sums,
                                          // all on the un-normalised d(pred): the InstanceNorm-backward / head reductions of the tail backward, taken in the forward pass
+  unsigned char* sign_mask;              // optional (k_tail_fwd, bf16 / 48 channels): [B*R^3][8] bytes (Cd = 48: 6 used), bit j of byte c = [d0[voxel][8c + j] > 0]: all the tail
+                                         // backward needs of d0 once its sums come from bwd_sums -- it then reads 6 bytes per voxel instead of the 96-byte residual row
 };
 int k_loss_fwd(const LossArgs& a, hipStream_t st);
 int k_loss_finalize(const double* sums, float* losses, hipStream_t st);
@@ -216,7 +218,7 @@ int k_loss_bwd(const LossArgs& a, void* dd0, float* dWout, float* dbout, hipStre
 int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void* r, void* out, float slope, hipStream_t st);
 // loss backward + backward of d0 = lrelu(IN(x)+r) in two elementwise passes over (d0, x, dp): dx, dr = g; also head weight/bias gradients
 int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
-               void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, const double* bwd_sums, hipStream_t st);
+               void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, const double* bwd_sums, hipStream_t st, const unsigned char* sign_mask = nullptr);
 int k_bias_grad(int dt, const void* dY, float* db, long M, int N, const float* rowscale, int rows_per_scale, hipStream_t st);
 int k_add_inplace(int dt, void* a, const void* b, long n, hipStream_t st);
 int k_add(int dt, void* out, const void* a, const void* b, long n, hipStream_t st);

@@ -707,7 +707,8 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
 template <typename T, int APPLY>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0, const T* __restrict__ rres, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dp,
                                                        const double* __restrict__ lsums, const float* __restrict__ Wout, double* in_sums, T* __restrict__ dx,
-                                                       T* __restrict__ dr, float slope, float* dWout, float* dbout, long V, int C, long vpb) {
+                                                       T* __restrict__ dr, float slope, float* dWout, float* dbout, long V, int C, long vpb,
+                                                       const unsigned char* __restrict__ smask) {
   extern __shared__ float sred[];  // [6][C]
   const int CL = C >> 3, NV = 256 / CL;
   const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
@@ -739,10 +740,15 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
         const long v = vb + (long)u * NV;
         if (v < v1) {
           const long o = ((long)b * V + v) * C + cl * 8;
-          Vec8<T>::load((d0 ? d0 : rres) + o, ov[u]);
+          if (APPLY && smask) {   // only the sign of d0 is needed (the sums came out of the forward pass): one byte instead of 16
+            const uint2 mw = *reinterpret_cast<const uint2*>(smask + ((long)b * V + v) * 8);   // 8-byte rows (C = 48: 6 used), one load per voxel row
+            const unsigned m8 = ((cl < 4 ? mw.x : mw.y) >> (8 * (cl & 3))) & 0xffu;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[u][j] = (m8 >> j) & 1u ? 1.0f : -1.0f;
+          } else Vec8<T>::load((d0 ? d0 : rres) + o, ov[u]);
           Vec8<T>::load(x + o, xv[u]);
           dq[u] = *reinterpret_cast<const float4*>(dp + ((long)b * V + v) * 4);
-          if (!d0) {  // d0 was not stored by the forward: rebuild it bit-exactly (same fp32 expression, same rounding) from x and r
+          if (!d0 && !(APPLY && smask)) {  // d0 was not stored by the forward: rebuild it bit-exactly (same fp32 expression, same rounding) from x and r
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               float y = (xv[u][j] - mu[j]) * rs[j] + ov[u][j];
@@ -814,8 +820,9 @@ __global__ void tail_sums_finalize_kernel(const double* __restrict__ bs, const d
   }
 }
 int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
-               void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, const double* bwd_sums, hipStream_t st) {
-  if (C % 8 || C / 8 > 256 || (!d0 && !r)) return -2;
+               void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, const double* bwd_sums, hipStream_t st, const unsigned char* sign_mask) {
+  if (C % 8 || C / 8 > 256 || (!d0 && !r && !(sign_mask && bwd_sums))) return -2;
+  if (sign_mask && (!bwd_sums || C != 48)) return -4;   // the sums pass needs d0 itself; the mask has 8-byte rows for 48 channels
   const long vpb = in_vox_per_block(V, B);
   const long vpa = in_apply_vpb(V, B, C);
   dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + vpa - 1) / vpa), B);
@@ -824,10 +831,10 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
     hipLaunchKernelGGL(tail_sums_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bwd_sums, loss_sums, in_sums, dWout, dbout, B, C);
     if (dt == NMH_DT_BF16)
       hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
-                         (bf16_t*)dr, slope, dWout, dbout, V, C, vpa);
+                         (bf16_t*)dr, slope, dWout, dbout, V, C, vpa, sign_mask);
     else
       hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), g1, dim3(256), 0, st, (const float*)d0, (const float*)r, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)dx,
-                         (float*)dr, slope, dWout, dbout, V, C, vpa);
+                         (float*)dr, slope, dWout, dbout, V, C, vpa, sign_mask);
     NMH_CHECK_LAUNCH();
     return 0;
   }
@@ -836,14 +843,14 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
   const size_t lds = 6 * C * sizeof(float);
   if (dt == NMH_DT_BF16) {
     hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 0>), g0, dim3(256), lds, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)nullptr,
-                       (bf16_t*)nullptr, slope, dWout, dbout, V, C, vpb);
+                       (bf16_t*)nullptr, slope, dWout, dbout, V, C, vpb, (const unsigned char*)nullptr);
     hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
-                       (bf16_t*)dr, slope, dWout, dbout, V, C, vpa);
+                       (bf16_t*)dr, slope, dWout, dbout, V, C, vpa, sign_mask);
   } else {
     hipLaunchKernelGGL((tail_bwd_kernel<float, 0>), g0, dim3(256), lds, st, (const float*)d0, (const float*)r, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)nullptr,
-                       (float*)nullptr, slope, dWout, dbout, V, C, vpb);
+                       (float*)nullptr, slope, dWout, dbout, V, C, vpb, (const unsigned char*)nullptr);
     hipLaunchKernelGGL((tail_bwd_kernel<float, 1>), g1, dim3(256), 0, st, (const float*)d0, (const float*)r, (const float*)xin, in_stats, dp, loss_sums, Wout, in_sums, (float*)dx,
-                       (float*)dr, slope, dWout, dbout, V, C, vpa);
+                       (float*)dr, slope, dWout, dbout, V, C, vpa, sign_mask);
   }
   NMH_CHECK_LAUNCH();
   return 0;
@@ -1099,15 +1106,17 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
     nx[2] = *reinterpret_cast<const uint4*>(xb + o2); nr[2] = *reinterpret_cast<const uint4*>(rb + o2);
   };
   // one chunk: x-hat, d0 (bf16), and the four packed operand rows for the reduction GEMMs
-  auto chunk = [&](const uint4& xw, const uint4& rw, const float (&mu)[8], const float (&rs)[8], uint4& ypk, uint4& mpk, uint4& mxpk, uint4& xpk) {
+  auto chunk = [&](const uint4& xw, const uint4& rw, const float (&mu)[8], const float (&rs)[8], uint4& ypk, uint4& mpk, uint4& mxpk, uint4& xpk, unsigned& bits) {
     const unsigned xs[4] = {xw.x, xw.y, xw.z, xw.w}, rr[4] = {rw.x, rw.y, rw.z, rw.w};
     unsigned yo[4], mo[4], mxo[4], xo[4];
+    bits = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float xa = (__uint_as_float(xs[i] << 16) - mu[2 * i]) * rs[2 * i], xc = (__uint_as_float(xs[i] & 0xffff0000u) - mu[2 * i + 1]) * rs[2 * i + 1];
       float ya = xa + __uint_as_float(rr[i] << 16), yc = xc + __uint_as_float(rr[i] & 0xffff0000u);
       // (the sign of the fp32 value is the sign of its bf16 rounding: same exponent range)
       const float ma = ya > 0.f ? 1.0f : 0.0f, mc = yc > 0.f ? 1.0f : 0.0f;
+      bits |= (ya > 0.f ? 1u : 0u) << (2 * i) | (yc > 0.f ? 1u : 0u) << (2 * i + 1);
       ya = fmaxf(ya, slope * ya); yc = fmaxf(yc, slope * yc);   // LeakyReLU, 0 < slope < 1
       const unsigned yp = pk_bf16(ya, yc);
       yo[i] = yp;
@@ -1134,9 +1143,18 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
     for (int k = 0; k < 3; ++k) { cx[k] = nx[k]; cr[k] = nr[k]; }
     if (base + gstep < v1) issue(base + gstep);
     uint4 y0, y1, y2, mp, mxp, xp;
-    chunk(cx[0], cr[0], mu0, rs0, y0, mp, mxp, xp); put(vi, c0, mp, mxp, xp, y0);
-    chunk(cx[1], cr[1], mu0, rs0, y1, mp, mxp, xp); put(16 + vi, c0, mp, mxp, xp, y1);
-    chunk(cx[2], cr[2], mu1, rs1, y2, mp, mxp, xp); put(16 * t2 + vi, c1, mp, mxp, xp, y2);
+    unsigned sb0, sb1, sb2;
+    chunk(cx[0], cr[0], mu0, rs0, y0, mp, mxp, xp, sb0); put(vi, c0, mp, mxp, xp, y0);
+    chunk(cx[1], cr[1], mu0, rs0, y1, mp, mxp, xp, sb1); put(16 + vi, c0, mp, mxp, xp, y1);
+    chunk(cx[2], cr[2], mu1, rs1, y2, mp, mxp, xp, sb2); put(16 * t2 + vi, c1, mp, mxp, xp, y2);
+    if (a.sign_mask) {   // [d0 > 0] of the lane's three chunks: byte c0 / 8 of voxels vi and 16 + vi, byte c1 / 8 of voxel 16 t2 + vi -- collected per
+      //                    voxel in a wave-private LDS row of 8 bytes (6 used) and stored by lanes 0..31 behind the wave barrier below: 256 contiguous bytes
+      //                    per step (single-byte global stores cost the pass 0.17 ms)
+      unsigned char* sm = reinterpret_cast<unsigned char*>(smem) + 4 * WLDS + wave * 256;
+      sm[vi * 8 + g] = (unsigned char)sb0;
+      sm[(16 + vi) * 8 + g] = (unsigned char)sb1;
+      sm[(16 * t2 + vi) * 8 + 4 + (g & 1)] = (unsigned char)sb2;
+    }
     // head: P[voxel][o] for both tiles
     Frag<bf16_t> f0, f1, f2;
     f0.v = __builtin_bit_cast(bf16x8, y0); f1.v = __builtin_bit_cast(bf16x8, y1); f2.v = __builtin_bit_cast(bf16x8, y2);
@@ -1184,6 +1202,8 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (a.sign_mask && lane < 32)
+      *reinterpret_cast<uint2*>(a.sign_mask + ((long)b * V + base + lane) * 8) = *reinterpret_cast<const uint2*>(smem + 4 * WLDS + wave * 256 + lane * 8);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -1263,10 +1283,11 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
     e = nmh_zero_async(a.bwd_sums, sizeof(double) * ((size_t)a.B * C * 4 + 4 * C), st);
     if (e != hipSuccess) return (int)e;
     const int use_mfma = getenv("NMH_TAIL_MFMA") ? atoi(getenv("NMH_TAIL_MFMA")) : 1;
+    if (a.sign_mask && !(use_mfma && a.dt == NMH_DT_BF16 && C == 48 && !out && a.R % 4 == 0 && V < (1L << 31) && slope > 0.f && slope < 1.f)) return -4;
     if (use_mfma && a.dt == NMH_DT_BF16 && C == 48 && !out && a.R % 4 == 0 && V < (1L << 31) && slope > 0.f && slope < 1.f) {
       const long vpm = (vpb + 127) / 128 * 128;   // whole 32-voxel steps per wave
       dim3 gm((unsigned)((V + vpm - 1) / vpm), a.B);
-      hipLaunchKernelGGL(tail_fwd_mfma_kernel, gm, dim3(256), 4 * 4 * 32 * 96, st, (const bf16_t*)x, stats, (const bf16_t*)r, a, V, slope, vpm);
+      hipLaunchKernelGGL(tail_fwd_mfma_kernel, gm, dim3(256), 4 * 4 * 32 * 96 + 4 * 256, st, (const bf16_t*)x, stats, (const bf16_t*)r, a, V, slope, vpm);
       NMH_CHECK_LAUNCH();
       return 0;
     }

@@ -468,9 +468,12 @@ class _UpBlockFn(torch.autograd.Function):
             # the reductions of the tail BACKWARD (InstanceNorm-backward sums, head weight gradient) are taken by the same pass
             bsum = torch.empty(B * Cout * 4 + 4 * Cout, dtype=torch.float64, device=dev) if (dpred is not None and model.fuse_tail_sums) else None
             # last InstanceNorm + residual + LeakyReLU, the 1x1 head and the loss terms in one pass over (y2, cat)
+            # with the backward's sums taken here, the sign of d0 is all the tail backward still needs of it: 6 bytes per voxel instead of the residual row
+            smask = (torch.empty((B * V, 8), dtype=torch.uint8, device=dev)
+                     if (bsum is not None and ops.TAIL_SIGN_MASK and dtype == torch.bfloat16 and Cout == 48 and out is None and S % 4 == 0) else None)
             ops.mae_tail_fwd(y2, st2, cat, out, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask, B, S, Cout, lsums, losses,
-                             pred_out, dpred, bwd_sums=bsum)
-            ctx.tail = (model, lsums, dpred, bsum)
+                             pred_out, dpred, bwd_sums=bsum, sign_mask=smask)
+            ctx.tail = (model, lsums, dpred, bsum, smask)
             return losses
         return out
 
@@ -489,9 +492,10 @@ class _UpBlockFn(torch.autograd.Function):
         dy2 = torch.empty_like(y2)
         dcat = torch.empty_like(cat)
         if ctx.tail is not None:   # d(loss)/d(losses[0]) == 1 (the reference calls loss.backward()); d(d0) is never materialised
-            model, lsums, dpred, bsum = ctx.tail
+            model, lsums, dpred, bsum, smask = ctx.tail
             ops.mae_tail_bwd(None, y2, st2, dpred, lsums, model.out.conv.weight, sums2, dy2, dcat,
-                             _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout, r=cat, bwd_sums=bsum)
+                             _gradbuf(model.out.conv.weight), _gradbuf(model.out.conv.bias), B, V, Cout, r=None if smask is not None else cat, bwd_sums=bsum,
+                             sign_mask=smask)
         elif m.has_proj:
             dout = dout.contiguous()
             sums3 = ops.acc_zeros((B, Cout, 2), dev)

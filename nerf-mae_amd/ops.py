@@ -268,6 +268,7 @@ def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None):
     return out
 
 
+TAIL_SIGN_MASK = __import__("os").environ.get("NMH_TAIL_SIGN_MASK", "1") != "0"   # tail backward reads [d0 > 0] bits written by the tail forward instead of the residual
 C48_BWD_REDUCE = __import__("os").environ.get("NMH_C48_BWD_REDUCE", "1") != "0"   # decoder1 conv2 input gradient: InstanceNorm-backward sums in the conv epilogue
 
 
@@ -714,29 +715,31 @@ def mae_loss_bwd(d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, 
     lib().call("nmh_mae_loss_bwd", dt_of(d0), d0, Wout, bout, target, extents, tokmask, B, R, Cd, sums, dd0, dpred8, dWout, dbout, _st())
 
 
-def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred=None, dpred=None, slope=0.01, bwd_sums=None):
+def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred=None, dpred=None, slope=0.01, bwd_sums=None, sign_mask=None):
     """d0 = lrelu(IN(y) + r), 1x1 head and loss terms in one pass (instnorm_apply rmode 1 + mae_loss_fwd); d0 = None: not stored"""
-    _chk(y, stats, r, d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred, bwd_sums)
+    _chk(y, stats, r, d0, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred, bwd_sums, sign_mask)
+    if sign_mask is not None and (bwd_sums is None or sign_mask.dtype != torch.uint8 or sign_mask.numel() < B * R ** 3 * 8 or C != 48):
+        raise ValueError("mae_tail_fwd: sign_mask needs bwd_sums, 48 channels and B*R^3*8 bytes")
     if dpred is not None and sums.numel() < 8:
         raise ValueError("mae_tail_fwd: sums needs 8 entries when dpred is requested")
     if bwd_sums is not None and (dpred is None or bwd_sums.numel() < B * C * 4 + 4 * C):
         raise ValueError("mae_tail_fwd: bwd_sums needs dpred and B*C*4 + 4*C entries")
     # algorithmic bytes: y and r read once, the fp32 target (4 channels) read once, d(pred) (16 B / voxel) and d0 written if requested
     ev = _prof(("mae_tail_fwd", B, R, C), (2 + (d0 is not None)) * y.numel() * y.element_size() + B * R ** 3 * 16 * (1 + (dpred is not None) + (pred is not None)))
-    lib().call("nmh_mae_tail_fwd", dt_of(y), y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope, bwd_sums, _st())
+    lib().call("nmh_mae_tail_fwd", dt_of(y), y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope, bwd_sums, sign_mask, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return losses
 
 
-def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01, r=None, bwd_sums=None):
+def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01, r=None, bwd_sums=None, sign_mask=None):
     """d0 may be None when r (the forward's residual input) is given: the kernel rebuilds d0 from y, stats and r"""
-    _chk(d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, bwd_sums)
-    if d0 is None and r is None:
-        raise ValueError("mae_tail_bwd needs d0 or r")
+    _chk(d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, bwd_sums, sign_mask)
+    if d0 is None and r is None and (sign_mask is None or bwd_sums is None):
+        raise ValueError("mae_tail_bwd needs d0, r, or the forward's sign mask together with its bwd_sums")
     # two passes (sums, then apply): y and r (or d0) read twice, d(pred) read twice, dy and dr written once
     ev = _prof(("mae_tail_bwd", B, V, C), (4 if bwd_sums is not None else 6) * y.numel() * y.element_size() + (1 if bwd_sums is not None else 2) * B * V * 16)
-    lib().call("nmh_mae_tail_bwd", dt_of(y), d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, bwd_sums, _st())
+    lib().call("nmh_mae_tail_bwd", dt_of(y), d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, bwd_sums, sign_mask, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
 
