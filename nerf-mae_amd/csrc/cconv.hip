@@ -423,9 +423,10 @@ int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int
     hipError_t e = nmh_zero_async(stats_acc, sizeof(double) * 2 * 48 * B, st);
     if (e != hipSuccess) return (int)e;
   }
-  long nb = a.total < 256 ? a.total : 256;
-  nb = nb / 8 * 8;          // the XCD-contiguous ranges need a multiple of 8 workgroups
-  if (nb < 8) nb = 8;
+  // the XCD-contiguous ranges need a multiple of 8 workgroups; rounded UP: one grid has 250 blocks -- 248 workgroups would walk 8 ranges of 32 blocks with
+  // a stride of 31 and the first workgroup of every range would run two blocks (the launch then takes two block times instead of one)
+  long nb = (a.total + 7) / 8 * 8;
+  if (nb > 256) nb = 256;
   static const int dbg = getenv("NMH_CCONV_DBG") ? atoi(getenv("NMH_CCONV_DBG")) : 0;
 #define CC_LAUNCH(D)                                                                                                              \
   {                                                                                                                               \
@@ -588,9 +589,8 @@ int k_upconv4_fwd(const void* X, const void* Wup, const float* bt, void* Y, int 
   a.B = B; a.v = v; a.nbz = v / BZ; a.nby = v / BY; a.nbx = v / BX;
   a.total = (long)B * a.nbz * a.nby * a.nbx;
   if (a.total >= (1L << 31) || (long)B * 64 * v * v * v * 48 >= (1L << 40)) return -2;
-  long nb = a.total < 256 ? a.total : 256;
-  nb = nb / 8 * 8;
-  if (nb < 8) nb = 8;
+  long nb = (a.total + 7) / 8 * 8;      // (rounded up: see k_cconv_fwd)
+  if (nb > 256) nb = 256;
   hipLaunchKernelGGL(upconv4_fwd_kernel, dim3((unsigned)nb), dim3(512), up4::LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
@@ -1293,9 +1293,8 @@ int k_cconv_dgrad(const void* dY, const void* Wdp, const void* add, void* DX, in
   a.B = B; a.v = v; a.nbz = v / BZ; a.nby = v / BY; a.nbx = v / BX;
   a.total = (long)B * a.nbz * a.nby * a.nbx;
   if (a.total >= (1L << 31) || (long)B * 64 * v * v * v * 48 >= (1L << 40)) return -2;
-  long nb = a.total < 256 ? a.total : 256;
-  nb = nb / 8 * 8;
-  if (nb < 8) nb = 8;
+  long nb = (a.total + 7) / 8 * 8;      // (rounded up: see k_cconv_fwd)
+  if (nb > 256) nb = 256;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)cconv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CD_RING * WHALF);
