@@ -854,18 +854,23 @@ __global__ __launch_bounds__(256) void cconv_wgrad_chain_kernel(const float* __r
     __syncthreads();
     for (int i = tid; i < 4608; i += 256) { const int r = i / 48, c = i - r * 48; sg[r * 49 + c] = gsrc[i]; sw[r * 49 + c] = wsrc[i]; }
     __syncthreads();
-#pragma unroll
-    for (int o = 0; o < 9; ++o) {
-      const int e = tid + 256 * o, c = e / 48, co = e - c * 48;
-      float s = 0.f;
-      for (int ci = 0; ci < 96; ++ci) s += sg[ci * 49 + c] * sw[ci * 49 + co];
-      acc[o] += s;
+    // thread (tc, to) of a 16 x 16 grid owns the 3 x 3 block c = 3 tc + i, co = 3 to + j: six LDS reads per nine products
+    {
+      const int c0 = 3 * (tid >> 4), o0 = 3 * (tid & 15);
+#pragma unroll 4
+      for (int ci = 0; ci < 96; ++ci) {
+        const float g0 = sg[ci * 49 + c0], g1 = sg[ci * 49 + c0 + 1], g2 = sg[ci * 49 + c0 + 2];
+        const float w0 = sw[ci * 49 + o0], w1 = sw[ci * 49 + o0 + 1], w2 = sw[ci * 49 + o0 + 2];
+        acc[0] += g0 * w0; acc[1] += g0 * w1; acc[2] += g0 * w2;
+        acc[3] += g1 * w0; acc[4] += g1 * w1; acc[5] += g1 * w2;
+        acc[6] += g2 * w0; acc[7] += g2 * w1; acc[8] += g2 * w2;
+      }
     }
   }
   if (agrp == 0) {
 #pragma unroll
     for (int o = 0; o < 9; ++o) {
-      const int e = tid + 256 * o, c = e / 48, co = e - c * 48;
+      const int c = 3 * (tid >> 4) + o / 3, co = 3 * (tid & 15) + o % 3;
       float sb = 0.f;
       for (int cls = 0; cls < 27; ++cls) {
         const int kz = cls / 9, ky = (cls / 3) % 3, kx = cls % 3;
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(256) void cconv_wgrad_chain_kernel(const float* __r
   }
 #pragma unroll
   for (int o = 0; o < 9; ++o) {
-    const int e = tid + 256 * o, c = e / 48, co = e - c * 48;
+    const int c = 3 * (tid >> 4) + o / 3, co = 3 * (tid & 15) + o % 3;
     atomicAdd(dW1 + ((long)c * 48 + co) * 27 + d, acc[o]);
   }
 }
@@ -914,12 +919,17 @@ __global__ __launch_bounds__(256) void cconv_wgrad_chain_t_kernel(const float* _
     for (int i = tid; i < 2304; i += 256) { const int r = i / 48, c = i - r * 48; sw[r * 49 + c] = wsrc[i]; }
     __syncthreads();
     // (c outermost, two at a time: fully unrolled the other way round the 18 x 48 products are all hoisted and spill -- measured 2.4 ms)
+    // thread (ti, to) of a 16 x 16 grid owns the 6 x 3 block ci = 6 ti + i, co = 3 to + j: nine LDS reads per eighteen products
+    {
+      const int i0 = 6 * (tid >> 4), o0 = 3 * (tid & 15);
 #pragma unroll 2
-    for (int c = 0; c < 48; ++c) {
+      for (int c = 0; c < 48; ++c) {
+        const float w0 = sw[c * 49 + o0], w1 = sw[c * 49 + o0 + 1], w2 = sw[c * 49 + o0 + 2];
 #pragma unroll
-      for (int o = 0; o < 18; ++o) {
-        const int e = tid + 256 * o, ci = e / 48, co = e - ci * 48;
-        acc[o] += sg[ci * 49 + c] * sw[c * 49 + co];
+        for (int i = 0; i < 6; ++i) {
+          const float gv = sg[(i0 + i) * 49 + c];
+          acc[3 * i] += gv * w0; acc[3 * i + 1] += gv * w1; acc[3 * i + 2] += gv * w2;
+        }
       }
     }
     if (ph == 0) {     // the bias (once per tap d: the phase-0 workgroups); the class sums sit in LDS
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(256) void cconv_wgrad_chain_t_kernel(const float* _
   // partial [workgroup][ci][co] (contiguous): the 192 workgroups walk the SAME elements in the same order -- atomics on dWt[e][ph] would all land on
   // one 256-byte line at a time (measured 2.4 ms); the kernel below folds the three d_z parts into dWt
 #pragma unroll
-  for (int o = 0; o < 18; ++o) part[(long)blockIdx.x * 4608 + tid + 256 * o] = acc[o];
+  for (int o = 0; o < 18; ++o) part[(long)blockIdx.x * 4608 + (6 * (tid >> 4) + o / 3) * 48 + 3 * (tid & 15) + o % 3] = acc[o];
   if (ph == 0 && tid < 48 && dbt) atomicAdd(dbt + tid, bacc);
 }
 
