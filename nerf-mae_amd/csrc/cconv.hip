@@ -796,31 +796,44 @@ __global__ __launch_bounds__(256) void cconv_dy_border_kernel(const bf16_t* __re
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[kx][j] = 0.f;
   if (vl < 42) {
+    const int lpb = (F + (int)gridDim.y - 1) / (int)gridDim.y, ly0 = (int)blockIdx.y * lpb, ly1 = ly0 + lpb < F ? ly0 + lpb : F;
+    // (1) border lines (first / last plane: every line; other planes: the first / last line): every voxel of them is a border voxel
     for (int fz = z0; fz < z0 + planes_per_block && fz < F; ++fz) {
       const int kz = fz == 0 ? 0 : (fz == F - 1 ? 2 : 1);
-      const int ly0 = (int)blockIdx.y * ((F + (int)gridDim.y - 1) / (int)gridDim.y), ly1 = ly0 + (F + (int)gridDim.y - 1) / (int)gridDim.y;
-      for (int fy = ly0; fy < ly1 && fy < F; ++fy) {
+      for (int fy = ly0; fy < ly1; ++fy) {
         const int ky = fy == 0 ? 0 : (fy == F - 1 ? 2 : 1);
+        if (kz == 1 && ky == 1) continue;
         const bf16_t* base = dY + ((((long)b * F + fz) * F + fy) * F) * 48 + c8 * 8;
-        if (kz != 1 || ky != 1) {            // a border line: every voxel of it is a border voxel
-          for (int fx = vl; fx < F; fx += 42) {
-            float v8[8];
-            Vec8<bf16_t>::load(base + (long)fx * 48, v8);
-            const int kx = fx == 0 ? 0 : (fx == F - 1 ? 2 : 1);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-              if (q == kx)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[q][j] += v8[j];
-          }
-        } else if (vl < 2) {                 // an interior line: its two end voxels
+        for (int fx = vl; fx < F; fx += 42) {
           float v8[8];
-          Vec8<bf16_t>::load(base + (long)(vl ? F - 1 : 0) * 48, v8);
+          Vec8<bf16_t>::load(base + (long)fx * 48, v8);
+          const int kx = fx == 0 ? 0 : (fx == F - 1 ? 2 : 1);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[vl ? 2 : 0][j] += v8[j];
+          for (int q = 0; q < 3; ++q)
+            if (q == kx)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[q][j] += v8[j];
         }
-        if (ky != 1 || fy == F - 2 || fy == ly1 - 1) flush(kz, ky);      // class changes after line 0, after the interior run and after the last line
+        if (ky != 1 || fy == F - 2 || fy == ly1 - 1) flush(kz, ky);      // the class changes after line 0, after the interior run and after the last line
       }
+    }
+    // (2) interior lines of interior planes: their two end voxels -- all (line, end) pairs of the workgroup spread over the 42 voxel lanes (one pair per
+    //     lane and iteration; walked line by line with two lanes, the pass was a chain of 100 dependent load round trips: 114 us for 15 MB)
+    {
+      const int zb = z0 < 1 ? 1 : z0, ze = z0 + planes_per_block < F - 1 ? z0 + planes_per_block : F - 1;      // interior planes [zb, ze)
+      const int yb = ly0 < 1 ? 1 : ly0, ye = ly1 < F - 1 ? ly1 : F - 1;                                        // interior lines [yb, ye)
+      const int ny = ye - yb, npair = (ze > zb && ny > 0) ? (ze - zb) * ny * 2 : 0;
+      for (int p = vl; p < npair; p += 42) {
+        const int end = p & 1, ln = p >> 1, fz = zb + ln / ny, fy = yb + ln % ny;
+        float v8[8];
+        Vec8<bf16_t>::load(dY + ((((long)b * F + fz) * F + fy) * F + (end ? F - 1 : 0)) * 48 + c8 * 8, v8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (end) acc[2][j] += v8[j];
+          else acc[0][j] += v8[j];
+        }
+      }
+      flush(1, 1);
     }
   }
   __syncthreads();
