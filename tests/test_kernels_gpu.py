@@ -1131,6 +1131,13 @@ def test_cconv_wgrad_matches_autograd_of_the_two_ops(B, v):
     check(dW3, W1r.grad, dt, "cconv wgrad (with dWt)", 2)
     check(dWt - 0.25, Wtr.grad, dt, f"transpose conv weight gradient through the composition B={B} v={v}", 2)
     check(dbt + 0.5, btr.grad, dt, "transpose conv bias gradient through the composition (border classes)", 3)
+    # the two phases of the entry (persistent kernel / the small launches behind it, which a caller may issue on a side stream) == the one-call form
+    dW4, dWt4, dbt4 = torch.zeros_like(dW3), torch.full_like(dWt, 0.25), torch.full_like(dbt, -0.5)
+    ops.cconv_wgrad(dev(x, dt), dy_cl, pws, dev(bt), dW4, B, v, dWt=dWt4, dbt=dbt4, phase=1)
+    assert float(dW4.abs().max()) == 0.0                      # phase 1 only fills the workspace
+    ops.cconv_wgrad(dev(x, dt), dy_cl, pws, dev(bt), dW4, B, v, dWt=dWt4, dbt=dbt4, phase=2)
+    assert_close(dW4.cpu(), dW3.cpu(), 1e-5, "cconv wgrad in two phases (dW1)")
+    assert_close((dWt4 - 0.25).cpu(), (dWt - 0.25).cpu(), 1e-5, "cconv wgrad in two phases (dWt)")
 
 
 @pytest.mark.parametrize("B,v", [(1, 8), (2, 8), (1, 16), (3, 24), (2, 40)])
