@@ -281,7 +281,7 @@ def conv3d_k3_c48_bwd_reduce(dY, Wkd, y1, stats1, sums, out=None, slope=0.01):
         raise RuntimeError("conv3d_k3_c48_bwd_reduce needs bf16 tensors with 48 channels and fp64 sums")
     if out is None:
         out = torch.empty((B, D, H, W, 48), dtype=dY.dtype, device=dY.device)
-    ev = _prof(("conv3d_k3_c48", B, D, 48, 48))
+    ev = _prof(("conv3d_k3_c48_bwd_reduce", B, D, 48, 48))
     lib().call("nmh_conv3d_k3_c48_bwd_reduce", dY, Wkd, out, B, D, H, W, y1, stats1, float(slope), sums, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())

@@ -11,7 +11,10 @@ for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
         agg[r["Kernel_Name"].split("(")[0].replace("void ", "")[:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 for key, name in (("conv48_kernel", "conv48"), ("conv48_wgrad_kernel", "conv48_wgrad")):
-    d = next((v for k, v in agg.items() if k.startswith(key + "<") or k == key), None)
+    # (conv48_kernel has three instantiations since round 3: the plain one -- forward / input gradient -- is <0, false, false>)
+    d = agg.get("conv48_kernel<0, false, false>") if key == "conv48_kernel" else None
+    if d is None:
+        d = next((v for k, v in agg.items() if k.startswith(key + "<") or k == key), None)
     if d is None:
         print("no counters for", key, list(agg)); continue
     m = {c: sum(v) / len(v) for c, v in d.items()}
