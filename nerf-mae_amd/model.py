@@ -309,7 +309,11 @@ class _BlockFn(torch.autograd.Function):
         wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
         dx = torch.empty_like(x)
         ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
-        ops.join_side()  # before any temporary of this block is released
+        # the block's own side-stream launches (fp32 parity mode) read temporaries of this block: join before they are released.  With the queue
+        # (bf16) the operands stay referenced by it and NOTHING may be joined here: a join makes this block's successor wait for every weight
+        # gradient the last flush put on the side stream -- the trace showed the two queues taking turns (>= 2 kernels in flight for 4 of 52 ms)
+        if q is None or not ops.WQ_LATE_JOIN:
+            ops.join_side()
         return dx, None, None, None, None
 
 
@@ -324,7 +328,12 @@ class _StageFlushFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ctx.wq.join()     # the previous stage's launch (if any) has had a whole stage of input-gradient work to finish under
+        # Joining the previous stage's launch here makes the next input-gradient kernel a successor of the side chain: the HIP graph executor then puts
+        # the whole next main segment on the side chain's queue, BEHIND the weight gradients just flushed -- the trace showed the two queues alternating
+        # (>= 2 kernels in flight for 4 of 52 ms).  With the late join the side chain only hangs off the main chain (fork edges), the operands stay
+        # referenced by the queue until the end-of-backward join.
+        if not ops.WQ_LATE_JOIN or ctx.wq.sync_after_flush:
+            ctx.wq.join()     # the previous stage's launch (if any) has had a whole stage of input-gradient work to finish under
         ctx.wq.flush()
         if ctx.wq.sync_after_flush:
             ctx.wq.join()

@@ -40,16 +40,17 @@ class side_stream:
 
     @staticmethod
     def auto(grids_per_step: int):
-        """Forked kernels cost extra dependency packets at launch: with 1-2 grids per step the replayed step is launch-bound and the
-        fork/join pairs only add to it (measured at 1 grid: 23.4 ms with, 19.4 ms without); from 3 grids on they hide ~1 ms of
-        weight-gradient work.  NMH_NO_SIDE=1 / NMH_SIDE=1 override."""
+        """Round 1-2: forked kernels cost extra dependency packets at launch, and with 1-2 grids per step the fork/join pairs only added to a
+        launch-bound step (23.4 ms with, 19.4 ms without), so the side stream was used from 3 grids on.  Round 3: most of those joins were the
+        per-block ones that also serialised the two queues (model._BlockFn.backward); without them the fork pays at every batch size (1 grid
+        11.59 -> 11.46 ms, 2 grids 17.63 -> 17.55, 8 grids 51.4 -> 50.5).  NMH_NO_SIDE=1 / NMH_SIDE=1 override; NMH_SIDE_MIN_GRIDS sets the threshold."""
         env = __import__("os").environ
         if env.get("NMH_NO_SIDE", "0") == "1":
             side_stream.enabled = False
         elif env.get("NMH_SIDE", "0") == "1":
             side_stream.enabled = True
         else:
-            side_stream.enabled = grids_per_step >= 3
+            side_stream.enabled = grids_per_step >= int(env.get("NMH_SIDE_MIN_GRIDS", "1"))
 
     def __enter__(self):
         if not (side_stream.enabled and self.enable):
@@ -161,6 +162,7 @@ class _TnProblem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_tn_problem
 
 GROUPED_WGRAD = __import__("os").environ.get("NMH_TNG", "1") != "0"
 DEFER_DECODER_WGRAD = __import__("os").environ.get("NMH_DEFER_DEC", "1") == "1"
+WQ_LATE_JOIN = __import__("os").environ.get("NMH_WQ_LATE_JOIN", "1") == "1"   # weight-gradient queue: join only at the end of the backward pass
 STAGE0_BLOCK_FLUSH = __import__("os").environ.get("NMH_STAGE0_BLOCK_FLUSH", "0") == "1"   # stage 0 flushes its queued weight gradients per block (measured 52.2-52.4 vs 52.0 ms at 8 grids: off)
 
 
