@@ -580,7 +580,11 @@ class _UpBlockFn(torch.autograd.Function):
         if cdg:
             ops.cconv_dgrad(dy1, pk.cconv[5], B, v, add=dx, out=dx)
         g_tw, g_tb = _gradbuf(m.transp_conv.weight), _gradbuf(m.transp_conv.bias)
-        if defer or (ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None):
+        if (ctx.c48 or ctx.c64) and ops.UPW_EARLY and ops.WQ_LATE_JOIN and ops.side_stream.enabled and getattr(m, "_wq", None) is not None:
+            # decoder1 (the FIRST block of the backward pass): queued, its 1.5 ms would join the weight gradients of every later level in front of the
+            # encoder's on the side stream, which is busy from the stage-3 flush to the end of the step; issued here it runs under the small decoder levels
+            m._wq.launch_now(lambda: ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout))
+        elif defer or (ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None):
             m._wq.defer(lambda: ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout))
         else:
             with ops.side_stream():

@@ -162,6 +162,7 @@ class _TnProblem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_tn_problem
 
 GROUPED_WGRAD = __import__("os").environ.get("NMH_TNG", "1") != "0"
 DEFER_DECODER_WGRAD = __import__("os").environ.get("NMH_DEFER_DEC", "1") == "1"
+UPW_EARLY = __import__("os").environ.get("NMH_UPW_EARLY", "0") == "1"   # decoder1 transpose-conv weight gradient on the side stream at the end of its block instead of queued (measured 51.1 / 51.0 vs 50.9 / 51.0 ms: off)
 WQ_LATE_JOIN = __import__("os").environ.get("NMH_WQ_LATE_JOIN", "1") == "1"   # weight-gradient queue: join only at the end of the backward pass
 STAGE0_BLOCK_FLUSH = __import__("os").environ.get("NMH_STAGE0_BLOCK_FLUSH", "0") == "1"   # stage 0 flushes its queued weight gradients per block (measured 52.2-52.4 vs 52.0 ms at 8 grids: off)
 
@@ -187,6 +188,16 @@ class WgradQueue:
         """queue an arbitrary weight-gradient launch (a closure that keeps its operands alive) for the next flush: the decoder's small-level
         weight gradients then share ONE fork / join with the grouped launch of the first encoder stage instead of a fork each"""
         self.deferred.append(fn)
+        if not self._cb:
+            self._cb = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._final)
+
+    def launch_now(self, fn):
+        """issue a weight-gradient launch on the forked side stream right away (no join: the closure keeps its operands alive until the end-of-backward
+        join) -- for work whose operands are ready long before the next flush"""
+        with side_stream():
+            fn()
+        self.inflight.append(fn)
         if not self._cb:
             self._cb = True
             torch.autograd.Variable._execution_engine.queue_callback(self._final)
