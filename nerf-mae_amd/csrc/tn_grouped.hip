@@ -22,8 +22,10 @@
 
 namespace tng {
 constexpr int MAXP = 40;
-constexpr int BN = 96, BK = 96, CH = 64, RS = 192, TILE = CH * RS, STAGE = 2 * TILE, ST = 3, PCS = 6;
-constexpr int LDS_BYTES = ST * STAGE;   // 73,728 B -> two workgroups per CU
+constexpr int BN = 96, BK = 96, CH = 64, RS = 192, TILE = CH * RS, STAGE = 2 * TILE, ST = 2, PCS = 6;
+// Ring of ST chunk stages.  Round 3: two instead of three (49,152 instead of 73,728 B per workgroup) -- the launches run on the side stream under the
+// input-gradient chain, whose GEMM workgroups need 25-45 KB of the same CUs' LDS: step 50.42 -> 50.17 ms at 8 grids (same box, three runs each)
+constexpr int LDS_BYTES = ST * STAGE;
 
 // one problem of a launch, compressed to 96 bytes so that 40 of them fit the 4 KB kernel-argument segment (a launch that carries a whole
 // stage's problems fills the chip for several rounds of workgroups: 16-problem launches ended in a half-empty second round each)
