@@ -57,6 +57,10 @@ NMH_API int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64
 typedef struct nmh_tn_problem { const void* A; int64_t lda; const void* B; int64_t ldb; float* dW; int64_t ldo; float* dbias; const float* rowscale; int64_t M; int N; int K; int rows_per_sample;
   int64_t stride_k; int up_k; int up_v; int bias_atomic; int n_inner; int64_t stride_n2; } nmh_tn_problem;
 NMH_API int nmh_gemm_tn_grouped(int dt, const nmh_tn_problem* probs, int nprob, float* ws, int64_t ws_floats, void* stream);
+/* The same call for a group that has the chip to itself -- the flush of the FIRST encoder stage, issued when the backward pass has nothing but
+ * the patch-embedding backward left (swin_mae3d.py:1455-1463 backward): the contraction splits aim at 640 workgroups instead of the 256 that
+ * suit a launch running underneath the input-gradient chain.  Same arguments, same results up to the summation order of the splits. */
+NMH_API int nmh_gemm_tn_grouped_fg(int dt, const nmh_tn_problem* probs, int nprob, float* ws, int64_t ws_floats, void* stream);
 /* Y[(b,z,y,x)][Cout] (+)= conv3d(k=3,pad=1) of channels-last X with packed weights [Cout][27][Cin] (nn.Conv3d in
  * UnetResBlock, unetr_block.py:35-44).  Input gradients use the same entry with the dgrad pack [Cin][27 flipped][Cout].
  * ws (optional, ws_floats fp32): scratch for a split contraction -- on small volumes (the 10^3 / 20^3 decoder levels: < 256 output tiles,

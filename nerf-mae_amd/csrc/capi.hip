@@ -60,6 +60,12 @@ int nmh_gemm_tn_grouped(int dt, const nmh_tn_problem* probs, int nprob, float* w
   static_assert(sizeof(nmh_tn_problem) == sizeof(TnProblemHost), "descriptor layouts must agree");
   return k_gemm_tn_grouped(reinterpret_cast<const TnProblemHost*>(probs), nprob, ws, ws ? (long)ws_floats : 0, ST);
 }
+int nmh_gemm_tn_grouped_fg(int dt, const nmh_tn_problem* probs, int nprob, float* ws, int64_t ws_floats, void* stream) {
+  CLR();
+  if (nprob <= 0) return 0;
+  if (dt != NMH_DT_BF16_C || probs == nullptr) return -4;
+  return k_gemm_tn_grouped(reinterpret_cast<const TnProblemHost*>(probs), nprob, ws, ws ? (long)ws_floats : 0, ST, true);
+}
 int nmh_upconv_fwd(int dt, const void* x, const void* Wt, const float* bias, void* cat, int64_t ldc, int B, int v, int k, int Cin, int Cout, void* stream) {
   CLR();
   REQ(x, Wt, cat);

@@ -111,7 +111,7 @@ struct TnProblemHost {
   int bias_atomic;                // dbias is shared with other problems of the call: atomic adds
   int n_inner; long stride_n2;    // n_inner > 0: column n = (n / n_inner, n % n_inner) -> dW[(n % n_inner)*ldo + (n / n_inner)*stride_n2 + k*stride_k], dbias[n % n_inner]
 };
-int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st);
+int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground = false);
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st,
              const void* Y1 = nullptr, const float* stats1 = nullptr, float slope = 0.f);
 int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, hipStream_t st);

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args g
 }
 
 // host side: chunk the problem list into launches of <= 16 problems, decide the contraction splits per launch
-int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st) {
+int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground) {
   using namespace tng;
   static bool attr_set = false;
   if (!attr_set) {
@@ -343,7 +343,10 @@ int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_
   // workgroups a split launch aims at.  Round 3: 256 instead of 640 -- the launches run on the side stream UNDER the input-gradient chain (since
   // the queues really overlap), where fewer, longer workgroups take less from the chain's latency-bound kernels: 8 grids 51.1-51.2 -> 50.6-50.8 ms,
   // 4 grids 28.9 -> 28.7, 2 grids 17.67 -> 17.54, 1 grid 11.54 -> 11.47 (1280: 51.6-51.8; 192: 51.3-51.7; 320: 51.2)
-  static const int target_wgs = getenv("NMH_TNG_TARGET") ? atoi(getenv("NMH_TNG_TARGET")) : 256;
+  static const int target_bg = getenv("NMH_TNG_TARGET") ? atoi(getenv("NMH_TNG_TARGET")) : 256;
+  // foreground launches (the last flushes of a backward pass: nothing but the patch-embedding backward is left to run beside them)
+  static const int target_fg = getenv("NMH_TNG_TARGET_FG") ? atoi(getenv("NMH_TNG_TARGET_FG")) : 640;
+  const int target_wgs = foreground ? target_fg : target_bg;
   static const int flat_tiles = getenv("NMH_TNG_FLAT") ? atoi(getenv("NMH_TNG_FLAT")) : 384;
   // longest contraction first: the workgroups of a launch are dealt in order, so the short tiles fill the tail of the last round
   std::vector<int> order(nprob);

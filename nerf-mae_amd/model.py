@@ -132,9 +132,13 @@ class _Packer:
         descs, blk2desc, blkstart = b"", [], []
         off = 0
         self.split = None   # first block of the decoder packs (they can be produced while the encoder runs)
+        self.late = None    # first block of the encoder packs of stages >= LATE_STAGE (96 % of the encoder's elements; produced while stages 0/1 run)
+        self._late_ev, self._late_pending = None, False
         for i, (key, p, mode, dims, n) in enumerate(self.items):
             if self.split is None and key.startswith("decoder"):
                 self.split = len(blk2desc)
+            if self.late is None and self.split is None and key.startswith(f"s{self.LATE_STAGE}."):
+                self.late = len(blk2desc)
             self.views[key] = self.buf[off:off + n]
             descs += struct.pack("<QQiiiiq", p.data_ptr(), self.buf.data_ptr() + off * esz, mode, dims[0], dims[1], dims[2], n)
             if mode in (self.TRANS, self.CONV_F, self.CONV_D):   # tiled modes: blkstart = block id (nmh_pack_weights)
@@ -153,14 +157,28 @@ class _Packer:
         self.blkstart = torch.tensor(blkstart, dtype=torch.int64, device=device)
         self.dt = ops.BF16 if dtype == torch.bfloat16 else ops.F32
 
-    def run(self):
+    LATE_STAGE = 2
+
+    def run(self, late_split: bool = True):
         """encoder layouts on the current stream; the decoder layouts (60 % of the elements, the stride-27 conv gathers) on the
-        forked side stream, where they overlap the latency-bound encoder -- `join()` before the decoder reads them"""
+        forked side stream, where they overlap the latency-bound encoder -- `join()` before the decoder reads them.  late_split: the
+        encoder layouts of stages >= LATE_STAGE go to the side stream as well (first in its order), and `wait_late()` -- called by the
+        model before such a stage runs -- makes the current stream wait for just that launch: the step starts 0.15 ms earlier at every
+        batch size.  (False for callers that capture the stages into separate graphs: an event does not cross captures.)"""
         n = self.blk2desc.numel()
-        sp = self.split if (self.split and ops.side_stream.enabled and os.environ.get("NMH_PACK_SPLIT", "1") != "0") else n
-        if sp > 0:
-            ops.pack_weights(self.dt, self.descs, self.blk2desc[:sp], self.blkstart[:sp], sp)
+        side = ops.side_stream.enabled and os.environ.get("NMH_PACK_SPLIT", "1") != "0"
+        sp = self.split if (self.split and side) else n
+        lt = self.late if (self.late and side and late_split and sp < n and os.environ.get("NMH_PACK_LATE", "1") != "0") else sp
+        self._late_pending = False
+        if lt > 0:
+            ops.pack_weights(self.dt, self.descs, self.blk2desc[:lt], self.blkstart[:lt], lt)
         with ops.side_stream(enable=sp < n):
+            if lt < sp:
+                ops.pack_weights(self.dt, self.descs, self.blk2desc[lt:sp], self.blkstart[lt:sp], sp - lt)
+                if self._late_ev is None:
+                    self._late_ev = torch.cuda.Event()
+                self._late_ev.record(torch.cuda.current_stream())
+                self._late_pending = True
             if sp < n:
                 ops.pack_weights(self.dt, self.descs, self.blk2desc[sp:], self.blkstart[sp:], n - sp)
             if self.cconv is not None:    # decoder1: ConvTranspose o conv1 composed weights (csrc/cconv.hip), from the fp32 masters
@@ -174,6 +192,11 @@ class _Packer:
     @staticmethod
     def join():
         ops.join_side()
+
+    def wait_late(self):
+        if self._late_pending:
+            torch.cuda.current_stream().wait_event(self._late_ev)
+            self._late_pending = False
 
     def __getitem__(self, key):
         return self.views[key]
@@ -222,7 +245,7 @@ class _EmbedFn(torch.autograd.Function):
         q = m._wq if (ops.GROUPED_WGRAD and dy0.dtype == torch.bfloat16) else None
         if q is not None:
             q.add(dy0, A, _gradbuf(conv.weight).view(C, 256), dbias=_gradbuf(conv.bias), rows_per_sample=g ** 3)
-            q.flush()
+            q.flush(foreground=True)
             q.join()      # the backward pass ends here: every deferred weight gradient has been issued and joined
         else:
             ops.gemm_tn(dy0, A, _gradbuf(conv.weight), dbias=_gradbuf(conv.bias))
@@ -322,8 +345,8 @@ class _StageFlushFn(torch.autograd.Function):
     weight gradients queued by the stage's blocks (and its patch merging) as grouped launches"""
 
     @staticmethod
-    def forward(ctx, x, wq):
-        ctx.wq = wq
+    def forward(ctx, x, wq, last=False):
+        ctx.wq, ctx.last = wq, last    # last: the first stage -- its flush ends the backward pass and has the chip to itself
         return x.view_as(x)
 
     @staticmethod
@@ -334,10 +357,10 @@ class _StageFlushFn(torch.autograd.Function):
         # referenced by the queue until the end-of-backward join.
         if not ops.WQ_LATE_JOIN or ctx.wq.sync_after_flush:
             ctx.wq.join()     # the previous stage's launch (if any) has had a whole stage of input-gradient work to finish under
-        ctx.wq.flush()
+        ctx.wq.flush(foreground=ctx.last)
         if ctx.wq.sync_after_flush:
             ctx.wq.join()
-        return g, None
+        return g, None, None
 
 
 class _Fork2Fn(torch.autograd.Function):
@@ -929,6 +952,8 @@ class SwinTransformer_MAE3D_New(nn.Module):
         With a data-parallel reducer the stage (each block group of the chunked stage, dist.GradReducer) is preceded by the trigger that
         launches its gradient range's all-reduce -- backward order: blocks of the group, the flush that issues (and joins) their queued weight
         gradients, then the trigger."""
+        if si >= _Packer.LATE_STAGE:
+            self._packer.wait_late()
         grouped = ops.GROUPED_WGRAD and self.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad
         groups = red.chunk_groups if (red is not None and si == getattr(red, "chunk_stage", -1) and red.chunk_groups) else [list(self.stages[si])]
         if red is None and si == 0 and grouped and ops.STAGE0_BLOCK_FLUSH and len(groups) == 1 and len(groups[0]) > 1:
@@ -939,7 +964,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
             if red is not None:
                 x = red.trigger(x, red.seg_stage(si, k))  # backward reaching here => this range's gradients are complete
             if grouped:
-                x = _StageFlushFn.apply(x, self._wq)
+                x = _StageFlushFn.apply(x, self._wq, si == 0 and k == 0)
             for mod in grp:
                 if isinstance(mod, SwinBlock3D):
                     x = mod(x, None if sd_noise is None else sd_noise[bi])

@@ -167,6 +167,9 @@ WQ_LATE_JOIN = __import__("os").environ.get("NMH_WQ_LATE_JOIN", "1") == "1"   # 
 STAGE0_BLOCK_FLUSH = __import__("os").environ.get("NMH_STAGE0_BLOCK_FLUSH", "0") == "1"   # stage 0 flushes its queued weight gradients per block (measured 52.2-52.4 vs 52.0 ms at 8 grids: off)
 
 
+TNG_FOREGROUND = __import__("os").environ.get("NMH_TNG_FOREGROUND", "1") != "0"
+
+
 class WgradQueue:
     """Deferred weight gradients of the encoder (bf16): `add` records one dW[N,K] += A[M,N]^T . B[M,K] problem (and keeps its operands
     alive), `flush` issues everything recorded so far through nmh_gemm_tn_grouped -- on the forked side stream when that is enabled, so
@@ -216,15 +219,17 @@ class WgradQueue:
         self.flush()
         self.join()
 
-    def _launch(self, group):
+    def _launch(self, group, foreground=False):
         arr = (_TnProblem * len(group))()
         for i, (A, B, dW, dbias, rs, rps) in enumerate(group):
             arr[i] = _TnProblem(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), dW.data_ptr(), B.shape[1],
                                 0 if dbias is None else dbias.data_ptr(), 0 if rs is None else rs.data_ptr(), A.shape[0], A.shape[1], B.shape[1], rps)
         ws = _tn_workspace(group[0][0].device)
-        lib().call("nmh_gemm_tn_grouped", BF16, arr, len(group), ws, 0 if ws is None else ws.numel(), _st())
+        lib().call("nmh_gemm_tn_grouped_fg" if foreground and TNG_FOREGROUND else "nmh_gemm_tn_grouped", BF16, arr, len(group), ws,
+                   0 if ws is None else ws.numel(), _st())
 
-    def flush(self):
+    def flush(self, foreground=False):
+        """foreground: the group will run (almost) alone -- the last flushes of a backward pass -- and may split for the whole chip"""
         if not self.pending and not self.deferred:
             return
         todo, self.pending = self.pending, []
@@ -238,11 +243,11 @@ class WgradQueue:
             group, seen = [], set()
             for pr in todo:
                 if pr[2].data_ptr() in seen:   # the same parameter twice (two forward passes before one backward): separate launches
-                    self._launch(group)
+                    self._launch(group, foreground)
                     group, seen = [], set()
                 group.append(pr)
                 seen.add(pr[2].data_ptr())
-            self._launch(group)
+            self._launch(group, foreground)
         self.inflight.extend(todo)   # operands stay referenced until the issuing stream has been joined
         self.inflight.extend(fns)
 

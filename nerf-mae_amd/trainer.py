@@ -245,7 +245,7 @@ class GraphedTrainStep:
             m.zero_grad()
         B, R = self.x.shape[0], m.resolution
         g = R // 4
-        m._packer.run()
+        m._packer.run(late_split=False)   # the stages are captured into separate graphs
         tok = _EmbedFn.apply(m._anchor, m, self.x, self.mask).view(B, g, g, g, m.embed_dim)
         sd = m._draw_sd_noise(B, tok.device)
         m._wq.sync_after_flush = False
