@@ -10,6 +10,7 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define NMH_DT_F32 0
 #define NMH_DT_BF16 1
@@ -43,6 +44,15 @@ template <> struct Vec8<float> {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
+  // streaming variants (non-temporal: the lines are not kept in L2 / MALL -- for one-pass tensors far larger than the caches)
+  static __device__ __forceinline__ void load_nt(const float* p, float (&v)[8]) {
+    const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  }
+  static __device__ __forceinline__ void store_nt(float* p, const float (&v)[8]) {
+    __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(p));
+    __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(p + 4));
+  }
 };
 template <> struct Vec8<bf16_t> {
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
@@ -56,6 +66,17 @@ template <> struct Vec8<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ void load_nt(const bf16_t* p, float (&v)[8]) {
+    const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store_nt(bf16_t* p, const float (&v)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
   }
 };
 

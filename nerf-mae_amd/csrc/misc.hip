@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* g, long n, dou
   __shared__ float sh[4];
   float s = 0.f;
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
-    if (i + 3 < n) { float4 v = *reinterpret_cast<const float4*>(g + i); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    if (i + 3 < n) { const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i)); s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
     else for (long j = i; j < n; ++j) s += g[j] * g[j];
   }
   s = wave_sum(s);
@@ -624,11 +624,16 @@ __global__ void adamw_kernel(float* p, float* g, float* m, float* v, long n, con
   };
   // four parameters per thread and iteration (16-byte accesses: the four flat buffers are 16-byte aligned); scalar tail
   const long n4 = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) ? n >> 2 : 0;
+  // streaming accesses (non-temporal: 8 x 280 MB pass through once per step) from SHORT blocks -- two iterations per thread: tools/probes/hbm_stream_probe.hip
+  // measures 5.3 TB/s for looping grids of 2048-4096 blocks against 6.0-6.25 for blocks that retire after 16-64 bytes per thread and tensor
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<float4*>(g)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-    upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
-    reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
-    if (zero_g) reinterpret_cast<float4*>(g)[i] = gv;
+    f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i), gv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(g) + i);
+    f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i), vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float a = pv[k], b = gv[k], c = mv[k], d = vv[k]; upd(a, b, c, d); pv[k] = a; gv[k] = b; mv[k] = c; vv[k] = d; }
+    __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p) + i); __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m) + i);
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v) + i);
+    if (zero_g) __builtin_nontemporal_store(gv, reinterpret_cast<f32x4*>(g) + i);
   }
   for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
@@ -638,7 +643,11 @@ __global__ void adamw_kernel(float* p, float* g, float* m, float* v, long n, con
   }
 }
 int k_adamw(float* p, float* g, float* m, float* v, long n, const float* hyper, const float* coef, hipStream_t st) {
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n, 4096)), dim3(256), 0, st, p, g, m, v, n, hyper, coef);
+  static const int per = getenv("NMH_ADAMW_ITERS") ? atoi(getenv("NMH_ADAMW_ITERS")) : 2;   // 16-byte groups per thread
+  long nb = ((n >> 2) + 256L * per - 1) / (256L * per);
+  if (nb < 1) nb = 1;
+  if (nb > (1L << 30)) nb = 1L << 30;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, g, m, v, n, hyper, coef);
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -582,25 +582,59 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
 }
 
 #define IN_APPLY_VOX_PER_BLOCK 2048
+#define IN_STREAM_MAX_C 96   // widest tensor the streaming form of the apply passes takes (LDS constant tables)
 // voxels per block of the apply passes: 2048 on the big volumes, fewer on the coarse decoder levels so that >= ~1024 blocks exist
-static inline long in_apply_vpb(long V, int B, int C) {
+// streaming form of the apply passes (bf16 tensors far larger than L2 + MALL, i.e. the 160^3 level): non-temporal loads and stores and SHORT
+// blocks.  tools/probes/hbm_stream_probe.hip: a 2-read + 1-write pass over 3.1-GB tensors runs at 5.3 TB/s from 2048-4096 looping blocks, 6.0-6.25
+// from blocks that touch 16-64 bytes per thread and tensor with non-temporal accesses.  NMH_IN_STREAM=0 disables, NMH_IN_STREAM_VPB sets the voxels per block.
+static inline bool in_apply_streaming(long V, int B, int C, int dt) {
+  static const int on = getenv("NMH_IN_STREAM") ? atoi(getenv("NMH_IN_STREAM")) : 1;
+  static const double min_bytes = 1.0e6 * (getenv("NMH_IN_STREAM_MIN_MB") ? atof(getenv("NMH_IN_STREAM_MIN_MB")) : 1000.0);
+  return on && dt == NMH_DT_BF16 && C <= IN_STREAM_MAX_C && (double)V * B * C * 2 >= min_bytes;
+}
+// voxels per thread of a streaming block (mult x 256 / (C/8) voxels per block).  Measured at 8 x 160^3 x 48 (tools/bench_inbwd.py, tools/bench_tail.py):
+// forward apply 1.23 ms looping -> 1.04 / 1.03 / 1.12 / 1.14 with 2 / 4 / 8 / 16; backward apply 1.78 -> 1.80 / 1.60 / 1.58 / 1.67; tail backward
+// 2.14 -> 2.45 / 2.18 / 2.09 / 2.06 with 4 / 8 / 16 / 32 (its table is 8 arrays and two fp64 divisions per block)
+static inline bool in_stream_nt() { static const int v = getenv("NMH_IN_STREAM_NT") ? atoi(getenv("NMH_IN_STREAM_NT")) : 1; return v != 0; }
+static inline long in_apply_vpb(long V, int B, int C, bool streaming = false, int mult = 8) {
   const int NV = 256 / (C >> 3);
+  if (streaming) {
+    static const int sv = getenv("NMH_IN_STREAM_VPB") ? atoi(getenv("NMH_IN_STREAM_VPB")) : 0;
+    return sv > 0 ? sv : (long)mult * NV;
+  }
   long vpb = (V * B + 1023) / 1024;
   if (vpb < 4L * NV) vpb = 4L * NV;
   return vpb > IN_APPLY_VOX_PER_BLOCK ? IN_APPLY_VOX_PER_BLOCK : vpb;
 }
-template <typename T>
+template <typename T, bool ST = false, bool NT = false>   // ST: short streaming blocks (LDS constant table); NT: non-temporal accesses
 __global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* stats, const T* r, const float* stats_r, int rmode, T* out, long V, int C, float slope, long vpb) {
   // grid (voxel blocks, B); thread = (8-channel chunk cl, voxel lane vl): no integer division in the loop, statistics in registers
   const int CL = C >> 3, NV = 256 / CL;
   const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
-  if (vl >= NV) return;
   float mu[8], rs[8], mur[8], rsr[8];
+  if (ST) {   // short streaming blocks: the per-channel constants reach the threads through an LDS table (one global load per channel and block
+    //           instead of 16-32 per thread: with 4-8 voxels per thread the per-thread prologue moved as many bytes through L2 as the pass itself)
+    __shared__ float tab[4 * IN_STREAM_MAX_C];
+    for (int i = threadIdx.x; i < C; i += 256) {
+      const long sc = ((long)b * C + i) * 2;
+      tab[i] = stats[sc]; tab[C + i] = stats[sc + 1];
+      if (rmode == 2) { tab[2 * C + i] = stats_r[sc]; tab[3 * C + i] = stats_r[sc + 1]; }
+    }
+    __syncthreads();
+    if (vl >= NV) return;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const long sc = ((long)b * C + cl * 8 + j) * 2;
-    mu[j] = stats[sc]; rs[j] = stats[sc + 1];
-    if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; }
+    for (int j = 0; j < 8; ++j) {
+      mu[j] = tab[cl * 8 + j]; rs[j] = tab[C + cl * 8 + j];
+      if (rmode == 2) { mur[j] = tab[2 * C + cl * 8 + j]; rsr[j] = tab[3 * C + cl * 8 + j]; }
+    }
+  } else {
+    if (vl >= NV) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long sc = ((long)b * C + cl * 8 + j) * 2;
+      mu[j] = stats[sc]; rs[j] = stats[sc + 1];
+      if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; }
+    }
   }
   const long v0 = (long)blockIdx.x * vpb;
   long v1 = v0 + vpb;
@@ -613,8 +647,8 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* 
       const long v = vb + (long)u * NV;
       if (v < v1) {
         const long o = ((long)b * V + v) * C + cl * 8;
-        Vec8<T>::load(x + o, xv[u]);
-        if (rmode) Vec8<T>::load(r + o, rv[u]);
+        if (NT) { Vec8<T>::load_nt(x + o, xv[u]); if (rmode) Vec8<T>::load_nt(r + o, rv[u]); }
+        else { Vec8<T>::load(x + o, xv[u]); if (rmode) Vec8<T>::load(r + o, rv[u]); }
       }
     }
 #pragma unroll
@@ -628,35 +662,57 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const T* x, const float* 
           else if (rmode == 2) y += (rv[u][j] - mur[j]) * rsr[j];
           xv[u][j] = y > 0.f ? y : slope * y;
         }
-        Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv[u]);
+        if (NT) Vec8<T>::store_nt(out + ((long)b * V + v) * C + cl * 8, xv[u]);
+        else Vec8<T>::store(out + ((long)b * V + v) * C + cl * 8, xv[u]);
       }
     }
   }
 }
 int k_in_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, long V, int C, float slope, hipStream_t st) {
   if (C % 8 || C / 8 > 256) return -2;
-  const long vpb = in_apply_vpb(V, B, C);
+  const bool nt = in_apply_streaming(V, B, C, dt);
+  const long vpb = in_apply_vpb(V, B, C, nt, 4);
   dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope, vpb);
+  if (nt && in_stream_nt()) hipLaunchKernelGGL((in_apply_kernel<bf16_t, true, true>), grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope, vpb);
+  else if (nt) hipLaunchKernelGGL((in_apply_kernel<bf16_t, true, false>), grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope, vpb);
+  else if (dt == NMH_DT_BF16) hipLaunchKernelGGL(in_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, stats, (const bf16_t*)r, stats_r, rmode, (bf16_t*)out, V, C, slope, vpb);
   else hipLaunchKernelGGL(in_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, stats, (const float*)r, stats_r, rmode, (float*)out, V, C, slope, vpb);
   NMH_CHECK_LAUNCH();
   return 0;
 }
 
-template <typename T>
+template <typename T, bool ST = false, bool NT = false>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const T* outp, const T* x, const float* stats, const double* sums, const T* r, const float* stats_r,
                                                             const double* sums_r, int rmode, T* dx, T* dr, int dr_acc, long V, int C, float slope, long vpb) {
   const int CL = C >> 3, NV = 256 / CL;
   const int cl = threadIdx.x % CL, vl = threadIdx.x / CL, b = blockIdx.y;
-  if (vl >= NV) return;
   const float invV = 1.0f / (float)V;
   float mu[8], rs[8], m1[8], m2[8], mur[8], rsr[8], n1[8], n2[8];
+  if (ST) {   // constants through an LDS table (see in_apply_kernel)
+    __shared__ float tab[8 * IN_STREAM_MAX_C];
+    for (int i = threadIdx.x; i < C; i += 256) {
+      const long sc = ((long)b * C + i) * 2;
+      tab[i] = stats[sc]; tab[C + i] = stats[sc + 1];
+      tab[2 * C + i] = (float)sums[sc] * invV; tab[3 * C + i] = (float)sums[sc + 1] * invV;
+      if (rmode == 2) { tab[4 * C + i] = stats_r[sc]; tab[5 * C + i] = stats_r[sc + 1]; tab[6 * C + i] = (float)sums_r[sc] * invV; tab[7 * C + i] = (float)sums_r[sc + 1] * invV; }
+    }
+    __syncthreads();
+    if (vl >= NV) return;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const long sc = ((long)b * C + cl * 8 + j) * 2;
-    mu[j] = stats[sc]; rs[j] = stats[sc + 1];
-    m1[j] = (float)sums[sc] * invV; m2[j] = (float)sums[sc + 1] * invV;
-    if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; n1[j] = (float)sums_r[sc] * invV; n2[j] = (float)sums_r[sc + 1] * invV; }
+    for (int j = 0; j < 8; ++j) {
+      const int c = cl * 8 + j;
+      mu[j] = tab[c]; rs[j] = tab[C + c]; m1[j] = tab[2 * C + c]; m2[j] = tab[3 * C + c];
+      if (rmode == 2) { mur[j] = tab[4 * C + c]; rsr[j] = tab[5 * C + c]; n1[j] = tab[6 * C + c]; n2[j] = tab[7 * C + c]; }
+    }
+  } else {
+    if (vl >= NV) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const long sc = ((long)b * C + cl * 8 + j) * 2;
+      mu[j] = stats[sc]; rs[j] = stats[sc + 1];
+      m1[j] = (float)sums[sc] * invV; m2[j] = (float)sums[sc + 1] * invV;
+      if (rmode == 2) { mur[j] = stats_r[sc]; rsr[j] = stats_r[sc + 1]; n1[j] = (float)sums_r[sc] * invV; n2[j] = (float)sums_r[sc + 1] * invV; }
+    }
   }
   const long v0 = (long)blockIdx.x * vpb;
   long v1 = v0 + vpb;
@@ -664,11 +720,19 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const 
   for (long v = v0 + vl; v < v1; v += NV) {
     const long o = ((long)b * V + v) * C + cl * 8;
     float dv[8], ov[8], xv[8], rv[8], od[8], orr[8];
-    Vec8<T>::load(dout + o, dv);
-    if (outp) Vec8<T>::load(outp + o, ov);
-    Vec8<T>::load(x + o, xv);
-    if (rmode == 2) Vec8<T>::load(r + o, rv);
-    if (rmode == 1 && dr_acc) Vec8<T>::load(dr + o, orr);
+    if (NT) {
+      Vec8<T>::load_nt(dout + o, dv);
+      if (outp) Vec8<T>::load_nt(outp + o, ov);
+      Vec8<T>::load_nt(x + o, xv);
+      if (rmode == 2) Vec8<T>::load_nt(r + o, rv);
+      if (rmode == 1 && dr_acc) Vec8<T>::load_nt(dr + o, orr);
+    } else {
+      Vec8<T>::load(dout + o, dv);
+      if (outp) Vec8<T>::load(outp + o, ov);
+      Vec8<T>::load(x + o, xv);
+      if (rmode == 2) Vec8<T>::load(r + o, rv);
+      if (rmode == 1 && dr_acc) Vec8<T>::load(dr + o, orr);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float g = dv[j] * ((outp ? ov[j] : xv[j] - mu[j]) > 0.f ? 1.0f : slope);
@@ -680,16 +744,23 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const 
         orr[j] = rsr[j] * (g - n1[j] - rh * n2[j]);
       }
     }
-    Vec8<T>::store(dx + o, od);
-    if (rmode) Vec8<T>::store(dr + o, orr);
+    if (NT) { Vec8<T>::store_nt(dx + o, od); if (rmode) Vec8<T>::store_nt(dr + o, orr); }
+    else { Vec8<T>::store(dx + o, od); if (rmode) Vec8<T>::store(dr + o, orr); }
   }
 }
 int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
                    const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st) {
   if (C % 8 || C / 8 > 256 || (!out && rmode != 0)) return -2;
-  const long vpb = in_apply_vpb(V, B, C);
+  const bool nt = in_apply_streaming(V, B, C, dt);
+  const long vpb = in_apply_vpb(V, B, C, nt);
   dim3 grid((unsigned)((V + vpb - 1) / vpb), B);
-  if (dt == NMH_DT_BF16)
+  if (nt && in_stream_nt())
+    hipLaunchKernelGGL((in_bwd_apply_kernel<bf16_t, true, true>), grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
+                       (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope, vpb);
+  else if (nt)
+    hipLaunchKernelGGL((in_bwd_apply_kernel<bf16_t, true, false>), grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
+                       (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope, vpb);
+  else if (dt == NMH_DT_BF16)
     hipLaunchKernelGGL(in_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)x, stats, sums,
                        (const bf16_t*)r, stats_r, sums_r, rmode, (bf16_t*)dx, (bf16_t*)dr, dr_accumulate, V, C, slope, vpb);
   else
@@ -704,7 +775,7 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
 // written by the loss forward) instead of being written by one kernel and re-read by two.  Pass 0 (APPLY=0): IN-backward sums
 // {sum g, sum g*xhat} with g = d(d0) * lrelu'(d0), plus the head weight gradient dW[o][c] = sum_v dp[v][o] d0[v][c];
 // pass 1 (APPLY=1): dx = rstd (g - S1/V - xhat S2/V), dr = g.  Same thread mapping as the InstanceNorm kernels above.
-template <typename T, int APPLY>
+template <typename T, int APPLY, bool ST = false, bool NT = false>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0, const T* __restrict__ rres, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dp,
                                                        const double* __restrict__ lsums, const float* __restrict__ Wout, double* in_sums, T* __restrict__ dx,
                                                        T* __restrict__ dr, float slope, float* dWout, float* dbout, long V, int C, long vpb,
@@ -716,18 +787,43 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
     for (int i = threadIdx.x; i < 6 * C; i += 256) sred[i] = 0.f;
     __syncthreads();
   }
-  const float inv_occ = (float)(1.0 / lsums[1]), inv_rm = (float)(1.0 / lsums[3]);
   float w[4][8], mu[8], rs[8], u1[8], u2[8], wacc[APPLY ? 1 : 4][8];
-  if (vl < NV) {
+  float inv_occ = 0.f, inv_rm = 0.f;
+  if (ST) {   // constants (incl. the scaled head weights: two fp64 divisions per BLOCK instead of per thread) through an LDS table (see in_apply_kernel)
+    __shared__ float tab[8 * IN_STREAM_MAX_C];
+    for (int i = threadIdx.x; i < C; i += 256) {
+      const long sc = ((long)b * C + i) * 2;
+      const float invV = 1.0f / (float)V, io = (float)(1.0 / lsums[1]), ir = (float)(1.0 / lsums[3]);
+      tab[i] = stats[sc]; tab[C + i] = stats[sc + 1];
+      tab[2 * C + i] = (float)in_sums[sc] * invV; tab[3 * C + i] = (float)in_sums[sc + 1] * invV;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const long sc = ((long)b * C + cl * 8 + j) * 2;
-      mu[j] = stats[sc]; rs[j] = stats[sc + 1];
-      u1[j] = u2[j] = 0.f;
-      if (APPLY) { const float invV = 1.0f / (float)V; u1[j] = (float)in_sums[sc] * invV; u2[j] = (float)in_sums[sc + 1] * invV; }
-#pragma unroll
-      for (int o = 0; o < 4; ++o) { w[o][j] = Wout[o * C + cl * 8 + j] * (o < 3 ? inv_occ : inv_rm); if (!APPLY) wacc[o][j] = 0.f; }
+      for (int o = 0; o < 4; ++o) tab[(4 + o) * C + i] = Wout[o * C + i] * (o < 3 ? io : ir);
     }
+    __syncthreads();
+    if (vl < NV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = cl * 8 + j;
+        mu[j] = tab[c]; rs[j] = tab[C + c]; u1[j] = tab[2 * C + c]; u2[j] = tab[3 * C + c];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) w[o][j] = tab[(4 + o) * C + c];
+      }
+    }
+  } else {
+    inv_occ = (float)(1.0 / lsums[1]); inv_rm = (float)(1.0 / lsums[3]);
+    if (vl < NV) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long sc = ((long)b * C + cl * 8 + j) * 2;
+        mu[j] = stats[sc]; rs[j] = stats[sc + 1];
+        u1[j] = u2[j] = 0.f;
+        if (APPLY) { const float invV = 1.0f / (float)V; u1[j] = (float)in_sums[sc] * invV; u2[j] = (float)in_sums[sc + 1] * invV; }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { w[o][j] = Wout[o * C + cl * 8 + j] * (o < 3 ? inv_occ : inv_rm); if (!APPLY) wacc[o][j] = 0.f; }
+      }
+    }
+  }
+  if (vl < NV) {
     const long v0 = (long)blockIdx.x * vpb;
     long v1 = v0 + vpb;
     if (v1 > V) v1 = V;
@@ -746,7 +842,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[u][j] = (m8 >> j) & 1u ? 1.0f : -1.0f;
           } else Vec8<T>::load((d0 ? d0 : rres) + o, ov[u]);
-          Vec8<T>::load(x + o, xv[u]);
+          if (NT) Vec8<T>::load_nt(x + o, xv[u]); else Vec8<T>::load(x + o, xv[u]);
           dq[u] = *reinterpret_cast<const float4*>(dp + ((long)b * V + v) * 4);
           if (!d0 && !(APPLY && smask)) {  // d0 was not stored by the forward: rebuild it bit-exactly (same fp32 expression, same rounding) from x and r
 #pragma unroll
@@ -778,8 +874,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
           }
           if (APPLY) {
             const long o = ((long)b * V + v) * C + cl * 8;
-            Vec8<T>::store(dx + o, od);
-            Vec8<T>::store(dr + o, gq);
+            if (NT) { Vec8<T>::store_nt(dx + o, od); Vec8<T>::store_nt(dr + o, gq); }
+            else { Vec8<T>::store(dx + o, od); Vec8<T>::store(dr + o, gq); }
           }
         }
       }
@@ -824,12 +920,20 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
   if (C % 8 || C / 8 > 256 || (!d0 && !r && !(sign_mask && bwd_sums))) return -2;
   if (sign_mask && (!bwd_sums || C != 48)) return -4;   // the sums pass needs d0 itself; the mask has 8-byte rows for 48 channels
   const long vpb = in_vox_per_block(V, B);
-  const long vpa = in_apply_vpb(V, B, C);
+  const bool nt = bwd_sums && sign_mask && in_apply_streaming(V, B, C, dt);
+  static const int tail_sv = getenv("NMH_TAIL_STREAM_VPB") ? atoi(getenv("NMH_TAIL_STREAM_VPB")) : 0;
+  const long vpa = nt && tail_sv > 0 ? tail_sv : in_apply_vpb(V, B, C, nt, 32);
   dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + vpa - 1) / vpa), B);
   if (bwd_sums) {   // the reductions were taken by the forward pass: one apply pass is all that is left
     const int n = B * C + 4 * C + 4;
     hipLaunchKernelGGL(tail_sums_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, bwd_sums, loss_sums, in_sums, dWout, dbout, B, C);
-    if (dt == NMH_DT_BF16)
+    if (nt && in_stream_nt())
+      hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1, true, true>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
+                         (bf16_t*)dr, slope, dWout, dbout, V, C, vpa, sign_mask);
+    else if (nt)
+      hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1, true, false>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
+                         (bf16_t*)dr, slope, dWout, dbout, V, C, vpa, sign_mask);
+    else if (dt == NMH_DT_BF16)
       hipLaunchKernelGGL((tail_bwd_kernel<bf16_t, 1>), g1, dim3(256), 0, st, (const bf16_t*)d0, (const bf16_t*)r, (const bf16_t*)xin, in_stats, dp, loss_sums, Wout, in_sums, (bf16_t*)dx,
                          (bf16_t*)dr, slope, dWout, dbout, V, C, vpa, sign_mask);
     else
@@ -1051,6 +1155,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const T* __restrict__ x, 
 //    [voxel][48] (96-byte rows: conflict-free ds_read_b64_tr_b16) and read back transposed as B fragments: 12 MFMAs per 32 voxels replace
 //    the per-lane FMAs.  The LeakyReLU slope enters as lr = slope + (1 - slope) [d0 > 0] when the block combines its sums, so no operand
 //    carries the inexact bf16 value of the slope.
+template <bool NT>
 __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ r, LossArgs a,
                                                             long V, float slope, long vpb) {
   constexpr int C = 48, OPB = 32 * 96, WLDS = 4 * OPB;   // per wave: 4 operand images of 32 voxel rows x 96 bytes
@@ -1101,9 +1206,14 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
   uint4 nx[3], nr[3];
   auto issue = [&](long base) {   // base + 32 <= V (V is a multiple of 64: R is a multiple of 4)
     const long o0 = (base + vi) * C + c0, o1 = (base + 16 + vi) * C + c0, o2 = (base + 16 * t2 + vi) * C + c1;
-    nx[0] = *reinterpret_cast<const uint4*>(xb + o0); nr[0] = *reinterpret_cast<const uint4*>(rb + o0);
-    nx[1] = *reinterpret_cast<const uint4*>(xb + o1); nr[1] = *reinterpret_cast<const uint4*>(rb + o1);
-    nx[2] = *reinterpret_cast<const uint4*>(xb + o2); nr[2] = *reinterpret_cast<const uint4*>(rb + o2);
+    if (NT) {   // one-pass operands far larger than the caches: non-temporal
+      auto ldn = [](const bf16_t* p) { const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); return make_uint4(w[0], w[1], w[2], w[3]); };
+      nx[0] = ldn(xb + o0); nr[0] = ldn(rb + o0); nx[1] = ldn(xb + o1); nr[1] = ldn(rb + o1); nx[2] = ldn(xb + o2); nr[2] = ldn(rb + o2);
+    } else {
+      nx[0] = *reinterpret_cast<const uint4*>(xb + o0); nr[0] = *reinterpret_cast<const uint4*>(rb + o0);
+      nx[1] = *reinterpret_cast<const uint4*>(xb + o1); nr[1] = *reinterpret_cast<const uint4*>(rb + o1);
+      nx[2] = *reinterpret_cast<const uint4*>(xb + o2); nr[2] = *reinterpret_cast<const uint4*>(rb + o2);
+    }
   };
   // one chunk: x-hat, d0 (bf16), and the four packed operand rows for the reduction GEMMs
   auto chunk = [&](const uint4& xw, const uint4& rw, const float (&mu)[8], const float (&rs)[8], uint4& ypk, uint4& mpk, uint4& mxpk, uint4& xpk, unsigned& bits) {
@@ -1287,7 +1397,9 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
     if (use_mfma && a.dt == NMH_DT_BF16 && C == 48 && !out && a.R % 4 == 0 && V < (1L << 31) && slope > 0.f && slope < 1.f) {
       const long vpm = (vpb + 127) / 128 * 128;   // whole 32-voxel steps per wave
       dim3 gm((unsigned)((V + vpm - 1) / vpm), a.B);
-      hipLaunchKernelGGL(tail_fwd_mfma_kernel, gm, dim3(256), 4 * 4 * 32 * 96 + 4 * 256, st, (const bf16_t*)x, stats, (const bf16_t*)r, a, V, slope, vpm);
+      static const int tnt = getenv("NMH_TAIL_FWD_NT") ? atoi(getenv("NMH_TAIL_FWD_NT")) : 0;   // measured inside the step: 49.78 ms with, 49.51 without (three alternating runs each)
+      if (tnt && in_apply_streaming(V, a.B, C, a.dt)) hipLaunchKernelGGL(tail_fwd_mfma_kernel<true>, gm, dim3(256), 4 * 4 * 32 * 96 + 4 * 256, st, (const bf16_t*)x, stats, (const bf16_t*)r, a, V, slope, vpm);
+      else hipLaunchKernelGGL(tail_fwd_mfma_kernel<false>, gm, dim3(256), 4 * 4 * 32 * 96 + 4 * 256, st, (const bf16_t*)x, stats, (const bf16_t*)r, a, V, slope, vpm);
       NMH_CHECK_LAUNCH();
       return 0;
     }

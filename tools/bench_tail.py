@@ -61,3 +61,8 @@ print(f"fused tail fwd {t_f:.3f} ms (d0 not stored: {t_f0:.3f})   unfused (in_ap
 bsum = torch.empty(B * Cd * 4 + 4 * Cd, dtype=torch.float64, device=dev)
 t_m = timeit(lambda: ops.mae_tail_fwd(y, stats, r, None, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred, bwd_sums=bsum))
 print(f"fused tail fwd + backward sums (the step's launch; bf16 C=48: matrix-core kernel) {t_m:.3f} ms")
+smask = torch.empty(B * V, 8, dtype=torch.uint8, device=dev)
+ops.mae_tail_fwd(y, stats, r, None, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred, bwd_sums=bsum, sign_mask=smask)
+t_b = timeit(lambda: ops.mae_tail_bwd(None, y, stats, dpred, lsums, Wo, sums, dy, dr, dW, db, B, V, Cd, bwd_sums=bsum, sign_mask=smask))
+gb = B * V * (3 * Cd * 2 + 8 + 16) / 1e9
+print(f"tail bwd apply pass with the forward's sums + sign mask (the step's launch) {t_b:.3f} ms ({gb / t_b:.2f} TB/s)")
