@@ -584,12 +584,13 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
 #define IN_APPLY_VOX_PER_BLOCK 2048
 #define IN_STREAM_MAX_C 96   // widest tensor the streaming form of the apply passes takes (LDS constant tables)
 // voxels per block of the apply passes: 2048 on the big volumes, fewer on the coarse decoder levels so that >= ~1024 blocks exist
-// streaming form of the apply passes (bf16 tensors far larger than L2 + MALL, i.e. the 160^3 level): non-temporal loads and stores and SHORT
-// blocks.  tools/probes/hbm_stream_probe.hip: a 2-read + 1-write pass over 3.1-GB tensors runs at 5.3 TB/s from 2048-4096 looping blocks, 6.0-6.25
+// streaming form of the apply passes (bf16 tensors larger than L2 + MALL, i.e. the 160^3 level -- 393 MB per grid): non-temporal loads and stores and SHORT
+// blocks.  In the replayed step (same box, three alternating runs each): 8 grids 49.22 ms against 49.66 without (49.45 with short blocks but temporal
+// accesses), 2 grids 16.71 against 16.97, 1 grid 11.06 against 11.18.  tools/probes/hbm_stream_probe.hip: a 2-read + 1-write pass over 3.1-GB tensors runs at 5.3 TB/s from 2048-4096 looping blocks, 6.0-6.25
 // from blocks that touch 16-64 bytes per thread and tensor with non-temporal accesses.  NMH_IN_STREAM=0 disables, NMH_IN_STREAM_VPB sets the voxels per block.
 static inline bool in_apply_streaming(long V, int B, int C, int dt) {
   static const int on = getenv("NMH_IN_STREAM") ? atoi(getenv("NMH_IN_STREAM")) : 1;
-  static const double min_bytes = 1.0e6 * (getenv("NMH_IN_STREAM_MIN_MB") ? atof(getenv("NMH_IN_STREAM_MIN_MB")) : 1000.0);
+  static const double min_bytes = 1.0e6 * (getenv("NMH_IN_STREAM_MIN_MB") ? atof(getenv("NMH_IN_STREAM_MIN_MB")) : 300.0);
   return on && dt == NMH_DT_BF16 && C <= IN_STREAM_MAX_C && (double)V * B * C * 2 >= min_bytes;
 }
 // voxels per thread of a streaming block (mult x 256 / (C/8) voxels per block).  Measured at 8 x 160^3 x 48 (tools/bench_inbwd.py, tools/bench_tail.py):
@@ -1387,6 +1388,8 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
   long vpb = (V * a.B + 2047) / 2048;
   if (vpb < 160) vpb = 160;
   if (vpb > 2048) vpb = 2048;
+  static const int tf_vpb = getenv("NMH_TAIL_FWD_VPB") ? atoi(getenv("NMH_TAIL_FWD_VPB")) : 0;
+  if (tf_vpb > 0 && a.bwd_sums) vpb = tf_vpb;
   dim3 grid((unsigned)((V + vpb - 1) / vpb), a.B);
   if (a.bwd_sums) {
     if (!a.dp) return -4;   // the fused backward sums are built from d(pred)
