@@ -743,7 +743,8 @@ def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C,
     if bwd_sums is not None and (dpred is None or bwd_sums.numel() < B * C * 4 + 4 * C):
         raise ValueError("mae_tail_fwd: bwd_sums needs dpred and B*C*4 + 4*C entries")
     # algorithmic bytes: y and r read once, the fp32 target (4 channels) read once, d(pred) (16 B / voxel) and d0 written if requested
-    ev = _prof(("mae_tail_fwd", B, R, C), (2 + (d0 is not None)) * y.numel() * y.element_size() + B * R ** 3 * 16 * (1 + (dpred is not None) + (pred is not None)))
+    ev = _prof(("mae_tail_fwd", B, R, C), (2 + (d0 is not None)) * y.numel() * y.element_size() + B * R ** 3 * 16 * (1 + (dpred is not None) + (pred is not None))
+               + (B * R ** 3 * 8 if sign_mask is not None else 0))
     lib().call("nmh_mae_tail_fwd", dt_of(y), y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope, bwd_sums, sign_mask, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
@@ -756,7 +757,10 @@ def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, d
     if d0 is None and r is None and (sign_mask is None or bwd_sums is None):
         raise ValueError("mae_tail_bwd needs d0, r, or the forward's sign mask together with its bwd_sums")
     # two passes (sums, then apply): y and r (or d0) read twice, d(pred) read twice, dy and dr written once
-    ev = _prof(("mae_tail_bwd", B, V, C), (4 if bwd_sums is not None else 6) * y.numel() * y.element_size() + (1 if bwd_sums is not None else 2) * B * V * 16)
+    # (with the forward's sign mask the apply pass reads y, 8 mask bytes and d(pred) per voxel and writes dy and dr: 3 tensor passes, not 4)
+    nt = (3 if sign_mask is not None else 4) if bwd_sums is not None else 6
+    ev = _prof(("mae_tail_bwd", B, V, C), nt * y.numel() * y.element_size() + (1 if bwd_sums is not None else 2) * B * V * 16
+               + (B * V * 8 if sign_mask is not None and bwd_sums is not None else 0))
     lib().call("nmh_mae_tail_bwd", dt_of(y), d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, slope, dWout, dbout, B, V, C, bwd_sums, sign_mask, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
