@@ -300,8 +300,13 @@ def test_window_attention_core(dt, shape, shift, heads, qsplit, monkeypatch):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("B,V,C,rmode", [(2, 1000, 48, 0), (2, 343, 96, 1), (1, 5000, 48, 1), (2, 216, 384, 2), (1, 8 ** 3, 192, 2), (2, 32 ** 3, 48, 2), (2, 32 ** 3, 48, 0)])
+@pytest.mark.parametrize("B,V,C,rmode", [(2, 1000, 48, 0), (2, 343, 96, 1), (1, 5000, 48, 1), (2, 216, 384, 2), (1, 8 ** 3, 192, 2), (2, 32 ** 3, 48, 2), (2, 32 ** 3, 48, 0),
+                                         (1, 160 ** 3, 48, 0), (1, 150 ** 3, 48, 2), (1, 118 ** 3, 96, 1)],
+                         ids=["1000x48", "343x96_r1", "5000x48_r1", "216x384_r2", "512x192_r2", "32cube_r2", "32cube", "160cube_streaming", "150cube_r2_streaming_ragged",
+                              "118cube_c96_r1_streaming_ragged"])
 def test_instnorm_fwd_bwd(dt, B, V, C, rmode):
+    """the last three cases are bf16 tensors above the 300-MB threshold of the streaming form of the apply passes (short blocks, per-channel constants
+    through an LDS table, non-temporal accesses: csrc/norm.hip in_apply_streaming), two of them with a ragged last block"""
     ops = _ops()
     x = q(rnd(B, V, C) * 1.5 + 0.3, dt)
     r = q(rnd(B, V, C, seed=1), dt) if rmode else None
@@ -746,7 +751,7 @@ def test_copy_cols_strided(dtype):
         ops.copy_cols(skip, cat[:, C:C + 8])
 
 
-@pytest.mark.parametrize("variant", ["dma", "reg", "big", "big_reg"])
+@pytest.mark.parametrize("variant", ["dma", "reg", "big", "big_reg", "dma_fg"])
 @pytest.mark.parametrize("case", ["flat_many_tiles", "split_few_tiles", "mixed_ragged", "all192"])
 def test_gemm_tn_grouped(case, variant, monkeypatch):
     """nmh_gemm_tn_grouped (bf16): several weight-gradient problems per launch -- flat (a workgroup walks every sample), split at
@@ -781,7 +786,7 @@ def test_gemm_tn_grouped(case, variant, monkeypatch):
         dW, db = dev(dW0), dev(db0) if bias else None
         outs.append((dW, db))
         q_.pending.append((dev(A, dt), dev(Bm, dt), dW, db, None if rs is None else dev(rs), rps))
-    q_.flush()
+    q_.flush(foreground="fg" in variant)   # fg: nmh_gemm_tn_grouped_fg (the split of the last flushes of a backward pass: 640 workgroups)
     q_.join()
     torch.cuda.synchronize()
     for i, ((dW, db), (rW, rb)) in enumerate(zip(outs, refs)):
