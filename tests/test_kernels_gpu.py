@@ -441,18 +441,19 @@ def test_loss_head(dt):
     check(db, br_.grad, dt, "dbout", 2)
 
 
-@pytest.mark.parametrize("dt", DTS)
-def test_tail_backward_fused(dt):
-    """d0 = lrelu(IN(y) + r) -> 1x1 head -> loss: the two-pass fused backward (d(d0) never stored) against autograd."""
+@pytest.mark.parametrize("dt,R", [(d, 32) for d in DTS] + [(torch.bfloat16, 120)], ids=lambda v: str(v).replace("torch.", ""))
+def test_tail_backward_fused(dt, R):
+    """d0 = lrelu(IN(y) + r) -> 1x1 head -> loss: the two-pass fused backward (d(d0) never stored) against autograd.  R = 120 (bf16): 2 x 120^3 x 48
+    is above the 300-MB threshold of the streaming form of the apply pass (csrc/norm.hip: tail_bwd_kernel<.., ST, NT>)."""
     from oracle import mae3d_oracle as O
     ops = _ops()
-    B, R, Cd = 2, 32, 48
+    B, Cd = 2, 48
     V = R ** 3
     x = torch.stack([O.synthetic_grid((R, R, R), 3), O.synthetic_grid((R, R, R), 4)])
     valid = torch.ones_like(x)
-    valid[1, :, 28:] = 0
+    valid[1, :, R - 4:] = 0
     x = x * valid
-    ext = torch.tensor([[R, R, R], [28, R, R]], dtype=torch.int32)
+    ext = torch.tensor([[R, R, R], [R - 4, R, R]], dtype=torch.int32)
     y, r = q(rnd(B, V, Cd) * 1.3 + 0.2, dt), q(rnd(B, V, Cd, seed=7), dt)
     Wo, bo = rnd(4, Cd, seed=1, scale=0.2), rnd(4, seed=2, scale=0.1)
     tm = O.draw_block_mask((R // 4,) * 3, 0.6, rng=__import__("random").Random(5))
@@ -525,7 +526,12 @@ def test_tail_backward_fused(dt):
     if mfma:
         # (d0 enters the head MFMAs as bf16 and the weights as bf16 hi + lo: |error of pred| <~ 2^-17 sum |w d0| ~ 5e-4; a d0 element whose fp32 value sits on a
         #  bf16 tie can land on either side depending on whether the compiler contracts (y - mean) * rstd + r: one ulp of one input, same size)
-        assert torch.allclose(dpred4, dpred2, rtol=1e-4, atol=1e-3), ("dpred", (dpred4 - dpred2).abs().max().item(), dpred2.abs().max().item())
+        #  -- so the bound on a single element is one bf16 ulp of the largest |d0| through the largest head weight (x 2: d(pred) = 2 (pred - target)), and
+        #  all but a vanishing fraction of the elements agree to 1e-3 (at 2 x 120^3 voxels a handful of tie cases exist, at 32^3 usually none)
+        diff = (dpred4 - dpred2).abs()
+        tie = 2.0 * 2.0 ** -8 * d0k.float().abs().max().item() * args[1].abs().max().item()
+        assert diff.max().item() <= max(1e-3, tie), ("dpred", diff.max().item(), tie, dpred2.abs().max().item())
+        assert (diff > 1e-3 + 1e-4 * dpred2.abs()).float().mean().item() < 1e-5, ("dpred outliers", (diff > 1e-3 + 1e-4 * dpred2.abs()).float().mean().item())
         assert torch.allclose(losses4, losses2, rtol=1e-5)   # head weights as bf16 hi+lo: 2^-17
     else:
         assert torch.equal(dpred4, dpred2) and torch.allclose(losses4, losses2, rtol=1e-6)
@@ -552,13 +558,25 @@ def test_tail_backward_fused(dt):
         smask = torch.full((B * V, 8), 0xAA, dtype=torch.uint8, device="cuda")
         ops.mae_tail_fwd(yd.view(-1, Cd), stats, rd.view(-1, Cd), None, args[1], args[2], args[3], args[4], args[5], B, R, Cd, lsums5, losses5, None, dpred5, bwd_sums=bsum5,
                          sign_mask=smask)
-        assert torch.equal(dpred5, dpred4) and torch.equal(losses5, losses4)
+        assert torch.equal(dpred5, dpred4) and torch.allclose(losses5, losses4, rtol=1e-6)   # (loss sums: fp32 partials meet in order-dependent atomics)
         bits = ((smask[:, :Cd // 8].reshape(B * V, Cd // 8, 1) >> torch.arange(8, device="cuda", dtype=torch.uint8).view(1, 1, 8)) & 1).view(B * V, Cd).bool()
-        assert torch.equal(bits, d0k.view(B * V, Cd).float() > 0)
+        # (the sign is that of the fp32 pre-activation; where x-hat + r cancels to the last place the two kernels' fp contraction may differ in sign:
+        #  such elements have |d0| at rounding level -- none at 32^3, a handful in 1.7e8 elements)
+        mism = bits != (d0k.view(B * V, Cd).float() > 0)
+        assert mism.float().mean().item() < 1e-6 and (mism.sum().item() == 0 or d0k.view(B * V, Cd).float().abs()[mism].max().item() < 1e-5), \
+            ("sign mask", mism.sum().item(), d0k.view(B * V, Cd).float().abs()[mism].max().item() if mism.any() else 0.0)
         dy5, dr5, dW5, db5, in_sums5 = torch.empty_like(dy), torch.empty_like(dr), torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda"), torch.empty_like(in_sums)
         ops.mae_tail_bwd(None, yd.view(-1, Cd), stats, dpred5, lsums5, args[1], in_sums5, dy5, dr5, dW5, db5, B, V, Cd, bwd_sums=bsum5, sign_mask=smask)
         # (in_sums / dW come from bsum's fp64 atomics: equal up to their summation order)
-        assert torch.equal(dr5, dr4) and torch.allclose(dy5.float(), dy4.float(), rtol=1e-2, atol=1e-6)
+        # dr: bit-identical except where the two sign sources disagree (the mask holds the sign of the forward kernel's fp32 pre-activation, the other path
+        # rebuilds d0 from y, stats and r: elements that cancel to the last place, see above)
+        # -- and, at the streaming size, a bf16 tie of the last place here and there: the two instantiations of the apply pass contract the 4-term head dot
+        # product differently (measured 227 of 1.7e8 elements, one bf16 ulp each)
+        dmis = dr5 != dr4
+        far = (dmis & ~torch.isclose(dr5.float(), dr4.float(), rtol=1e-2, atol=1e-6)).view(B * V, Cd)
+        assert dmis.float().mean().item() < 1e-5 and (far.sum().item() == 0 or d0k.view(B * V, Cd).float().abs()[far].max().item() < 1e-5), \
+            ("dr", dmis.sum().item(), far.sum().item(), d0k.view(B * V, Cd).float().abs()[far].max().item() if far.any() else 0.0)
+        assert torch.allclose(dy5.float(), dy4.float(), rtol=1e-2, atol=1e-6 if not far.any() else 1e-3)
         assert torch.allclose(in_sums5, in_sums4, rtol=1e-6, atol=1e-9 * scale) and torch.allclose(dW5, dW4, rtol=1e-5, atol=1e-7)
 
 
