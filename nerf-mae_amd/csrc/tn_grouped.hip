@@ -381,7 +381,11 @@ int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_
       any_rs |= h.rowscale != nullptr;
     }
     // 192x192 tiles (8 waves, one workgroup per CU) when they tile every problem exactly and still fill the chip a few times over
-    const int big_min = getenv("NMH_TNG_BIG") ? atoi(getenv("NMH_TNG_BIG")) : 0;   // minimum number of large tiles; 0 (default) disables: see below
+    // (minimum number of large tiles; 0 disables.  Round 3, end: 256 -- stage 2's and stage 3's launches.  With the two queues really overlapping the
+    //  large tile's halved L2->LDS traffic shows in the step: 8 grids 49.74 -> 49.27 ms, 4 grids 28.05 -> 27.81, 2 grids 16.95 -> 16.80, 1 grid
+    //  11.15 -> 11.11 (64: the same within noise); a timing-only run without ANY grouped launch reads 45.4 ms at 8 grids -- 4.4 ms of the step is what
+    //  these "background" launches still cost the input-gradient chain)
+    const int big_min = getenv("NMH_TNG_BIG") ? atoi(getenv("NMH_TNG_BIG")) : 256;
     const bool big = big_min > 0 && all192 && tiles_big >= big_min;
     const int bt = big ? 192 : 96;
     if (big) tiles = tiles_big;
@@ -415,9 +419,9 @@ int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_
     }
     // Measured (tools/bench_tng.py, 16-40 stage-2 problems per launch): LDS-DMA 96x96 0.30-0.40 PF, register-staged 96x96 0.33-0.40 PF,
     // 192x192 0.38-0.50 PF; PMC: L2 hit rate 86 %, no LDS bank conflicts, waves parked in s_waitcnt / s_barrier 55-63 % of their cycles
-    // (every tile of a problem waits for the same first-touch lines of the next chunk).  Inside the training step the three variants are
-    // indistinguishable (the launches overlap the input-gradient chain on the side stream): the DMA kernel stays the default, the others
-    // remain selectable (NMH_TNG_REG=1, NMH_TNG_BIG=<min tiles>) and are covered by the parity tests.
+    // (every tile of a problem waits for the same first-touch lines of the next chunk).  Inside the training step of rounds 1-2 the three variants
+    // were indistinguishable (the two queues took turns); since the queue fix the large tile pays (above) and the register-staged transport costs
+    // (+0.5 ms): LDS-DMA stays the transport, NMH_TNG_REG=1 / NMH_TNG_BIG=<min tiles> select the others (all covered by the parity tests).
     const int reg_stage = getenv("NMH_TNG_REG") ? atoi(getenv("NMH_TNG_REG")) : 0;
     if (reg_stage) {
       if (big) {
