@@ -239,6 +239,29 @@ int nmh_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamma, const
   const WinMap w = to_wm(wm);
   return k_mlp_fused_bwd(x1, dx2, gamma, beta, W1, b1, W2T, rowscale, rows_per_scale, dx1, x1n, hact, dh, dgamma, dbeta, dyw, dyw_scale, wm ? &w : nullptr, (long)M, C, eps, ST);
 }
+int nmh_swin_supported(int C) { return k_swin_supported(C); }
+int64_t nmh_swin_stream_numel(int type, int C) { return (int64_t)k_swin_stream_numel(type, C); }
+int nmh_swin_pack(const nmh_swin_pack_item* items, int n, void* stream) {
+  CLR();
+  if (n <= 0) return 0;
+  REQ(items);
+  static_assert(sizeof(nmh_swin_pack_item) == sizeof(SwinPackItem), "descriptor layouts must agree");
+  return k_swin_pack(reinterpret_cast<const SwinPackItem*>(items), n, ST);
+}
+int nmh_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* bias_table, const float* bproj,
+                      const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1, const int* wm, int C,
+                      float eps, void* stream) {
+  CLR();
+  REQ(x, gamma, beta, wstream, bqkv, bias_table, bproj, xnw, mean, rstd, qkv, o, lse, x1, wm);
+  return k_swin_attn_fwd(x, gamma, beta, wstream, bqkv, bias_table, bproj, rowscale, rows_per_scale, xnw, mean, rstd, qkv, o, lse, x1, to_wm(wm), C, eps, ST);
+}
+int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
+                     void* x2, void* x1n, void* hp, float* mean, float* rstd, int64_t M, int C, float eps, void* stream) {
+  CLR();
+  REQ(x1, gamma, beta, wstream, b1, b2, x2, x1n, hp, mean, rstd);
+  if (M <= 0) return 0;
+  return k_swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, mean, rstd, (long)M, C, eps, ST);
+}
 int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream) {
   CLR();
   return k_window_scatter_residual(dt, yw, x, out, rowscale, C, to_wm(wm), ST);

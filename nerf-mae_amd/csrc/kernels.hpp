@@ -179,6 +179,17 @@ int k_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamma, const f
                     int rows_per_scale, void* dx1, void* x1n, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const WinMap* wm,
                     long M, int C, float eps, hipStream_t st);
 
+// ---- swin_block.hip: fused Swin-block kernels (bf16, C = 96 NW) ----
+struct SwinPackItem { const float* w0; const float* w1; void* dst; int type; int C; };   // mirrors nmh_swin_pack_item
+int k_swin_supported(int C);
+long k_swin_stream_numel(int type, int C);
+int k_swin_pack(const SwinPackItem* items, int n, hipStream_t st);
+int k_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
+                   void* x2, void* x1n, void* hp, float* mean, float* rstd, long M, int C, float eps, hipStream_t st);
+int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* table, const float* bproj,
+                    const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1,
+                    const WinMap& wm, int C, float eps, hipStream_t st);
+
 // instance norm over channels-last [B, V, C]; stats[b][c] = {mean, rstd}
 int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st);
 // out = lrelu( IN(x) [+ r | + IN(r)] ); rmode 0 none, 1 plain residual, 2 normalized residual (stats_r)

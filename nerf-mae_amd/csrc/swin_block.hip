@@ -1,0 +1,1433 @@
+// Fused Swin-block kernels for the encoder stages of width C = 96 * NW, NW in {1, 2, 4} (stage 0 / 1 / 2 of swin_t / swin_s), bf16, gfx950.
+// SURVEY 2a "K1" + "K2" (reference: swin_mae3d.py:27-197 shifted_window_attention, :352-358 MLP, :366-369 the two residual branches).
+//
+// One workgroup owns 64 token rows -- a 4x4x4 window for the attention branch, 64 consecutive tokens for the MLP branch -- and keeps them in
+// REGISTERS as MFMA operand fragments for the whole branch: NW waves (one per SIMD, the 512-register budget), every wave holds all 64 rows
+// (4 row tiles x C / 32 k-steps x 4 registers = 192 registers at C = 384) and owns a slice of the OUTPUT features of every product, so that
+//   * a weight fragment is read from LDS by exactly one wave, once, and used for 4 MFMAs (the 4 row tiles);
+//   * the weights of a wave are a private, pre-packed, linear STREAM of lane-linear 1-KB fragment images in the order the wave consumes them
+//     (swin_pack_kernel builds the streams from the fp32 masters once per step); a wave moves its stream through a private LDS ring with
+//     LDS-DMA (global_load_lds) a few steps ahead of its MFMAs under counted vmcnt waits -- no workgroup barrier is involved in the weight
+//     path, the waves drift freely (the 64-row unfused GEMMs re-read 120 KB of operands per 4.7 MFLOP tile and are L2 -> LDS bound);
+//   * products are formed "transposed" (weights = MFMA A operand, tokens = B operand): a lane then holds, for token `lane & 15`, four
+//     consecutive output features, and two such tiles pack into the operand fragment of the NEXT product without leaving the registers
+//     (row map np_row below makes the packed fragment come out in natural feature order).
+// A stream "step" is always 6 fragments = 24 MFMAs (6 weight tiles x 4 token tiles).
+//
+// Kernels:
+//   swin_attn_fwd_kernel   per window:  gather x (pad -> roll -> partition folded into addressing) -> LN1 -> QKV (per head: the wave that owns
+//                          the head computes its Q, K, V and the whole 64 x 64 attention in registers) -> O exchanged through LDS -> proj ->
+//                          row scale -> + residual -> x1 scattered to token order.  Saves xnw, qkv, o, lse, mean1 / rstd1 in the layouts of the
+//                          unfused path (the weight gradients stay on the grouped path and read them).
+//   swin_mlp_fwd_kernel    per 64 tokens: LN2 -> fc1 -> GELU (hidden slices exchanged through LDS, one barrier per 32 NW hidden units) -> fc2
+//                          -> row scale -> + residual.  Saves x1n, the fc1 pre-activation, mean2 / rstd2.
+//   swin_mlp_bwd_kernel    per 64 tokens: dh = s (dy W2) gelu'(hp), hact = gelu(hp) (operands of the two weight gradients), dx1n = dh W1,
+//                          LayerNorm backward, dx1 (+ its window-ordered, row-scaled copy), dgamma / dbeta.
+//   swin_attn_bwd_kernel   per window: dO = dyw Wproj, attention backward per head in the wave that owns it -> dqkv, d(bias table).
+//   swin_qkv_bwd_kernel    per window: dxn = dqkv Wqkv (both operands streamed), LayerNorm-1 backward, + residual gradient -> dx, dgamma / dbeta.
+#include "common.hpp"
+#include "kernels.hpp"
+#include <cstdlib>
+#include <cstdio>
+#include <type_traits>
+
+namespace sw {
+
+constexpr int G = 6;                 // fragments per stream step
+constexpr int STEP_BYTES = G * 1024;
+constexpr int MLP_ROUNDS = 12;       // 4 C hidden units / (32 per wave and round x NW waves) with C = 96 NW
+
+// row map of a PAIR of weight tiles (32 output features): tile t in {0,1}, A-operand row li <-> feature 8 (li >> 2) + 4 t + (li & 3).
+// In the C layout (row = 4 g + r) a lane then holds features 8 g + 4 t + r, and pack_tr(tile 0, tile 1) is the natural-order operand
+// fragment (slot j of lane group g <-> feature 8 g + j) of the next product.
+__host__ __device__ __forceinline__ int np_row(int t, int li) { return 8 * (li >> 2) + 4 * t + (li & 3); }
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  u4v u = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+  return __builtin_bit_cast(bf16x8, u);
+}
+__device__ __forceinline__ Frag<bf16_t> pack_tr(const f32x4& lo, const f32x4& hi) {
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  u4v u = {pk_bf16(lo[0], lo[1]), pk_bf16(lo[2], lo[3]), pk_bf16(hi[0], hi[1]), pk_bf16(hi[2], hi[3])};
+  Frag<bf16_t> f;
+  f.v = __builtin_bit_cast(bf16x8, u);
+  return f;
+}
+__device__ __forceinline__ uint2 pack4(const f32x4& v) { return make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3])); }
+__device__ __forceinline__ float quad_row_sum(float v) {   // sum over the 4 lanes (g = 0..3) that share row lane & 15
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ void unpack4(const uint2& u, float (&v)[4]) {
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u); v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+
+// raw LDS stores (a compiler-visible LDS store is preceded by `s_waitcnt vmcnt(0)` while an LDS-DMA is in flight: the backend cannot tell
+// the regions apart -- that would drain the weight prefetch at every exchange).  The caller orders them with lgk0() before a barrier / a read.
+__device__ __forceinline__ void lds_write16(unsigned addr, const bf16x8& v) { asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_write8(unsigned addr, const uint2& v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_write4(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lgk0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() {   // raw barrier: __syncthreads() would also wait for vmcnt(0), i.e. drain the weight prefetch
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
+template <int OFF> __device__ __forceinline__ void dma16(const char* src, char* dst) {   // 64 lanes x 16 bytes -> 1 KB of LDS at dst + OFF (+ 16 lane)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, OFF, 0);
+}
+
+// ---- a wave's private weight stream: linear in global memory, A steps of it in flight / unread in the wave's LDS ring ----
+template <int A, int DBG = 0> struct WStream {
+  const char* gsrc;     // wave's stream (global)
+  char* ring;           // wave's ring (LDS), A * STEP_BYTES
+  int total;            // steps in the stream
+  int is_step, is_slot; // next step to request, its slot
+  int rd_slot;          // slot of the next step to read
+  __device__ __forceinline__ void init(const char* src, char* r, int tot) { gsrc = src; ring = r; total = tot; is_step = 0; is_slot = 0; rd_slot = 0; }
+  __device__ __forceinline__ void issue(int lane) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const char* s = gsrc + (long)is_step * STEP_BYTES + lv * 16;
+    char* d = ring + is_slot * STEP_BYTES;
+    if (!(DBG & 1)) {
+      // two address / M0 set-ups per step: the instruction's immediate offset advances the global AND the LDS address (13 bits: four pieces per base)
+      dma16<0>(s, d); dma16<1024>(s, d); dma16<2048>(s, d); dma16<3072>(s, d);
+      dma16<0>(s + 4096, d + 4096); dma16<1024>(s + 4096, d + 4096);
+    }
+    is_step = is_step + 1 == total ? 0 : is_step + 1;   // behind the end the stream wraps: the in-flight count stays constant (the data is never used)
+    is_slot = is_slot + 1 == A ? 0 : is_slot + 1;
+  }
+  // the oldest requested-and-unread step has landed once at most (A - 1) steps' worth of younger vector-memory operations are outstanding (they
+  // retire in order; stores and loads issued in between only make the wait stricter)
+  __device__ __forceinline__ void wait() const { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A - 1) * G) : "memory"); }
+  // raw ds_reads (volatile asm keeps them where they are written: right behind the vmcnt wait, in front of the step's MFMAs -- left to the
+  // scheduler they end up BEHIND the MFMAs with their latency exposed); the data counts as landed only after settle(), which names the six
+  // destinations as read-write operands so that no consumer can be scheduled above it
+  __device__ __forceinline__ void read(Frag<bf16_t> (&wf)[G], int lane) {
+    const unsigned ad = lds_addr(ring) + (unsigned)(rd_slot * STEP_BYTES + lane * 16);
+#pragma unroll
+    for (int i = 0; i < G; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i].v) : "v"(ad), "n"(i * 1024));
+    rd_slot = rd_slot + 1 == A ? 0 : rd_slot + 1;
+  }
+  static __device__ __forceinline__ void settle(Frag<bf16_t> (&f)[G]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].v), "+v"(f[1].v), "+v"(f[2].v), "+v"(f[3].v), "+v"(f[4].v), "+v"(f[5].v)::"memory");
+  }
+  __device__ __forceinline__ void start(Frag<bf16_t> (&wf)[G], int lane) {   // requests steps 0 .. A, leaves step 0 in wf
+#pragma unroll
+    for (int k = 0; k < A; ++k) issue(lane);
+    wait();
+    read(wf, lane);
+    settle(wf);
+    issue(lane);
+  }
+  // one pipeline step: fetch the fragments of the NEXT step from the ring, run `f` (24 MFMAs) on the current ones, refill the slot just read
+  template <class F> __device__ __forceinline__ void step(Frag<bf16_t> (&wf)[G], int lane, F&& f) {
+    Frag<bf16_t> nx[G];
+    wait();
+    read(nx, lane);
+    f(wf);
+    settle(nx);
+    issue(lane);
+#pragma unroll
+    for (int i = 0; i < G; ++i) wf[i] = nx[i];
+  }
+  __device__ __forceinline__ void drain() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// weight streams from the fp32 masters
+// ------------------------------------------------------------------------------------------------
+enum { ST_ATTN_FWD = 0, ST_MLP_FWD = 1, ST_MLP_BWD = 2, ST_ATTN_BWD = 3, ST_QKV_BWD = 4 };
+
+struct PackDesc { const float* w0; const float* w1; bf16_t* dst; int type, NW; };
+constexpr int MAX_PACK = 96;
+struct PackArgs { PackDesc d[MAX_PACK]; };
+
+__host__ __device__ inline int stream_steps(int type, int NW) {
+  const int KS = 3 * NW;
+  switch (type) {
+    case ST_ATTN_FWD: return 4 * KS;
+    case ST_MLP_FWD: case ST_MLP_BWD: return 2 * MLP_ROUNDS * NW;
+    case ST_ATTN_BWD: return KS;
+    case ST_QKV_BWD: return 3 * KS;
+  }
+  return 0;
+}
+
+// one thread = one lane's 16 bytes of one fragment image
+__global__ __launch_bounds__(256) void swin_pack_kernel(PackArgs pa) {
+  const PackDesc& d = pa.d[blockIdx.y];
+  const int NW = d.NW, KS = 3 * NW, C = 32 * KS;
+  const int steps = stream_steps(d.type, NW);
+  const long nthr = (long)NW * steps * G * 64;
+  for (long id = (long)blockIdx.x * 256 + threadIdx.x; id < nthr; id += (long)gridDim.x * 256) {
+    const int lane = (int)(id & 63);
+    long q = id >> 6;
+    const int i = (int)(q % G); q /= G;
+    const int s = (int)(q % steps);
+    const int w = (int)(q / steps);
+    const int li = lane & 15, g = lane >> 4, t = i & 1, p = i >> 1;
+    const float* base = nullptr; long idx0 = 0, stride = 1;
+    if (d.type == ST_ATTN_FWD) {
+      const int seg = s / KS, ks = s - seg * KS;
+      if (seg < 3) { const int h = 3 * w + seg; base = d.w0; idx0 = (long)(p * C + 32 * h + np_row(t, li)) * C + 32 * ks + 8 * g; }          // qkv.weight [3C][C]: part p (Q, K, V)
+      else { base = d.w1; idx0 = (long)(96 * w + 32 * p + np_row(t, li)) * C + 32 * ks + 8 * g; }                                          // proj.weight [C][C]
+    } else if (d.type == ST_ATTN_BWD) {   // dO[f] = sum_c dyw[c] proj.weight[c][f]
+      base = d.w0; idx0 = (long)(32 * s + 8 * g) * C + 96 * w + 32 * p + np_row(t, li); stride = C;
+    } else if (d.type == ST_QKV_BWD) {    // dxn[n] = sum_kf dqkv[kf] qkv.weight[kf][n]
+      base = d.w0; idx0 = (long)(32 * s + 8 * g) * C + 96 * w + 32 * p + np_row(t, li); stride = C;
+    } else {
+      // step order: fc1(0) | { fc1(c + 1), fc2(c) } for c = 0 .. 10 | fc2(11); every part NW steps
+      int c, kind, u;   // kind 0: first product of round c (rows = hidden), 1: second product of round c (rows = channels)
+      if (s < NW) { c = 0; kind = 0; u = s; }
+      else {
+        const int s2 = s - NW, blk = s2 / (2 * NW), r = s2 - blk * 2 * NW;
+        if (blk < MLP_ROUNDS - 1) { if (r < NW) { c = blk + 1; kind = 0; u = r; } else { c = blk; kind = 1; u = r - NW; } }
+        else { c = MLP_ROUNDS - 1; kind = 1; u = r; }
+      }
+      const int H = 4 * C;
+      if (kind == 0) {      // fragment i: k-step 3 u + (i >> 1), tile t = i & 1 of the wave's hidden pair of the round
+        const int hid = 32 * (NW * c + w) + np_row(t, li), k0 = 32 * (3 * u + p) + 8 * g;
+        if (d.type == ST_MLP_FWD) { base = d.w0; idx0 = (long)hid * C + k0; }               // fc1.weight [4C][C]
+        else { base = d.w0; idx0 = (long)k0 * H + hid; stride = H; }                         // fc2.weight [C][4C] read as [hidden][channel]
+      } else {              // fragment i: channel pair p, tile t; k-step = the 32 hidden units of wave u in round c
+        const int ch = 96 * w + 32 * p + np_row(t, li), h0 = 32 * (NW * c + u) + 8 * g;
+        if (d.type == ST_MLP_FWD) { base = d.w1; idx0 = (long)ch * H + h0; }                // fc2.weight [C][4C]
+        else { base = d.w1; idx0 = (long)h0 * C + ch; stride = C; }                          // fc1.weight [4C][C] read as [channel][hidden]
+      }
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = base[idx0 + j * stride];
+    *reinterpret_cast<bf16x8*>(d.dst + id * 8) = pack8(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm of the workgroup's 64 rows into operand fragments held by EVERY wave: af[m][k] <- LN(row 16 m + li)[32 k + 8 g ..+7].
+// Row tile m is normalised by wave m % NW only (all waves doing all rows cost 4x the VALU work of the whole prologue), written to the LDS
+// tile xt as lane-linear fragment images [k][m] and read back by everyone after a barrier.  rowfn(m) -> {load row, save row, stat row} of this
+// lane's row of tile m: load row < 0 = a pad token of the window -> zero fragment (the reference pads AFTER the norm, swin_mae3d.py:62-66);
+// the normalised row is also stored to xsave[save row] (the operand of a weight gradient) and its statistics to mean / rstd[stat row].
+// Ends with a barrier: xt may be reused at once.
+// ------------------------------------------------------------------------------------------------
+struct RowIdx { long load, save, stat; };
+template <int KS, int NW, class RowFn>
+__device__ __forceinline__ void ln_exchange(const bf16_t* __restrict__ x, RowFn&& rowfn, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                            bf16_t* __restrict__ xsave, float* __restrict__ mean_out, float* __restrict__ rstd_out, char* xt,
+                                            Frag<bf16_t> (&af)[4][KS], int wave, int lane) {
+  constexpr int C = 32 * KS;
+  const int g = lane >> 4;
+  const unsigned xt_a = lds_addr(xt);
+  // the affine parameters of the lane's channels, requested before anything waits (per k-step inside the loop they were KS serial load -> use
+  // round trips: 12 x ~1000 cycles at C = 384)
+  float4 gmv[KS][2], btv[KS][2];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    gmv[k][0] = *reinterpret_cast<const float4*>(gamma + 32 * k + 8 * g); gmv[k][1] = *reinterpret_cast<const float4*>(gamma + 32 * k + 8 * g + 4);
+    btv[k][0] = *reinterpret_cast<const float4*>(beta + 32 * k + 8 * g); btv[k][1] = *reinterpret_cast<const float4*>(beta + 32 * k + 8 * g + 4);
+  }
+#pragma unroll 1
+  for (int m = wave; m < 4; m += NW) {
+    const RowIdx ri = rowfn(m);
+    const bf16_t* xr = x + (ri.load < 0 ? 0 : ri.load) * C + 8 * g;
+    uint4 raw[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) raw[k] = *reinterpret_cast<const uint4*>(xr + 32 * k);
+    float xv[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      unpack8(raw[k], xv[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += xv[k][j];
+    }
+    const float mean = quad_row_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = xv[k][j] - mean; q += d * d; }
+    const float rstd = rsqrtf(quad_row_sum(q) * (1.0f / C) + eps);
+    if (g == 0 && ri.stat >= 0) { mean_out[ri.stat] = mean; rstd_out[ri.stat] = rstd; }
+    bf16_t* const xs = xsave + (ri.save < 0 ? 0 : ri.save) * C + 8 * g;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const float gm[8] = {gmv[k][0].x, gmv[k][0].y, gmv[k][0].z, gmv[k][0].w, gmv[k][1].x, gmv[k][1].y, gmv[k][1].z, gmv[k][1].w};
+      const float bt[8] = {btv[k][0].x, btv[k][0].y, btv[k][0].z, btv[k][0].w, btv[k][1].x, btv[k][1].y, btv[k][1].z, btv[k][1].w};
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = ri.load < 0 ? 0.f : (xv[k][j] - mean) * rstd * gm[j] + bt[j];
+      const bf16x8 f = pack8(o);
+      lds_write16(xt_a + (k * 4 + m) * 1024 + lane * 16, f);
+      if (ri.save >= 0) *reinterpret_cast<bf16x8*>(xs + 32 * k) = f;
+    }
+  }
+  wg_barrier();
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) af[m][k].v = *reinterpret_cast<const bf16x8*>(xt + (k * 4 + m) * 1024 + lane * 16);
+  wg_barrier();
+}
+
+// ================================================================================================
+// MLP branch, forward:  x2 = x1 + s_row (gelu(LN2(x1) W1^T + b1) W2^T + b2)
+// ================================================================================================
+struct MlpFwdArgs {
+  const bf16_t* x1; const float* gamma; const float* beta; const char* wstream; const float* b1; const float* b2;
+  const float* rowscale; int rows_per_scale;
+  bf16_t* x2; bf16_t* x1n; bf16_t* hp; float* mean; float* rstd; long M; float eps; long long* ts;
+};
+
+template <int NW, int A> constexpr int mlp_lds() { return NW * A * STEP_BYTES + (12 * NW * 1024 > 2 * NW * 4096 ? 12 * NW * 1024 : 2 * NW * 4096) + 4 * 96 * NW * 4; }
+
+// DBG & 8: wave 0 of workgroup 0 records the shader clock at phase boundaries (launchers print the differences)
+template <int DBG> __device__ __forceinline__ void stamp(long long* ts, int i) {
+  if ((DBG & 8) && ts && blockIdx.x == 0 && threadIdx.x == 0) ts[i] = (long long)__builtin_readcyclecounter();
+}
+template <int DBG> __device__ __forceinline__ void mmad(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {   // DBG & 2: timing-only builds without the MFMAs
+  if (DBG & 2) asm volatile("" ::"v"(a.v), "v"(b.v)); else mma(acc, a, b);
+}
+
+template <int NW, int A, int DBG = 0>
+__global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
+  constexpr int KS = 3 * NW, C = 32 * KS, H = 4 * C, TPS = 4 / NW;   // TPS: row tiles whose activation a step of the first product carries
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  char* exch = smem + NW * A * STEP_BYTES;     // LayerNorm tile [KS][4] fragment images, then [2][NW k-steps][4 row tiles] images of gelu(h)
+  const unsigned exch_a = lds_addr(exch);
+  const long rbase = (long)blockIdx.x * 64;
+
+  stamp<DBG>(a.ts, 0);
+  WStream<A, DBG> ws;
+  ws.init(a.wstream + (long)wave * (2 * MLP_ROUNDS * NW) * STEP_BYTES, smem + wave * A * STEP_BYTES, 2 * MLP_ROUNDS * NW);
+  Frag<bf16_t> wf[G];
+  ws.start(wf, lane);
+  stamp<DBG>(a.ts, 1);
+
+  Frag<bf16_t> af[4][KS];
+  long rows[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) { const long row = rbase + 16 * m + li; rows[m] = row < a.M ? row : -1; }
+  // the fc1 bias goes to LDS once: a global load inside the rounds is consumed behind the whole weight prefetch (vector-memory operations retire
+  // in order) -- two bias loads per round drained the ring every round (3 k of a round's 8 k cycles)
+  float* const sB1 = reinterpret_cast<float*>(exch + (12 * NW * 1024 > 2 * NW * 4096 ? 12 * NW * 1024 : 2 * NW * 4096));
+  {
+    constexpr int NB = (H / 4 + 64 * NW - 1) / (64 * NW);
+    float4 bv[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { const int i = tid + 64 * NW * q; bv[q] = i < H / 4 ? *reinterpret_cast<const float4*>(a.b1 + 4 * i) : float4{0.f, 0.f, 0.f, 0.f}; }
+    const unsigned b_a = lds_addr(sB1);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int i = tid + 64 * NW * q;
+      if (i < H / 4) { lds_write4(b_a + 16 * i, bv[q].x); lds_write4(b_a + 16 * i + 4, bv[q].y); lds_write4(b_a + 16 * i + 8, bv[q].z); lds_write4(b_a + 16 * i + 12, bv[q].w); }
+    }
+  }
+  ln_exchange<KS, NW>(a.x1, [&](int m) { const long row = rbase + 16 * m + li; const long v = row < a.M ? row : -1; return RowIdx{row < a.M ? row : a.M - 1, v, v}; },
+                      a.gamma, a.beta, a.eps, a.x1n, a.mean, a.rstd, exch, af, wave, lane);
+  bf16_t* hprow[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) hprow[m] = a.hp + (rows[m] < 0 ? 0 : rows[m]) * H + 32 * wave + 8 * g;
+
+  f32x4 out[6][4];
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 hcur[2][4], hnxt[2][4];
+
+  // bias + store of the pre-activation + GELU of row tile m + hand-over of the wave's 32 hidden units of round c as an operand fragment
+  auto act_tile = [&](int c, f32x4 (&h)[2][4], int m, const float4 (&bb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { h[t][m][0] += bb[t].x; h[t][m][1] += bb[t].y; h[t][m][2] += bb[t].z; h[t][m][3] += bb[t].w; }
+    // the two tiles of the pair are 8 consecutive hidden units of the lane's token: ONE 16-byte store (a store instruction costs the same issue
+    // time whatever its width -- it touches 16 rows -- and 8-byte stores of the pre-activation were 3 k of a round's 8 k cycles)
+    if (rows[m] >= 0) *reinterpret_cast<bf16x8*>(hprow[m] + 32 * NW * c) = pack_tr(h[0][m], h[1][m]).v;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[t][m][r] = (DBG & 4) ? h[t][m][r] : gelu_fast_f(h[t][m][r]);
+    const Frag<bf16_t> hf = pack_tr(h[0][m], h[1][m]);
+    lds_write16(exch_a + ((c & 1) * NW + wave) * 4096 + m * 1024 + lane * 16, hf.v);
+  };
+  // first product of a round (into h); with ACT, step u also carries the activation of row tiles u TPS .. of the PREVIOUS round (hp): its
+  // ~160 VALU instructions per tile then issue in the shadow of the step's 24 MFMAs instead of behind them
+  auto fc1 = [&](f32x4 (&h)[2][4], auto with_act, int c_act, f32x4 (&hp)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) h[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bb[2];
+    if (decltype(with_act)::value) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bb[t] = *reinterpret_cast<const float4*>(sB1 + 32 * (NW * c_act + wave) + 8 * g + 4 * t);
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+      ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) mmad<DBG>(h[t][m], w[2 * q + t], af[m][3 * u + q]);
+        if (decltype(with_act)::value) {
+#pragma unroll
+          for (int mm = 0; mm < TPS; ++mm) act_tile(c_act, hp, u * TPS + mm, bb);
+        }
+      });
+  };
+  auto fc2 = [&](int c) __attribute__((always_inline)) {
+    Frag<bf16_t> hf[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hf[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW) * 4096 + m * 1024 + lane * 16);
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+      ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
+        Frag<bf16_t> hn[4];
+        if (u + 1 < NW) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) hn[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW + u + 1) * 4096 + m * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mmad<DBG>(out[n][m], w[n], hf[m]);
+        if (u + 1 < NW) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) hf[m] = hn[m];
+        }
+      });
+  };
+
+  stamp<DBG>(a.ts, 2);
+  fc1(hcur, std::false_type{}, 0, hcur);
+  stamp<DBG>(a.ts, 3);
+#pragma unroll 1
+  for (int c = 0; c < MLP_ROUNDS - 1; ++c) {
+    fc1(hnxt, std::true_type{}, c, hcur);
+    if (c == 5) stamp<DBG>(a.ts, 4);
+    wg_barrier();
+    if (c == 5) stamp<DBG>(a.ts, 5);
+    fc2(c);
+    if (c == 5) stamp<DBG>(a.ts, 6);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) hcur[t][m] = hnxt[t][m];
+  }
+  {
+    float4 bb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bb[t] = *reinterpret_cast<const float4*>(sB1 + 32 * (NW * (MLP_ROUNDS - 1) + wave) + 8 * g + 4 * t);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) act_tile(MLP_ROUNDS - 1, hcur, m, bb);
+  }
+  wg_barrier();
+  fc2(MLP_ROUNDS - 1);
+  stamp<DBG>(a.ts, 7);
+
+  // epilogue: lane (li, g) owns channels 96 w + 32 p + 8 g + 4 t + r of token li.  Every load first (24 + 6 + 4 requests in flight), then the stores:
+  // written load -> use per piece, the epilogue was 24 serial L2 round trips (15 k of the kernel's 130 k cycles)
+  {
+    uint4 xres[4][3];
+    float4 b2v[6];
+    float scv[4];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) b2v[n] = *reinterpret_cast<const float4*>(a.b2 + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1));
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long row = rows[m] < 0 ? 0 : rows[m];
+      scv[m] = a.rowscale ? a.rowscale[row / a.rows_per_scale] : 1.0f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) xres[m][p] = *reinterpret_cast<const uint4*>(a.x1 + row * C + 96 * wave + 32 * p + 8 * g);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (rows[m] < 0) continue;
+      bf16_t* const orow = a.x2 + rows[m] * C + 96 * wave + 8 * g;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float xr[8];
+        unpack8(xres[m][p], xr);
+        f32x4 v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float b0 = r == 0 ? b2v[2 * p].x : r == 1 ? b2v[2 * p].y : r == 2 ? b2v[2 * p].z : b2v[2 * p].w;
+          const float b1 = r == 0 ? b2v[2 * p + 1].x : r == 1 ? b2v[2 * p + 1].y : r == 2 ? b2v[2 * p + 1].z : b2v[2 * p + 1].w;
+          v0[r] = (out[2 * p][m][r] + b0) * scv[m] + xr[r];
+          v1[r] = (out[2 * p + 1][m][r] + b1) * scv[m] + xr[4 + r];
+        }
+        *reinterpret_cast<bf16x8*>(orow + 32 * p) = pack_tr(v0, v1).v;
+      }
+    }
+  }
+  stamp<DBG>(a.ts, 8);
+  ws.drain();
+  stamp<DBG>(a.ts, 9);
+}
+
+// ================================================================================================
+// attention branch, forward:  x1 = x + s_row * window_reverse(proj(attn(window_partition(LN1(x)))))
+// ================================================================================================
+struct AttnFwdArgs {
+  const bf16_t* x; const float* gamma; const float* beta; const char* wstream; const float* bqkv; const float* table; const float* bproj;
+  const float* rowscale; int rows_per_scale;
+  bf16_t* xnw; float* mean; float* rstd; bf16_t* qkv; bf16_t* o; float* lse; bf16_t* x1;
+  WinMap wm; float eps; long long* ts;
+};
+
+__device__ __forceinline__ int relidx(int i, int j) {
+  return ((i >> 4) - (j >> 4) + 3) * 49 + (((i >> 2) & 3) - ((j >> 2) & 3) + 3) * 7 + ((i & 3) - (j & 3) + 3);
+}
+__device__ __forceinline__ int axis_region(int p, int P, int s) { return s == 0 ? 0 : (p < P - 4 ? 0 : (p < P - s ? 1 : 2)); }
+__device__ __forceinline__ int token_region(const WinMap& w, int winl, int t) {
+  const int nwy = w.PW >> 2, nwx = w.PD >> 2;
+  int wx = winl % nwx, wy = (winl / nwx) % nwy, wz = winl / (nwx * nwy);
+  return axis_region(wz * 4 + (t >> 4), w.PH, w.s0) * 9 + axis_region(wy * 4 + ((t >> 2) & 3), w.PW, w.s1) * 3 + axis_region(wx * 4 + (t & 3), w.PD, w.s2);
+}
+
+constexpr int VRS = 96;                                  // row stride of the wave's V tile [64 tokens][32 features] (conflict-free transpose reads)
+template <int NW, int A> constexpr int attn_fwd_lds() {
+  constexpr int scratch = NW * 64 * VRS + 3 * NW * 344 * 4 + 256;   // V tiles, bias table [heads][344], region ids
+  constexpr int exch = 3 * NW * 4096;                                 // O fragments [head][row tile]: aliases the scratch after the attention
+  return NW * A * STEP_BYTES + (scratch > exch ? scratch : exch);
+}
+
+template <int NW, int A, int DBG = 0>
+__global__ __launch_bounds__(64 * NW) void swin_attn_fwd_kernel(AttnFwdArgs a) {
+  constexpr int KS = 3 * NW, C = 32 * KS, HEADS = KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  char* scratch = smem + NW * A * STEP_BYTES;
+  char* sV = scratch + wave * 64 * VRS;
+  float* sTab = reinterpret_cast<float*>(scratch + NW * 64 * VRS);        // [HEADS][344]
+  unsigned char* sRb = reinterpret_cast<unsigned char*>(scratch + NW * 64 * VRS + HEADS * 344 * 4);   // region id of the 64 tokens, one byte each
+  const long win = blockIdx.x;
+  const int nW = (a.wm.PH >> 2) * (a.wm.PW >> 2) * (a.wm.PD >> 2);
+  const bool shifted = (a.wm.s0 + a.wm.s1 + a.wm.s2) > 0;
+
+  stamp<DBG>(a.ts, 0);
+  WStream<A, DBG> ws;
+  ws.init(a.wstream + (long)wave * (4 * KS) * STEP_BYTES, smem + wave * A * STEP_BYTES, 4 * KS);
+  Frag<bf16_t> wf[G];
+  ws.start(wf, lane);
+  stamp<DBG>(a.ts, 1);
+
+  // ---- gather + LN1 (the LayerNorm tile uses the scratch area before the bias table is staged there)
+  Frag<bf16_t> xn[4][KS];
+  long tok[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) tok[m] = win_to_tok(a.wm, win * 64 + 16 * m + li);
+  ln_exchange<KS, NW>(a.x, [&](int m) { const long t = win_to_tok(a.wm, win * 64 + 16 * m + li); return RowIdx{t, win * 64 + 16 * m + li, t}; },
+                      a.gamma, a.beta, a.eps, a.xnw, a.mean, a.rstd, scratch, xn, wave, lane);
+  {
+    const unsigned tab_a = lds_addr(sTab), sr_a = lds_addr(sRb);
+    // all requests first, then the LDS stores (volatile asm: a load cannot pass one -- load -> store per element was 17 serial round trips)
+    constexpr int NT = (HEADS * 343 + 64 * NW - 1) / (64 * NW);
+    float tv[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) { const int i = tid + 64 * NW * q; tv[q] = i < HEADS * 343 ? a.table[i] : 0.f; }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int i = tid + 64 * NW * q;
+      const int t = i / HEADS, h = i - t * HEADS;
+      if (i < HEADS * 343) lds_write4(tab_a + (h * 344 + t) * 4, tv[q]);
+    }
+    if (tid < 16) {
+      unsigned pk = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pk |= (unsigned)(shifted ? token_region(a.wm, (int)(win % nW), 4 * tid + q) : 0) << (8 * q);
+      lds_write4(sr_a + 4 * tid, __uint_as_float(pk));
+    }
+  }
+  wg_barrier();
+  stamp<DBG>(a.ts, 2);
+
+  Frag<bf16_t> of[3][4];      // this wave's heads: O fragments (token tile m, k = the head's 32 features)
+  const float scale = 0.17677669529663689f;  // 32^-0.5
+  const unsigned sV_a = lds_addr(sV);
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+    const int h = 3 * wave + j;
+    Frag<bf16_t> ofj[4];
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 bq[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bq[i] = *reinterpret_cast<const float4*>(a.bqkv + (i >> 1) * C + 32 * h + 8 * g + 4 * (i & 1));
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+      ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mmad<DBG>(acc[i][m], w[i], xn[m][k]);
+      });
+    if (j == 1) stamp<DBG>(a.ts, 3);
+    // bias, stores in the unfused layout qkv[row][3C] (the packed pair of tiles = 8 consecutive features of the lane's token: 16-byte stores), V tile to LDS
+    Frag<bf16_t> qf[4], kf[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      bf16_t* qrow = a.qkv + (win * 64 + 16 * m + li) * (3L * C) + 32 * h + 8 * g;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { acc[i][m][0] += bq[i].x; acc[i][m][1] += bq[i].y; acc[i][m][2] += bq[i].z; acc[i][m][3] += bq[i].w; }
+      qf[m] = pack_tr(acc[0][m], acc[1][m]);
+      kf[m] = pack_tr(acc[2][m], acc[3][m]);
+      const Frag<bf16_t> vfm = pack_tr(acc[4][m], acc[5][m]);
+      *reinterpret_cast<bf16x8*>(qrow) = qf[m].v;
+      *reinterpret_cast<bf16x8*>(qrow + C) = kf[m].v;
+      *reinterpret_cast<bf16x8*>(qrow + 2 * C) = vfm.v;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) lds_write8(sV_a + (16 * m + li) * VRS + (16 * t + 4 * g) * 2, pack4(acc[4 + t][m]));   // feature 8g+4t+r at column 16t+4g+r
+    }
+    lgk0();
+    if (j == 1) stamp<DBG>(a.ts, 4);
+    // S^T = K Q^T: key j = 16 jt + 4 g + r, query i = 16 it + li
+    f32x4 s[4][4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) { s[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(s[jt][it], kf[jt], qf[it]); }
+    // bias bin of (query i = 16 it + li, key j = 16 jt + 4 g + r): binA + (it - jt + 3) * 49 - r -- one LDS read with an immediate offset each
+    const float* tb = sTab + h * 344 + ((li >> 2) - g + 3) * 7 + (li & 3);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = 16 * it + li;
+      const unsigned ri = shifted ? sRb[i] : 0u;
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const unsigned rw = shifted ? *reinterpret_cast<const unsigned*>(sRb + 16 * jt + 4 * g) : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[jt][it][r] * scale + tb[(it - jt + 3) * 49 + 3 - r];
+          if (shifted && ((rw >> (8 * r)) & 255u) != ri) v += -100.0f;
+          s[jt][it][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __expf(s[jt][it][r] - mx); s[jt][it][r] = e; sum += e; }
+      sum = quad_row_sum(sum);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[jt][it][r] *= inv;
+      if (g == 0) a.lse[(win * HEADS + h) * 64 + i] = mx + __logf(sum);
+    }
+    if (j == 1) stamp<DBG>(a.ts, 5);
+    // O^T = V^T P^T: feature 8 g + 4 dt + r of query li
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      f32x4 oT[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const Frag<bf16_t> pa = pack_tr(s[2 * ks2][it], s[2 * ks2 + 1][it]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const Frag<bf16_t> vfr = lds_frag_t(sV, VRS, ks2 * 32, dt * 16, lane, (bf16_t*)nullptr);
+          mma(oT[dt], vfr, pa);
+        }
+      }
+      ofj[it] = pack_tr(oT[0], oT[1]);
+      *reinterpret_cast<bf16x8*>(a.o + (win * 64 + 16 * it + li) * C + 32 * h + 8 * g) = ofj[it].v;
+    }
+    // (no dynamic register indexing: `of[j]` with a run-time j would put the array into scratch memory)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (j == 0) of[0][it] = ofj[it];
+      else if (j == 1) of[1][it] = ofj[it];
+      else of[2][it] = ofj[it];
+    }
+  }
+
+  // ---- O of all heads to every wave (the exchange area aliases the attention scratch: everyone is done with it first)
+  stamp<DBG>(a.ts, 6);
+  wg_barrier();
+  const unsigned ex_a = lds_addr(scratch);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) lds_write16(ex_a + ((3 * wave + j) * 4 + m) * 1024 + lane * 16, of[j][m].v);
+  wg_barrier();
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int k = 0; k < KS; ++k) xn[m][k].v = *reinterpret_cast<const bf16x8*>(scratch + (k * 4 + m) * 1024 + lane * 16);
+
+  stamp<DBG>(a.ts, 7);
+  // ---- proj: this wave's 96 output channels
+  f32x4 pacc[6][4];
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) pacc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < KS; ++k)
+    ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int n = 0; n < 6; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) mmad<DBG>(pacc[n][m], w[n], xn[m][k]);
+    });
+  stamp<DBG>(a.ts, 8);
+  {
+    uint4 xres[4][3];
+    float4 bpv[6];
+    float scv[4];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) bpv[n] = *reinterpret_cast<const float4*>(a.bproj + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1));
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long t = tok[m] < 0 ? 0 : tok[m];
+      scv[m] = a.rowscale ? a.rowscale[t / a.rows_per_scale] : 1.0f;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) xres[m][p] = *reinterpret_cast<const uint4*>(a.x + t * C + 96 * wave + 32 * p + 8 * g);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (tok[m] < 0) continue;
+      bf16_t* const orow = a.x1 + tok[m] * C + 96 * wave + 8 * g;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float xr[8];
+        unpack8(xres[m][p], xr);
+        f32x4 v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float b0 = r == 0 ? bpv[2 * p].x : r == 1 ? bpv[2 * p].y : r == 2 ? bpv[2 * p].z : bpv[2 * p].w;
+          const float b1 = r == 0 ? bpv[2 * p + 1].x : r == 1 ? bpv[2 * p + 1].y : r == 2 ? bpv[2 * p + 1].z : bpv[2 * p + 1].w;
+          v0[r] = (pacc[2 * p][m][r] + b0) * scv[m] + xr[r];
+          v1[r] = (pacc[2 * p + 1][m][r] + b1) * scv[m] + xr[4 + r];
+        }
+        *reinterpret_cast<bf16x8*>(orow + 32 * p) = pack_tr(v0, v1).v;
+      }
+    }
+  }
+  stamp<DBG>(a.ts, 9);
+  ws.drain();
+  stamp<DBG>(a.ts, 10);
+}
+
+
+// ================================================================================================
+// shared tail of the two backward kernels: LayerNorm backward on acc = dL/d(LN output) in the accumulator layout
+//   (token li of row tile m, channels 96 w + 32 (n >> 1) + 8 g + 4 (n & 1) + r), plus the residual gradient:
+//   dx[row] = dres[row] + rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = acc * gamma;   dgamma += sum_rows acc xhat;  dbeta += sum_rows acc
+// rows[m] < 0: no such row.  The row sums over the C channels are completed across the NW waves through `red` (LDS, [NW][64][2] floats).
+// dyw (optional): second copy of dx at window row tok_to_win(row), times dyw_scale[row / rows_per_scale].
+// Call with the weight stream drained (plain LDS accesses and __syncthreads() below).
+// ================================================================================================
+template <int NW>
+__device__ __forceinline__ void ln_bwd_tail(f32x4 (&acc)[6][4], const long (&rows)[4], const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, const float* __restrict__ gamma, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+                                            bf16_t* __restrict__ dyw, const float* __restrict__ dyw_scale, int rows_per_scale, const WinMap& wm,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* red, int wave, int lane) {
+  constexpr int C = 96 * NW;
+  const int g = lane >> 4, li = lane & 15;
+  float gm[6][4];
+#pragma unroll
+  for (int n = 0; n < 6; ++n) {
+    const float4 t4 = *reinterpret_cast<const float4*>(gamma + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1));
+    gm[n][0] = t4.x; gm[n][1] = t4.y; gm[n][2] = t4.z; gm[n][3] = t4.w;
+  }
+  float pg[6][4], pb[6][4];
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pg[n][r] = 0.f; pb[n][r] = 0.f; }
+  float xh[6][4][4];
+  float rs_[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const bool ok = rows[m] >= 0;
+    const long row = ok ? rows[m] : 0;
+    const float mu = mean[row];
+    rs_[m] = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      float xv[4];
+      unpack4(*reinterpret_cast<const uint2*>(x + row * C + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1)), xv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = ok ? acc[n][m][r] : 0.f;
+        const float h = (xv[r] - mu) * rs_[m];
+        xh[n][m][r] = h;
+        pg[n][r] += d * h;
+        pb[n][r] += d;
+        const float gg = d * gm[n][r];
+        acc[n][m][r] = gg;
+        s1 += gg;
+        s2 += gg * h;
+      }
+    }
+    s1 = quad_row_sum(s1);
+    s2 = quad_row_sum(s2);
+    if (g == 0) { red[(wave * 64 + 16 * m + li) * 2] = s1; red[(wave * 64 + 16 * m + li) * 2 + 1] = s2; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    if (rows[m] < 0) continue;
+    const long row = rows[m];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { m1 += red[(w * 64 + 16 * m + li) * 2]; m2 += red[(w * 64 + 16 * m + li) * 2 + 1]; }
+    m1 *= (1.0f / C); m2 *= (1.0f / C);
+    const float dsc = (dyw && dyw_scale) ? dyw_scale[row / rows_per_scale] : 1.0f;
+    const long wrow = dyw ? tok_to_win(wm, row) : 0;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const int col = 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1);
+      float rv[4];
+      unpack4(*reinterpret_cast<const uint2*>(dres + row * C + col), rv);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = rs_[m] * (acc[n][m][r] - m1 - xh[n][m][r] * m2) + rv[r];
+      *reinterpret_cast<uint2*>(dx + row * C + col) = pack4(v);
+      if (dyw) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= dsc;
+        *reinterpret_cast<uint2*>(dyw + wrow * C + col) = pack4(v);
+      }
+    }
+  }
+  // column sums over the 64 rows: butterfly over the 16 token lanes; lane li == 0 of group g owns channels 96 w + 32 p + 8 g + 4 t + r (no other wave does)
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float vg = pg[n][r], vb = pb[n][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { vg += __shfl_xor(vg, o, 64); vb += __shfl_xor(vb, o, 64); }
+      if (li == 0) {
+        const int col = 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1) + r;
+        atomicAdd(dgamma + col, vg);
+        atomicAdd(dbeta + col, vb);
+      }
+    }
+}
+
+// ================================================================================================
+// MLP branch, backward.  Given dy = dL/dx2:
+//   hact = gelu(hp)                                          [M][4C]  (written: B operand of dW2 = (s dy)^T hact)
+//   dh   = s_row (dy W2) gelu'(hp)                           [M][4C]  (written: A operand of dW1 = dh^T x1n)
+//   dx1  = dy + LN2_backward(dh W1);  dgamma2 / dbeta2;  dyw = window-ordered copy of dx1 times dyw_scale (the attention branch's incoming gradient)
+// ================================================================================================
+struct MlpBwdArgs {
+  const bf16_t* dy; const bf16_t* x1; const bf16_t* hp; const float* mean; const float* rstd; const float* gamma; const char* wstream;
+  const float* rowscale; int rows_per_scale;
+  bf16_t* dx1; bf16_t* hact; bf16_t* dh; float* dgamma; float* dbeta;
+  bf16_t* dyw; const float* dyw_scale; WinMap wm; int dyw_pads;
+  long M;
+};
+
+template <int NW, int A> constexpr int mlp_bwd_lds() { return NW * A * STEP_BYTES + 2 * NW * 4096 + NW * 64 * 2 * 4; }
+
+template <int NW, int A>
+__global__ __launch_bounds__(64 * NW) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
+  constexpr int KS = 3 * NW, C = 32 * KS, H = 4 * C;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  char* exch = smem + NW * A * STEP_BYTES;
+  float* red = reinterpret_cast<float*>(exch + 2 * NW * 4096);
+  const unsigned exch_a = lds_addr(exch);
+  const long rbase = (long)blockIdx.x * 64;
+
+  WStream<A> ws;
+  ws.init(a.wstream + (long)wave * (2 * MLP_ROUNDS * NW) * STEP_BYTES, smem + wave * A * STEP_BYTES, 2 * MLP_ROUNDS * NW);
+  Frag<bf16_t> wf[G];
+  ws.start(wf, lane);
+
+  if (a.dyw && a.dyw_pads) {   // pad rows of the window-ordered output receive no token: zeroed here
+    const long wrows = (long)a.wm.B * a.wm.PH * a.wm.PW * a.wm.PD;
+    for (long i = (long)blockIdx.x * (64 * NW) + tid; i < wrows * (C / 8); i += (long)gridDim.x * (64 * NW)) {
+      const unsigned m = (unsigned)i / (unsigned)(C / 8), c = (unsigned)i - m * (unsigned)(C / 8);
+      if (win_to_tok(a.wm, (long)m) < 0) *reinterpret_cast<uint4*>(a.dyw + (long)m * C + c * 8) = make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  Frag<bf16_t> df[4][KS];
+  long rows[4], lrows[4];
+  float sc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const long row = rbase + 16 * m + li;
+    rows[m] = row < a.M ? row : -1;
+    lrows[m] = row < a.M ? row : a.M - 1;
+    sc[m] = a.rowscale ? a.rowscale[lrows[m] / a.rows_per_scale] : 1.0f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) df[m][k].v = *reinterpret_cast<const bf16x8*>(a.dy + lrows[m] * C + 32 * k + 8 * g);
+  }
+
+  f32x4 acc[6][4];
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 hcur[2][4], hnxt[2][4];
+  uint2 hpc[2][4], hpn[2][4];
+
+  auto hp_load = [&](int c, uint2 (&q)[2][4]) __attribute__((always_inline)) {
+    const int hb = 32 * (NW * c + wave) + 8 * g;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) q[t][m] = *reinterpret_cast<const uint2*>(a.hp + lrows[m] * H + hb + 4 * t);
+  };
+  auto dha = [&](f32x4 (&h)[2][4]) __attribute__((always_inline)) {   // (dy W2) for the wave's 32 hidden units of the round
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) h[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+      ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) mma(h[t][m], w[2 * q + t], df[m][3 * u + q]);
+      });
+  };
+  auto act = [&](int c, f32x4 (&h)[2][4], const uint2 (&q)[2][4]) __attribute__((always_inline)) {
+    const int hb = 32 * (NW * c + wave) + 8 * g;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float xv[4];
+        unpack4(q[t][m], xv);
+        f32x4 ha;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float er, e;
+          erf_as_parts(xv[r] * 0.70710678118654752f, er, e);
+          const float cdf = 0.5f * (1.0f + er);
+          ha[r] = xv[r] * cdf;
+          h[t][m][r] = h[t][m][r] * (cdf + xv[r] * 0.39894228040143268f * e) * sc[m];
+        }
+        if (rows[m] >= 0) {
+          *reinterpret_cast<uint2*>(a.hact + rows[m] * H + hb + 4 * t) = pack4(ha);
+          *reinterpret_cast<uint2*>(a.dh + rows[m] * H + hb + 4 * t) = pack4(h[t][m]);
+        }
+      }
+      const Frag<bf16_t> hf = pack_tr(h[0][m], h[1][m]);
+      lds_write16(exch_a + ((c & 1) * NW + wave) * 4096 + m * 1024 + lane * 16, hf.v);
+    }
+  };
+  auto dxn = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NW; ++u)
+      ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
+        Frag<bf16_t> hf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hf[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW + u) * 4096 + m * 1024 + lane * 16);
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mma(acc[n][m], w[n], hf[m]);
+      });
+  };
+
+  hp_load(0, hpc);
+  dha(hcur);
+#pragma unroll 1
+  for (int c = 0; c < MLP_ROUNDS - 1; ++c) {
+    hp_load(c + 1, hpn);    // a round ahead: vector-memory operations retire in order, a load requested where it is used waits for the whole weight prefetch
+    dha(hnxt);
+    act(c, hcur, hpc);
+    wg_barrier();
+    dxn(c);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { hcur[t][m] = hnxt[t][m]; hpc[t][m] = hpn[t][m]; }
+  }
+  act(MLP_ROUNDS - 1, hcur, hpc);
+  wg_barrier();
+  dxn(MLP_ROUNDS - 1);
+  ws.drain();
+  ln_bwd_tail<NW>(acc, rows, a.x1, a.mean, a.rstd, a.gamma, a.dy, a.dx1, a.dyw, a.dyw_scale, a.rows_per_scale, a.wm, a.dgamma, a.dbeta, red, wave, lane);
+}
+
+// ================================================================================================
+// attention branch, backward, first half: dO = dyw Wproj, then per head (in the wave that owns it) the backward of
+// softmax(q k^T / sqrt(32) + bias + mask) v from the saved qkv and log-sum-exp -> dqkv (layout of the unfused path), d(bias table).
+//   phase A (S^T layout, lane <-> query): P, dP -> D_i = sum_j P dP, dS, d(bias), dQ = dS K
+//   phase B (S layout,   lane <-> key)  : P, dS recomputed -> dV = P^T dO, dK = dS^T Q        (the algorithm of csrc/attn.hip attn_bwd_kernel)
+// ================================================================================================
+struct AttnBwdArgs {
+  const bf16_t* dyw; const bf16_t* qkv; const float* table; const float* lse; const char* wstream;
+  bf16_t* dqkv; float* dtable; WinMap wm;
+};
+
+constexpr int ARS = 96;   // row stride of the [64][32] LDS tiles
+template <int NW, int A> constexpr int attn_bwd_lds() {
+  return NW * A * STEP_BYTES + NW * (2 * 64 * ARS + 344 * 4 + 64 * 4 + 64 * 4 + 64) + 3 * NW * 344 * 4;
+}
+__device__ __forceinline__ Frag<bf16_t> gfrag16(const bf16_t* base, long ld, int row, int g) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(base + row * ld + 8 * g);
+  return f;
+}
+__device__ __forceinline__ Frag<bf16_t> lds_row_frag(const char* tile, int row, int g) {
+  Frag<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(tile + row * ARS + 16 * g);
+  return f;
+}
+__device__ __forceinline__ void store4s(bf16_t* p, const f32x4& v, float s) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pk_bf16(v[0] * s, v[1] * s), pk_bf16(v[2] * s, v[3] * s));
+}
+
+template <int NW, int A>
+__global__ __launch_bounds__(64 * NW) void swin_attn_bwd_kernel(AttnBwdArgs a) {
+  constexpr int KS = 3 * NW, C = 32 * KS, HEADS = KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* wscr = smem + NW * A * STEP_BYTES + wave * (2 * 64 * ARS + 344 * 4 + 64 * 4 + 64 * 4 + 64);
+  char* tA = wscr;                                     // K tile (phase A), then Q tile (phase B)
+  char* tO = wscr + 64 * ARS;                          // dO tile
+  float* sDB = reinterpret_cast<float*>(wscr + 2 * 64 * ARS);        // [344] d(bias) of the current head
+  float* sD = sDB + 344;                               // [64]
+  float* sL = sD + 64;                                 // [64]
+  unsigned char* sRb = reinterpret_cast<unsigned char*>(sL + 64);   // [64] region ids
+  float* sTab = reinterpret_cast<float*>(smem + NW * A * STEP_BYTES + NW * (2 * 64 * ARS + 344 * 4 + 64 * 4 + 64 * 4 + 64));   // [HEADS][344]
+  const long win = blockIdx.x;
+  const int nW = (a.wm.PH >> 2) * (a.wm.PW >> 2) * (a.wm.PD >> 2);
+  const bool shifted = (a.wm.s0 + a.wm.s1 + a.wm.s2) > 0;
+  const float scale = 0.17677669529663689f;
+
+  for (int i = tid; i < HEADS * 343; i += 64 * NW) { const int t = i / HEADS, h = i - t * HEADS; sTab[h * 344 + t] = a.table[i]; }
+  for (int t = lane0; t < 344; t += 64) sDB[t] = 0.f;
+  sRb[lane0] = shifted ? (unsigned char)token_region(a.wm, (int)(win % nW), lane0) : 0;
+  __syncthreads();
+
+  WStream<A> ws;
+  ws.init(a.wstream + (long)wave * KS * STEP_BYTES, smem + wave * A * STEP_BYTES, KS);
+  Frag<bf16_t> wf[G];
+  ws.start(wf, lane0);
+
+  // ---- dO^T for this wave's three heads: rows = head features (natural order after packing), columns = tokens
+  Frag<bf16_t> dof[3][4];
+  {
+    const int g = lane0 >> 4, li = lane0 & 15;
+    Frag<bf16_t> dfw[4][KS];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) dfw[m][k].v = *reinterpret_cast<const bf16x8*>(a.dyw + (win * 64 + 16 * m + li) * C + 32 * k + 8 * g);
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+      ws.step(wf, lane0, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) mma(acc[n][m], w[n], dfw[m][k]);
+      });
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) dof[p][m] = pack_tr(acc[2 * p][m], acc[2 * p + 1][m]);
+  }
+  ws.drain();   // (the stream is through: plain LDS accesses below)
+
+  const long ld = 3L * C;
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+    const int h = 3 * wave + j;
+    const float* sB = sTab + h * 344;
+    const bf16_t* qb = a.qkv + win * 64 * ld + h * 32;
+    const bf16_t* kb = qb + C;
+    const bf16_t* vb = qb + 2 * C;
+    bf16_t* dqb = a.dqkv + win * 64 * ld + h * 32;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));     // opaque: what derives from it is loop-invariant and would be hoisted into ~200 registers (attn.hip)
+    const int g = lane >> 4, li = lane & 15;
+    const int c1 = (li >> 2) - g, c2 = li & 3;
+    const int binA = (c1 + 3) * 7 + c2 + 3;  // phase A (i = 16it+li, j = 16jt+4g+r): binA + (it-jt+3)*49 - r
+    const int binB = (3 - c1) * 7 + 3 - c2;  // phase B (i = 16it+4g+r, j = 16jt+li): binB + (it-jt+3)*49 + r
+    float dsacc[7][4];
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsacc[q][r] = 0.f;
+    Frag<bf16_t> kf[4], qf[4], vf[4], df[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      kf[t] = gfrag16(kb, ld, t * 16 + li, g); qf[t] = gfrag16(qb, ld, t * 16 + li, g); vf[t] = gfrag16(vb, ld, t * 16 + li, g);
+      if (j == 0) df[t] = dof[0][t]; else if (j == 1) df[t] = dof[1][t]; else df[t] = dof[2][t];
+    }
+    sL[lane] = a.lse[(win * HEADS + h) * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      *reinterpret_cast<bf16x8*>(tA + (t * 16 + li) * ARS + 16 * g) = kf[t].v;
+      *reinterpret_cast<bf16x8*>(tO + (t * 16 + li) * ARS + 16 * g) = df[t].v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- phase A ----------------
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      f32x4 p[4], dp[4];
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        p[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[jt], kf[jt], qf[it]);
+        dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[jt], vf[jt], df[it]);
+      }
+      const int i = 16 * it + li;
+      const unsigned ri = shifted ? sRb[i] : 0u;
+      const float L = sL[i];
+      float dsum = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const unsigned rw = shifted ? *reinterpret_cast<const unsigned*>(sRb + 16 * jt + 4 * g) : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = p[jt][r] * scale + sB[binA + (it - jt + 3) * 49 - r];
+          if (shifted && ((rw >> (8 * r)) & 255u) != ri) v += -100.0f;
+          const float e = __expf(v - L);
+          p[jt][r] = e;
+          dsum += e * dp[jt][r];
+        }
+      }
+      dsum = quad_row_sum(dsum);
+      if (g == 0) sD[i] = dsum;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ds = p[jt][r] * (dp[jt][r] - dsum);
+          dp[jt][r] = ds;
+          dsacc[it - jt + 3][r] += ds;
+        }
+      // dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]
+      f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const Frag<bf16_t> pa = pack_tr(dp[2 * ks], dp[2 * ks + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const Frag<bf16_t> b = lds_frag_t(tA, ARS, ks * 32, dt * 16, lane, (bf16_t*)nullptr);
+          mma(o[dt], b, pa);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) store4s(dqb + (long)i * ld + 16 * dt + 4 * g, o[dt], scale);
+      __builtin_amdgcn_sched_barrier(0);   // keeps the query tiles sequential (interleaved, they need 4x the registers)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(tA + (t * 16 + li) * ARS + 16 * g) = qf[t].v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- phase B ----------------
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+      f32x4 p[4], dp[4];  // [it]: query i = 16it+4g+r, key j = 16jt+li
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        p[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[it], qf[it], kf[jt]);
+        dp[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[it], df[it], vf[jt]);
+      }
+      const int jj = 16 * jt + li;
+      const unsigned rj = shifted ? sRb[jj] : 0u;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const unsigned rw = shifted ? *reinterpret_cast<const unsigned*>(sRb + 16 * it + 4 * g) : 0u;
+        const float4 L4 = *reinterpret_cast<const float4*>(&sL[16 * it + 4 * g]);
+        const float4 D4 = *reinterpret_cast<const float4*>(&sD[16 * it + 4 * g]);
+        const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = p[it][r] * scale + sB[binB + (it - jt + 3) * 49 + r];
+          if (shifted && ((rw >> (8 * r)) & 255u) != rj) v += -100.0f;
+          const float e = __expf(v - Lr[r]);
+          p[it][r] = e;
+          dp[it][r] = e * (dp[it][r] - Dr[r]);
+        }
+      }
+      // dV^T[d][j] = sum_i dO[i][d] P[i][j];  dK^T[d][j] = sum_i Q[i][d] dS[i][j]
+      f32x4 ov[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, ok[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const Frag<bf16_t> ap = pack_tr(p[2 * ks], p[2 * ks + 1]);
+        const Frag<bf16_t> ad = pack_tr(dp[2 * ks], dp[2 * ks + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const Frag<bf16_t> bo = lds_frag_t(tO, ARS, ks * 32, dt * 16, lane, (bf16_t*)nullptr);
+          mma(ov[dt], bo, ap);
+          const Frag<bf16_t> bq = lds_frag_t(tA, ARS, ks * 32, dt * 16, lane, (bf16_t*)nullptr);
+          mma(ok[dt], bq, ad);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        store4s(dqb + (long)jj * ld + 2 * C + 16 * dt + 4 * g, ov[dt], 1.0f);
+        store4s(dqb + (long)jj * ld + C + 16 * dt + 4 * g, ok[dt], scale);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // d(bias) of this (window, head): lanes of one 16-lane group hit 16 distinct bins, lanes of different groups may share one -- one group at a time
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      if (g == ph) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(&sDB[binA + q * 49 - r], dsacc[q][r]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (int t = lane; t < 343; t += 64) { atomicAdd(a.dtable + t * HEADS + h, sDB[t]); sDB[t] = 0.f; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ================================================================================================
+// attention branch, backward, second half (per window): dxn = dqkv Wqkv -- BOTH operands streamed, the 64 dqkv rows as four more 1-KB
+// pieces per step through the same ring (per-lane source addresses land them as lane-linear fragment images) -- then LayerNorm-1 backward and
+// the residual: dx[tok] = dres[tok] + LN1_backward(dxn)[tok];  dgamma1 / dbeta1.
+// ================================================================================================
+struct QkvBwdArgs {
+  const bf16_t* dqkv; const bf16_t* x; const bf16_t* dres; const float* mean; const float* rstd; const float* gamma; const char* wstream;
+  bf16_t* dx; float* dgamma; float* dbeta; WinMap wm;
+};
+constexpr int QB_STEP = (G + 4) * 1024;
+template <int NW, int A> constexpr int qkv_bwd_lds() { return NW * A * QB_STEP + NW * 64 * 2 * 4; }
+
+template <int NW, int A>
+__global__ __launch_bounds__(64 * NW) void swin_qkv_bwd_kernel(QkvBwdArgs a) {
+  constexpr int KS = 3 * NW, C = 32 * KS, NSTEP = 3 * KS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  char* ring = smem + wave * A * QB_STEP;
+  float* red = reinterpret_cast<float*>(smem + NW * A * QB_STEP);
+  const long win = blockIdx.x;
+  const char* wsrc = a.wstream + (long)wave * NSTEP * STEP_BYTES;
+  const char* rowp[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) rowp[m] = reinterpret_cast<const char*>(a.dqkv + (win * 64 + 16 * m + li) * (3L * C) + 8 * g);
+
+  int is_step = 0, is_slot = 0, rd_slot = 0;
+  auto issue = [&]() __attribute__((always_inline)) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const char* s = wsrc + (long)is_step * STEP_BYTES + lv * 16;
+    char* d = ring + is_slot * QB_STEP;
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + i * 1024), (__attribute__((address_space(3))) void*)(d + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp[m] + is_step * 64), (__attribute__((address_space(3))) void*)(d + (G + m) * 1024), 16, 0, 0);
+    is_step = is_step + 1 == NSTEP ? 0 : is_step + 1;
+    is_slot = is_slot + 1 == A ? 0 : is_slot + 1;
+  };
+  auto wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A - 1) * (G + 4)) : "memory"); };
+  auto read = [&](Frag<bf16_t> (&f)[G + 4]) __attribute__((always_inline)) {
+    const char* s = ring + rd_slot * QB_STEP + lane * 16;
+#pragma unroll
+    for (int i = 0; i < G + 4; ++i) f[i].v = *reinterpret_cast<const bf16x8*>(s + i * 1024);
+    rd_slot = rd_slot + 1 == A ? 0 : rd_slot + 1;
+  };
+
+  Frag<bf16_t> cur[G + 4];
+#pragma unroll
+  for (int k = 0; k < A; ++k) issue();
+  wait();
+  read(cur);
+  lgk0();
+  issue();
+
+  f32x4 acc[6][4];
+#pragma unroll
+  for (int n = 0; n < 6; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int s = 0; s < NSTEP; ++s) {
+    Frag<bf16_t> nx[G + 4];
+    wait();
+    read(nx);
+#pragma unroll
+    for (int n = 0; n < 6; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) mma(acc[n][m], cur[n], cur[G + m]);
+    lgk0();
+    issue();
+#pragma unroll
+    for (int i = 0; i < G + 4; ++i) cur[i] = nx[i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  long tok[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) tok[m] = win_to_tok(a.wm, win * 64 + 16 * m + li);
+  ln_bwd_tail<NW>(acc, tok, a.x, a.mean, a.rstd, a.gamma, a.dres, a.dx, nullptr, nullptr, 1, a.wm, a.dgamma, a.dbeta, red, wave, lane);
+}
+
+}  // namespace sw
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <class K> int set_lds(K kernel, int bytes) {   // per device: a second GPU driven from the same process needs its own attribute
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = true;
+  }
+  return 0;
+}
+constexpr int RING_A = 4;
+long long* ts_buf() { static long long* p = nullptr; if (!p) { hipMalloc(&p, 64 * sizeof(long long)); hipMemset(p, 0, 64 * sizeof(long long)); } return p; }
+void ts_print(const char* what, int n, hipStream_t st) {
+  long long h[64];
+  hipStreamSynchronize(st);
+  hipMemcpy(h, ts_buf(), sizeof(h), hipMemcpyDeviceToHost);
+  fprintf(stderr, "[swin ts] %s:", what);
+  for (int i = 1; i < n; ++i) fprintf(stderr, " %d-%d: %lld", i - 1, i, h[i] - h[i - 1]);
+  fprintf(stderr, "  total %lld\n", h[n - 1] - h[0]);
+}
+}  // namespace
+
+int k_swin_supported(int C) { return C == 96 || C == 192 || C == 384; }
+long k_swin_stream_numel(int type, int C) {   // bf16 elements of a weight stream
+  if (!k_swin_supported(C)) return -1;
+  const int NW = C / 96;
+  return (long)NW * sw::stream_steps(type, NW) * sw::STEP_BYTES / 2;
+}
+
+int k_swin_pack(const SwinPackItem* items, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += sw::MAX_PACK) {
+    const int cnt = n - base < sw::MAX_PACK ? n - base : sw::MAX_PACK;
+    sw::PackArgs pa;
+    long maxthr = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const SwinPackItem& it = items[base + i];
+      if (!k_swin_supported(it.C) || it.type < 0 || it.type > 4 || !it.w0 || !it.dst) return -4;
+      const int NW = it.C / 96;
+      pa.d[i] = sw::PackDesc{it.w0, it.w1, (bf16_t*)it.dst, it.type, NW};
+      const long thr = (long)NW * sw::stream_steps(it.type, NW) * sw::G * 64;
+      if (thr > maxthr) maxthr = thr;
+    }
+    long gx = (maxthr + 255) / 256;
+    if (gx > 1152) gx = 1152;
+    hipLaunchKernelGGL(sw::swin_pack_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, st, pa);
+    NMH_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+template <int NW> static int launch_mlp_fwd(const sw::MlpFwdArgs& a, hipStream_t st) {
+  constexpr int lds = sw::mlp_lds<NW, RING_A>();
+  const int dbg = getenv("NMH_SWIN_DBG") ? atoi(getenv("NMH_SWIN_DBG")) : 0;   // timing-only variants (wrong results): 1 no weight DMA, 2 no MFMAs, 4 no GELU / softmax
+  if (NW == 4 && dbg) {
+#define DBG_CASE(D) case D: if (int e = set_lds(sw::swin_mlp_fwd_kernel<4, RING_A, D>, lds)) return e; \
+    hipLaunchKernelGGL((sw::swin_mlp_fwd_kernel<4, RING_A, D>), dim3((unsigned)((a.M + 63) / 64)), dim3(256), lds, st, a); break;
+    if (dbg == 8) {
+      sw::MlpFwdArgs b = a; b.ts = ts_buf();
+      if (int e = set_lds(sw::swin_mlp_fwd_kernel<4, RING_A, 8>, lds)) return e;
+      hipLaunchKernelGGL((sw::swin_mlp_fwd_kernel<4, RING_A, 8>), dim3((unsigned)((a.M + 63) / 64)), dim3(256), lds, st, b);
+      ts_print("mlp_fwd  start|ln|fc1(0)|.. round5: fc1+act|barrier|fc2 ..|tail|epilogue|drain", 10, st);
+      return 0;
+    }
+    switch (dbg) { DBG_CASE(1) DBG_CASE(2) DBG_CASE(3) DBG_CASE(4) DBG_CASE(6) DBG_CASE(7) default: return -4; }
+#undef DBG_CASE
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
+  if (int e = set_lds(sw::swin_mlp_fwd_kernel<NW, RING_A>, lds)) return e;
+  hipLaunchKernelGGL((sw::swin_mlp_fwd_kernel<NW, RING_A>), dim3((unsigned)((a.M + 63) / 64)), dim3(64 * NW), lds, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
+                   void* x2, void* x1n, void* hp, float* mean, float* rstd, long M, int C, float eps, hipStream_t st) {
+  sw::MlpFwdArgs a{(const bf16_t*)x1, gamma, beta, (const char*)wstream, b1, b2, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
+                   (bf16_t*)x2, (bf16_t*)x1n, (bf16_t*)hp, mean, rstd, M, eps, nullptr};
+  switch (C) {
+    case 96: return launch_mlp_fwd<1>(a, st);
+    case 192: return launch_mlp_fwd<2>(a, st);
+    case 384: return launch_mlp_fwd<4>(a, st);
+  }
+  return -1;
+}
+
+template <int NW> static int launch_attn_fwd(const sw::AttnFwdArgs& a, long nwin, hipStream_t st) {
+  constexpr int lds = sw::attn_fwd_lds<NW, RING_A>();
+  const int dbg_all = getenv("NMH_SWIN_DBG") ? atoi(getenv("NMH_SWIN_DBG")) : 0;
+  const int dbg = dbg_all & 3;
+  if (NW == 4 && dbg_all == 8) {
+    sw::AttnFwdArgs b = a; b.ts = ts_buf();
+    if (int e = set_lds(sw::swin_attn_fwd_kernel<4, RING_A, 8>, lds)) return e;
+    hipLaunchKernelGGL((sw::swin_attn_fwd_kernel<4, RING_A, 8>), dim3((unsigned)nwin), dim3(256), lds, st, b);
+    ts_print("attn_fwd  start|ln+table|heads0..: qkv(1)|pack+stores(1)|S+softmax(1)|PV(1)+head2|exchange|proj|epilogue|drain", 11, st);
+    return 0;
+  }
+  if (NW == 4 && dbg) {
+#define DBG_CASE(D) case D: if (int e = set_lds(sw::swin_attn_fwd_kernel<4, RING_A, D>, lds)) return e; \
+    hipLaunchKernelGGL((sw::swin_attn_fwd_kernel<4, RING_A, D>), dim3((unsigned)nwin), dim3(256), lds, st, a); break;
+    switch (dbg) { DBG_CASE(1) DBG_CASE(2) DBG_CASE(3) default: return -4; }
+#undef DBG_CASE
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
+  if (int e = set_lds(sw::swin_attn_fwd_kernel<NW, RING_A>, lds)) return e;
+  hipLaunchKernelGGL((sw::swin_attn_fwd_kernel<NW, RING_A>), dim3((unsigned)nwin), dim3(64 * NW), lds, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* table, const float* bproj,
+                    const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1,
+                    const WinMap& wm, int C, float eps, hipStream_t st) {
+  sw::AttnFwdArgs a{(const bf16_t*)x, gamma, beta, (const char*)wstream, bqkv, table, bproj, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
+                    (bf16_t*)xnw, mean, rstd, (bf16_t*)qkv, (bf16_t*)o, lse, (bf16_t*)x1, wm, eps, nullptr};
+  const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
+  if (nwin <= 0) return 0;
+  if (nwin * 64 >= (1L << 31)) return -2;
+  switch (C) {
+    case 96: return launch_attn_fwd<1>(a, nwin, st);
+    case 192: return launch_attn_fwd<2>(a, nwin, st);
+    case 384: return launch_attn_fwd<4>(a, nwin, st);
+  }
+  return -1;
+}

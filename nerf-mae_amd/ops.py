@@ -595,6 +595,69 @@ def mlp_fused_bwd(x1, dx2, gamma, beta, W1, b1, W2T, dgamma, dbeta, rowscale=Non
     return dx1, x1n, hact, dh
 
 
+# ---- fused Swin-block kernels (csrc/swin_block.hip): bf16, C = 96 * {1, 2, 4} ----
+SWIN_ATTN_FWD, SWIN_MLP_FWD, SWIN_MLP_BWD, SWIN_ATTN_BWD, SWIN_QKV_BWD = range(5)
+
+
+class _SwinPackItem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_swin_pack_item
+    _fields_ = [("w0", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("type", ctypes.c_int), ("C", ctypes.c_int)]
+
+
+def swin_supported(C: int) -> bool:
+    return bool(lib().call("nmh_swin_supported", C))
+
+
+def swin_stream_numel(kind: int, C: int) -> int:
+    return int(lib().call("nmh_swin_stream_numel", kind, C))
+
+
+def swin_pack_items(items):
+    """items: [(w0, w1 | None, dst, kind, C)] -> ctypes array for swin_pack (built once; the pointers are stable: flat parameter buffer, packed buffer)"""
+    arr = (_SwinPackItem * len(items))()
+    for i, (w0, w1, dst, kind, C) in enumerate(items):
+        _chk(w0, w1, dst)
+        arr[i] = _SwinPackItem(w0.data_ptr(), w1.data_ptr() if w1 is not None else None, dst.data_ptr(), kind, C)
+    return arr
+
+
+def swin_pack(arr):
+    lib().call("nmh_swin_pack", arr, len(arr), _st())
+
+
+def swin_attn_fwd(x, gamma, beta, wstream, bqkv, table, bproj, geom: WinGeom, rowscale=None, rows_per_scale=1, eps=1e-5):
+    """-> (x1, xnw, mean, rstd, qkv, o, lse): the whole attention branch of a Swin block in one launch (+ what its backward / weight gradients read)"""
+    _chk(x, gamma, beta, wstream, bqkv, table, bproj, rowscale)
+    T, C = x.shape
+    heads = C // 32
+    dev, dt = x.device, x.dtype
+    x1 = torch.empty_like(x)
+    xnw = torch.empty((geom.rows, C), dtype=dt, device=dev)
+    mean, rstd = torch.empty(T, device=dev), torch.empty(T, device=dev)
+    qkv = torch.empty((geom.rows, 3 * C), dtype=dt, device=dev)
+    o = torch.empty((geom.rows, C), dtype=dt, device=dev)
+    lse = torch.empty(geom.rows * heads, device=dev)
+    ev = _prof(("swin_attn_fwd", geom.rows, C))
+    lib().call("nmh_swin_attn_fwd", x, gamma, beta, wstream, bqkv, table, bproj, rowscale, rows_per_scale, xnw, mean, rstd, qkv, o, lse, x1, geom.carr, C, eps, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return x1, xnw, mean, rstd, qkv, o, lse
+
+
+def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale=1, eps=1e-5):
+    """-> (x2, x1n, hp, mean, rstd): the MLP branch in one launch; hp = fc1 pre-activation [M, 4C]"""
+    _chk(x1, gamma, beta, wstream, b1, b2, rowscale)
+    M, C = x1.shape
+    dev = x1.device
+    x2, x1n = torch.empty_like(x1), torch.empty_like(x1)
+    hp = torch.empty((M, 4 * C), dtype=x1.dtype, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ev = _prof(("swin_mlp_fwd", M, C))
+    lib().call("nmh_swin_mlp_fwd", x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, mean, rstd, M, C, eps, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return x2, x1n, hp, mean, rstd
+
+
 def window_scatter_residual(yw, x, out, rowscale, C, geom: WinGeom):
     _chk(yw, x, out, rowscale)
     lib().call("nmh_window_scatter_residual", dt_of(x), yw, x, out, rowscale, C, geom.carr, _st())

@@ -1,0 +1,129 @@
+"""Fused Swin-block kernels (csrc/swin_block.hip: nmh_swin_*) against the oracle's fp32 restatement of a Swin block
+(oracle/mae3d_oracle.py SwinBlock3D = swin_mae3d.py:310-369 with shifted_window_attention :27-197) and against the unfused HIP chain,
+bf16, all six window geometries of tests/test_kernels_gpu.py (plain, shifted, padded, padded + shifted, window >= volume, ragged axes),
+widths 96 / 192 / 384, forward and every gradient.  Tolerances are bf16 rounding (tests/_metrics.py three-part metric)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests._metrics import assert_close  # noqa: E402
+
+BF = torch.bfloat16
+TOL = 3e-2
+GEOMS = [((2, 8, 8, 8), 0), ((2, 8, 8, 8), 2), ((1, 5, 5, 5), 2), ((2, 10, 10, 10), 2), ((1, 2, 2, 2), 2), ((1, 6, 8, 4), 2)]
+WIDTHS = [96, 192, 384]
+
+
+def _ops():
+    from nerf_mae_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + int(np.prod(shape)) % 1000)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def qb(t):
+    return t.to(BF).float()
+
+
+def dev(t, dt=None):
+    return (t if dt is None else t.to(dt)).cuda().contiguous()
+
+
+def make_block(C, shift, seed=0):
+    """oracle block with bf16-representable Linear weights (the fused kernels see the same values) and non-trivial biases / affine parameters"""
+    from oracle import mae3d_oracle as O
+    torch.manual_seed(seed)
+    blk = O.SwinBlock3D(C, C // 32, [shift] * 3, 0.0)
+    with torch.no_grad():
+        for name, p in blk.named_parameters():
+            if p.dim() == 2 and "table" not in name:
+                p.copy_(qb(torch.randn_like(p) * (p.shape[1] ** -0.5)))
+            elif "table" in name:
+                p.copy_(torch.randn_like(p) * 0.5)
+            elif "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+            else:
+                p.copy_(0.2 * torch.randn_like(p))
+    return blk.double()
+
+
+def streams(ops, blk, C, kinds):
+    """weight streams of the requested kinds from the block's fp32 parameters"""
+    w = {"qkv": dev(blk.attn.qkv.weight.float()), "proj": dev(blk.attn.proj.weight.float()), "fc1": dev(blk.mlp[0].weight.float()), "fc2": dev(blk.mlp[3].weight.float())}
+    src = {ops.SWIN_ATTN_FWD: ("qkv", "proj"), ops.SWIN_MLP_FWD: ("fc1", "fc2"), ops.SWIN_MLP_BWD: ("fc2", "fc1"), ops.SWIN_ATTN_BWD: ("proj", None), ops.SWIN_QKV_BWD: ("qkv", None)}
+    out, items = {}, []
+    for k in kinds:
+        out[k] = torch.empty(ops.swin_stream_numel(k, C), dtype=BF, device="cuda")
+        a, b = src[k]
+        items.append((w[a], w[b] if b else None, out[k], k, C))
+    arr = ops.swin_pack_items(items)
+    ops.swin_pack(arr)
+    torch.cuda.synchronize()
+    return out, w
+
+
+def reference(blk, x, sd1, sd2):
+    """fp64 block with explicit per-sample branch scales; returns x1, x2 (leaf x requires grad)"""
+    B = x.shape[0]
+    s1 = sd1.double().view(B, 1, 1, 1, 1)
+    s2 = sd2.double().view(B, 1, 1, 1, 1)
+    x1 = x + s1 * blk.attn(blk.norm1(x))
+    x2 = x1 + s2 * blk.mlp(blk.norm2(x1))
+    return x1, x2
+
+
+@pytest.mark.parametrize("C", WIDTHS)
+@pytest.mark.parametrize("shape,shift", GEOMS)
+def test_swin_block_forward(C, shape, shift):
+    ops = _ops()
+    B, H, W, D = shape
+    geom = ops.WinGeom(B, H, W, D, [shift] * 3)
+    T, heads = geom.tokens, C // 32
+    tps = T // B
+    blk = make_block(C, shift)
+    x = qb(rnd(B, H, W, D, C, seed=3) * 1.3 + 0.1)
+    sd1 = torch.tensor([1.0 / 0.9, 0.0] if B == 2 else [1.0 / 0.95])
+    sd2 = torch.tensor([1.0, 1.0 / 0.8] if B == 2 else [1.0 / 0.9])
+    with torch.no_grad():
+        x1_ref, x2_ref = reference(blk, x.double(), sd1, sd2)
+    st, w = streams(ops, blk, C, [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD])
+    f = lambda p: dev(p.detach().float())
+    xd = dev(x.view(T, C), BF)
+    x1, xnw, mean1, rstd1, qkv, o, lse = ops.swin_attn_fwd(xd, f(blk.norm1.weight), f(blk.norm1.bias), st[ops.SWIN_ATTN_FWD], f(blk.attn.qkv.bias),
+                                                           f(blk.attn.relative_position_bias_table), f(blk.attn.proj.bias), geom, rowscale=dev(sd1), rows_per_scale=tps)
+    torch.cuda.synchronize()
+    # --- the saved tensors against the unfused HIP kernels (same layouts by contract)
+    xnw_u = torch.empty_like(xnw)
+    m_u, r_u = torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    ops.layernorm_fwd(xd, f(blk.norm1.weight), f(blk.norm1.bias), xnw_u, m_u, r_u, geom.rows, C, src_mode=1, geom=geom)
+    assert_close(xnw, xnw_u.float().cpu(), 1e-2, "xnw")
+    assert_close(mean1, m_u.cpu(), 1e-4, "mean1")
+    assert_close(rstd1, r_u.cpu(), 1e-4, "rstd1")
+    qkv_u = ops.gemm_nt(xnw_u, dev(w["qkv"], BF), bias=f(blk.attn.qkv.bias))
+    assert_close(qkv, qkv_u.float().cpu(), TOL, "qkv")
+    o_u, lse_u = torch.empty_like(o), torch.empty_like(lse)
+    ops.window_attn_fwd(qkv, f(blk.attn.relative_position_bias_table), o_u, lse_u, heads, C, geom)   # on the fused kernel's own qkv: isolates the attention core
+    assert_close(o, o_u.float().cpu(), TOL, "o")
+    assert_close(lse, lse_u.cpu(), 1e-3, "lse")
+    assert_close(x1, x1_ref.view(T, C), TOL, "x1")
+    # --- MLP branch on the fused x1
+    x2, x1n, hp, mean2, rstd2 = ops.swin_mlp_fwd(x1, f(blk.norm2.weight), f(blk.norm2.bias), st[ops.SWIN_MLP_FWD], f(blk.mlp[0].bias), f(blk.mlp[3].bias),
+                                                 rowscale=dev(sd2), rows_per_scale=tps)
+    torch.cuda.synchronize()
+    x1f = x1.float().cpu().double()
+    with torch.no_grad():
+        n2 = blk.norm2(x1f)
+        hp_ref = blk.mlp[0](n2)
+        x2_own = x1f + sd2.double().repeat_interleave(tps)[:, None] * blk.mlp(n2)
+    assert_close(x1n, n2, 1e-2, "x1n")
+    assert_close(hp, hp_ref, TOL, "hp")
+    assert_close(x2, x2_own, TOL, "x2 (from the fused x1)")
+    assert_close(x2, x2_ref.view(T, C), TOL, "x2", elem_mult=2.0)
+    mu = x1f.mean(-1)
+    assert_close(mean2, mu, 1e-4, "mean2")
+    assert_close(rstd2, (x1f.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-4, "rstd2")
