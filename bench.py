@@ -61,6 +61,20 @@ def fwd_flops_per_grid(cfg, R):
     return fl
 
 
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-run the same command line as N ranks of one node."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:       # a free port for the rendezvous (the reference picks a random one, run_swin_mae3d.py:890-893)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL / CUDA-IPC across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +101,10 @@ def main():
     from nerf_mae_amd.trainer import FusedAdamW, GraphedTrainStep, OneCycle
     from nerf_mae_amd import data
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: spawn the ranks ourselves, as the reference's main() does (run_swin_mae3d.py:897-902 mp.spawn) -- here by
+        # re-executing this command under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1); rank 0's JSON line is the output
+        return _self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -608,4 +626,4 @@ def cpu_baseline(args, R, exts):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -287,7 +287,7 @@ __device__ __forceinline__ void ln_exchange(const bf16_t* __restrict__ x, RowFn&
 struct MlpFwdArgs {
   const bf16_t* x1; const float* gamma; const float* beta; const char* wstream; const float* b1; const float* b2;
   const float* rowscale; int rows_per_scale;
-  bf16_t* x2; bf16_t* x1n; bf16_t* hp; float* mean; float* rstd; long M; float eps; long long* ts;
+  bf16_t* x2; bf16_t* x1n; bf16_t* hp; float* mean; float* rstd; long M; float eps; long long* ts; bf16_t* hact;
 };
 
 template <int NW, int A> constexpr int mlp_lds() { return NW * A * STEP_BYTES + (12 * NW * 1024 > 2 * NW * 4096 ? 12 * NW * 1024 : 2 * NW * 4096) + 4 * 96 * NW * 4; }
@@ -361,6 +361,7 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
       for (int r = 0; r < 4; ++r) h[t][m][r] = (DBG & 4) ? h[t][m][r] : gelu_fast_f(h[t][m][r]);
     const Frag<bf16_t> hf = pack_tr(h[0][m], h[1][m]);
     lds_write16(exch_a + ((c & 1) * NW + wave) * 4096 + m * 1024 + lane * 16, hf.v);
+    if (a.hact && rows[m] >= 0) *reinterpret_cast<bf16x8*>(a.hact + (hprow[m] - a.hp) + 32 * NW * c) = hf.v;   // (only for the unfused backward)
   };
   // first product of a round (into h); with ACT, step u also carries the activation of row tiles u TPS .. of the PREVIOUS round (hp): its
   // ~160 VALU instructions per tile then issue in the shadow of the step's 24 MFMAs instead of behind them
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(64 * NW) void swin_attn_fwd_kernel(AttnFwdArgs a) {
 //   dx[row] = dres[row] + rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = acc * gamma;   dgamma += sum_rows acc xhat;  dbeta += sum_rows acc
 // rows[m] < 0: no such row.  The row sums over the C channels are completed across the NW waves through `red` (LDS, [NW][64][2] floats).
 // dyw (optional): second copy of dx at window row tok_to_win(row), times dyw_scale[row / rows_per_scale].
-// Call with the weight stream drained (plain LDS accesses and __syncthreads() below).
+// Call with the weight stream drained (plain LDS accesses and __syncthreads() below).  Every global load is requested before the first is used.
 // ================================================================================================
 template <int NW>
 __device__ __forceinline__ void ln_bwd_tail(f32x4 (&acc)[6][4], const long (&rows)[4], const bf16_t* __restrict__ x, const float* __restrict__ mean,
@@ -747,11 +748,22 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&acc)[6][4], const long (&row
                                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* red, int wave, int lane) {
   constexpr int C = 96 * NW;
   const int g = lane >> 4, li = lane & 15;
-  float gm[6][4];
+  float4 gmv[6];
+  uint4 xraw[4][3], draw[4][3];
+  float mu[4], rs_[4], dsc[4];
 #pragma unroll
-  for (int n = 0; n < 6; ++n) {
-    const float4 t4 = *reinterpret_cast<const float4*>(gamma + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1));
-    gm[n][0] = t4.x; gm[n][1] = t4.y; gm[n][2] = t4.z; gm[n][3] = t4.w;
+  for (int n = 0; n < 6; ++n) gmv[n] = *reinterpret_cast<const float4*>(gamma + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1));
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const long row = rows[m] < 0 ? 0 : rows[m];
+    mu[m] = mean[row];
+    rs_[m] = rstd[row];
+    dsc[m] = (dyw && dyw_scale) ? dyw_scale[row / rows_per_scale] : 1.0f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      xraw[m][p] = *reinterpret_cast<const uint4*>(x + row * C + 96 * wave + 32 * p + 8 * g);
+      draw[m][p] = *reinterpret_cast<const uint4*>(dres + row * C + 96 * wave + 32 * p + 8 * g);
+    }
   }
   float pg[6][4], pb[6][4];
 #pragma unroll
@@ -759,29 +771,30 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&acc)[6][4], const long (&row
 #pragma unroll
     for (int r = 0; r < 4; ++r) { pg[n][r] = 0.f; pb[n][r] = 0.f; }
   float xh[6][4][4];
-  float rs_[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const bool ok = rows[m] >= 0;
-    const long row = ok ? rows[m] : 0;
-    const float mu = mean[row];
-    rs_[m] = rstd[row];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) {
-      float xv[4];
-      unpack4(*reinterpret_cast<const uint2*>(x + row * C + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1)), xv);
+    for (int p = 0; p < 3; ++p) {
+      float xv[8];
+      unpack8(xraw[m][p], xv);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = ok ? acc[n][m][r] : 0.f;
-        const float h = (xv[r] - mu) * rs_[m];
-        xh[n][m][r] = h;
-        pg[n][r] += d * h;
-        pb[n][r] += d;
-        const float gg = d * gm[n][r];
-        acc[n][m][r] = gg;
-        s1 += gg;
-        s2 += gg * h;
+      for (int t = 0; t < 2; ++t) {
+        const int n = 2 * p + t;
+        const float gm[4] = {gmv[n].x, gmv[n].y, gmv[n].z, gmv[n].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = ok ? acc[n][m][r] : 0.f;
+          const float h = (xv[4 * t + r] - mu[m]) * rs_[m];
+          xh[n][m][r] = h;
+          pg[n][r] += d * h;
+          pb[n][r] += d;
+          const float gg = d * gm[r];
+          acc[n][m][r] = gg;
+          s1 += gg;
+          s2 += gg * h;
+        }
       }
     }
     s1 = quad_row_sum(s1);
@@ -797,21 +810,22 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&acc)[6][4], const long (&row
 #pragma unroll
     for (int w = 0; w < NW; ++w) { m1 += red[(w * 64 + 16 * m + li) * 2]; m2 += red[(w * 64 + 16 * m + li) * 2 + 1]; }
     m1 *= (1.0f / C); m2 *= (1.0f / C);
-    const float dsc = (dyw && dyw_scale) ? dyw_scale[row / rows_per_scale] : 1.0f;
     const long wrow = dyw ? tok_to_win(wm, row) : 0;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) {
-      const int col = 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1);
-      float rv[4];
-      unpack4(*reinterpret_cast<const uint2*>(dres + row * C + col), rv);
-      f32x4 v;
+    for (int p = 0; p < 3; ++p) {
+      float rv[8];
+      unpack8(draw[m][p], rv);
+      f32x4 v0, v1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = rs_[m] * (acc[n][m][r] - m1 - xh[n][m][r] * m2) + rv[r];
-      *reinterpret_cast<uint2*>(dx + row * C + col) = pack4(v);
+      for (int r = 0; r < 4; ++r) {
+        v0[r] = rs_[m] * (acc[2 * p][m][r] - m1 - xh[2 * p][m][r] * m2) + rv[r];
+        v1[r] = rs_[m] * (acc[2 * p + 1][m][r] - m1 - xh[2 * p + 1][m][r] * m2) + rv[4 + r];
+      }
+      *reinterpret_cast<bf16x8*>(dx + row * C + 96 * wave + 32 * p + 8 * g) = pack_tr(v0, v1).v;
       if (dyw) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= dsc;
-        *reinterpret_cast<uint2*>(dyw + wrow * C + col) = pack4(v);
+        for (int r = 0; r < 4; ++r) { v0[r] *= dsc[m]; v1[r] *= dsc[m]; }
+        *reinterpret_cast<bf16x8*>(dyw + wrow * C + 96 * wave + 32 * p + 8 * g) = pack_tr(v0, v1).v;
       }
     }
   }
@@ -836,6 +850,9 @@ __device__ __forceinline__ void ln_bwd_tail(f32x4 (&acc)[6][4], const long (&row
 //   hact = gelu(hp)                                          [M][4C]  (written: B operand of dW2 = (s dy)^T hact)
 //   dh   = s_row (dy W2) gelu'(hp)                           [M][4C]  (written: A operand of dW1 = dh^T x1n)
 //   dx1  = dy + LN2_backward(dh W1);  dgamma2 / dbeta2;  dyw = window-ordered copy of dx1 times dyw_scale (the attention branch's incoming gradient)
+// Same round structure as the forward: the first product of round c + 1 (dy W2 for the wave's 32 hidden units) carries the elementwise part of
+// round c tile by tile; the pre-activation of a round is requested a round ahead (a load consumed where it is requested waits for the whole
+// weight prefetch: vector-memory operations retire in order).
 // ================================================================================================
 struct MlpBwdArgs {
   const bf16_t* dy; const bf16_t* x1; const bf16_t* hp; const float* mean; const float* rstd; const float* gamma; const char* wstream;
@@ -849,7 +866,7 @@ template <int NW, int A> constexpr int mlp_bwd_lds() { return NW * A * STEP_BYTE
 
 template <int NW, int A>
 __global__ __launch_bounds__(64 * NW) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
-  constexpr int KS = 3 * NW, C = 32 * KS, H = 4 * C;
+  constexpr int KS = 3 * NW, C = 32 * KS, H = 4 * C, TPS = 4 / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   char* exch = smem + NW * A * STEP_BYTES;
@@ -871,16 +888,20 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
   }
 
   Frag<bf16_t> df[4][KS];
-  long rows[4], lrows[4];
+  long rows[4];
   float sc[4];
+  const bf16_t* hprow[4];
+  long hoff[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const long row = rbase + 16 * m + li;
     rows[m] = row < a.M ? row : -1;
-    lrows[m] = row < a.M ? row : a.M - 1;
-    sc[m] = a.rowscale ? a.rowscale[lrows[m] / a.rows_per_scale] : 1.0f;
+    const long lr = row < a.M ? row : a.M - 1;
+    sc[m] = a.rowscale ? a.rowscale[lr / a.rows_per_scale] : 1.0f;
+    hoff[m] = lr * H + 32 * wave + 8 * g;
+    hprow[m] = a.hp + hoff[m];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) df[m][k].v = *reinterpret_cast<const bf16x8*>(a.dy + lrows[m] * C + 32 * k + 8 * g);
+    for (int k = 0; k < KS; ++k) df[m][k].v = *reinterpret_cast<const bf16x8*>(a.dy + lr * C + 32 * k + 8 * g);
   }
 
   f32x4 acc[6][4];
@@ -889,16 +910,36 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 hcur[2][4], hnxt[2][4];
-  uint2 hpc[2][4], hpn[2][4];
+  uint4 hpc[4], hpn[4];
 
-  auto hp_load = [&](int c, uint2 (&q)[2][4]) __attribute__((always_inline)) {
-    const int hb = 32 * (NW * c + wave) + 8 * g;
+  auto hp_load = [&](int c, uint4 (&q)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) q[m] = *reinterpret_cast<const uint4*>(hprow[m] + 32 * NW * c);
+  };
+  // elementwise part of round c, row tile m: hact, dh (stored: 16 bytes each), dh as the operand fragment of the second product
+  auto act_tile = [&](int c, f32x4 (&h)[2][4], int m, const uint4 (&q)[4]) __attribute__((always_inline)) {
+    float xv[8];
+    unpack8(q[m], xv);
+    f32x4 ha[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) q[t][m] = *reinterpret_cast<const uint2*>(a.hp + lrows[m] * H + hb + 4 * t);
+      for (int r = 0; r < 4; ++r) {
+        const float xx = xv[4 * t + r];
+        float er, e;
+        erf_as_parts(xx * 0.70710678118654752f, er, e);
+        const float cdf = 0.5f * (1.0f + er);
+        ha[t][r] = xx * cdf;
+        h[t][m][r] = h[t][m][r] * (cdf + xx * 0.39894228040143268f * e) * sc[m];
+      }
+    const Frag<bf16_t> hf = pack_tr(h[0][m], h[1][m]);
+    if (rows[m] >= 0) {
+      *reinterpret_cast<bf16x8*>(a.hact + hoff[m] + 32 * NW * c) = pack_tr(ha[0], ha[1]).v;
+      *reinterpret_cast<bf16x8*>(a.dh + hoff[m] + 32 * NW * c) = hf.v;
+    }
+    lds_write16(exch_a + ((c & 1) * NW + wave) * 4096 + m * 1024 + lane * 16, hf.v);
   };
-  auto dha = [&](f32x4 (&h)[2][4]) __attribute__((always_inline)) {   // (dy W2) for the wave's 32 hidden units of the round
+  auto dha = [&](f32x4 (&h)[2][4], auto with_act, int c_act, f32x4 (&hp)[2][4], const uint4 (&q)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -907,68 +948,53 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
     for (int u = 0; u < NW; ++u)
       ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int qq = 0; qq < 3; ++qq)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) mma(h[t][m], w[2 * q + t], df[m][3 * u + q]);
+            for (int m = 0; m < 4; ++m) mma(h[t][m], w[2 * qq + t], df[m][3 * u + qq]);
+        if (decltype(with_act)::value) {
+#pragma unroll
+          for (int mm = 0; mm < TPS; ++mm) act_tile(c_act, hp, u * TPS + mm, q);
+        }
       });
   };
-  auto act = [&](int c, f32x4 (&h)[2][4], const uint2 (&q)[2][4]) __attribute__((always_inline)) {
-    const int hb = 32 * (NW * c + wave) + 8 * g;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float xv[4];
-        unpack4(q[t][m], xv);
-        f32x4 ha;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float er, e;
-          erf_as_parts(xv[r] * 0.70710678118654752f, er, e);
-          const float cdf = 0.5f * (1.0f + er);
-          ha[r] = xv[r] * cdf;
-          h[t][m][r] = h[t][m][r] * (cdf + xv[r] * 0.39894228040143268f * e) * sc[m];
-        }
-        if (rows[m] >= 0) {
-          *reinterpret_cast<uint2*>(a.hact + rows[m] * H + hb + 4 * t) = pack4(ha);
-          *reinterpret_cast<uint2*>(a.dh + rows[m] * H + hb + 4 * t) = pack4(h[t][m]);
-        }
-      }
-      const Frag<bf16_t> hf = pack_tr(h[0][m], h[1][m]);
-      lds_write16(exch_a + ((c & 1) * NW + wave) * 4096 + m * 1024 + lane * 16, hf.v);
-    }
-  };
   auto dxn = [&](int c) __attribute__((always_inline)) {
+    Frag<bf16_t> hf[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hf[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW) * 4096 + m * 1024 + lane * 16);
 #pragma unroll
     for (int u = 0; u < NW; ++u)
       ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
-        Frag<bf16_t> hf[4];
+        Frag<bf16_t> hn[4];
+        if (u + 1 < NW) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) hf[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW + u) * 4096 + m * 1024 + lane * 16);
+          for (int m = 0; m < 4; ++m) hn[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW + u + 1) * 4096 + m * 1024 + lane * 16);
+        }
 #pragma unroll
         for (int n = 0; n < 6; ++n)
 #pragma unroll
           for (int m = 0; m < 4; ++m) mma(acc[n][m], w[n], hf[m]);
+        if (u + 1 < NW) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) hf[m] = hn[m];
+        }
       });
   };
 
   hp_load(0, hpc);
-  dha(hcur);
+  dha(hcur, std::false_type{}, 0, hcur, hpc);
 #pragma unroll 1
   for (int c = 0; c < MLP_ROUNDS - 1; ++c) {
-    hp_load(c + 1, hpn);    // a round ahead: vector-memory operations retire in order, a load requested where it is used waits for the whole weight prefetch
-    dha(hnxt);
-    act(c, hcur, hpc);
+    hp_load(c + 1, hpn);
+    dha(hnxt, std::true_type{}, c, hcur, hpc);
     wg_barrier();
     dxn(c);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) { hcur[t][m] = hnxt[t][m]; hpc[t][m] = hpn[t][m]; }
+    for (int m = 0; m < 4; ++m) { hpc[m] = hpn[m]; hcur[0][m] = hnxt[0][m]; hcur[1][m] = hnxt[1][m]; }
   }
-  act(MLP_ROUNDS - 1, hcur, hpc);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) act_tile(MLP_ROUNDS - 1, hcur, m, hpc);
   wg_barrier();
   dxn(MLP_ROUNDS - 1);
   ws.drain();
@@ -1249,21 +1275,22 @@ __global__ __launch_bounds__(64 * NW) void swin_qkv_bwd_kernel(QkvBwdArgs a) {
     asm volatile("" : "+v"(lv));
     const char* s = wsrc + (long)is_step * STEP_BYTES + lv * 16;
     char* d = ring + is_slot * QB_STEP;
+    dma16<0>(s, d); dma16<1024>(s, d); dma16<2048>(s, d); dma16<3072>(s, d);
+    dma16<0>(s + 4096, d + 4096); dma16<1024>(s + 4096, d + 4096);
 #pragma unroll
-    for (int i = 0; i < G; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + i * 1024), (__attribute__((address_space(3))) void*)(d + i * 1024), 16, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(rowp[m] + is_step * 64), (__attribute__((address_space(3))) void*)(d + (G + m) * 1024), 16, 0, 0);
+    for (int m = 0; m < 4; ++m) dma16<0>(rowp[m] + is_step * 64, d + (G + m) * 1024);
     is_step = is_step + 1 == NSTEP ? 0 : is_step + 1;
     is_slot = is_slot + 1 == A ? 0 : is_slot + 1;
   };
   auto wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A - 1) * (G + 4)) : "memory"); };
   auto read = [&](Frag<bf16_t> (&f)[G + 4]) __attribute__((always_inline)) {
-    const char* s = ring + rd_slot * QB_STEP + lane * 16;
+    const unsigned ad = lds_addr(ring) + (unsigned)(rd_slot * QB_STEP + lane * 16);
 #pragma unroll
-    for (int i = 0; i < G + 4; ++i) f[i].v = *reinterpret_cast<const bf16x8*>(s + i * 1024);
+    for (int i = 0; i < G + 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i].v) : "v"(ad), "n"(i * 1024));
     rd_slot = rd_slot + 1 == A ? 0 : rd_slot + 1;
+  };
+  auto settle = [&](Frag<bf16_t> (&f)[G + 4]) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].v), "+v"(f[1].v), "+v"(f[2].v), "+v"(f[3].v), "+v"(f[4].v), "+v"(f[5].v), "+v"(f[6].v), "+v"(f[7].v), "+v"(f[8].v), "+v"(f[9].v)::"memory");
   };
 
   Frag<bf16_t> cur[G + 4];
@@ -1271,7 +1298,7 @@ __global__ __launch_bounds__(64 * NW) void swin_qkv_bwd_kernel(QkvBwdArgs a) {
   for (int k = 0; k < A; ++k) issue();
   wait();
   read(cur);
-  lgk0();
+  settle(cur);
   issue();
 
   f32x4 acc[6][4];
@@ -1288,7 +1315,7 @@ __global__ __launch_bounds__(64 * NW) void swin_qkv_bwd_kernel(QkvBwdArgs a) {
     for (int n = 0; n < 6; ++n)
 #pragma unroll
       for (int m = 0; m < 4; ++m) mma(acc[n][m], cur[n], cur[G + m]);
-    lgk0();
+    settle(nx);
     issue();
 #pragma unroll
     for (int i = 0; i < G + 4; ++i) cur[i] = nx[i];
@@ -1381,9 +1408,9 @@ template <int NW> static int launch_mlp_fwd(const sw::MlpFwdArgs& a, hipStream_t
   return 0;
 }
 int k_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
-                   void* x2, void* x1n, void* hp, float* mean, float* rstd, long M, int C, float eps, hipStream_t st) {
+                   void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, long M, int C, float eps, hipStream_t st) {
   sw::MlpFwdArgs a{(const bf16_t*)x1, gamma, beta, (const char*)wstream, b1, b2, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
-                   (bf16_t*)x2, (bf16_t*)x1n, (bf16_t*)hp, mean, rstd, M, eps, nullptr};
+                   (bf16_t*)x2, (bf16_t*)x1n, (bf16_t*)hp, mean, rstd, M, eps, nullptr, (bf16_t*)hact};
   switch (C) {
     case 96: return launch_mlp_fwd<1>(a, st);
     case 192: return launch_mlp_fwd<2>(a, st);
@@ -1428,6 +1455,76 @@ int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const 
     case 96: return launch_attn_fwd<1>(a, nwin, st);
     case 192: return launch_attn_fwd<2>(a, nwin, st);
     case 384: return launch_attn_fwd<4>(a, nwin, st);
+  }
+  return -1;
+}
+
+template <int NW> static int launch_mlp_bwd(const sw::MlpBwdArgs& a, hipStream_t st) {
+  constexpr int lds = sw::mlp_bwd_lds<NW, RING_A>();
+  if (int e = set_lds(sw::swin_mlp_bwd_kernel<NW, RING_A>, lds)) return e;
+  hipLaunchKernelGGL((sw::swin_mlp_bwd_kernel<NW, RING_A>), dim3((unsigned)((a.M + 63) / 64)), dim3(64 * NW), lds, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale,
+                   int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const WinMap* wm, long M, int C,
+                   hipStream_t st) {
+  sw::MlpBwdArgs a{(const bf16_t*)dy, (const bf16_t*)x1, (const bf16_t*)hp, mean, rstd, gamma, (const char*)wstream, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
+                   (bf16_t*)dx1, (bf16_t*)hact, (bf16_t*)dh, dgamma, dbeta, (bf16_t*)dyw, dyw_scale, WinMap{}, 0, M};
+  if (dyw) {
+    if (!wm) return -4;
+    a.wm = *wm;
+    if ((long)wm->B * wm->PH * wm->PW * wm->PD * (C / 8) >= (1L << 32)) return -2;
+    a.dyw_pads = (long)wm->PH * wm->PW * wm->PD != (long)wm->H * wm->W * wm->D;
+  }
+  switch (C) {
+    case 96: return launch_mlp_bwd<1>(a, st);
+    case 192: return launch_mlp_bwd<2>(a, st);
+    case 384: return launch_mlp_bwd<4>(a, st);
+  }
+  return -1;
+}
+
+template <int NW> static int launch_attn_bwd(const sw::AttnBwdArgs& a, long nwin, hipStream_t st) {
+  constexpr int A = 3;
+  constexpr int lds = sw::attn_bwd_lds<NW, A>();
+  if (int e = set_lds(sw::swin_attn_bwd_kernel<NW, A>, lds)) return e;
+  hipLaunchKernelGGL((sw::swin_attn_bwd_kernel<NW, A>), dim3((unsigned)nwin), dim3(64 * NW), lds, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_swin_attn_bwd(const void* dyw, const void* qkv, const float* table, const float* lse, const void* wstream, void* dqkv, float* dtable, const WinMap& wm, int C,
+                    hipStream_t st) {
+  sw::AttnBwdArgs a{(const bf16_t*)dyw, (const bf16_t*)qkv, table, lse, (const char*)wstream, (bf16_t*)dqkv, dtable, wm};
+  const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
+  if (nwin <= 0) return 0;
+  if (nwin * 64 >= (1L << 31)) return -2;
+  switch (C) {
+    case 96: return launch_attn_bwd<1>(a, nwin, st);
+    case 192: return launch_attn_bwd<2>(a, nwin, st);
+    case 384: return launch_attn_bwd<4>(a, nwin, st);
+  }
+  return -1;
+}
+
+template <int NW> static int launch_qkv_bwd(const sw::QkvBwdArgs& a, long nwin, hipStream_t st) {
+  constexpr int A = 3;
+  constexpr int lds = sw::qkv_bwd_lds<NW, A>();
+  if (int e = set_lds(sw::swin_qkv_bwd_kernel<NW, A>, lds)) return e;
+  hipLaunchKernelGGL((sw::swin_qkv_bwd_kernel<NW, A>), dim3((unsigned)nwin), dim3(64 * NW), lds, st, a);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+int k_swin_qkv_bwd(const void* dqkv, const void* x, const void* dres, const float* mean, const float* rstd, const float* gamma, const void* wstream, void* dx,
+                   float* dgamma, float* dbeta, const WinMap& wm, int C, hipStream_t st) {
+  sw::QkvBwdArgs a{(const bf16_t*)dqkv, (const bf16_t*)x, (const bf16_t*)dres, mean, rstd, gamma, (const char*)wstream, (bf16_t*)dx, dgamma, dbeta, wm};
+  const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
+  if (nwin <= 0) return 0;
+  if (nwin * 64 >= (1L << 31)) return -2;
+  switch (C) {
+    case 96: return launch_qkv_bwd<1>(a, nwin, st);
+    case 192: return launch_qkv_bwd<2>(a, nwin, st);
+    case 384: return launch_qkv_bwd<4>(a, nwin, st);
   }
   return -1;
 }

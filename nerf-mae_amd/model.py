@@ -105,6 +105,7 @@ class _Packer:
         self.items = []  # (key, param, mode, dims, numel)
         self.views = {}
         self.cconv = None   # (decoder1 UpBlock3D, composed weight buffer, border table) when the composed forward applies
+        self.swin_early = self.swin_late = None   # ctypes item arrays of the fused Swin-block weight streams (csrc/swin_block.hip), stages < / >= LATE_STAGE
 
     def add(self, key: str, p: nn.Parameter, mode: int):
         sh = tuple(p.shape)
@@ -172,9 +173,15 @@ class _Packer:
         self._late_pending = False
         if lt > 0:
             ops.pack_weights(self.dt, self.descs, self.blk2desc[:lt], self.blkstart[:lt], lt)
+        if self.swin_early is not None:
+            ops.swin_pack(self.swin_early)
+        if self.swin_late is not None and not lt < sp:
+            ops.swin_pack(self.swin_late)
         with ops.side_stream(enable=sp < n):
             if lt < sp:
                 ops.pack_weights(self.dt, self.descs, self.blk2desc[lt:sp], self.blkstart[lt:sp], sp - lt)
+                if self.swin_late is not None:
+                    ops.swin_pack(self.swin_late)
                 if self._late_ev is None:
                     self._late_ev = torch.cuda.Event()
                 self._late_ev.record(torch.cuda.current_stream())
@@ -262,17 +269,34 @@ class _BlockFn(torch.autograd.Function):
         T, C, heads = geom.tokens, b.dim, b.num_heads
         dev, dtype = x.device, x.dtype
         tps = T // geom.B
-        xnw = torch.empty((geom.rows, C), dtype=dtype, device=dev)
-        mean1, rstd1 = torch.empty(T, device=dev), torch.empty(T, device=dev)
-        ops.layernorm_fwd(x, b.norm1.weight, b.norm1.bias, xnw, mean1, rstd1, geom.rows, C, src_mode=1, geom=geom)
-        qkv = ops.gemm_nt(xnw, pk[key + "qkv.w"].view(3 * C, C), bias=b.attn.qkv.bias)
-        o = torch.empty((geom.rows, C), dtype=dtype, device=dev)
-        lse = torch.empty(geom.rows * heads, device=dev)
-        ops.window_attn_fwd(qkv, b.attn.relative_position_bias_table, o, lse, heads, C, geom)
-        x1 = torch.empty_like(x)   # x1 = x + sd1 * window_reverse(proj(o)): the reverse + residual are the GEMM's store
-        ops.gemm_nt_window_scatter(o, pk[key + "proj.w"].view(C, C), x1, x, b.attn.proj.bias, sd1, tps, geom)
+        sw = getattr(b, "_sw", None)
+        if sw is not None and ops.swin_attn_ok(x, C, geom):
+            # LN1 -> QKV -> window attention -> proj -> row scale -> + residual in ONE launch (csrc/swin_block.hip); saves the same tensors
+            x1, xnw, mean1, rstd1, qkv, o, lse = ops.swin_attn_fwd(x, b.norm1.weight, b.norm1.bias, sw[ops.SWIN_ATTN_FWD], b.attn.qkv.bias,
+                                                                   b.attn.relative_position_bias_table, b.attn.proj.bias, geom, rowscale=sd1, rows_per_scale=tps)
+        else:
+            xnw = torch.empty((geom.rows, C), dtype=dtype, device=dev)
+            mean1, rstd1 = torch.empty(T, device=dev), torch.empty(T, device=dev)
+            ops.layernorm_fwd(x, b.norm1.weight, b.norm1.bias, xnw, mean1, rstd1, geom.rows, C, src_mode=1, geom=geom)
+            qkv = ops.gemm_nt(xnw, pk[key + "qkv.w"].view(3 * C, C), bias=b.attn.qkv.bias)
+            o = torch.empty((geom.rows, C), dtype=dtype, device=dev)
+            lse = torch.empty(geom.rows * heads, device=dev)
+            ops.window_attn_fwd(qkv, b.attn.relative_position_bias_table, o, lse, heads, C, geom)
+            x1 = torch.empty_like(x)   # x1 = x + sd1 * window_reverse(proj(o)): the reverse + residual are the GEMM's store
+            ops.gemm_nt_window_scatter(o, pk[key + "proj.w"].view(C, C), x1, x, b.attn.proj.bias, sd1, tps, geom)
         ctx.mlp_fused = ops.mlp_fused_ok(x, C, T)
-        if ctx.mlp_fused:
+        ctx.sw_mlp_bwd = False
+        if not ctx.mlp_fused and sw is not None and ops.swin_mlp_ok(x, C, T):
+            # LN2 -> fc1 -> GELU -> fc2 -> row scale -> + residual in one launch; keeps what the backward reads (gelu(hp) only for the unfused one)
+            ctx.sw_mlp_bwd = ops.SWIN_MLP_BWD in sw
+            if ctx.sw_mlp_bwd:
+                x2, x1n, h_pre, mean2, rstd2 = ops.swin_mlp_fwd(x1, b.norm2.weight, b.norm2.bias, sw[ops.SWIN_MLP_FWD], b.mlp[0].bias, b.mlp[3].bias,
+                                                               rowscale=sd2, rows_per_scale=tps)
+                h_act = None
+            else:
+                x2, x1n, h_pre, mean2, rstd2, h_act = ops.swin_mlp_fwd(x1, b.norm2.weight, b.norm2.bias, sw[ops.SWIN_MLP_FWD], b.mlp[0].bias, b.mlp[3].bias,
+                                                                      rowscale=sd2, rows_per_scale=tps, want_hact=True)
+        elif ctx.mlp_fused:
             # LN2 -> fc1 -> GELU -> fc2 -> row scale -> + residual in one launch; nothing but x1 is kept for the backward (csrc/mlp_fused.hip)
             x2 = ops.mlp_fused_fwd(x1, b.norm2.weight, b.norm2.bias, pk[key + "fc1.w"].view(4 * C, C), b.mlp[0].bias, pk[key + "fc2.wT"].view(4 * C, C),
                                    b.mlp[3].bias, rowscale=sd2, rows_per_scale=tps)
@@ -308,7 +332,14 @@ class _BlockFn(torch.autograd.Function):
                     ops.gemm_tn(A, Bm, _gradbuf(lin.weight), rowscale=rowscale, rows_per_scale=rps, dbias=_gradbuf(lin.bias))
         # ---- MLP branch
         dyw = torch.empty_like(xnw)   # = sd1 * dx1 in window order (adjoint of the window reverse), second output of the LN backward
-        if ctx.mlp_fused:
+        sw = getattr(b, "_sw", None)
+        if ctx.sw_mlp_bwd:
+            # one launch: hact / dh (operands of the two weight gradients), dx1 and its window-ordered copy, dgamma / dbeta (csrc/swin_block.hip)
+            dx1, h_act, dh, _ = ops.swin_mlp_bwd(dx2, x1, h_pre, mean2, rstd2, b.norm2.weight, sw[ops.SWIN_MLP_BWD], _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias),
+                                                 geom, rowscale=sd2, rows_per_scale=tps, dyw=dyw, dyw_scale=sd1)
+            wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
+            wgrad(dh, x1n, b.mlp[0])
+        elif ctx.mlp_fused:
             # one launch: recomputes LN2 / the hidden activations, writes the operands of the two weight gradients and dx1 (+ its window-ordered copy)
             dx1, x1n, h_act, dh = ops.mlp_fused_bwd(x1, dx2, b.norm2.weight, b.norm2.bias, pk[key + "fc1.w"].view(4 * C, C), b.mlp[0].bias,
                                                     pk[key + "fc2.wT"].view(4 * C, C), _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias),
@@ -324,14 +355,23 @@ class _BlockFn(torch.autograd.Function):
             ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
                               geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1)
         # ---- attention branch
-        do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
-        wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
-        dqkv = torch.empty_like(qkv)
-        ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
-        dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
-        wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
-        dx = torch.empty_like(x)
-        ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
+        fused_ok = sw is not None and ops.swin_attn_ok(x, C, geom)
+        if fused_ok and ops.SWIN_ATTN_BWD in sw:
+            dqkv = ops.swin_attn_bwd(dyw, qkv, b.attn.relative_position_bias_table, lse, sw[ops.SWIN_ATTN_BWD], _gradbuf(b.attn.relative_position_bias_table), geom)
+            wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
+        else:
+            do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
+            wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
+            dqkv = torch.empty_like(qkv)
+            ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
+        if fused_ok and ops.SWIN_QKV_BWD in sw:
+            dx = ops.swin_qkv_bwd(dqkv, x, dx1, mean1, rstd1, b.norm1.weight, sw[ops.SWIN_QKV_BWD], _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), geom)
+            wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
+        else:
+            dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
+            wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
+            dx = torch.empty_like(x)
+            ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
         # the block's own side-stream launches (fp32 parity mode) read temporaries of this block: join before they are released.  With the queue
         # (bf16) the operands stay referenced by it and NOTHING may be joined here: a join makes this block's successor wait for every weight
         # gradient the last flush put on the side stream -- the trace showed the two queues taking turns (>= 2 kernels in flight for 4 of 52 ms)
@@ -725,6 +765,7 @@ class _Stage(nn.Sequential):
             x = x.to(m.compute_dtype)
         if ops.GROUPED_WGRAD and m.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad:
             x = _StageFlushFn.apply(x, m._wq)
+        m._packer.wait_late()   # the layouts of stages >= LATE_STAGE are produced on the side stream: a stage called on its own must wait for them too
         for mod in self:
             x = mod(x.contiguous())
         return x
@@ -889,6 +930,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
                 P.add(key + "c3.w", d.conv_block.conv3.weight, P.CAST)
                 P.add(key + "c3.wT", d.conv_block.conv3.weight, P.TRANS)
         P.build(self.compute_dtype, device)
+        self._build_swin_streams(P, device)
         d1 = getattr(self, "decoder1", None)
         if (ops.CCONV and d1 is not None and self.compute_dtype == torch.bfloat16 and (d1.cin, d1.cout, d1.k) == (96, 48, 4) and not d1.has_proj
                 and (self.resolution // 4) % 8 == 0):
@@ -904,6 +946,34 @@ class SwinTransformer_MAE3D_New(nn.Module):
                 mod._pk = P
                 mod._wq = self._wq
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
+
+    def _build_swin_streams(self, P, device):
+        """weight streams of the fused Swin-block kernels (csrc/swin_block.hip) for every block of a supported width: one flat bf16 buffer, packed from
+        the fp32 masters by one launch per group (stages < / >= LATE_STAGE, like the other encoder layouts)"""
+        if not (ops.SWIN_FUSED and self.compute_dtype == torch.bfloat16):
+            return
+        kinds = [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD] + ([ops.SWIN_MLP_BWD] if "mlp" in ops.SWIN_BWD else []) + ([ops.SWIN_ATTN_BWD] if "attn" in ops.SWIN_BWD else []) + \
+                ([ops.SWIN_QKV_BWD] if "qkv" in ops.SWIN_BWD else [])
+        src = {ops.SWIN_ATTN_FWD: lambda b: (b.attn.qkv.weight, b.attn.proj.weight), ops.SWIN_MLP_FWD: lambda b: (b.mlp[0].weight, b.mlp[3].weight),
+               ops.SWIN_MLP_BWD: lambda b: (b.mlp[3].weight, b.mlp[0].weight), ops.SWIN_ATTN_BWD: lambda b: (b.attn.proj.weight, None),
+               ops.SWIN_QKV_BWD: lambda b: (b.attn.qkv.weight, None)}
+        blocks = [(s, b) for s, st in enumerate(self.stages) for b in st if isinstance(b, SwinBlock3D) and ops.swin_supported(b.dim)]
+        total = sum((ops.swin_stream_numel(k, b.dim) + 63) // 64 * 64 for _, b in blocks for k in kinds)
+        if not total:
+            return
+        buf = torch.empty(total, dtype=torch.bfloat16, device=device)
+        early, late, off = [], [], 0
+        for s, b in blocks:
+            b._sw = {}
+            for k in kinds:
+                n = ops.swin_stream_numel(k, b.dim)
+                b._sw[k] = buf[off:off + n]
+                w0, w1 = src[k](b)
+                (late if s >= _Packer.LATE_STAGE else early).append((w0.data, w1.data if w1 is not None else None, b._sw[k], k, b.dim))
+                off += (n + 63) // 64 * 64
+        P.swin_buf = buf
+        P.swin_early = ops.swin_pack_items(early) if early else None
+        P.swin_late = ops.swin_pack_items(late) if late else None
 
     def _ensure_ready(self, device):
         ps = self._trainable()

@@ -603,6 +603,27 @@ class _SwinPackItem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_swin_pack_
     _fields_ = [("w0", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("type", ctypes.c_int), ("C", ctypes.c_int)]
 
 
+SWIN_FUSED = __import__("os").environ.get("NMH_SWIN", "1") != "0"
+# dispatch thresholds (tools/bench_swin_block.py): a fused workgroup is one dependent chain of ~45 us whatever the launch size, so launches that
+# cannot give most CUs a workgroup stay on the unfused kernels (one grid per GPU: 27 windows / 16 row tiles at stage 2)
+SWIN_ATTN_MIN_WINDOWS = int(__import__("os").environ.get("NMH_SWIN_ATTN_MIN_WIN", "100"))
+SWIN_MLP_MIN_ROWS = int(__import__("os").environ.get("NMH_SWIN_MLP_MIN_ROWS", "6000"))
+SWIN_MLP_WIDTHS = tuple(int(v) for v in __import__("os").environ.get("NMH_SWIN_MLP_WIDTHS", "192,384").split(",") if v)   # C = 96 keeps csrc/mlp_fused.hip (weights resident in LDS)
+SWIN_ATTN_WIDTHS = tuple(int(v) for v in __import__("os").environ.get("NMH_SWIN_ATTN_WIDTHS", "96,192,384").split(",") if v)
+
+
+# backward kernels taken by default ("mlp", "attn", "qkv"; measured in the replayed step): NMH_SWIN_BWD=mlp,attn,qkv to force
+SWIN_BWD = tuple(v for v in __import__("os").environ.get("NMH_SWIN_BWD", "").split(",") if v)
+
+
+def swin_attn_ok(x, C: int, geom) -> bool:
+    return SWIN_FUSED and x.dtype == torch.bfloat16 and C in SWIN_ATTN_WIDTHS and geom.rows // 64 >= SWIN_ATTN_MIN_WINDOWS
+
+
+def swin_mlp_ok(x, C: int, rows: int) -> bool:
+    return SWIN_FUSED and x.dtype == torch.bfloat16 and C in SWIN_MLP_WIDTHS and rows >= SWIN_MLP_MIN_ROWS
+
+
 def swin_supported(C: int) -> bool:
     return bool(lib().call("nmh_swin_supported", C))
 
@@ -643,19 +664,60 @@ def swin_attn_fwd(x, gamma, beta, wstream, bqkv, table, bproj, geom: WinGeom, ro
     return x1, xnw, mean, rstd, qkv, o, lse
 
 
-def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale=1, eps=1e-5):
-    """-> (x2, x1n, hp, mean, rstd): the MLP branch in one launch; hp = fc1 pre-activation [M, 4C]"""
+def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale=1, eps=1e-5, want_hact=False):
+    """-> (x2, x1n, hp, mean, rstd[, hact]): the MLP branch in one launch; hp = fc1 pre-activation [M, 4C], hact = gelu(hp) on request"""
     _chk(x1, gamma, beta, wstream, b1, b2, rowscale)
     M, C = x1.shape
     dev = x1.device
     x2, x1n = torch.empty_like(x1), torch.empty_like(x1)
     hp = torch.empty((M, 4 * C), dtype=x1.dtype, device=dev)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    hact = torch.empty_like(hp) if want_hact else None
     ev = _prof(("swin_mlp_fwd", M, C))
-    lib().call("nmh_swin_mlp_fwd", x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, mean, rstd, M, C, eps, _st())
+    lib().call("nmh_swin_mlp_fwd", x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, hact, mean, rstd, M, C, eps, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
-    return x2, x1n, hp, mean, rstd
+    return (x2, x1n, hp, mean, rstd, hact) if want_hact else (x2, x1n, hp, mean, rstd)
+
+
+def swin_mlp_bwd(dy, x1, hp, mean, rstd, gamma, wstream, dgamma, dbeta, geom: Optional[WinGeom] = None, rowscale=None, rows_per_scale=1, dyw=None, dyw_scale=None):
+    """-> (dx1, hact, dh[, dyw]); dgamma / dbeta accumulated.  dyw (with geom): dx1 in window order times dyw_scale[sample] -- allocated here when geom is given"""
+    _chk(dy, x1, hp, mean, rstd, gamma, wstream, dgamma, dbeta, rowscale, dyw, dyw_scale)
+    M, C = x1.shape
+    dx1 = torch.empty_like(x1)
+    hact, dh = torch.empty_like(hp), torch.empty_like(hp)
+    if dyw is None and geom is not None:
+        dyw = torch.empty((geom.rows, C), dtype=x1.dtype, device=x1.device)
+    ev = _prof(("swin_mlp_bwd", M, C))
+    lib().call("nmh_swin_mlp_bwd", dy, x1, hp, mean, rstd, gamma, wstream, rowscale, rows_per_scale, dx1, hact, dh, dgamma, dbeta, dyw, dyw_scale,
+               geom.carr if geom is not None else None, M, C, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return (dx1, hact, dh, dyw) if dyw is not None else (dx1, hact, dh)
+
+
+def swin_attn_bwd(dyw, qkv, table, lse, wstream, dtable, geom: WinGeom):
+    """-> dqkv [rows, 3C]; dtable accumulated"""
+    _chk(dyw, qkv, table, lse, wstream, dtable)
+    C = dyw.shape[1]
+    dqkv = torch.empty_like(qkv)
+    ev = _prof(("swin_attn_bwd", geom.rows, C))
+    lib().call("nmh_swin_attn_bwd", dyw, qkv, table, lse, wstream, dqkv, dtable, geom.carr, C, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return dqkv
+
+
+def swin_qkv_bwd(dqkv, x, dres, mean, rstd, gamma, wstream, dgamma, dbeta, geom: WinGeom):
+    """-> dx [T, C] = dres + LN1_backward(dqkv @ Wqkv) scattered from window order; dgamma / dbeta accumulated"""
+    _chk(dqkv, x, dres, mean, rstd, gamma, wstream, dgamma, dbeta)
+    C = x.shape[1]
+    dx = torch.empty_like(x)
+    ev = _prof(("swin_qkv_bwd", geom.rows, C))
+    lib().call("nmh_swin_qkv_bwd", dqkv, x, dres, mean, rstd, gamma, wstream, dx, dgamma, dbeta, geom.carr, C, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return dx
 
 
 def window_scatter_residual(yw, x, out, rowscale, C, geom: WinGeom):

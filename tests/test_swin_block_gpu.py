@@ -127,3 +127,76 @@ def test_swin_block_forward(C, shape, shift):
     mu = x1f.mean(-1)
     assert_close(mean2, mu, 1e-4, "mean2")
     assert_close(rstd2, (x1f.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-4, "rstd2")
+
+
+@pytest.mark.parametrize("C", WIDTHS)
+@pytest.mark.parametrize("shape,shift", GEOMS)
+def test_swin_block_backward(C, shape, shift):
+    """the three backward kernels chained (nmh_swin_mlp_bwd -> nmh_swin_attn_bwd -> nmh_swin_qkv_bwd) on the fused forward's saved tensors: the input gradient,
+    every LayerNorm / bias-table gradient and -- through plain matmuls of the operands the kernels write -- every Linear weight / bias gradient
+    against fp64 autograd of the oracle block; the attention half also against the unfused HIP kernels"""
+    ops = _ops()
+    B, H, W, D = shape
+    geom = ops.WinGeom(B, H, W, D, [shift] * 3)
+    T, heads = geom.tokens, C // 32
+    tps = T // B
+    blk = make_block(C, shift, seed=1)
+    x = qb(rnd(B, H, W, D, C, seed=4) * 1.3 + 0.1)
+    dy = qb(rnd(B, H, W, D, C, seed=5))
+    sd1 = torch.tensor([1.0 / 0.9, 0.5] if B == 2 else [1.0 / 0.95])
+    sd2 = torch.tensor([1.0, 1.0 / 0.8] if B == 2 else [1.0 / 0.9])
+    xr = x.double().requires_grad_(True)
+    x1_ref, x2_ref = reference(blk, xr, sd1, sd2)
+    x1_ref.retain_grad()
+    x2_ref.backward(dy.double())
+    st, w = streams(ops, blk, C, [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD, ops.SWIN_MLP_BWD, ops.SWIN_ATTN_BWD, ops.SWIN_QKV_BWD])
+    f = lambda p: dev(p.detach().float())
+    xd, dyd = dev(x.view(T, C), BF), dev(dy.view(T, C), BF)
+    sd1d, sd2d = dev(sd1), dev(sd2)
+    g1, b1n, g2, b2n, tab = f(blk.norm1.weight), f(blk.norm1.bias), f(blk.norm2.weight), f(blk.norm2.bias), f(blk.attn.relative_position_bias_table)
+    x1, xnw, mean1, rstd1, qkv, o, lse = ops.swin_attn_fwd(xd, g1, b1n, st[ops.SWIN_ATTN_FWD], f(blk.attn.qkv.bias), tab, f(blk.attn.proj.bias), geom, rowscale=sd1d, rows_per_scale=tps)
+    x2, x1n, hp, mean2, rstd2 = ops.swin_mlp_fwd(x1, g2, b2n, st[ops.SWIN_MLP_FWD], f(blk.mlp[0].bias), f(blk.mlp[3].bias), rowscale=sd2d, rows_per_scale=tps)
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    # ---- MLP branch
+    dg2, db2 = z(C), z(C)
+    dx1, hact, dh, dyw = ops.swin_mlp_bwd(dyd, x1, hp, mean2, rstd2, g2, st[ops.SWIN_MLP_BWD], dg2, db2, geom, rowscale=sd2d, rows_per_scale=tps, dyw_scale=sd1d)
+    torch.cuda.synchronize()
+    assert_close(hact, torch.nn.functional.gelu(hp.float().cpu().double()), 1e-2, "hact")
+    assert_close(dx1, x1_ref.grad.view(T, C), TOL, "dx1", elem_mult=2.0)
+    assert_close(dg2, blk.norm2.weight.grad, TOL, "dgamma2")
+    assert_close(db2, blk.norm2.bias.grad, TOL, "dbeta2")
+    dyw_u = torch.empty_like(dyw)
+    ops.window_gather_scale(dx1, dyw_u, sd1d, C, geom)
+    assert_close(dyw, dyw_u.float().cpu(), 1e-2, "dyw (window-ordered, scaled copy)")
+    rs2 = sd2.double().repeat_interleave(tps)[:, None]
+    dhf, hactf, x1nf, dyf = dh.float().cpu().double(), hact.float().cpu().double(), x1n.float().cpu().double(), dy.view(T, C).double()
+    assert_close(dhf.T @ x1nf, blk.mlp[0].weight.grad, 2 * TOL, "fc1 weight gradient from (dh, x1n)")   # (products of two bf16-rounded operands over as few as 8 rows)
+    assert_close(dhf.sum(0), blk.mlp[0].bias.grad, 2 * TOL, "fc1 bias gradient")
+    assert_close((rs2 * dyf).T @ hactf, blk.mlp[3].weight.grad, 2 * TOL, "fc2 weight gradient from (dy, hact)")
+    # ---- attention branch: dO + attention core
+    dtab = z(343, heads)
+    dqkv = ops.swin_attn_bwd(dyw, qkv, tab, lse, st[ops.SWIN_ATTN_BWD], dtab, geom)
+    torch.cuda.synchronize()
+    do_u = ops.gemm_nt(dyw, dev(w["proj"].T.contiguous(), BF))
+    dqkv_u, dtab_u = torch.empty_like(dqkv), z(343, heads)
+    ops.window_attn_bwd(qkv, tab, do_u, lse, dqkv_u, dtab_u, heads, C, geom)
+    assert_close(dqkv, dqkv_u.float().cpu(), TOL, "dqkv vs the unfused kernels")
+    assert_close(dtab, dtab_u.cpu(), TOL, "d(bias table) vs the unfused kernels")
+    assert_close(dtab, blk.attn.relative_position_bias_table.grad, 2 * TOL, "d(bias table) vs autograd")
+    dywf, of, dqf, xnwf = dyw.float().cpu().double(), o.float().cpu().double(), dqkv.float().cpu().double(), xnw.float().cpu().double()
+    assert_close(dywf.T @ of, blk.attn.proj.weight.grad, 2 * TOL, "proj weight gradient from (dyw, o)")
+    assert_close(dqf.T @ xnwf, blk.attn.qkv.weight.grad, 2 * TOL, "qkv weight gradient from (dqkv, xnw)")
+    assert_close(dqf.sum(0), blk.attn.qkv.bias.grad, 2 * TOL, "qkv bias gradient", elem_mult=2.0)
+    # ---- QKV + LayerNorm-1 backward
+    dg1, db1 = z(C), z(C)
+    dx = ops.swin_qkv_bwd(dqkv, xd, dx1, mean1, rstd1, g1, st[ops.SWIN_QKV_BWD], dg1, db1, geom)
+    torch.cuda.synchronize()
+    dxnw_u = ops.gemm_nt(dqkv, dev(w["qkv"].T.contiguous(), BF))
+    dx_u, dg1u, db1u = torch.empty_like(dx), z(C), z(C)
+    ops.layernorm_bwd(dxnw_u, xd, g1, mean1, rstd1, dx_u, dg1u, db1u, T, C, src_mode=1, geom=geom, dres=dx1)
+    assert_close(dx, dx_u.float().cpu(), TOL, "dx vs the unfused kernels")
+    assert_close(dg1, dg1u.cpu(), TOL, "dgamma1 vs the unfused kernels")
+    assert_close(db1, db1u.cpu(), TOL, "dbeta1 vs the unfused kernels")
+    assert_close(dx, xr.grad.view(T, C), 2 * TOL, "dx vs autograd", elem_mult=2.0)
+    assert_close(dg1, blk.norm1.weight.grad, 2 * TOL, "dgamma1 vs autograd")
+    assert_close(db1, blk.norm1.bias.grad, 2 * TOL, "dbeta1 vs autograd")

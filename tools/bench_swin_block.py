@@ -89,11 +89,11 @@ for C in widths:
             ops.layernorm_bwd(dxnw, x, gam, mean, rstd, dx, dg, db, M, C, src_mode=1, geom=geom, dres=dx1)
 
         res["unfused mlp bwd"] = bench(unf_mlp_bwd)
-        res["fused mlp bwd"] = bench(lambda: ops.swin_mlp_bwd(dy, x, hpre, mean, rstd, gam, st[ops.SWIN_MLP_BWD], b1, dg, db, geom, rowscale=rs, rows_per_scale=tps, dyw_scale=rs))
+        res["fused mlp bwd"] = bench(lambda: ops.swin_mlp_bwd(dy, x, hpre, mean, rstd, gam, st[ops.SWIN_MLP_BWD], dg, db, geom, rowscale=rs, rows_per_scale=tps, dyw_scale=rs))
         res["unfused attn bwd"] = bench(unf_attn_bwd)
 
-        def fused_attn_bwd():
-            dq = ops.swin_attn_bwd(dyw, qkv, table, lse, st[ops.SWIN_ATTN_BWD], dtab, geom)
-            ops.swin_qkv_bwd(dq, x, dx1, mean, rstd, gam, st[ops.SWIN_QKV_BWD], dg, db, geom)
-        res["fused attn bwd"] = bench(fused_attn_bwd)
+        res["unfused proj-dgrad + attn core bwd"] = bench(lambda: (ops.gemm_nt(dyw, WpT_b, out=do), ops.window_attn_bwd(qkv, table, do, lse, dqkv, dtab, heads, C, geom)))
+        res["fused attn bwd (dO + core)"] = bench(lambda: ops.swin_attn_bwd(dyw, qkv, table, lse, st[ops.SWIN_ATTN_BWD], dtab, geom))
+        res["unfused qkv-dgrad + LN1 bwd"] = bench(lambda: (ops.gemm_nt(dqkv, WqkvT_b, out=dxnw), ops.layernorm_bwd(dxnw, x, gam, mean, rstd, dx, dg, db, M, C, src_mode=1, geom=geom, dres=dx1)))
+        res["fused qkv bwd"] = bench(lambda: ops.swin_qkv_bwd(dqkv, x, dx1, mean, rstd, gam, st[ops.SWIN_QKV_BWD], dg, db, geom))
     print(f"C={C} grids={grids} rows={M} window rows={geom.rows}: " + "  ".join(f"{k} {v:.1f} us" for k, v in res.items()), flush=True)
