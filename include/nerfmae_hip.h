@@ -206,6 +206,10 @@ NMH_API int nmh_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamm
  *     [T], qkv [rows][3C], o [rows][C], lse [rows * heads] -- the operands of the weight gradients and of the backward kernels.
  *   nmh_swin_mlp_fwd: x2[row] = x1[row] + rowscale[..] * (gelu(LN2(x1) W1^T + b1) W2^T + b2); also writes x1n = LN2(x1) [M][C], the fc1
  *     pre-activation hp [M][4C], mean / rstd [M] and, when hact != NULL, gelu(hp) [M][4C] (the unfused backward's fc2 weight-gradient operand).
+ *     split_ws (optional): nmh_swin_mlp_split_ws_bytes(M, C) bytes, zero before the first call and left zero by every call (calls that share it
+ *     must be ordered on one stream).  When that size is > 0 (C = 384 and <= 128 row tiles: fewer workgroups than half of the CUs) and the workspace
+ *     is given, two workgroups share a row tile -- half of the hidden units each, fp32 partial sums added by whichever finishes last; the sum of two
+ *     terms does not depend on the arrival order, so results are reproducible.
  *   nmh_swin_mlp_bwd: from dy = dL/dx2 and the saved x1, hp, mean / rstd: hact = gelu(hp) and dh = rowscale (dy W2) gelu'(hp) [M][4C] (written: the
  *     operands of the two weight gradients, which stay nmh_gemm_tn(_grouped) calls on (dy, hact, rowscale) and (dh, x1n)), dx1 = dy + LN2_backward(dh W1),
  *     dgamma / dbeta accumulated (fp32 atomics) and, with dyw != NULL, dx1 in window order times dyw_scale[row / rows_per_scale] (pad rows zeroed).
@@ -220,7 +224,8 @@ NMH_API int nmh_swin_supported(int C);
 NMH_API int64_t nmh_swin_stream_numel(int type, int C);
 NMH_API int nmh_swin_pack(const nmh_swin_pack_item* items, int n, void* stream);
 NMH_API int nmh_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* bias_table, const float* bproj, const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1, const int* wm, int C, float eps, void* stream);
-NMH_API int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale, void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, int64_t M, int C, float eps, void* stream);
+NMH_API int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale, void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, int64_t M, int C, float eps, void* split_ws, int64_t split_ws_bytes, void* stream);
+NMH_API int64_t nmh_swin_mlp_split_ws_bytes(int64_t M, int C);
 NMH_API int nmh_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale, int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm, int64_t M, int C, void* stream);
 NMH_API int nmh_swin_attn_bwd(const void* dyw, const void* qkv, const float* bias_table, const float* lse, const void* wstream, void* dqkv, float* dbias_table, const int* wm, int C, void* stream);
 NMH_API int nmh_swin_qkv_bwd(const void* dqkv, const void* x, const void* dres, const float* mean, const float* rstd, const float* gamma, const void* wstream, void* dx, float* dgamma, float* dbeta, const int* wm, int C, void* stream);

@@ -262,13 +262,15 @@ int nmh_swin_attn_fwd(const void* x, const float* gamma, const float* beta, cons
   return k_swin_attn_fwd(x, gamma, beta, wstream, bqkv, bias_table, bproj, rowscale, rows_per_scale, xnw, mean, rstd, qkv, o, lse, x1, to_wm(wm), C, eps, ST);
 }
 int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
-                     void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, int64_t M, int C, float eps, void* stream) {
+                     void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, int64_t M, int C, float eps, void* split_ws, int64_t split_ws_bytes,
+                     void* stream) {
   CLR();
   REQ(x1, gamma, beta, wstream, b1, b2, x2, x1n, hp, mean, rstd);
   if (M <= 0) return 0;
   if ((long)M * 4 * C >= (1L << 31)) return -2;
-  return k_swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, hact, mean, rstd, (long)M, C, eps, ST);
+  return k_swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, hact, mean, rstd, (long)M, C, eps, split_ws, (long)split_ws_bytes, ST);
 }
+int64_t nmh_swin_mlp_split_ws_bytes(int64_t M, int C) { return k_swin_mlp_split_ws_bytes((long)M, C); }
 int nmh_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale,
                      int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm, int64_t M, int C,
                      void* stream) {

@@ -187,8 +187,9 @@ struct SwinPackItem { const float* w0; const float* w1; void* dst; int type; int
 int k_swin_supported(int C);
 long k_swin_stream_numel(int type, int C);
 int k_swin_pack(const SwinPackItem* items, int n, hipStream_t st);
+long k_swin_mlp_split_ws_bytes(long M, int C);
 int k_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
-                   void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, long M, int C, float eps, hipStream_t st);
+                   void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, long M, int C, float eps, void* split_ws, long split_ws_bytes, hipStream_t st);
 int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* table, const float* bproj,
                     const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1,
                     const WinMap& wm, int C, float eps, hipStream_t st);

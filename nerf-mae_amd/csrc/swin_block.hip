@@ -36,6 +36,9 @@ namespace sw {
 constexpr int G = 6;                 // fragments per stream step
 constexpr int STEP_BYTES = G * 1024;
 constexpr int MLP_ROUNDS = 12;       // 4 C hidden units / (32 per wave and round x NW waves) with C = 96 NW
+// segments of the forward MLP stream: the rounds of a segment are packed in pipeline order on their own, so that a segment can be walked by its
+// own workgroup.  C = 384 at 8 grids is 125 row tiles for 256 CUs: two workgroups per tile, each with half of the hidden units, then fill the chip
+__host__ __device__ constexpr int mlp_segments(int NW) { return NW == 4 ? 2 : 1; }
 
 // row map of a PAIR of weight tiles (32 output features): tile t in {0,1}, A-operand row li <-> feature 8 (li >> 2) + 4 t + (li & 3).
 // In the C layout (row = 4 g + r) a lane then holds features 8 g + 4 t + r, and pack_tr(tile 0, tile 1) is the natural-order operand
@@ -187,14 +190,18 @@ __global__ __launch_bounds__(256) void swin_pack_kernel(PackArgs pa) {
     } else if (d.type == ST_QKV_BWD) {    // dxn[n] = sum_kf dqkv[kf] qkv.weight[kf][n]
       base = d.w0; idx0 = (long)(32 * s + 8 * g) * C + 96 * w + 32 * p + np_row(t, li); stride = C;
     } else {
-      // step order: fc1(0) | { fc1(c + 1), fc2(c) } for c = 0 .. 10 | fc2(11); every part NW steps
+      // step order within a segment of R rounds: fc1(0) | { fc1(c + 1), fc2(c) } for c = 0 .. R - 2 | fc2(R - 1); every part NW steps
+      // (one segment of 12 rounds, or mlp_segments(NW) of them for the forward stream)
+      const int NSEG = d.type == ST_MLP_FWD ? mlp_segments(NW) : 1, R = MLP_ROUNDS / NSEG, per = 2 * R * NW;
+      const int sg = s / per, sl = s - sg * per;
       int c, kind, u;   // kind 0: first product of round c (rows = hidden), 1: second product of round c (rows = channels)
-      if (s < NW) { c = 0; kind = 0; u = s; }
+      if (sl < NW) { c = 0; kind = 0; u = sl; }
       else {
-        const int s2 = s - NW, blk = s2 / (2 * NW), r = s2 - blk * 2 * NW;
-        if (blk < MLP_ROUNDS - 1) { if (r < NW) { c = blk + 1; kind = 0; u = r; } else { c = blk; kind = 1; u = r - NW; } }
-        else { c = MLP_ROUNDS - 1; kind = 1; u = r; }
+        const int s2 = sl - NW, blk = s2 / (2 * NW), r = s2 - blk * 2 * NW;
+        if (blk < R - 1) { if (r < NW) { c = blk + 1; kind = 0; u = r; } else { c = blk; kind = 1; u = r - NW; } }
+        else { c = R - 1; kind = 1; u = r; }
       }
+      c += sg * R;
       const int H = 4 * C;
       if (kind == 0) {      // fragment i: k-step 3 u + (i >> 1), tile t = i & 1 of the wave's hidden pair of the round
         const int hid = 32 * (NW * c + w) + np_row(t, li), k0 = 32 * (3 * u + p) + 8 * g;
@@ -288,6 +295,7 @@ struct MlpFwdArgs {
   const bf16_t* x1; const float* gamma; const float* beta; const char* wstream; const float* b1; const float* b2;
   const float* rowscale; int rows_per_scale;
   bf16_t* x2; bf16_t* x1n; bf16_t* hp; float* mean; float* rstd; long M; float eps; long long* ts; bf16_t* hact;
+  float* part; int* cnt;   // SPLIT: fp32 partial outputs [tile][segment][wave][24 tiles][64 lanes][4] and one arrival counter per row tile (zero between launches)
 };
 
 template <int NW, int A> constexpr int mlp_lds() { return NW * A * STEP_BYTES + (12 * NW * 1024 > 2 * NW * 4096 ? 12 * NW * 1024 : 2 * NW * 4096) + 4 * 96 * NW * 4; }
@@ -300,18 +308,27 @@ template <int DBG> __device__ __forceinline__ void mmad(f32x4& acc, const Frag<b
   if (DBG & 2) asm volatile("" ::"v"(a.v), "v"(b.v)); else mma(acc, a, b);
 }
 
-template <int NW, int A, int DBG = 0>
+// SPLIT: one workgroup per (row tile, segment of the hidden units); the workgroups of a tile leave their fp32 partial products in a.part, and the
+// one that arrives last (a.cnt) adds the others' to its own and runs the epilogue.  Block b -> tile 8 (b / 16) + b % 8, segment (b / 8) % 2: the
+// two workgroups of a tile are 8 blocks apart (same XCD under the round-robin block placement; correctness does not depend on it: the partials
+// and the counter are accessed device-coherently).
+template <int NW, int A, int DBG = 0, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
   constexpr int KS = 3 * NW, C = 32 * KS, H = 4 * C, TPS = 4 / NW;   // TPS: row tiles whose activation a step of the first product carries
+  constexpr int NSEG = mlp_segments(NW), R = MLP_ROUNDS / NSEG, SEG_STEPS = 2 * R * NW, MYSEG = SPLIT ? 1 : NSEG;
+  static_assert(!SPLIT || NSEG == 2, "the block -> (tile, segment) map is written for two segments");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
   char* exch = smem + NW * A * STEP_BYTES;     // LayerNorm tile [KS][4] fragment images, then [2][NW k-steps][4 row tiles] images of gelu(h)
   const unsigned exch_a = lds_addr(exch);
-  const long rbase = (long)blockIdx.x * 64;
+  const long tile = SPLIT ? 8 * (long)(blockIdx.x >> 4) + (blockIdx.x & 7) : (long)blockIdx.x;
+  const int seg0 = SPLIT ? (blockIdx.x >> 3) & 1 : 0;
+  const long rbase = tile * 64;
+  if (SPLIT && rbase >= a.M) return;
 
   stamp<DBG>(a.ts, 0);
   WStream<A, DBG> ws;
-  ws.init(a.wstream + (long)wave * (2 * MLP_ROUNDS * NW) * STEP_BYTES, smem + wave * A * STEP_BYTES, 2 * MLP_ROUNDS * NW);
+  ws.init(a.wstream + ((long)wave * (NSEG * SEG_STEPS) + (long)seg0 * SEG_STEPS) * STEP_BYTES, smem + wave * A * STEP_BYTES, MYSEG * SEG_STEPS);
   Frag<bf16_t> wf[G];
   ws.start(wf, lane);
   stamp<DBG>(a.ts, 1);
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
       if (i < H / 4) { lds_write4(b_a + 16 * i, bv[q].x); lds_write4(b_a + 16 * i + 4, bv[q].y); lds_write4(b_a + 16 * i + 8, bv[q].z); lds_write4(b_a + 16 * i + 12, bv[q].w); }
     }
   }
-  ln_exchange<KS, NW>(a.x1, [&](int m) { const long row = rbase + 16 * m + li; const long v = row < a.M ? row : -1; return RowIdx{row < a.M ? row : a.M - 1, v, v}; },
+  ln_exchange<KS, NW>(a.x1, [&](int m) { const long row = rbase + 16 * m + li; const long v = row < a.M && seg0 == 0 ? row : -1; return RowIdx{row < a.M ? row : a.M - 1, v, v}; },
                       a.gamma, a.beta, a.eps, a.x1n, a.mean, a.rstd, exch, af, wave, lane);
   bf16_t* hprow[4];
 #pragma unroll
@@ -414,31 +431,86 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
   };
 
   stamp<DBG>(a.ts, 2);
-  fc1(hcur, std::false_type{}, 0, hcur);
-  stamp<DBG>(a.ts, 3);
 #pragma unroll 1
-  for (int c = 0; c < MLP_ROUNDS - 1; ++c) {
-    fc1(hnxt, std::true_type{}, c, hcur);
-    if (c == 5) stamp<DBG>(a.ts, 4);
+  for (int sg = 0; sg < MYSEG; ++sg) {
+    const int c0 = (seg0 + sg) * R, cl = c0 + R - 1;
+    fc1(hcur, std::false_type{}, 0, hcur);
+    if (sg == 0) stamp<DBG>(a.ts, 3);
+#pragma unroll 1
+    for (int c = c0; c < cl; ++c) {
+      fc1(hnxt, std::true_type{}, c, hcur);
+      if (c == 5) stamp<DBG>(a.ts, 4);
+      wg_barrier();
+      if (c == 5) stamp<DBG>(a.ts, 5);
+      fc2(c);
+      if (c == 5) stamp<DBG>(a.ts, 6);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hcur[t][m] = hnxt[t][m];
+    }
+    {
+      float4 bb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bb[t] = *reinterpret_cast<const float4*>(sB1 + 32 * (NW * cl + wave) + 8 * g + 4 * t);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) act_tile(cl, hcur, m, bb);
+    }
     wg_barrier();
-    if (c == 5) stamp<DBG>(a.ts, 5);
-    fc2(c);
-    if (c == 5) stamp<DBG>(a.ts, 6);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) hcur[t][m] = hnxt[t][m];
+    fc2(cl);
   }
-  {
-    float4 bb[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) bb[t] = *reinterpret_cast<const float4*>(sB1 + 32 * (NW * (MLP_ROUNDS - 1) + wave) + 8 * g + 4 * t);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) act_tile(MLP_ROUNDS - 1, hcur, m, bb);
-  }
-  wg_barrier();
-  fc2(MLP_ROUNDS - 1);
   stamp<DBG>(a.ts, 7);
+
+  if (SPLIT) {
+    // partial products of this segment -> a.part (1 KB per store instruction, lane-linear), then the arrival counter of the tile
+    // Device-coherent accesses (sc1: performed at the memory side, past the per-XCD L2s) instead of fences: a release / acquire fence at agent
+    // scope is a write-back / invalidate walk of the whole L2 per wave -- 1000 of them at the end of a launch cost more than the split saves
+    // (78 vs 52 us).  Order: every wave's stores acknowledged (vmcnt 0) -> workgroup barrier -> counter -> barrier -> loads.
+    const char* const pbase = reinterpret_cast<const char*>(a.part) + ((((tile * NSEG) * NW + wave) * 24) * 64 + lane) * 16;
+    const long seg_bytes = (long)NW * 24 * 64 * 16;
+    {
+      // (one asm statement per group of stores, closed by wait states: the compiler recycles the data registers -- copies out of the accumulation
+      // registers -- for the next group, and its hazard handling does not look inside asm)
+      const char* mine = pbase + seg0 * seg_bytes;
+#pragma unroll
+      for (int n = 0; n < 6; ++n)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:1024 sc1\n\t"
+                     "global_store_dwordx4 %0, %3, off offset:2048 sc1\n\tglobal_store_dwordx4 %0, %4, off offset:3072 sc1\n\ts_nop 3"
+                     ::"v"(mine + n * 4096), "v"(out[n][0]), "v"(out[n][1]), "v"(out[n][2]), "v"(out[n][3]) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    volatile int* const flag = reinterpret_cast<volatile int*>(exch);
+    if (tid == 0) {
+      const int old = atomicAdd(a.cnt + tile, 1);
+      if (old == NSEG - 1) atomicExch(a.cnt + tile, 0);   // everyone has arrived: ready for the next launch
+      *flag = old == NSEG - 1;
+    }
+    __syncthreads();
+    if (!*flag) { ws.drain(); return; }
+    {
+      // all 24 loads and their wait in ONE asm statement: between separate statements the compiler may copy a destination register (to make room:
+      // 96 + 96 live values here) before the data has arrived -- asm loads are not counted by its waitcnt insertion
+      const char* oth = pbase + (seg0 ^ 1) * seg_bytes;
+      f32x4 pv[24];
+      asm volatile(
+          "global_load_dwordx4 %0, %24, off sc1\n\tglobal_load_dwordx4 %1, %24, off offset:1024 sc1\n\tglobal_load_dwordx4 %2, %24, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %24, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %4, %25, off sc1\n\tglobal_load_dwordx4 %5, %25, off offset:1024 sc1\n\tglobal_load_dwordx4 %6, %25, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %25, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %8, %26, off sc1\n\tglobal_load_dwordx4 %9, %26, off offset:1024 sc1\n\tglobal_load_dwordx4 %10, %26, off offset:2048 sc1\n\tglobal_load_dwordx4 %11, %26, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %12, %27, off sc1\n\tglobal_load_dwordx4 %13, %27, off offset:1024 sc1\n\tglobal_load_dwordx4 %14, %27, off offset:2048 sc1\n\tglobal_load_dwordx4 %15, %27, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %16, %28, off sc1\n\tglobal_load_dwordx4 %17, %28, off offset:1024 sc1\n\tglobal_load_dwordx4 %18, %28, off offset:2048 sc1\n\tglobal_load_dwordx4 %19, %28, off offset:3072 sc1\n\t"
+          "global_load_dwordx4 %20, %29, off sc1\n\tglobal_load_dwordx4 %21, %29, off offset:1024 sc1\n\tglobal_load_dwordx4 %22, %29, off offset:2048 sc1\n\tglobal_load_dwordx4 %23, %29, off offset:3072 sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(pv[0]), "=&v"(pv[1]), "=&v"(pv[2]), "=&v"(pv[3]), "=&v"(pv[4]), "=&v"(pv[5]), "=&v"(pv[6]), "=&v"(pv[7]), "=&v"(pv[8]), "=&v"(pv[9]), "=&v"(pv[10]), "=&v"(pv[11]),
+            "=&v"(pv[12]), "=&v"(pv[13]), "=&v"(pv[14]), "=&v"(pv[15]), "=&v"(pv[16]), "=&v"(pv[17]), "=&v"(pv[18]), "=&v"(pv[19]), "=&v"(pv[20]), "=&v"(pv[21]), "=&v"(pv[22]), "=&v"(pv[23])
+          : "v"(oth), "v"(oth + 4096), "v"(oth + 2 * 4096), "v"(oth + 3 * 4096), "v"(oth + 4 * 4096), "v"(oth + 5 * 4096)
+          : "memory");
+#pragma unroll
+      for (int n = 0; n < 6; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) out[n][m] += pv[n * 4 + m];
+    }
+  }
 
   // epilogue: lane (li, g) owns channels 96 w + 32 p + 8 g + 4 t + r of token li.  Every load first (24 + 6 + 4 requests in flight), then the stores:
   // written load -> use per piece, the epilogue was 24 serial L2 round trips (15 k of the kernel's 130 k cycles)
@@ -1384,6 +1456,13 @@ int k_swin_pack(const SwinPackItem* items, int n, hipStream_t st) {
   return 0;
 }
 
+constexpr long SPLIT_MAX_TILES = 128, SPLIT_CNT_BYTES = 1024;
+// bytes of the zero-initialised workspace the split MLP forward needs for M rows of width C (0: this shape is not split): arrival counters, fp32 partials
+long k_swin_mlp_split_ws_bytes(long M, int C) {
+  const long tiles = (M + 63) / 64;
+  if (C != 384 || tiles > SPLIT_MAX_TILES || M <= 0) return 0;
+  return SPLIT_CNT_BYTES + tiles * sw::mlp_segments(4) * 64 * C * 4;
+}
 template <int NW> static int launch_mlp_fwd(const sw::MlpFwdArgs& a, hipStream_t st) {
   constexpr int lds = sw::mlp_lds<NW, RING_A>();
   const int dbg = getenv("NMH_SWIN_DBG") ? atoi(getenv("NMH_SWIN_DBG")) : 0;   // timing-only variants (wrong results): 1 no weight DMA, 2 no MFMAs, 4 no GELU / softmax
@@ -1402,15 +1481,29 @@ template <int NW> static int launch_mlp_fwd(const sw::MlpFwdArgs& a, hipStream_t
     NMH_CHECK_LAUNCH();
     return 0;
   }
+  if constexpr (NW == 4) {
+    if (a.part) {   // (k_swin_mlp_fwd: a workspace was passed and the row tiles alone would leave half of the CUs idle)
+      if (int e = set_lds(sw::swin_mlp_fwd_kernel<NW, RING_A, 0, true>, lds)) return e;
+      const long tiles = (a.M + 63) / 64;
+      hipLaunchKernelGGL((sw::swin_mlp_fwd_kernel<NW, RING_A, 0, true>), dim3((unsigned)((tiles + 7) / 8 * 16)), dim3(64 * NW), lds, st, a);
+      NMH_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (int e = set_lds(sw::swin_mlp_fwd_kernel<NW, RING_A>, lds)) return e;
   hipLaunchKernelGGL((sw::swin_mlp_fwd_kernel<NW, RING_A>), dim3((unsigned)((a.M + 63) / 64)), dim3(64 * NW), lds, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
 }
 int k_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
-                   void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, long M, int C, float eps, hipStream_t st) {
+                   void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, long M, int C, float eps, void* split_ws, long split_ws_bytes, hipStream_t st) {
   sw::MlpFwdArgs a{(const bf16_t*)x1, gamma, beta, (const char*)wstream, b1, b2, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
-                   (bf16_t*)x2, (bf16_t*)x1n, (bf16_t*)hp, mean, rstd, M, eps, nullptr, (bf16_t*)hact};
+                   (bf16_t*)x2, (bf16_t*)x1n, (bf16_t*)hp, mean, rstd, M, eps, nullptr, (bf16_t*)hact, nullptr, nullptr};
+  // two workgroups per row tile when the tiles alone cannot fill the chip (<= 128 tiles) and the caller lent the workspace (k_swin_mlp_split_ws_bytes)
+  if (split_ws && C == 384 && k_swin_mlp_split_ws_bytes(M, C) > 0 && split_ws_bytes >= k_swin_mlp_split_ws_bytes(M, C)) {
+    a.cnt = (int*)split_ws;
+    a.part = (float*)((char*)split_ws + SPLIT_CNT_BYTES);
+  }
   switch (C) {
     case 96: return launch_mlp_fwd<1>(a, st);
     case 192: return launch_mlp_fwd<2>(a, st);

@@ -684,17 +684,34 @@ def swin_attn_fwd(x, gamma, beta, wstream, bqkv, table, bproj, geom: WinGeom, ro
     return x1, xnw, mean, rstd, qkv, o, lse
 
 
-def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale=1, eps=1e-5, want_hact=False):
-    """-> (x2, x1n, hp, mean, rstd[, hact]): the MLP branch in one launch; hp = fc1 pre-activation [M, 4C], hact = gelu(hp) on request"""
+SWIN_MLP_SPLIT = __import__("os").environ.get("NMH_SWIN_SPLIT", "1") != "0"
+_SPLIT_WS = {}
+
+
+def swin_mlp_split_ws(M, C, device):
+    """the zero-initialised workspace of the two-workgroups-per-tile MLP forward (None: this shape runs one workgroup per tile); one per shape and
+    device, shared by the blocks of a stage (their launches are ordered on the stream and each leaves the counters zero)"""
+    key = (device.index, M, C)
+    if key not in _SPLIT_WS:
+        n = int(lib().call("nmh_swin_mlp_split_ws_bytes", M, C))
+        _SPLIT_WS[key] = torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
+    return _SPLIT_WS[key]
+
+
+def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale=1, eps=1e-5, want_hact=False, split=None):
+    """-> (x2, x1n, hp, mean, rstd[, hact]): the MLP branch in one launch; hp = fc1 pre-activation [M, 4C], hact = gelu(hp) on request.
+    split (default SWIN_MLP_SPLIT): two workgroups per 64-row tile where the tiles alone leave half of the chip idle (C = 384, <= 8192 rows)"""
     _chk(x1, gamma, beta, wstream, b1, b2, rowscale)
     M, C = x1.shape
     dev = x1.device
+    ws = swin_mlp_split_ws(M, C, dev) if (SWIN_MLP_SPLIT if split is None else split) else None
     x2, x1n = torch.empty_like(x1), torch.empty_like(x1)
     hp = torch.empty((M, 4 * C), dtype=x1.dtype, device=dev)
     mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
     hact = torch.empty_like(hp) if want_hact else None
     ev = _prof(("swin_mlp_fwd", M, C))
-    lib().call("nmh_swin_mlp_fwd", x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, hact, mean, rstd, M, C, eps, _st())
+    lib().call("nmh_swin_mlp_fwd", x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, hact, mean, rstd, M, C, eps,
+               ws, ws.numel() if ws is not None else 0, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return (x2, x1n, hp, mean, rstd, hact) if want_hact else (x2, x1n, hp, mean, rstd)

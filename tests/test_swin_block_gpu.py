@@ -111,22 +111,34 @@ def test_swin_block_forward(C, shape, shift):
     assert_close(o, o_u.float().cpu(), TOL, "o")
     assert_close(lse, lse_u.cpu(), 1e-3, "lse")
     assert_close(x1, x1_ref.view(T, C), TOL, "x1")
-    # --- MLP branch on the fused x1
-    x2, x1n, hp, mean2, rstd2 = ops.swin_mlp_fwd(x1, f(blk.norm2.weight), f(blk.norm2.bias), st[ops.SWIN_MLP_FWD], f(blk.mlp[0].bias), f(blk.mlp[3].bias),
-                                                 rowscale=dev(sd2), rows_per_scale=tps)
-    torch.cuda.synchronize()
+    # --- MLP branch on the fused x1: one workgroup per row tile, and (C = 384) two per tile with the partial sums combined by the last to arrive
     x1f = x1.float().cpu().double()
     with torch.no_grad():
         n2 = blk.norm2(x1f)
         hp_ref = blk.mlp[0](n2)
         x2_own = x1f + sd2.double().repeat_interleave(tps)[:, None] * blk.mlp(n2)
-    assert_close(x1n, n2, 1e-2, "x1n")
-    assert_close(hp, hp_ref, TOL, "hp")
-    assert_close(x2, x2_own, TOL, "x2 (from the fused x1)")
-    assert_close(x2, x2_ref.view(T, C), TOL, "x2", elem_mult=2.0)
     mu = x1f.mean(-1)
-    assert_close(mean2, mu, 1e-4, "mean2")
-    assert_close(rstd2, (x1f.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-4, "rstd2")
+    outs = {}
+    for split in (False, True):
+        for rep in range(3 if split else 1):
+            x2, x1n, hp, mean2, rstd2, hact = ops.swin_mlp_fwd(x1, f(blk.norm2.weight), f(blk.norm2.bias), st[ops.SWIN_MLP_FWD], f(blk.mlp[0].bias), f(blk.mlp[3].bias),
+                                                               rowscale=dev(sd2), rows_per_scale=tps, want_hact=True, split=split)
+            torch.cuda.synchronize()
+            if rep:
+                assert torch.equal(x2, outs[split]), "the split kernel is not reproducible"
+            outs[split] = x2
+        name = f" (split={split})"
+        assert_close(x1n, n2, 1e-2, "x1n" + name)
+        assert_close(hp, hp_ref, TOL, "hp" + name)
+        assert_close(hact, torch.nn.functional.gelu(hp.float().cpu().double()), TOL, "hact" + name)
+        assert_close(x2, x2_own, TOL, "x2 (from the fused x1)" + name)
+        assert_close(x2, x2_ref.view(T, C), TOL, "x2" + name, elem_mult=2.0)
+        assert_close(mean2, mu, 1e-4, "mean2" + name)
+        assert_close(rstd2, (x1f.var(-1, unbiased=False) + 1e-5).rsqrt(), 1e-4, "rstd2" + name)
+    if C == 384:
+        assert ops.swin_mlp_split_ws(T, C, x1.device) is not None
+        assert int(ops.swin_mlp_split_ws(T, C, x1.device)[:1024].sum()) == 0      # the arrival counters are back at zero
+        assert_close(outs[True], outs[False].float().cpu(), 1e-2, "split vs one workgroup per tile")   # (fp32 sums in another order, one bf16 rounding)
 
 
 @pytest.mark.parametrize("C", WIDTHS)
@@ -200,3 +212,33 @@ def test_swin_block_backward(C, shape, shift):
     assert_close(dx, xr.grad.view(T, C), 2 * TOL, "dx vs autograd", elem_mult=2.0)
     assert_close(dg1, blk.norm1.weight.grad, 2 * TOL, "dgamma1 vs autograd")
     assert_close(db1, blk.norm1.bias.grad, 2 * TOL, "dbeta1 vs autograd")
+
+
+def test_swin_mlp_split_full_size_is_reproducible_and_matches_unsplit():
+    """stage-2 shape of the headline config (8 grids: 8000 rows = 125 row tiles, 250 workgroups): 40 back-to-back launches of the two-workgroups-per-tile
+    kernel on one stream give bit-identical outputs (the combine does not depend on which workgroup arrives last, and the counters re-arm), and they
+    agree with the one-workgroup-per-tile kernel to bf16 rounding"""
+    ops = _ops()
+    C, M, tps = 384, 8000, 1000
+    g = torch.Generator().manual_seed(5)
+    x1 = (torch.randn(M, C, generator=g) * 1.2).to(BF).cuda()
+    W1, W2 = torch.randn(4 * C, C, generator=g) * C ** -0.5, torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5
+    b1, b2 = torch.randn(4 * C, generator=g).cuda() * 0.1, torch.randn(C, generator=g).cuda() * 0.1
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    rs = (torch.rand(M // tps, generator=g) + 0.5).cuda()
+    st = torch.empty(ops.swin_stream_numel(ops.SWIN_MLP_FWD, C), dtype=BF, device="cuda")
+    ops.swin_pack(ops.swin_pack_items([(W1.cuda(), W2.cuda(), st, ops.SWIN_MLP_FWD, C)]))
+    ref = ops.swin_mlp_fwd(x1, gam, bet, st, b1, b2, rowscale=rs, rows_per_scale=tps, split=False)
+    outs = [ops.swin_mlp_fwd(x1, gam, bet, st, b1, b2, rowscale=rs, rows_per_scale=tps, split=True) for _ in range(40)]
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs[1:]):
+        assert torch.equal(o[0], outs[0][0]), f"launch {i + 1} differs from launch 0"
+    for a, b, name in zip(outs[0], ref, ("x2", "x1n", "hp", "mean", "rstd")):
+        assert_close(a, b.float().cpu(), 1e-2, name)
+    assert int(ops.swin_mlp_split_ws(M, C, x1.device)[:1024].sum()) == 0
+    with torch.no_grad():
+        xf = x1.float().cpu().double()
+        n2 = torch.nn.functional.layer_norm(xf, (C,), gam.cpu().double(), bet.cpu().double(), 1e-5)
+        y = torch.nn.functional.gelu(n2 @ W1.to(BF).double().T + b1.cpu().double()) @ W2.to(BF).double().T + b2.cpu().double()
+        x2_ref = xf + rs.cpu().double().repeat_interleave(tps)[:, None] * y
+    assert_close(outs[0][0], x2_ref, TOL, "x2 vs fp64")

@@ -70,6 +70,10 @@ for C in widths:
     res["fused attn fwd"] = bench(lambda: ops.swin_attn_fwd(x, gam, bet, st[ops.SWIN_ATTN_FWD], bqkv, table, bp, geom, rowscale=rs, rows_per_scale=tps))
     res["unfused mlp fwd"] = bench(unf_mlp_fwd)
     res["fused mlp fwd"] = bench(lambda: ops.swin_mlp_fwd(x, gam, bet, st[ops.SWIN_MLP_FWD], b1, b2, rowscale=rs, rows_per_scale=tps))
+    if ops.swin_mlp_split_ws(M, C, x.device) is not None:
+        res["fused mlp fwd, one workgroup per tile"] = bench(lambda: ops.swin_mlp_fwd(x, gam, bet, st[ops.SWIN_MLP_FWD], b1, b2, rowscale=rs, rows_per_scale=tps, split=False))
+        res["fused mlp fwd + hact"] = bench(lambda: ops.swin_mlp_fwd(x, gam, bet, st[ops.SWIN_MLP_FWD], b1, b2, rowscale=rs, rows_per_scale=tps, want_hact=True))
+        res["fused mlp fwd + hact, one workgroup per tile"] = bench(lambda: ops.swin_mlp_fwd(x, gam, bet, st[ops.SWIN_MLP_FWD], b1, b2, rowscale=rs, rows_per_scale=tps, want_hact=True, split=False))
     if hasattr(ops, "swin_mlp_bwd"):
         dh = torch.empty_like(hpre); dxn = torch.empty_like(x); dx1 = torch.empty_like(x); dx = torch.empty_like(x)
         dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
