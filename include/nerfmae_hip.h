@@ -131,6 +131,16 @@ NMH_API int nmh_conv3d_k3_wgrad(int dt, const void* dY, const void* X, float* dW
  * (the adjoint of the attention branch's window reverse; replaces nmh_window_gather_scale). */
 NMH_API int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C, const int* wm, const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, void* stream);
 NMH_API int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int C, const int* wm, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, void* dyw, const float* dyw_scale, void* stream);
+/* nmh_layernorm_bwd with the parameter gradients taken off the dependent chain: every workgroup of the launch leaves its dgamma / dbeta partial sums in
+ * partials [nmh_layernorm_bwd_partial_rows(rows, C)][2C] (fp32, plain stores) instead of adding them to dgamma / dbeta with 2C same-address atomics, and
+ * ONE nmh_layernorm_param_grad_reduce launch for any number of such LayerNorms -- issued wherever the caller runs its weight gradients -- adds the
+ * column sums: dgamma[c] += sum_b partials[b][c], dbeta[c] += sum_b partials[b][C + c] (partial_rows = the value nmh_layernorm_bwd_partial_rows gave).
+ * The input gradient dx (and dyw) are as nmh_layernorm_bwd's; no token mask (the embedding norm keeps the atomic form).  (norm1 / norm2 of a Swin
+ * block, swin_mae3d.py:366-369 backward: 2 x 24 launches per step.) */
+typedef struct nmh_ln_reduce_item { const float* partials; float* dgamma; float* dbeta; int64_t partial_rows; int C; int reserved; } nmh_ln_reduce_item;
+NMH_API int64_t nmh_layernorm_bwd_partial_rows(int64_t rows, int C);
+NMH_API int nmh_layernorm_bwd_deferred(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx, float* partials, int64_t rows, int C, const int* wm, void* dyw, const float* dyw_scale, int64_t tokens_per_sample, void* stream);
+NMH_API int nmh_layernorm_param_grad_reduce(const nmh_ln_reduce_item* items, int n, void* stream);
 /* decoder1, forward, bf16: ConvTranspose3d(96 -> 48, kernel = stride = 4) (unetr_block.py:151-158) COMPOSED with the first 3x3x3 conv of the
  * residual block that follows it (unetr_block.py:35-44; swin_mae3d.py:1246-1257): the conv of the up-sampled map at fine voxel 4j + a only
  * touches 1..8 coarse cells j + n, so y1[4j + a] = sum_n x[j + n] . Wc[a][n] with 216 composed 96 x 48 blocks -- 31 instead of 133 kFLOP per

@@ -179,8 +179,25 @@ int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const
   CLR();
   if (rows <= 0) return 0;
   LnBwdArgs a{dt, src_mode, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, C, to_wm(wm), mask, dmask_token, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1),
-              dyw, dyw_scale};
+              dyw, dyw_scale, 0, nullptr};
   return k_ln_bwd(a, ST);
+}
+int64_t nmh_layernorm_bwd_partial_rows(int64_t rows, int C) { return rows > 0 && C > 0 && C % 8 == 0 ? (int64_t)k_ln_bwd_blocks((long)rows, C) : 0; }
+int nmh_layernorm_bwd_deferred(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx,
+                               float* partials, int64_t rows, int C, const int* wm, void* dyw, const float* dyw_scale, int64_t tokens_per_sample, void* stream) {
+  CLR();
+  REQ(dy, x, gamma, mean, rstd, dx, partials);
+  if (rows <= 0) return 0;
+  LnBwdArgs a{dt, src_mode, dy, x, gamma, mean, rstd, dres, dx, nullptr, nullptr, (long)rows, C, to_wm(wm), nullptr, nullptr, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1),
+              dyw, dyw_scale, 0, partials};
+  return k_ln_bwd(a, ST);
+}
+int nmh_layernorm_param_grad_reduce(const nmh_ln_reduce_item* items, int n, void* stream) {
+  CLR();
+  static_assert(sizeof(nmh_ln_reduce_item) == sizeof(LnReduceItem), "layout");
+  if (n <= 0) return 0;
+  REQ(items);
+  return k_ln_param_reduce(reinterpret_cast<const LnReduceItem*>(items), n, ST);
 }
 int64_t nmh_cconv_pack_numel(void) { return (int64_t)k_cconv_pack_numel(); }
 int64_t nmh_cconv_pack_ws_floats(void) { return (int64_t)k_cconv_pack_ws_floats(); }

@@ -154,8 +154,14 @@ struct LnBwdArgs {
   const unsigned char* mask; float* dmask_token; long tokens_per_sample;
   void* dyw; const float* dyw_scale;    // MODE 0 only: second output in window order (wm), scaled per sample (fused window gather)
   int dyw_pads;                         // set by k_ln_bwd: the window-ordered tensor has pad rows (no token) -- the kernel writes their zeros
+  float* part;                          // optional [k_ln_bwd_blocks(rows, C)][2C]: every workgroup leaves its dgamma / dbeta sums here (plain stores) instead of adding
+                                        // them to dgamma / dbeta with 2C same-address atomics; k_ln_param_reduce adds the column sums later, off the dependent chain
 };
 int k_ln_bwd(const LnBwdArgs& a, hipStream_t st);
+long k_ln_bwd_blocks(long rows, int C);
+struct LnReduceItem { const float* part; float* dgamma; float* dbeta; long nb; int C; int pad_; };   // == nmh_ln_reduce_item
+constexpr int LN_REDUCE_MAX = 96;
+int k_ln_param_reduce(const LnReduceItem* items, int n, hipStream_t st);
 
 int k_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
 int k_window_gather_scale(int dt, const void* dx, void* dyw, const float* rowscale, int C, const WinMap& wm, hipStream_t st);

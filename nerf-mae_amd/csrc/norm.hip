@@ -322,22 +322,76 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
       for (int w = 1; w < 4; ++w) { g += sacc[w * 3 * C + i]; b += sacc[w * 3 * C + C + i]; m += sacc[w * 3 * C + 2 * C + i]; }
     }
-    atomicAdd(a.dgamma + i, g);
-    atomicAdd(a.dbeta + i, b);
+    if (a.part) {   // (two coalesced stores per workgroup instead of 2C atomics that 256 workgroups aim at the same 2C addresses: 3 of this kernel's 24 us alone,
+      //               0.26 ms of the step at 8 grids)
+      a.part[(long)blockIdx.x * 2 * C + i] = g;
+      a.part[(long)blockIdx.x * 2 * C + C + i] = b;
+    } else {
+      atomicAdd(a.dgamma + i, g);
+      atomicAdd(a.dbeta + i, b);
+    }
     if (MODE == 0 && a.mask) atomicAdd(a.dmask_token + i, m);
   }
 }
-
+// dgamma[c] += sum_b part[b][c], dbeta[c] += sum_b part[b][C + c] for every queued LayerNorm of a stage in ONE launch (the descriptors travel in the
+// kernel arguments): 64 columns x 4 row slices per workgroup, grid (column blocks of the widest item, items)
+struct LnReduceArgs { LnReduceItem it[LN_REDUCE_MAX]; };
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnReduceArgs ra) {
+  __shared__ float s[4][64];
+  const LnReduceItem& d = ra.it[blockIdx.y];
+  const int C = d.C;
+  const long nb = d.nb;
+  const float* __restrict__ part = d.part;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= 2 * C) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < 2 * C) {
+    long b = sl;
+    for (; b + 12 < nb; b += 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += part[(b + 4 * u) * 2 * C + col];
+    }
+    for (; b < nb; b += 4) acc[0] += part[b * 2 * C + col];
+  }
+  s[sl][threadIdx.x & 63] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (sl == 0 && col < 2 * C) {
+    const float t = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (col < C) d.dgamma[col] += t; else d.dbeta[col - C] += t;
+  }
+}
+int k_ln_param_reduce(const LnReduceItem* items, int n, hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += LN_REDUCE_MAX) {
+    LnReduceArgs ra;
+    const int m = n - i0 < LN_REDUCE_MAX ? n - i0 : LN_REDUCE_MAX;
+    int cmax = 0;
+    for (int i = 0; i < m; ++i) {
+      ra.it[i] = items[i0 + i];
+      if (!ra.it[i].part || !ra.it[i].dgamma || !ra.it[i].dbeta || ra.it[i].C <= 0 || ra.it[i].nb < 0) return -2;
+      if (ra.it[i].C > cmax) cmax = ra.it[i].C;
+    }
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((2 * cmax + 63) / 64), (unsigned)m), dim3(256), 0, st, ra);
+    NMH_CHECK_LAUNCH();
+  }
+  return 0;
+}
 static long lnb_max_blocks() { static const long v = getenv("NMH_LN_BWD_BLOCKS") ? atol(getenv("NMH_LN_BWD_BLOCKS")) : 1024; return v; }
+// workgroups of the backward launch for `rows` rows of width C (also the rows of LnBwdArgs::part)
+long k_ln_bwd_blocks(long rows, int C) {
+  const int nch = C / 8, lpr = nch <= 48 ? 16 : 64;
+  long nb = (rows + (256 / lpr) - 1) / (256 / lpr);
+  /* every workgroup ends with 2C same-address fp32 atomics: measured optimum ~256 workgroups, ~512 from 16k row groups on */
+  long cap = nb / 32 < 256 ? 256 : nb / 32;
+  if (cap > lnb_max_blocks()) cap = lnb_max_blocks();
+  return nb > cap ? cap : nb;
+}
 template <typename T, int MODE> static int ln_bwd_dispatch(const LnBwdArgs& a, hipStream_t st) {
   const int nch = a.C / 8;
   if (a.C % 8) return -2;
+  const long nb = k_ln_bwd_blocks(a.rows, a.C);
 #define LNB_LAUNCH(LPR, NCH)                                                                        \
   {                                                                                                 \
     const size_t lds = ((NCH) >= 4 ? 3 : 12) * (size_t)a.C * sizeof(float);                         \
-    long nb = (a.rows + (256 / LPR) - 1) / (256 / LPR);                                             \
-    /* every workgroup ends with 2C same-address fp32 atomics: measured optimum ~256 workgroups, ~512 from 16k row groups on */ \
-    { long cap = nb / 32 < 256 ? 256 : nb / 32; if (cap > lnb_max_blocks()) cap = lnb_max_blocks(); if (nb > cap) nb = cap; } \
     hipLaunchKernelGGL((ln_bwd_kernel<T, LPR, NCH, MODE>), dim3((unsigned)nb), dim3(256), lds, st, a); \
   }
   if (nch <= 16) LNB_LAUNCH(16, 1)

@@ -353,7 +353,7 @@ class _BlockFn(torch.autograd.Function):
             wgrad(dh, x1n, b.mlp[0])
             dx1 = torch.empty_like(x)
             ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
-                              geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1)
+                              geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1, wq=q)   # (dgamma / dbeta: partial sums now, reduced with the stage's weight gradients)
         # ---- attention branch
         fused_ok = sw is not None and ops.swin_attn_ok(x, C, geom)
         if fused_ok and ops.SWIN_ATTN_BWD in sw:
@@ -378,7 +378,7 @@ class _BlockFn(torch.autograd.Function):
                 dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
             wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
             dx = torch.empty_like(x)
-            ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1)
+            ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1, wq=q)
         # the block's own side-stream launches (fp32 parity mode) read temporaries of this block: join before they are released.  With the queue
         # (bf16) the operands stay referenced by it and NOTHING may be joined here: a join makes this block's successor wait for every weight
         # gradient the last flush put on the side stream -- the trace showed the two queues taking turns (>= 2 kernels in flight for 4 of 52 ms)

@@ -170,6 +170,20 @@ STAGE0_BLOCK_FLUSH = __import__("os").environ.get("NMH_STAGE0_BLOCK_FLUSH", "0")
 TNG_FOREGROUND = __import__("os").environ.get("NMH_TNG_FOREGROUND", "1") != "0"
 
 
+class _LnReduceItem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_ln_reduce_item
+    _fields_ = [("partials", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p), ("partial_rows", ctypes.c_int64), ("C", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+def ln_param_grad_reduce(items):
+    """items: [(partials, partial_rows, C, dgamma, dbeta)] -> one launch (nmh_layernorm_param_grad_reduce)"""
+    arr = (_LnReduceItem * len(items))()
+    for i, (part, nb, C, dg, db) in enumerate(items):
+        _chk(part, dg, db)
+        arr[i] = _LnReduceItem(part.data_ptr(), dg.data_ptr(), db.data_ptr(), nb, C, 0)
+    lib().call("nmh_layernorm_param_grad_reduce", arr, len(items), _st())
+
+
 class WgradQueue:
     """Deferred weight gradients of the encoder (bf16): `add` records one dW[N,K] += A[M,N]^T . B[M,K] problem (and keeps its operands
     alive), `flush` issues everything recorded so far through nmh_gemm_tn_grouped -- on the forked side stream when that is enabled, so
@@ -178,6 +192,7 @@ class WgradQueue:
 
     def __init__(self):
         self.pending, self.inflight, self._cb, self.sync_after_flush = [], [], False, False
+        self.ln_items = []   # LayerNorm parameter-gradient partials of the current flush group (add_ln_partials)
         self.deferred = []   # closures (other weight-gradient launches) to issue with the next flush, inside the same fork
 
     def reset(self):
@@ -186,6 +201,7 @@ class WgradQueue:
         if self.pending or self.deferred or self.inflight or self._cb:
             join_side()
             self.pending, self.deferred, self.inflight, self._cb = [], [], [], False
+            self.ln_items = []
 
     def defer(self, fn):
         """queue an arbitrary weight-gradient launch (a closure that keeps its operands alive) for the next flush: the decoder's small-level
@@ -194,6 +210,13 @@ class WgradQueue:
         if not self._cb:
             self._cb = True
             torch.autograd.Variable._execution_engine.queue_callback(self._final)
+
+    def add_ln_partials(self, part, nb, C, dgamma, dbeta):
+        """the dgamma / dbeta partial sums of a LayerNorm backward (ops.layernorm_bwd(wq=...)): all of a flush are reduced by ONE launch"""
+        if not self.ln_items:
+            items = self.ln_items = []
+            self.defer(lambda: ln_param_grad_reduce(items))   # (the list object: filled until the flush runs the closure)
+        self.ln_items.append((part, nb, C, dgamma, dbeta))
 
     def launch_now(self, fn):
         """issue a weight-gradient launch on the forked side stream right away (no join: the closure keeps its operands alive until the end-of-backward
@@ -234,6 +257,7 @@ class WgradQueue:
             return
         todo, self.pending = self.pending, []
         fns, self.deferred = self.deferred, []
+        self.ln_items = []   # (the queued closure holds the list it reduces)
         with side_stream():
             for fn in fns:
                 fn()
@@ -531,10 +555,21 @@ def layernorm_fwd(x, gamma, beta, out, mean, rstd, rows, C, src_mode=0, geom: Op
     return out
 
 
+LN_DEFER_PARAM_GRADS = __import__("os").environ.get("NMH_LN_DEFER", "1") != "0"
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, src_mode=0, geom: Optional[WinGeom] = None, dres=None,
-                  mask=None, dmask_token=None, tokens_per_sample=1, dyw=None, dyw_scale=None):
-    """dyw (mode 0, with geom): second output = dx in window order times dyw_scale[sample] (fused window gather)"""
+                  mask=None, dmask_token=None, tokens_per_sample=1, dyw=None, dyw_scale=None, wq=None):
+    """dyw (mode 0, with geom): second output = dx in window order times dyw_scale[sample] (fused window gather).
+    wq (a WgradQueue): dgamma / dbeta leave the launch as per-workgroup partial sums and are added by a reduce queued with the stage's weight gradients"""
     _chk(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, dres, mask, dmask_token, dyw, dyw_scale)
+    if wq is not None and LN_DEFER_PARAM_GRADS and mask is None and src_mode != 2:
+        nb = int(lib().call("nmh_layernorm_bwd_partial_rows", rows, C))
+        part = torch.empty((nb, 2 * C), dtype=torch.float32, device=x.device)
+        lib().call("nmh_layernorm_bwd_deferred", dt_of(x), src_mode, dy, x, gamma, mean, rstd, dres, dx, part, rows, C,
+                   geom.carr if geom is not None else None, dyw, dyw_scale, tokens_per_sample, _st())
+        wq.add_ln_partials(part, nb, C, dgamma, dbeta)
+        return dx
     lib().call("nmh_layernorm_bwd", dt_of(x), src_mode, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C,
                geom.carr if geom is not None else None, mask, dmask_token, tokens_per_sample, dyw, dyw_scale, _st())
     return dx

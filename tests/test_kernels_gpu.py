@@ -264,6 +264,59 @@ def test_layernorm_plain_and_embed_post(dt, C):
     check(dm, mr.grad, dt, "dmask_token", 2)
 
 
+class _Defer:
+    """stands in for ops.WgradQueue: keeps the queued closures, runs them on request"""
+
+    def __init__(self):
+        self.fns = []
+
+    def defer(self, fn):
+        self.fns.append(fn)
+
+    def add_ln_partials(self, *item):
+        self.fns.append(lambda: _ops().ln_param_grad_reduce([item]))
+
+    def run(self):
+        for fn in self.fns:
+            fn()
+        self.fns = []
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("shape,C,shift", [((2, 8, 8, 8), 96, 2), ((1, 5, 5, 5), 192, 2), ((8, 10, 10, 10), 384, 2), ((2, 10, 10, 10), 384, 0), ((3, 40, 12, 40), 96, 2), ((1, 5, 5, 5), 768, 0)])
+def test_layernorm_bwd_deferred_parameter_gradients(dt, shape, C, shift):
+    """the parameter gradients as per-workgroup partial sums + a later column-sum launch (nmh_layernorm_bwd_deferred / _param_grad_reduce) against the
+    atomic form of the same kernel: identical dx / dyw, dgamma / dbeta equal up to the fp32 summation order, accumulated INTO their buffers"""
+    ops = _ops()
+    B, H, W, D = shape
+    geom = _geom(ops, B, H, W, D, shift)
+    T, tps = geom.tokens, geom.tokens // B
+    x, dres = q(rnd(T, C, seed=1), dt), q(rnd(T, C, seed=2), dt)
+    gam = 1 + 0.2 * rnd(C, seed=3)
+    mean, rstd = dev(x.mean(-1)), dev((x.var(-1, unbiased=False) + 1e-5).rsqrt())
+    sc = dev(torch.rand(B) + 0.5)
+    for mode in (0, 1):
+        dy = q(rnd(T if mode == 0 else geom.rows, C, seed=4 + mode), dt)
+        res = []
+        for deferred in (False, True):
+            dq = _Defer()
+            dx = torch.empty(T, C, dtype=dt, device="cuda")
+            dg, db = torch.full((C,), 0.25, device="cuda"), torch.full((C,), -0.5, device="cuda")
+            dyw = torch.full((geom.rows, C), 7.0, dtype=dt, device="cuda") if mode == 0 else None
+            ops.layernorm_bwd(dev(dy, dt), dev(x, dt), dev(gam), mean, rstd, dx, dg, db, T, C, src_mode=mode, geom=geom, dres=dev(dres, dt),
+                              tokens_per_sample=tps, dyw=dyw, dyw_scale=sc if mode == 0 else None, wq=dq if deferred else None)
+            if deferred:
+                assert len(dq.fns) == 1 and float(dg[0]) == 0.25      # nothing added yet
+                dq.run()
+            torch.cuda.synchronize()
+            res.append((dx, dyw, dg, db))
+        assert torch.equal(res[0][0], res[1][0]), f"dx differs (mode {mode})"
+        if mode == 0:
+            assert torch.equal(res[0][1], res[1][1]), "dyw differs"
+        check(res[1][2], res[0][2].cpu(), torch.float32, f"dgamma (mode {mode})", 5)
+        check(res[1][3], res[0][3].cpu(), torch.float32, f"dbeta (mode {mode})", 5)
+
+
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("shape,C", [((2, 8, 8, 8), 96), ((1, 5, 5, 5), 96), ((1, 6, 5, 4), 192), ((1, 3, 3, 3), 384)])
 def test_patch_merge_layernorm(dt, shape, C):
