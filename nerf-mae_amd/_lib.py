@@ -15,7 +15,7 @@ from typing import Dict, List, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "nerfmae_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libnerfmae_hip.so")
+LIB_PATH = os.environ.get("NMH_LIB_PATH") or os.path.join(_HERE, "csrc", "libnerfmae_hip.so")   # (NMH_LIB_PATH: another build of the same ABI, for same-box A/B runs)
 
 _CT = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,

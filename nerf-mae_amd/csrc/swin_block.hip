@@ -439,11 +439,11 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll 1
     for (int c = c0; c < cl; ++c) {
       fc1(hnxt, std::true_type{}, c, hcur);
-      if (c == 5) stamp<DBG>(a.ts, 4);
+      if (c == 2) stamp<DBG>(a.ts, 4);
       wg_barrier();
-      if (c == 5) stamp<DBG>(a.ts, 5);
+      if (c == 2) stamp<DBG>(a.ts, 5);
       fc2(c);
-      if (c == 5) stamp<DBG>(a.ts, 6);
+      if (c == 2) stamp<DBG>(a.ts, 6);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1473,7 +1473,7 @@ template <int NW> static int launch_mlp_fwd(const sw::MlpFwdArgs& a, hipStream_t
       sw::MlpFwdArgs b = a; b.ts = ts_buf();
       if (int e = set_lds(sw::swin_mlp_fwd_kernel<4, RING_A, 8>, lds)) return e;
       hipLaunchKernelGGL((sw::swin_mlp_fwd_kernel<4, RING_A, 8>), dim3((unsigned)((a.M + 63) / 64)), dim3(256), lds, st, b);
-      ts_print("mlp_fwd  start|ln|fc1(0)|.. round5: fc1+act|barrier|fc2 ..|tail|epilogue|drain", 10, st);
+      ts_print("mlp_fwd  start|ln|fc1(0)|.. round2: fc1+act|barrier|fc2 ..|tail|epilogue|drain", 10, st);
       return 0;
     }
     switch (dbg) { DBG_CASE(1) DBG_CASE(2) DBG_CASE(3) DBG_CASE(4) DBG_CASE(6) DBG_CASE(7) default: return -4; }
