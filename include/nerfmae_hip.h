@@ -214,6 +214,8 @@ NMH_API int nmh_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamm
  *     window partition and their inverses are address arithmetic (wm as for nmh_layernorm_fwd).  Also writes, in the layouts of the unfused
  *     kernels (nmh_layernorm_fwd src_mode 1, nmh_gemm_nt, nmh_window_attn_fwd): xnw [rows][C] = LN1(x) in window order (pad rows zero), mean / rstd
  *     [T], qkv [rows][3C], o [rows][C], lse [rows * heads] -- the operands of the weight gradients and of the backward kernels.
+ *     token_saves != 0: xnw and o are written in TOKEN order instead ([T][C]; pad rows, which are zero / carry no gradient, are dropped): the operands of
+ *     weight gradients that run on the real tokens only (with nmh_window_attn_bwd_tokens).
  *   nmh_swin_mlp_fwd: x2[row] = x1[row] + rowscale[..] * (gelu(LN2(x1) W1^T + b1) W2^T + b2); also writes x1n = LN2(x1) [M][C], the fc1
  *     pre-activation hp [M][4C], mean / rstd [M] and, when hact != NULL, gelu(hp) [M][4C] (the unfused backward's fc2 weight-gradient operand).
  *     split_ws (optional): nmh_swin_mlp_split_ws_bytes(M, C) bytes, zero before the first call and left zero by every call (calls that share it
@@ -233,7 +235,7 @@ typedef struct nmh_swin_pack_item { const float* w0; const float* w1; void* dst;
 NMH_API int nmh_swin_supported(int C);
 NMH_API int64_t nmh_swin_stream_numel(int type, int C);
 NMH_API int nmh_swin_pack(const nmh_swin_pack_item* items, int n, void* stream);
-NMH_API int nmh_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* bias_table, const float* bproj, const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1, const int* wm, int C, float eps, void* stream);
+NMH_API int nmh_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* bias_table, const float* bproj, const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1, const int* wm, int C, float eps, int token_saves, void* stream);
 NMH_API int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale, void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, int64_t M, int C, float eps, void* split_ws, int64_t split_ws_bytes, void* stream);
 NMH_API int64_t nmh_swin_mlp_split_ws_bytes(int64_t M, int C);
 NMH_API int nmh_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale, int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm, int64_t M, int C, void* stream);
@@ -247,6 +249,14 @@ NMH_API int nmh_window_gather_scale(int dt, const void* dx, void* dyw, const flo
  * qkv [windows*64, 3C] window-ordered ([q|k|v], head-major), out [windows*64, C], lse [windows*heads*64]. head_dim must be 32. */
 NMH_API int nmh_window_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const int* wm, void* stream);
 NMH_API int nmh_window_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C, const int* wm, void* stream);
+/* The same backward with window order confined to the kernel: dout_tok [T][C] is the TOKEN-ordered gradient of the attention output (rows of a window that
+ * are pads read as zero -- the reference's x[:, :H, :W, :D] slice, swin_mae3d.py:196), and the rows of d(qkv) that belong to a token are written to
+ * dqkv_tok [T][3C] at their token, so that the Linear layers either side (proj, qkv: input gradients and weight gradients) run on the T real tokens
+ * instead of the padded window rows (58 % of them at 10^3 tokens in 12^3, 24 % at 5^3 in 8^3).  Pad rows' d(qkv) -- not zero: pad tokens are keys and
+ * values with q = k = v = bias -- go to dqkv_pad [rows][3C] at their window row (real rows of that buffer are not touched), and
+ * nmh_window_pad_rows_colsum adds their column sums to the qkv bias gradient: out[n] += sum over pad rows of x[row][n]. */
+NMH_API int nmh_window_attn_bwd_tokens(int dt, const void* qkv, const float* bias_table, const void* dout_tok, const float* lse, void* dqkv_tok, void* dqkv_pad, float* dbias_table, int heads, int C, const int* wm, void* stream);
+NMH_API int nmh_window_pad_rows_colsum(int dt, const void* x, int N, const int* wm, float* out, void* stream);
 
 /* InstanceNorm3d (eps, no affine, biased var) + LeakyReLU(slope) + residual over channels-last [B][V][C] (unetr_block.py:57-71).
  * stats[b][c] = {mean, rstd}; scratch/sums: fp64 [B][C][2].  rmode 0: lrelu(IN(x)); 1: lrelu(IN(x)+r); 2: lrelu(IN(x)+IN(r)). */

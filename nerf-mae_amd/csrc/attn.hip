@@ -211,7 +211,10 @@ __device__ __forceinline__ void store4(float* p, const f32x4& v, float s) { *rei
 
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table, const T* __restrict__ dout, const float* __restrict__ lse,
-                                                        T* __restrict__ dqkv, float* __restrict__ dtable, int heads, int C, WinMap wm, long nwin) {
+                                                        T* __restrict__ dqkv, float* __restrict__ dtable, int heads, int C, WinMap wm, long nwin, T* __restrict__ dqkv_tok) {
+  // dqkv_tok != nullptr (token mode): dout is TOKEN-ordered [T][C] (pad rows of a window read as zero) and the rows of dqkv that belong to a token go to
+  // dqkv_tok[token] -- window order then lives inside this kernel only, and the GEMMs either side of it run on the real tokens.  Pad rows are still
+  // written to dqkv at their window row: the qkv bias gradient sums them too (k_attn_pad_rows_colsum).
   constexpr int RS = OddRS32<32 * (int)sizeof(T)>::v;
   __shared__ __attribute__((aligned(16))) char sA[NW][64 * RS];   // K tile (phase A), then Q tile (phase B)
   __shared__ __attribute__((aligned(16))) char sO[NW][64 * RS];   // dO tile
@@ -252,12 +255,24 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
     const int binA = (c1 + 3) * 7 + c2 + 3;  // phase A (i = 16it+li, j = 16jt+4g+r): binA + (it-jt+3)*49 - r
     const int binB = (3 - c1) * 7 + 3 - c2;  // phase B (i = 16it+4g+r, j = 16jt+li): binB + (it-jt+3)*49 + r
     Frag<T> kf[4], qf[4], vf[4];
+    int tk[4] = {0, 0, 0, 0};   // token mode: token of window row 16 t + li, -1 = pad
+    if (dqkv_tok) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) tk[t] = (int)win_to_tok(wm, win * 64 + 16 * t + li);
+    }
     {
       Frag<T> df[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         kf[t] = gfrag<T>(kb, ld, t * 16 + li, g); qf[t] = gfrag<T>(qb, ld, t * 16 + li, g);
-        vf[t] = gfrag<T>(vb, ld, t * 16 + li, g); df[t] = gfrag<T>(dob, (long)C, t * 16 + li, g);
+        vf[t] = gfrag<T>(vb, ld, t * 16 + li, g);
+        if (dqkv_tok) {
+          if (tk[t] >= 0) df[t] = gfrag<T>(dout + h * 32, (long)C, tk[t], g);
+          else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) df[t].v[j] = 0;
+          }
+        } else df[t] = gfrag<T>(dob, (long)C, t * 16 + li, g);
       }
       sL[wave][lane] = lse[(win * heads + h) * 64 + lane];
       if (shifted) reinterpret_cast<unsigned char*>(sR[wave])[lane] = (unsigned char)token_region(wm, (int)(win % nW), lane);
@@ -316,8 +331,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
           mma(o[dt], b, a);
         }
       }
+      {
+        T* const rowp = (dqkv_tok && tk[it] >= 0) ? dqkv_tok + (long)tk[it] * ld + h * 32 : dqb + (long)i * ld;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) store4(dqb + (long)i * ld + 16 * dt + 4 * g, o[dt], scale);
+        for (int dt = 0; dt < 2; ++dt) store4(rowp + 16 * dt + 4 * g, o[dt], scale);
+      }
       __builtin_amdgcn_sched_barrier(0);   // keeps the query tiles sequential (interleaved, they need 4x the registers)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -367,10 +385,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
           mma(ok[dt], bq, ad);
         }
       }
+      {
+        T* const rowp = (dqkv_tok && tk[jt] >= 0) ? dqkv_tok + (long)tk[jt] * ld + h * 32 : dqb + (long)j * ld;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        store4(dqb + (long)j * ld + 2 * C + 16 * dt + 4 * g, ov[dt], 1.0f);
-        store4(dqb + (long)j * ld + C + 16 * dt + 4 * g, ok[dt], scale);
+        for (int dt = 0; dt < 2; ++dt) {
+          store4(rowp + 2 * C + 16 * dt + 4 * g, ov[dt], 1.0f);
+          store4(rowp + C + 16 * dt + 4 * g, ok[dt], scale);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -393,7 +414,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
   for (int t = threadIdx.x; t < 343; t += 64 * NW) atomicAdd(dtable + t * heads + h, sDB[t]);
 }
 
-int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, const float* lse, void* dqkv, float* dtable, int heads, int C, const WinMap& wm, hipStream_t st) {
+int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, const float* lse, void* dqkv, float* dtable, int heads, int C, const WinMap& wm, hipStream_t st,
+               void* dqkv_tok) {
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   // one wave per (window, head); a wave loops over several windows only when there are more waves than the chip holds at once -- 8 per CU in
@@ -411,9 +433,70 @@ int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, co
   if (gx > cap) gx = cap;
   dim3 grid((unsigned)gx, heads);
   if (dt == NMH_DT_BF16) {
-    if (nw == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin);
-    else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin);
-  } else hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), dim3((unsigned)gx, heads), dim3(128), 0, st, (const float*)qkv, table, (const float*)dout, lse, (float*)dqkv, dtable, heads, C, wm, nwin);
+    if (nw == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
+    else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
+  } else hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), dim3((unsigned)gx, heads), dim3(128), 0, st, (const float*)qkv, table, (const float*)dout, lse, (float*)dqkv, dtable, heads, C, wm, nwin, (float*)dqkv_tok);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[n] += sum over the PAD rows (window rows without a token) of x[row][n]: the part of the qkv bias gradient that the token-ordered weight-gradient
+// GEMM does not see (pad tokens enter the attention as keys / values with q = k = v = bias, swin_mae3d.py:62-112, so their d(qkv) is not zero).
+// A workgroup walks every gridDim.x-th window: thread = (8-column chunk, row slice); the window's pad rows are listed once per window (wave ballot).
+template <typename T>
+__global__ __launch_bounds__(512) void attn_pad_rows_colsum_kernel(const T* __restrict__ x, int N, WinMap wm, long nwin, float* __restrict__ out) {
+  extern __shared__ float ssum[];   // [N]
+  __shared__ unsigned char list[64];   // the window's pad rows, compacted
+  __shared__ int npad;
+  const int nch = N >> 3, S = 512 / nch > 0 ? 512 / nch : 1;   // nch <= 512 (launcher)
+  const int c = threadIdx.x % nch, sl = threadIdx.x / nch;
+  for (int i = threadIdx.x; i < N; i += 512) ssum[i] = 0.f;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long win = blockIdx.x; win < nwin; win += gridDim.x) {
+    __syncthreads();
+    if (threadIdx.x < 64) {   // wave 0: ballot of the pad rows -> compact list
+      const bool p = win_to_tok(wm, win * 64 + threadIdx.x) < 0;
+      const unsigned long long m = __ballot(p);
+      if (p) list[__popcll(m & ((1ull << threadIdx.x) - 1ull))] = (unsigned char)threadIdx.x;
+      if (threadIdx.x == 0) npad = __popcll(m);
+    }
+    __syncthreads();
+    const int n = npad;
+    if (sl < S) {
+      const T* const base = x + win * 64 * (long)N + c * 8;
+      int i = sl;
+      for (; i + 3 * S < n; i += 4 * S) {   // four independent loads in flight
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Vec8<T>::load(base + (long)list[i + u * S] * N, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += v[u][j];
+      }
+      for (; i < n; i += S) {
+        float v[8];
+        Vec8<T>::load(base + (long)list[i] * N, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      }
+    }
+  }
+  if (sl < S) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&ssum[c * 8 + j], acc[j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += 512) atomicAdd(out + i, ssum[i]);
+}
+int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float* out, hipStream_t st) {
+  if (N % 8) return -2;
+  const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
+  if ((long)wm.PH * wm.PW * wm.PD == (long)wm.H * wm.W * wm.D) return 0;   // no pad rows
+  if (N > 4096) return -2;   // (one chunk per thread: N / 8 <= 512)
+  const unsigned nb = (unsigned)(nwin < 128 ? nwin : 128);
+  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<bf16_t>, dim3(nb), dim3(512), N * sizeof(float), st, (const bf16_t*)x, N, wm, nwin, out);
+  else hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<float>, dim3(nb), dim3(512), N * sizeof(float), st, (const float*)x, N, wm, nwin, out);
   NMH_CHECK_LAUNCH();
   return 0;
 }

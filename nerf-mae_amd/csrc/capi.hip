@@ -273,10 +273,10 @@ int nmh_swin_pack(const nmh_swin_pack_item* items, int n, void* stream) {
 }
 int nmh_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* bias_table, const float* bproj,
                       const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1, const int* wm, int C,
-                      float eps, void* stream) {
+                      float eps, int token_saves, void* stream) {
   CLR();
   REQ(x, gamma, beta, wstream, bqkv, bias_table, bproj, xnw, mean, rstd, qkv, o, lse, x1, wm);
-  return k_swin_attn_fwd(x, gamma, beta, wstream, bqkv, bias_table, bproj, rowscale, rows_per_scale, xnw, mean, rstd, qkv, o, lse, x1, to_wm(wm), C, eps, ST);
+  return k_swin_attn_fwd(x, gamma, beta, wstream, bqkv, bias_table, bproj, rowscale, rows_per_scale, xnw, mean, rstd, qkv, o, lse, x1, to_wm(wm), C, eps, token_saves, ST);
 }
 int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale,
                      void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, int64_t M, int C, float eps, void* split_ws, int64_t split_ws_bytes,
@@ -327,6 +327,17 @@ int nmh_window_attn_bwd(int dt, const void* qkv, const float* bias_table, const 
                         const int* wm, void* stream) {
   CLR();
   return k_attn_bwd(dt, qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, to_wm(wm), ST);
+}
+int nmh_window_attn_bwd_tokens(int dt, const void* qkv, const float* bias_table, const void* dout_tok, const float* lse, void* dqkv_tok, void* dqkv_pad, float* dbias_table,
+                               int heads, int C, const int* wm, void* stream) {
+  CLR();
+  REQ(qkv, bias_table, dout_tok, lse, dqkv_tok, dqkv_pad, dbias_table, wm);
+  return k_attn_bwd(dt, qkv, bias_table, dout_tok, lse, dqkv_pad, dbias_table, heads, C, to_wm(wm), ST, dqkv_tok);
+}
+int nmh_window_pad_rows_colsum(int dt, const void* x, int N, const int* wm, float* out, void* stream) {
+  CLR();
+  REQ(x, wm, out);
+  return k_attn_pad_rows_colsum(dt, x, N, to_wm(wm), out, ST);
 }
 int nmh_instnorm_stats(int dt, const void* x, float* stats, double* scratch, int B, int64_t V, int C, float eps, void* stream) {
   CLR();

@@ -198,7 +198,7 @@ int k_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const 
                    void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, long M, int C, float eps, void* split_ws, long split_ws_bytes, hipStream_t st);
 int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* table, const float* bproj,
                     const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1,
-                    const WinMap& wm, int C, float eps, hipStream_t st);
+                    const WinMap& wm, int C, float eps, int token_saves, hipStream_t st);
 
 int k_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale,
                    int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const WinMap* wm, long M, int C,
@@ -221,7 +221,8 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
 
 // ---- attn.hip ----
 int k_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st);
-int k_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C, const WinMap& wm, hipStream_t st);
+int k_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C, const WinMap& wm, hipStream_t st, void* dqkv_tok = nullptr);
+int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float* out, hipStream_t st);
 
 // ---- misc.hip ----
 int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st);

@@ -560,6 +560,7 @@ struct AttnFwdArgs {
   const float* rowscale; int rows_per_scale;
   bf16_t* xnw; float* mean; float* rstd; bf16_t* qkv; bf16_t* o; float* lse; bf16_t* x1;
   WinMap wm; float eps; long long* ts;
+  int tok_saves;   // xnw and o are written in TOKEN order ([T][C], pad rows dropped) -- the operands of token-ordered weight gradients (nmh_window_attn_bwd_tokens)
 };
 
 __device__ __forceinline__ int relidx(int i, int j) {
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(64 * NW) void swin_attn_fwd_kernel(AttnFwdArgs a) {
   long tok[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) tok[m] = win_to_tok(a.wm, win * 64 + 16 * m + li);
-  ln_exchange<KS, NW>(a.x, [&](int m) { const long t = win_to_tok(a.wm, win * 64 + 16 * m + li); return RowIdx{t, win * 64 + 16 * m + li, t}; },
+  ln_exchange<KS, NW>(a.x, [&](int m) { const long t = win_to_tok(a.wm, win * 64 + 16 * m + li); return RowIdx{t, a.tok_saves ? t : win * 64 + 16 * m + li, t}; },
                       a.gamma, a.beta, a.eps, a.xnw, a.mean, a.rstd, scratch, xn, wave, lane);
   {
     const unsigned tab_a = lds_addr(sTab), sr_a = lds_addr(sRb);
@@ -725,7 +726,8 @@ __global__ __launch_bounds__(64 * NW) void swin_attn_fwd_kernel(AttnFwdArgs a) {
         }
       }
       ofj[it] = pack_tr(oT[0], oT[1]);
-      *reinterpret_cast<bf16x8*>(a.o + (win * 64 + 16 * it + li) * C + 32 * h + 8 * g) = ofj[it].v;
+      if (!a.tok_saves) *reinterpret_cast<bf16x8*>(a.o + (win * 64 + 16 * it + li) * C + 32 * h + 8 * g) = ofj[it].v;
+      else if (tok[it] >= 0) *reinterpret_cast<bf16x8*>(a.o + tok[it] * C + 32 * h + 8 * g) = ofj[it].v;
     }
     // (no dynamic register indexing: `of[j]` with a run-time j would put the array into scratch memory)
 #pragma unroll
@@ -1538,9 +1540,9 @@ template <int NW> static int launch_attn_fwd(const sw::AttnFwdArgs& a, long nwin
 }
 int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* table, const float* bproj,
                     const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1,
-                    const WinMap& wm, int C, float eps, hipStream_t st) {
+                    const WinMap& wm, int C, float eps, int token_saves, hipStream_t st) {
   sw::AttnFwdArgs a{(const bf16_t*)x, gamma, beta, (const char*)wstream, bqkv, table, bproj, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
-                    (bf16_t*)xnw, mean, rstd, (bf16_t*)qkv, (bf16_t*)o, lse, (bf16_t*)x1, wm, eps, nullptr};
+                    (bf16_t*)xnw, mean, rstd, (bf16_t*)qkv, (bf16_t*)o, lse, (bf16_t*)x1, wm, eps, nullptr, token_saves};
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   if (nwin <= 0) return 0;
   if (nwin * 64 >= (1L << 31)) return -2;

@@ -270,10 +270,15 @@ class _BlockFn(torch.autograd.Function):
         dev, dtype = x.device, x.dtype
         tps = T // geom.B
         sw = getattr(b, "_sw", None)
+        # token-ordered backward (padded stages: 10^3 tokens in 12^3 window rows): window order stays inside the attention kernels, the Linear layers of the
+        # attention branch see the real tokens only in the backward pass -- the forward then saves LN1(x) and o in token order
+        ctx.tok_bwd = (sw is not None and ops.swin_attn_ok(x, C, geom) and ops.TOKEN_BWD and geom.rows != geom.tokens and ctx.needs_input_grad[0]
+                       and ops.SWIN_ATTN_BWD not in sw and ops.SWIN_QKV_BWD not in sw and ops.SWIN_MLP_BWD not in sw and not ops.mlp_fused_ok(x, C, T))
         if sw is not None and ops.swin_attn_ok(x, C, geom):
             # LN1 -> QKV -> window attention -> proj -> row scale -> + residual in ONE launch (csrc/swin_block.hip); saves the same tensors
             x1, xnw, mean1, rstd1, qkv, o, lse = ops.swin_attn_fwd(x, b.norm1.weight, b.norm1.bias, sw[ops.SWIN_ATTN_FWD], b.attn.qkv.bias,
-                                                                   b.attn.relative_position_bias_table, b.attn.proj.bias, geom, rowscale=sd1, rows_per_scale=tps)
+                                                                   b.attn.relative_position_bias_table, b.attn.proj.bias, geom, rowscale=sd1, rows_per_scale=tps,
+                                                                   token_saves=ctx.tok_bwd)
         else:
             xnw = torch.empty((geom.rows, C), dtype=dtype, device=dev)
             mean1, rstd1 = torch.empty(T, device=dev), torch.empty(T, device=dev)
@@ -331,7 +336,9 @@ class _BlockFn(torch.autograd.Function):
                 with ops.side_stream(enable=T >= ops.side_stream.min_rows):
                     ops.gemm_tn(A, Bm, _gradbuf(lin.weight), rowscale=rowscale, rows_per_scale=rps, dbias=_gradbuf(lin.bias))
         # ---- MLP branch
-        dyw = torch.empty_like(xnw)   # = sd1 * dx1 in window order (adjoint of the window reverse), second output of the LN backward
+        tok_bwd = ctx.tok_bwd
+        # = sd1 * dx1 in window order (adjoint of the window reverse), second output of the LN backward; not formed by the token-ordered backward
+        dyw = None if tok_bwd else torch.empty_like(xnw)
         sw = getattr(b, "_sw", None)
         if ctx.sw_mlp_bwd:
             # one launch: hact / dh (operands of the two weight gradients), dx1 and its window-ordered copy, dgamma / dbeta (csrc/swin_block.hip)
@@ -353,10 +360,28 @@ class _BlockFn(torch.autograd.Function):
             wgrad(dh, x1n, b.mlp[0])
             dx1 = torch.empty_like(x)
             ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
-                              geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1, wq=q)   # (dgamma / dbeta: partial sums now, reduced with the stage's weight gradients)
+                              geom=None if tok_bwd else geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=None if tok_bwd else sd1, wq=q)   # (dgamma / dbeta: partial sums now, reduced with the stage's weight gradients)
         # ---- attention branch
         fused_ok = sw is not None and ops.swin_attn_ok(x, C, geom)
-        if fused_ok and ops.SWIN_ATTN_BWD in sw:
+        if tok_bwd:
+            # xnw / o hold LN1(x) / the attention output in TOKEN order here; every GEMM below has T rows
+            dtab = _gradbuf(b.attn.relative_position_bias_table)
+            do = ops.gemm_nt(dx1, pk[key + "proj.wT"].view(C, C), rowscale=sd1, rows_per_scale=tps)           # gradient of the attention output, token order
+            wgrad(dx1, o, b.attn.proj, rowscale=sd1)
+            dqkv = torch.empty((T, 3 * C), dtype=x.dtype, device=x.device)
+            dq_pad = torch.empty_like(qkv)                                                                     # only its pad rows are written (and read)
+            ops.window_attn_bwd_tokens(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, dq_pad, dtab, heads, C, geom)
+            dxn = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
+            wgrad(dqkv, xnw, b.attn.qkv)
+            g_qb = _gradbuf(b.attn.qkv.bias)
+            if q is not None:   # the pad rows' share of the qkv bias gradient, with the stage's weight gradients
+                q.defer(lambda: ops.window_pad_rows_colsum(dq_pad, g_qb, geom))
+            else:
+                with ops.side_stream():
+                    ops.window_pad_rows_colsum(dq_pad, g_qb, geom)
+            dx = torch.empty_like(x)
+            ops.layernorm_bwd(dxn, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, dres=dx1, wq=q)
+        elif fused_ok and ops.SWIN_ATTN_BWD in sw:
             dqkv = ops.swin_attn_bwd(dyw, qkv, b.attn.relative_position_bias_table, lse, sw[ops.SWIN_ATTN_BWD], _gradbuf(b.attn.relative_position_bias_table), geom)
             wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
         else:
@@ -368,7 +393,9 @@ class _BlockFn(torch.autograd.Function):
             wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
             dqkv = torch.empty_like(qkv)
             ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
-        if fused_ok and ops.SWIN_QKV_BWD in sw:
+        if tok_bwd:
+            pass
+        elif fused_ok and ops.SWIN_QKV_BWD in sw:
             dx = ops.swin_qkv_bwd(dqkv, x, dx1, mean1, rstd1, b.norm1.weight, sw[ops.SWIN_QKV_BWD], _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), geom)
             wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
         else:

@@ -585,6 +585,7 @@ def gemm_nt_window_scatter(A, W, out, resid, bias, rowscale, tokens_per_sample, 
     return out
 
 
+TOKEN_BWD = __import__("os").environ.get("NMH_TOKEN_BWD", "1") != "0"   # padded stages behind a fused attention forward: token-ordered backward (model._BlockFn)
 TOKEN_ROWS = __import__("os").environ.get("NMH_TOKEN_ROWS", "0") != "0"   # padded stages: the window-ordered input-gradient GEMMs run on the real tokens only
 _PAD_ZERO = {}
 
@@ -700,20 +701,22 @@ def swin_pack(arr):
     lib().call("nmh_swin_pack", arr, len(arr), _st())
 
 
-def swin_attn_fwd(x, gamma, beta, wstream, bqkv, table, bproj, geom: WinGeom, rowscale=None, rows_per_scale=1, eps=1e-5):
-    """-> (x1, xnw, mean, rstd, qkv, o, lse): the whole attention branch of a Swin block in one launch (+ what its backward / weight gradients read)"""
+def swin_attn_fwd(x, gamma, beta, wstream, bqkv, table, bproj, geom: WinGeom, rowscale=None, rows_per_scale=1, eps=1e-5, token_saves=False):
+    """-> (x1, xnw, mean, rstd, qkv, o, lse): the whole attention branch of a Swin block in one launch (+ what its backward / weight gradients read).
+    token_saves: xnw and o come back in token order, [T, C] (for the token-ordered backward: window_attn_bwd_tokens)"""
     _chk(x, gamma, beta, wstream, bqkv, table, bproj, rowscale)
     T, C = x.shape
     heads = C // 32
     dev, dt = x.device, x.dtype
     x1 = torch.empty_like(x)
-    xnw = torch.empty((geom.rows, C), dtype=dt, device=dev)
+    xnw = torch.empty((T if token_saves else geom.rows, C), dtype=dt, device=dev)
     mean, rstd = torch.empty(T, device=dev), torch.empty(T, device=dev)
     qkv = torch.empty((geom.rows, 3 * C), dtype=dt, device=dev)
-    o = torch.empty((geom.rows, C), dtype=dt, device=dev)
+    o = torch.empty((T if token_saves else geom.rows, C), dtype=dt, device=dev)
     lse = torch.empty(geom.rows * heads, device=dev)
     ev = _prof(("swin_attn_fwd", geom.rows, C))
-    lib().call("nmh_swin_attn_fwd", x, gamma, beta, wstream, bqkv, table, bproj, rowscale, rows_per_scale, xnw, mean, rstd, qkv, o, lse, x1, geom.carr, C, eps, _st())
+    lib().call("nmh_swin_attn_fwd", x, gamma, beta, wstream, bqkv, table, bproj, rowscale, rows_per_scale, xnw, mean, rstd, qkv, o, lse, x1, geom.carr, C, eps,
+               int(token_saves), _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return x1, xnw, mean, rstd, qkv, o, lse
@@ -814,6 +817,19 @@ def window_attn_bwd(qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, geo
     _chk(qkv, bias_table, dout, lse, dqkv, dbias_table)
     lib().call("nmh_window_attn_bwd", dt_of(qkv), qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, geom.carr, _st())
     return dqkv
+
+
+def window_attn_bwd_tokens(qkv, bias_table, dout_tok, lse, dqkv_tok, dqkv_pad, dbias_table, heads, C, geom: WinGeom):
+    """attention-core backward with token-ordered dO in / d(qkv) out (include/nerfmae_hip.h: nmh_window_attn_bwd_tokens); dqkv_pad [geom.rows, 3C] receives the pad rows"""
+    _chk(qkv, bias_table, dout_tok, lse, dqkv_tok, dqkv_pad, dbias_table)
+    lib().call("nmh_window_attn_bwd_tokens", dt_of(qkv), qkv, bias_table, dout_tok, lse, dqkv_tok, dqkv_pad, dbias_table, heads, C, geom.carr, _st())
+    return dqkv_tok
+
+
+def window_pad_rows_colsum(x, out, geom: WinGeom):
+    """out[n] += sum of x[row][n] over the window rows that hold no token"""
+    _chk(x, out)
+    lib().call("nmh_window_pad_rows_colsum", dt_of(x), x, x.shape[1], geom.carr, out, _st())
 
 
 def instnorm_stats(x, stats, scratch, B, V, C, eps=1e-5):

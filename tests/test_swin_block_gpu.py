@@ -242,3 +242,92 @@ def test_swin_mlp_split_full_size_is_reproducible_and_matches_unsplit():
         y = torch.nn.functional.gelu(n2 @ W1.to(BF).double().T + b1.cpu().double()) @ W2.to(BF).double().T + b2.cpu().double()
         x2_ref = xf + rs.cpu().double().repeat_interleave(tps)[:, None] * y
     assert_close(outs[0][0], x2_ref, TOL, "x2 vs fp64")
+
+
+@pytest.mark.parametrize("C", [96, 384])
+@pytest.mark.parametrize("shape,shift", [((2, 10, 10, 10), 2), ((1, 5, 5, 5), 2), ((2, 10, 10, 10), 0), ((1, 6, 8, 4), 2), ((2, 8, 8, 8), 2)])
+def test_token_ordered_attention_backward(C, shape, shift):
+    """the attention branch's backward with window order confined to the attention kernels (model._BlockFn, padded stages): fused forward with token-ordered
+    saves -> proj input gradient on T rows -> nmh_window_attn_bwd_tokens -> qkv input gradient on T rows -> plain LayerNorm backward.  Against (1) the
+    window-ordered kernels on the same data, row by row -- the token rows bit-identical -- and (2) fp64 autograd of the oracle block, including the
+    weight / bias gradients formed from the token-ordered operands plus the pad rows' share of the qkv bias gradient (nmh_window_pad_rows_colsum)"""
+    ops = _ops()
+    B, H, W, D = shape
+    geom = ops.WinGeom(B, H, W, D, [shift] * 3)
+    T, heads = geom.tokens, C // 32
+    tps = T // B
+    blk = make_block(C, shift, seed=2)
+    x = qb(rnd(B, H, W, D, C, seed=6) * 1.3 + 0.1)
+    dy1 = qb(rnd(B, H, W, D, C, seed=7))     # gradient arriving at x1 (the MLP branch's backward output in the model)
+    sd1 = torch.tensor([1.0 / 0.9, 0.5] if B == 2 else [1.0 / 0.95])
+    xr = x.double().requires_grad_(True)
+    x1_ref = xr + sd1.double().view(B, 1, 1, 1, 1) * blk.attn(blk.norm1(xr))
+    x1_ref.backward(dy1.double())
+    st, w = streams(ops, blk, C, [ops.SWIN_ATTN_FWD])
+    f = lambda p: dev(p.detach().float())
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    xd, dx1 = dev(x.view(T, C), BF), dev(dy1.view(T, C), BF)
+    sd1d = dev(sd1)
+    g1, b1n, tab = f(blk.norm1.weight), f(blk.norm1.bias), f(blk.attn.relative_position_bias_table)
+    args = (xd, g1, b1n, st[ops.SWIN_ATTN_FWD], f(blk.attn.qkv.bias), tab, f(blk.attn.proj.bias), geom)
+    x1w, xnw, mean1, rstd1, qkv, o_w, lse = ops.swin_attn_fwd(*args, rowscale=sd1d, rows_per_scale=tps)
+    x1t, xn_t, mean1t, rstd1t, qkv_t, o_t, lse_t = ops.swin_attn_fwd(*args, rowscale=sd1d, rows_per_scale=tps, token_saves=True)
+    torch.cuda.synchronize()
+    # window row of every token (the reference's pad -> roll -> partition applied to an index volume)
+    from oracle import mae3d_oracle as O
+    idx = torch.arange(1, T + 1, dtype=torch.float32).view(B, H, W, D, 1)
+    pad = [g_ - s_ for g_, s_ in zip(geom.P, (H, W, D))]
+    ip = torch.nn.functional.pad(idx, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+    if shift:
+        ip = torch.roll(ip, shifts=[-s_ for s_ in geom.shift], dims=(1, 2, 3))
+    tok_of_row = O.window_partition(ip).reshape(-1).long() - 1            # -1: pad row
+    real = (tok_of_row >= 0).cuda()
+    row_of_tok = torch.empty(T, dtype=torch.long)
+    row_of_tok[tok_of_row[tok_of_row >= 0]] = torch.nonzero(tok_of_row >= 0).flatten()
+    row_of_tok = row_of_tok.cuda()
+    assert torch.equal(x1t, x1w) and torch.equal(qkv_t, qkv) and torch.equal(lse_t, lse)
+    assert torch.equal(xn_t, xnw[row_of_tok]) and torch.equal(o_t, o_w[row_of_tok]), "token-ordered saves differ from the window-ordered ones"
+    # ---- window-ordered chain (the kernels the model used before)
+    WpT, WqT = dev(w["proj"].T.contiguous(), BF), dev(w["qkv"].T.contiguous(), BF)
+    dyw = torch.empty_like(xnw)
+    ops.window_gather_scale(dx1, dyw, sd1d, C, geom)
+    do_w = ops.gemm_nt(dyw, WpT)
+    dqkv_w, dtab_w = torch.empty_like(qkv), z(343, heads)
+    ops.window_attn_bwd(qkv, tab, do_w, lse, dqkv_w, dtab_w, heads, C, geom)
+    # ---- token-ordered chain
+    # (a) the kernel alone, on the window chain's own dO gathered to token order: the same arithmetic, so the rows must be bit-identical
+    dq_x, dq_padx, dtab_x = torch.empty(T, 3 * C, dtype=BF, device="cuda"), torch.full_like(qkv, float("nan")), z(343, heads)
+    ops.window_attn_bwd_tokens(qkv, tab, do_w[row_of_tok].contiguous(), lse, dq_x, dq_padx, dtab_x, heads, C, geom)
+    torch.cuda.synchronize()
+    assert torch.equal(dq_x, dqkv_w[row_of_tok]), "d(qkv) of the tokens differs from the window-ordered kernel's rows"
+    if int((~real).sum()):
+        assert torch.equal(dq_padx[~real], dqkv_w[~real]), "d(qkv) of the pad rows differs"
+        assert bool(torch.isnan(dq_padx[real].float()).all()), "token rows of the pad buffer were written"
+    assert_close(dtab_x, dtab_w.cpu(), 1e-3, "d(bias table) (fp32 atomics in another order)")
+    # (b) the chain the model runs: dO from the token-ordered gradient with the stochastic-depth scale in the GEMM's epilogue
+    do_t = ops.gemm_nt(dx1, WpT, rowscale=sd1d, rows_per_scale=tps)
+    dq_t, dq_pad, dtab_t = torch.empty(T, 3 * C, dtype=BF, device="cuda"), torch.full_like(qkv, float("nan")), z(343, heads)
+    ops.window_attn_bwd_tokens(qkv, tab, do_t, lse, dq_t, dq_pad, dtab_t, heads, C, geom)
+    torch.cuda.synchronize()
+    assert_close(do_t, do_w[row_of_tok].float().cpu(), 1e-2, "dO (scaled in the epilogue vs scaled before the product)")
+    assert_close(dq_t, dqkv_w[row_of_tok].float().cpu(), 2 * TOL, "d(qkv) of the tokens (dO rounded once instead of twice)")
+    assert_close(dtab_t, dtab_w.cpu(), TOL, "d(bias table)")
+    dbq = z(3 * C)
+    ops.window_pad_rows_colsum(dq_pad, dbq, geom)
+    ref_pad = dq_pad[~real].float().sum(0).cpu() if int((~real).sum()) else torch.zeros(3 * C)
+    assert_close(dbq, ref_pad, 1e-3, "pad rows' column sums")
+    dxn = ops.gemm_nt(dq_t, WqT)
+    dx, dg1, db1 = torch.empty_like(xd), z(C), z(C)
+    ops.layernorm_bwd(dxn, xd, g1, mean1, rstd1, dx, dg1, db1, T, C, dres=dx1)
+    torch.cuda.synchronize()
+    # ---- against autograd
+    assert_close(dx, xr.grad.view(T, C), 2 * TOL, "dx vs autograd", elem_mult=2.0)
+    assert_close(dg1, blk.norm1.weight.grad, 2 * TOL, "dgamma1 vs autograd")
+    assert_close(db1, blk.norm1.bias.grad, 2 * TOL, "dbeta1 vs autograd")
+    assert_close(dtab_t, blk.attn.relative_position_bias_table.grad, 2 * TOL, "d(bias table) vs autograd")
+    rs1 = sd1.double().repeat_interleave(tps)[:, None]
+    dyf, of, dqf, xnf = dy1.view(T, C).double(), o_t.float().cpu().double(), dq_t.float().cpu().double(), xn_t.float().cpu().double()
+    assert_close((rs1 * dyf).T @ of, blk.attn.proj.weight.grad, 2 * TOL, "proj weight gradient from (sd1 dx1, o) in token order")
+    assert_close((rs1 * dyf).sum(0), blk.attn.proj.bias.grad, 2 * TOL, "proj bias gradient")
+    assert_close(dqf.T @ xnf, blk.attn.qkv.weight.grad, 2 * TOL, "qkv weight gradient from (dqkv, LN1 x) in token order")
+    assert_close(dqf.sum(0) + dbq.cpu().double(), blk.attn.qkv.bias.grad, 2 * TOL, "qkv bias gradient = token rows + pad rows", elem_mult=2.0)
