@@ -11,7 +11,7 @@ run() { # label, grids, env...
   echo "$G grids  $L  ($*)  $ms ms" | tee -a $O
 }
 for G in 8 4 1; do
-  run "default (fused forward, split MLP, deferred LN parameter gradients)" $G X=0
+  run "default (fused forward, split MLP, deferred LN parameter gradients, token-ordered backward at stage 2)" $G X=0
   run "unfused encoder forward" $G NMH_SWIN=0
 done
 run "default, second run" 8 X=0
@@ -20,7 +20,7 @@ run "LayerNorm parameter gradients by atomics in the launch" 8 NMH_LN_DEFER=0
 run "fused MLP backward" 8 NMH_SWIN_BWD=mlp
 run "fused attention backward" 8 NMH_SWIN_BWD=attn
 run "fused qkv + LN1 backward" 8 NMH_SWIN_BWD=qkv
-run "token-rows input-gradient GEMMs at the padded stages" 8 NMH_TOKEN_ROWS=1
+run "window-ordered backward of the attention branch at stage 2" 8 NMH_TOKEN_BWD=0
 run "default, third run" 8 X=0
 NMH_SWIN_DBG=8 python tools/swin_phase_cycles.py 8 > gpurun_out/${T}_swin_phase_cycles.txt 2>&1
 tail -4 gpurun_out/${T}_swin_phase_cycles.txt

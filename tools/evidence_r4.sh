@@ -10,3 +10,5 @@ bash tools/pmc_kernel.sh ${T}_pmc "NONE" nerf-mae_amd/csrc/norm.hip -- python be
 python tools/pmc_families.py gpurun_out/${T}_pmc ${T} >> gpurun_out/${T}_pmc.log 2>&1
 find gpurun_out/${T}_pmc -name '*.csv' -size +20M -delete
 tail -3 gpurun_out/${T}_pmc.log
+bash tools/ab_round4.sh $T > gpurun_out/${T}_ab.log 2>&1
+tail -3 gpurun_out/${T}_ab.log
