@@ -255,6 +255,11 @@ NMH_API int nmh_window_attn_bwd(int dt, const void* qkv, const float* bias_table
  * instead of the padded window rows (58 % of them at 10^3 tokens in 12^3, 24 % at 5^3 in 8^3).  Pad rows' d(qkv) -- not zero: pad tokens are keys and
  * values with q = k = v = bias -- go to dqkv_pad [rows][3C] at their window row (real rows of that buffer are not touched), and
  * nmh_window_pad_rows_colsum adds their column sums to the qkv bias gradient: out[n] += sum over pad rows of x[row][n]. */
+/* Forward counterparts for the UNFUSED chain (small launches, fp32 parity mode): nmh_layernorm_fwd_window_tokens = nmh_layernorm_fwd src_mode 1 with a second,
+ * token-ordered copy of the normalised rows (out_tokens [T][C]); nmh_window_attn_fwd_tokens = nmh_window_attn_fwd with its output scattered to token
+ * order (out_tok [T][C], pad rows dropped) -- proj is then a plain T-row nmh_gemm_nt with the residual / row-scale epilogue. */
+NMH_API int nmh_layernorm_fwd_window_tokens(int dt, const void* x, void* out_window, void* out_tokens, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C, const int* wm, void* stream);
+NMH_API int nmh_window_attn_fwd_tokens(int dt, const void* qkv, const float* bias_table, void* out_tok, float* lse, int heads, int C, const int* wm, void* stream);
 NMH_API int nmh_window_attn_bwd_tokens(int dt, const void* qkv, const float* bias_table, const void* dout_tok, const float* lse, void* dqkv_tok, void* dqkv_pad, float* dbias_table, int heads, int C, const int* wm, void* stream);
 NMH_API int nmh_window_pad_rows_colsum(int dt, const void* x, int N, const int* wm, float* out, void* stream);
 

@@ -65,7 +65,9 @@ template <typename T, int RS> __device__ __forceinline__ void stage_tile(char* d
 // dependent chain per wave, and the chain gets shorter
 template <typename T, int NIT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ table, T* __restrict__ out, float* __restrict__ lse,
-                                                        int heads, int C, WinMap wm, long npairs) {
+                                                        int heads, int C, WinMap wm, long npairs, int tok_out) {
+  // tok_out: `out` is TOKEN-ordered [T][C] -- the row of a window goes to its token, pad rows are dropped (the proj GEMM and its weight gradient then run on
+  // the real tokens: nmh_window_attn_fwd_tokens)
   constexpr int RS = OddRS32<32 * (int)sizeof(T)>::v;
   __shared__ __attribute__((aligned(16))) char sV[4][64 * RS];
   __shared__ float sB[4][344];
@@ -147,11 +149,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) out[(win * 64 + 16 * (it0 + it) + 4 * g + r) * C + h * 32 + 16 * dt + li] = from_f<T>(o[dt][r]);
+      for (int r = 0; r < 4; ++r) {
+        long orow = win * 64 + 16 * (it0 + it) + 4 * g + r;
+        if (tok_out) orow = win_to_tok(wm, orow);
+        if (orow >= 0) out[orow * C + h * 32 + 16 * dt + li] = from_f<T>(o[dt][r]);
+      }
   }
 }
 
-int k_attn_fwd(int dt, const void* qkv, const float* table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st) {
+int k_attn_fwd(int dt, const void* qkv, const float* table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st, int tok_out) {
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   const long npairs = nwin * heads;
@@ -161,7 +167,7 @@ int k_attn_fwd(int dt, const void* qkv, const float* table, void* out, float* ls
   const char* qs_s = getenv("NMH_ATTN_QSPLIT");
   const int qs_env = qs_s ? atoi(qs_s) : 0;
   const int qs = qs_env ? qs_env : (npairs <= 768 ? 4 : (npairs <= 2560 ? 2 : (npairs <= 4000 ? 1 : 2)));
-#define ATTN_FWD(T, NIT) hipLaunchKernelGGL((attn_fwd_kernel<T, NIT>), dim3((unsigned)((npairs * (4 / NIT) + 3) / 4)), dim3(256), 0, st, (const T*)qkv, table, (T*)out, lse, heads, C, wm, npairs)
+#define ATTN_FWD(T, NIT) hipLaunchKernelGGL((attn_fwd_kernel<T, NIT>), dim3((unsigned)((npairs * (4 / NIT) + 3) / 4)), dim3(256), 0, st, (const T*)qkv, table, (T*)out, lse, heads, C, wm, npairs, tok_out)
   if (dt == NMH_DT_BF16) { if (qs == 4) ATTN_FWD(bf16_t, 1); else if (qs == 2) ATTN_FWD(bf16_t, 2); else ATTN_FWD(bf16_t, 4); }
   else { if (qs == 4) ATTN_FWD(float, 1); else if (qs == 2) ATTN_FWD(float, 2); else ATTN_FWD(float, 4); }
 #undef ATTN_FWD

@@ -170,7 +170,15 @@ int nmh_layernorm_fwd(int dt, int src_mode, const void* x, void* out, const floa
                       const int* wm, const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, void* stream) {
   CLR();
   if (rows <= 0) return 0;
-  LnArgs a{dt, src_mode, x, out, gamma, beta, eps, mean, rstd, (long)rows, C, to_wm(wm), pos, mask, mask_token, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1)};
+  LnArgs a{dt, src_mode, x, out, gamma, beta, eps, mean, rstd, (long)rows, C, to_wm(wm), pos, mask, mask_token, (long)(tokens_per_sample > 0 ? tokens_per_sample : 1), nullptr};
+  return k_ln_fwd(a, ST);
+}
+int nmh_layernorm_fwd_window_tokens(int dt, const void* x, void* out_window, void* out_tokens, const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                                    int64_t rows, int C, const int* wm, void* stream) {
+  CLR();
+  REQ(x, out_window, out_tokens, gamma, beta, mean, rstd, wm);
+  if (rows <= 0) return 0;
+  LnArgs a{dt, 1, x, out_window, gamma, beta, eps, mean, rstd, (long)rows, C, to_wm(wm), nullptr, nullptr, nullptr, 1, out_tokens};
   return k_ln_fwd(a, ST);
 }
 int nmh_layernorm_bwd(int dt, int src_mode, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres, void* dx,
@@ -322,6 +330,11 @@ int nmh_window_gather_scale(int dt, const void* dx, void* dyw, const float* rows
 int nmh_window_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const int* wm, void* stream) {
   CLR();
   return k_attn_fwd(dt, qkv, bias_table, out, lse, heads, C, to_wm(wm), ST);
+}
+int nmh_window_attn_fwd_tokens(int dt, const void* qkv, const float* bias_table, void* out_tok, float* lse, int heads, int C, const int* wm, void* stream) {
+  CLR();
+  REQ(qkv, bias_table, out_tok, lse, wm);
+  return k_attn_fwd(dt, qkv, bias_table, out_tok, lse, heads, C, to_wm(wm), ST, 1);
 }
 int nmh_window_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C,
                         const int* wm, void* stream) {

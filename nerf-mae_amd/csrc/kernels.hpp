@@ -141,6 +141,7 @@ struct LnArgs {
   long rows; int C;                     // rows = output rows; C = normalized width (8*Cin for mode 2)
   WinMap wm;                            // modes 1, 2 (mode 2 uses B,H,W,D as the *input* grid)
   const float* pos; const unsigned char* mask; const float* mask_token; long tokens_per_sample;  // patch-embed post-ops (mode 0)
+  void* out_tok;                        // mode 1, optional: a second, TOKEN-ordered copy of the normalised rows [T,C] (operand of a token-ordered weight gradient)
 };
 int k_ln_fwd(const LnArgs& a, hipStream_t st);
 struct LnBwdArgs {
@@ -220,7 +221,7 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
                    const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st);
 
 // ---- attn.hip ----
-int k_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st);
+int k_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st, int tok_out = 0);
 int k_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C, const WinMap& wm, hipStream_t st, void* dqkv_tok = nullptr);
 int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float* out, hipStream_t st);
 

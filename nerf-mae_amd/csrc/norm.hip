@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
           }
         }
         Vec8<T>::store(out + row * C + c * 8, o);
+        if (MODE == 1 && a.out_tok && valid) Vec8<T>::store((T*)a.out_tok + tok * C + c * 8, o);
       }
     }
     if (sub == 0 && valid) { a.mean[tok] = mean; a.rstd[tok] = rstd; }

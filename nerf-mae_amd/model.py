@@ -272,13 +272,27 @@ class _BlockFn(torch.autograd.Function):
         sw = getattr(b, "_sw", None)
         # token-ordered backward (padded stages: 10^3 tokens in 12^3 window rows): window order stays inside the attention kernels, the Linear layers of the
         # attention branch see the real tokens only in the backward pass -- the forward then saves LN1(x) and o in token order
-        ctx.tok_bwd = (sw is not None and ops.swin_attn_ok(x, C, geom) and ops.TOKEN_BWD and geom.rows != geom.tokens and ctx.needs_input_grad[0]
-                       and ops.SWIN_ATTN_BWD not in sw and ops.SWIN_QKV_BWD not in sw and ops.SWIN_MLP_BWD not in sw and not ops.mlp_fused_ok(x, C, T))
+        fused_attn = sw is not None and ops.swin_attn_ok(x, C, geom)
+        no_sw_bwd = sw is None or (ops.SWIN_ATTN_BWD not in sw and ops.SWIN_QKV_BWD not in sw and ops.SWIN_MLP_BWD not in sw)
+        ctx.tok_bwd = bool(ops.TOKEN_BWD and geom.rows != geom.tokens and ctx.needs_input_grad[0] and no_sw_bwd and not ops.mlp_fused_ok(x, C, T)
+                           and (fused_attn or ops.TOKEN_BWD_UNFUSED))
         if sw is not None and ops.swin_attn_ok(x, C, geom):
             # LN1 -> QKV -> window attention -> proj -> row scale -> + residual in ONE launch (csrc/swin_block.hip); saves the same tensors
             x1, xnw, mean1, rstd1, qkv, o, lse = ops.swin_attn_fwd(x, b.norm1.weight, b.norm1.bias, sw[ops.SWIN_ATTN_FWD], b.attn.qkv.bias,
                                                                    b.attn.relative_position_bias_table, b.attn.proj.bias, geom, rowscale=sd1, rows_per_scale=tps,
                                                                    token_saves=ctx.tok_bwd)
+        elif ctx.tok_bwd:
+            # unfused chain with token-ordered saves: LN1 writes its window-ordered output (operand of the qkv product: pad tokens are keys / values) and a
+            # token-ordered copy (operand of the qkv weight gradient); the attention core scatters o to token order, proj is a plain T-row GEMM
+            xw = torch.empty((geom.rows, C), dtype=dtype, device=dev)
+            xnw = torch.empty((T, C), dtype=dtype, device=dev)
+            mean1, rstd1 = torch.empty(T, device=dev), torch.empty(T, device=dev)
+            ops.layernorm_fwd_window_tokens(x, b.norm1.weight, b.norm1.bias, xw, xnw, mean1, rstd1, C, geom)
+            qkv = ops.gemm_nt(xw, pk[key + "qkv.w"].view(3 * C, C), bias=b.attn.qkv.bias)
+            o = torch.empty((T, C), dtype=dtype, device=dev)
+            lse = torch.empty(geom.rows * heads, device=dev)
+            ops.window_attn_fwd_tokens(qkv, b.attn.relative_position_bias_table, o, lse, heads, C, geom)
+            x1 = ops.gemm_nt(o, pk[key + "proj.w"].view(C, C), bias=b.attn.proj.bias, resid=x, rowscale=sd1, rows_per_scale=tps)
         else:
             xnw = torch.empty((geom.rows, C), dtype=dtype, device=dev)
             mean1, rstd1 = torch.empty(T, device=dev), torch.empty(T, device=dev)

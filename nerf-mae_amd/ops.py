@@ -585,6 +585,7 @@ def gemm_nt_window_scatter(A, W, out, resid, bias, rowscale, tokens_per_sample, 
     return out
 
 
+TOKEN_BWD_UNFUSED = __import__("os").environ.get("NMH_TOKEN_BWD_UNFUSED", "1") != "0"   # ... also behind the unfused attention forward (small launches, stage 3, fp32)
 TOKEN_BWD = __import__("os").environ.get("NMH_TOKEN_BWD", "1") != "0"   # padded stages behind a fused attention forward: token-ordered backward (model._BlockFn)
 TOKEN_ROWS = __import__("os").environ.get("NMH_TOKEN_ROWS", "0") != "0"   # padded stages: the window-ordered input-gradient GEMMs run on the real tokens only
 _PAD_ZERO = {}
@@ -817,6 +818,19 @@ def window_attn_bwd(qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, geo
     _chk(qkv, bias_table, dout, lse, dqkv, dbias_table)
     lib().call("nmh_window_attn_bwd", dt_of(qkv), qkv, bias_table, dout, lse, dqkv, dbias_table, heads, C, geom.carr, _st())
     return dqkv
+
+
+def layernorm_fwd_window_tokens(x, gamma, beta, out_window, out_tokens, mean, rstd, C, geom: WinGeom, eps=1e-5):
+    """LN1 with the pad -> roll -> partition gather (out_window [geom.rows, C]) plus a token-ordered copy (out_tokens [T, C])"""
+    _chk(x, gamma, beta, out_window, out_tokens, mean, rstd)
+    lib().call("nmh_layernorm_fwd_window_tokens", dt_of(x), x, out_window, out_tokens, gamma, beta, eps, mean, rstd, geom.rows, C, geom.carr, _st())
+
+
+def window_attn_fwd_tokens(qkv, bias_table, out_tok, lse, heads, C, geom: WinGeom):
+    """window attention core with its output in token order (out_tok [T, C])"""
+    _chk(qkv, bias_table, out_tok, lse)
+    lib().call("nmh_window_attn_fwd_tokens", dt_of(qkv), qkv, bias_table, out_tok, lse, heads, C, geom.carr, _st())
+    return out_tok
 
 
 def window_attn_bwd_tokens(qkv, bias_table, dout_tok, lse, dqkv_tok, dqkv_pad, dbias_table, heads, C, geom: WinGeom):

@@ -331,3 +331,43 @@ def test_token_ordered_attention_backward(C, shape, shift):
     assert_close((rs1 * dyf).sum(0), blk.attn.proj.bias.grad, 2 * TOL, "proj bias gradient")
     assert_close(dqf.T @ xnf, blk.attn.qkv.weight.grad, 2 * TOL, "qkv weight gradient from (dqkv, LN1 x) in token order")
     assert_close(dqf.sum(0) + dbq.cpu().double(), blk.attn.qkv.bias.grad, 2 * TOL, "qkv bias gradient = token rows + pad rows", elem_mult=2.0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,shift,C", [((2, 10, 10, 10), 2, 384), ((1, 5, 5, 5), 2, 768), ((1, 5, 5, 5), 0, 96), ((1, 6, 8, 4), 2, 192), ((2, 8, 8, 8), 2, 96)])
+def test_unfused_forward_with_token_ordered_saves(dt, shape, shift, C):
+    """nmh_layernorm_fwd_window_tokens / nmh_window_attn_fwd_tokens (the unfused chain's side of the token-ordered backward): the window-ordered LN output is
+    the plain kernel's, the token-ordered copy and the scattered attention output are the same rows -- bit for bit -- at their tokens"""
+    ops = _ops()
+    from oracle import mae3d_oracle as O
+    B, H, W, D = shape
+    geom = ops.WinGeom(B, H, W, D, [shift] * 3)
+    T, heads = geom.tokens, C // 32
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(T, C, generator=g) * 1.3 + 0.1).to(dt).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    idx = torch.arange(1, T + 1, dtype=torch.float32).view(B, H, W, D, 1)
+    pad = [g_ - s_ for g_, s_ in zip(geom.P, (H, W, D))]
+    ip = torch.nn.functional.pad(idx, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+    if shift:
+        ip = torch.roll(ip, shifts=[-s_ for s_ in geom.shift], dims=(1, 2, 3))
+    tok_of_row = O.window_partition(ip).reshape(-1).long() - 1
+    row_of_tok = torch.empty(T, dtype=torch.long)
+    row_of_tok[tok_of_row[tok_of_row >= 0]] = torch.nonzero(tok_of_row >= 0).flatten()
+    row_of_tok = row_of_tok.cuda()
+    e = lambda *s: torch.empty(*s, dtype=dt, device="cuda")
+    xw_ref, m_ref, r_ref = e(geom.rows, C), torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    ops.layernorm_fwd(x, gam, bet, xw_ref, m_ref, r_ref, geom.rows, C, src_mode=1, geom=geom)
+    xw, xt, m, r = e(geom.rows, C), torch.full((T, C), float("nan"), dtype=dt, device="cuda"), torch.empty(T, device="cuda"), torch.empty(T, device="cuda")
+    ops.layernorm_fwd_window_tokens(x, gam, bet, xw, xt, m, r, C, geom)
+    torch.cuda.synchronize()
+    assert torch.equal(xw, xw_ref) and torch.equal(m, m_ref) and torch.equal(r, r_ref)
+    assert torch.equal(xt, xw_ref[row_of_tok])
+    qkv = (torch.randn(geom.rows, 3 * C, generator=g) * 0.7).to(dt).cuda()
+    tab = (torch.randn(343, heads, generator=g) * 0.2).cuda()
+    o_ref, lse_ref = e(geom.rows, C), torch.empty(geom.rows * heads, device="cuda")
+    ops.window_attn_fwd(qkv, tab, o_ref, lse_ref, heads, C, geom)
+    o_t, lse = torch.full((T, C), float("nan"), dtype=dt, device="cuda"), torch.empty(geom.rows * heads, device="cuda")
+    ops.window_attn_fwd_tokens(qkv, tab, o_t, lse, heads, C, geom)
+    torch.cuda.synchronize()
+    assert torch.equal(o_t, o_ref[row_of_tok]) and torch.equal(lse, lse_ref)
