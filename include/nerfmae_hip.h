@@ -35,12 +35,6 @@ NMH_API int nmh_gemm_nt(int dt, const void* A, int64_t lda, const void* W, int64
  * out[tok] = resid[tok] + rowscale[tok / tokens_per_sample] * (A[m] . W^T + bias) for every window-ordered row m that maps to a token
  * (pad rows are dropped); wm as in nmh_window_scatter_residual, which this replaces. */
 NMH_API int nmh_gemm_nt_window_scatter(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, void* out, const void* resid, const float* bias, const float* rowscale, int tokens_per_sample, const int* wm, void* stream);
-/* The input-gradient GEMMs of the attention branch on WINDOW-ordered operands, restricted to the real tokens: C[w(t)] = A[w(t)] . W^T for
- * t in [0, T), w(t) = window row of token t (pad -> roll -> partition, swin_mae3d.py:62-101).  The reference computes these products on every
- * window row (F.linear on the padded, partitioned tensor, :103-112 backward); pad rows of the incoming gradient are zero and pad rows of the
- * outgoing one are sliced away (:196), so only real rows carry information: 58 % of the rows at 10^3 tokens, 24 % at 5^3.  Pad rows of C are
- * not written. */
-NMH_API int nmh_gemm_nt_token_rows(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int T, int N, int K, void* C, int64_t ldc, const int* wm, void* stream);
 /* dW[N,K] += sum_m A[m,N]*rowscale . B[m,K]  (fp32 atomics): weight gradients of the ops above.
  * omode 0: dW[n*ldo+k]; omode 2: ConvTranspose3d weight [Cin=K][Cout=p0][k3=p1] with n = tap*Cout+co.
  * dbias (optional): dbias[n] += sum_m A[m,n]*rowscale -- the layer's bias gradient from the same pass over A.

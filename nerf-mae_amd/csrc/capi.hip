@@ -43,12 +43,6 @@ int nmh_gemm_nt_window_scatter(int dt, const void* A, int64_t lda, const void* W
   ep.win_on = 1; ep.wm = to_wm(wm);
   return k_gemm_nt(dt, A, lda, W, ldw, M, N, K, ep, ST);
 }
-int nmh_gemm_nt_token_rows(int dt, const void* A, int64_t lda, const void* W, int64_t ldw, int T, int N, int K, void* C, int64_t ldc, const int* wm, void* stream) {
-  CLR();
-  REQ(A, W, C, wm);
-  if (T <= 0) return 0;
-  return k_gemm_nt_tok(dt, A, lda, W, ldw, T, N, K, C, ldc, to_wm(wm), ST);
-}
 int nmh_gemm_tn(int dt, const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, int64_t M, int N, int K, const float* rowscale, int rows_per_scale,
                 int omode, int64_t ldo, int p0, int p1, float* dbias, float* ws, int64_t ws_floats, void* stream) {
   CLR();

@@ -49,23 +49,6 @@ template <typename T> struct ADirect {
   }
 };
 
-// rows of a WINDOW-ordered matrix addressed by token: GEMM row m = token m -> physical row tok_to_win(m).  With the same map in the store
-// (EpiParams::tok_on) a window-ordered GEMM runs on the real tokens only: at the padded stages (10^3 tokens in 12^3 window rows, 5^3 in 8^3) the
-// pad rows of the attention branch's input gradients are either known (zero) or never read
-template <typename T> struct ATok {
-  const T* A; long lda; WinMap wm;
-  struct Row { const T* p; };
-  struct Kst { int k; bool ok; };
-  __device__ __forceinline__ void init_row(Row& r, int m, int M, int /*zb*/) const {
-    r.p = (m < M) ? A + tok_to_win(wm, (long)m) * lda : nullptr;
-  }
-  __device__ __forceinline__ Kst init_k(int k, int K) const { return Kst{k, k < K}; }
-  __device__ __forceinline__ uint4 load(const Row& r, const Kst& ks) const {
-    if (r.p == nullptr || !ks.ok) return make_uint4(0, 0, 0, 0);
-    return *reinterpret_cast<const uint4*>(r.p + ks.k);
-  }
-};
-
 // pixel-shuffled view of a fine-grid tensor: A[m][tap*Cout + co] = X[fine(m, tap)][co] (ConvTranspose3d k = stride, input gradient)
 template <typename T> struct AUp {
   const T* X; long ldc; int v, k, Cout; FDiv dv, dk, dc;
@@ -155,7 +138,6 @@ template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams&
     grow = win_to_tok(ep.wm, grow);
     if (grow < 0) return;
   }
-  if (ep.tok_on) grow = tok_to_win(ep.wm, grow);   // token-ordered GEMM row -> its window row (ATok)
   const long o = grow * ep.ldc + gcol;
   if (ep.act == 1) {
     Vec8<T>::store((T*)ep.C2 + o, v);
@@ -618,18 +600,6 @@ int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, 
   }
   ADirect<float> al{(const float*)A, lda, (long)M};
   return dispatch_nt<float>(al, Bw, ldb, M, N, K, 1, ep, st);
-}
-
-int k_gemm_nt_tok(int dt, const void* A, long lda, const void* Bw, long ldb, int T, int N, int K, void* C, long ldc, const WinMap& wm, hipStream_t st) {
-  EpiParams ep{};
-  ep.C = C; ep.ldc = ldc; ep.rows_per_scale = 1;
-  ep.tok_on = 1; ep.wm = wm;
-  if (dt == NMH_DT_BF16) {
-    ATok<bf16_t> al{(const bf16_t*)A, lda, wm};
-    return dispatch_nt<bf16_t>(al, Bw, ldb, T, N, K, 1, ep, st);
-  }
-  ATok<float> al{(const float*)A, lda, wm};
-  return dispatch_nt<float>(al, Bw, ldb, T, N, K, 1, ep, st);
 }
 
 // output tiles of the tile shape dispatch_nt picks for a conv (see there): used to decide the contraction split

@@ -25,7 +25,6 @@ struct EpiParams {
   // window reverse folded into the store (win_on): GEMM row = window-ordered row -> token row (pad rows dropped); bias, rowscale
   // (indexed by token / rows_per_scale) and resid (token order) as usual: x1[tok] = x[tok] + s_b * (o . Wproj^T + b)
   int win_on; WinMap wm;
-  int tok_on;           // the converse: GEMM row = token -> stored at its window row tok_to_win(wm, row) (k_gemm_nt_tok)
   // split contraction (implicit-GEMM convs on small volumes: too few output tiles to fill the chip, K = 27*Cin long): grid.z = batch * ksplit,
   // every split stores its fp32 accumulators to kpart[split][batch*M][N]; a second launch sums them and applies `accumulate` (no other epilogue)
   int ksplit; int nbatch; float* kpart;
@@ -89,8 +88,6 @@ __device__ __forceinline__ long tok_to_win(const WinMap& w, long tok) {
 
 #endif
 int k_gemm_nt(int dt, const void* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st);
-// C[win(t)][0:N] = A[win(t)][0:K] . W^T for the T real tokens t of a window-ordered A / C (pad rows neither read nor written)
-int k_gemm_nt_tok(int dt, const void* A, long lda, const void* Bw, long ldb, int T, int N, int K, void* C, long ldc, const WinMap& wm, hipStream_t st);
 // ConvTranspose3d (kernel = stride = k) as GEMMs with the pixel shuffle folded into addressing (unetr_block.py:151-158):
 //   fwd:   cat[fine][0:Cout] = x[coarse] . Wt^T + bias   (Wt packed [(tap,co)][ci])
 //   dgrad: dx[coarse][ci] = sum_(tap,co) dcat[fine][co] Wd[ci][(tap,co)]

@@ -399,11 +399,7 @@ class _BlockFn(torch.autograd.Function):
             dqkv = ops.swin_attn_bwd(dyw, qkv, b.attn.relative_position_bias_table, lse, sw[ops.SWIN_ATTN_BWD], _gradbuf(b.attn.relative_position_bias_table), geom)
             wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
         else:
-            padded = ops.TOKEN_ROWS and geom.rows != geom.tokens    # windows with pad rows: only the real tokens' rows carry gradient
-            if padded:
-                do = ops.gemm_nt_token_rows(dyw, pk[key + "proj.wT"].view(C, C), geom, zero_pads=True)   # (the attention backward reads every row of a window)
-            else:
-                do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
+            do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
             wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
             dqkv = torch.empty_like(qkv)
             ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
@@ -413,10 +409,7 @@ class _BlockFn(torch.autograd.Function):
             dx = ops.swin_qkv_bwd(dqkv, x, dx1, mean1, rstd1, b.norm1.weight, sw[ops.SWIN_QKV_BWD], _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), geom)
             wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
         else:
-            if ops.TOKEN_ROWS and geom.rows != geom.tokens:
-                dxnw = ops.gemm_nt_token_rows(dqkv, pk[key + "qkv.wT"].view(C, 3 * C), geom)     # (the LayerNorm backward reads the real tokens' rows only)
-            else:
-                dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
+            dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
             wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
             dx = torch.empty_like(x)
             ops.layernorm_bwd(dxnw, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, src_mode=1, geom=geom, dres=dx1, wq=q)

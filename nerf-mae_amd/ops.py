@@ -587,26 +587,6 @@ def gemm_nt_window_scatter(A, W, out, resid, bias, rowscale, tokens_per_sample, 
 
 TOKEN_BWD_UNFUSED = __import__("os").environ.get("NMH_TOKEN_BWD_UNFUSED", "1") != "0"   # ... also behind the unfused attention forward (small launches, stage 3, fp32)
 TOKEN_BWD = __import__("os").environ.get("NMH_TOKEN_BWD", "1") != "0"   # padded stages behind a fused attention forward: token-ordered backward (model._BlockFn)
-TOKEN_ROWS = __import__("os").environ.get("NMH_TOKEN_ROWS", "0") != "0"   # padded stages: the window-ordered input-gradient GEMMs run on the real tokens only
-_PAD_ZERO = {}
-
-
-def gemm_nt_token_rows(A, W, geom: WinGeom, zero_pads: bool = False):
-    """out[w(t)] = A[w(t)] @ W^T for the real tokens t of window-ordered A [geom.rows, K]; pad rows of `out` are not written.  zero_pads: `out` is a
-    cached buffer per shape whose pad rows were zeroed once and are never written again (every caller consumes it before the next call on the stream)"""
-    _chk(A, W)
-    K, N = A.shape[1], W.shape[0]
-    if zero_pads:
-        key = (A.device.index, geom.rows, N, A.dtype, tuple(geom.carr))
-        out = _PAD_ZERO.get(key)
-        if out is None:
-            out = _PAD_ZERO[key] = torch.zeros((geom.rows, N), dtype=A.dtype, device=A.device)
-    else:
-        out = torch.empty((geom.rows, N), dtype=A.dtype, device=A.device)
-    lib().call("nmh_gemm_nt_token_rows", dt_of(A), A, A.stride(0), W, W.stride(0), geom.tokens, N, K, out, out.stride(0), geom.carr, _st())
-    return out
-
-
 MLP_FUSED = __import__("os").environ.get("NMH_MLP_FUSED", "1") != "0"
 MLP_FUSED_MIN_ROWS = int(__import__("os").environ.get("NMH_MLP_FUSED_MIN_ROWS", "4096"))   # fewer rows: too few 64-row workgroups to fill the chip, the unfused chain wins
 

@@ -206,37 +206,6 @@ def test_layernorm_window_modes(dt, shape, shift, C):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape,shift", [((2, 8, 8, 8), 2), ((1, 5, 5, 5), 2), ((2, 10, 10, 10), 2), ((8, 10, 10, 10), 0), ((1, 2, 2, 2), 2), ((1, 6, 8, 4), 2)])
-@pytest.mark.parametrize("K,N", [(96, 96), (384, 384), (1152, 384), (576, 192)])
-def test_gemm_nt_token_rows(dt, shape, shift, K, N):
-    """the window-ordered input-gradient GEMMs on the real tokens' rows only: those rows equal the plain GEMM's, pad rows are not written"""
-    ops = _ops()
-    from oracle import mae3d_oracle as O
-    B, H, W, D = shape
-    geom = _geom(ops, B, H, W, D, shift)
-    A = q(rnd(geom.rows, K, seed=1), dt)
-    Wt = q(rnd(N, K, seed=2, scale=K ** -0.5), dt)
-    ref = A @ Wt.T
-    # which window rows are real tokens: partition an index volume the way the reference partitions activations (swin_mae3d.py:62-101)
-    idx = torch.arange(1, geom.tokens + 1, dtype=torch.float32).view(B, H, W, D, 1)
-    pad = [g_ - s for g_, s in zip(geom.P, (H, W, D))]
-    ip = F.pad(idx, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
-    if sum(geom.shift) > 0:
-        ip = torch.roll(ip, shifts=[-s for s in geom.shift], dims=(1, 2, 3))
-    real = O.window_partition(ip).reshape(-1) > 0
-    assert int(real.sum()) == geom.tokens
-    out = ops.gemm_nt_token_rows(dev(A, dt), dev(Wt, dt), geom)
-    full = ops.gemm_nt(dev(A, dt), dev(Wt, dt))
-    assert relerr(out[real.cuda()], full[real.cuda()]) < (1e-5 if dt == torch.float32 else 1e-2)   # (tile shapes may differ: same sums, other order)
-    check(out[real.cuda()], ref[real], dt, "token rows")
-    # the cached zero-padded form: pad rows stay exactly zero over repeated calls
-    for _ in range(2):
-        oz = ops.gemm_nt_token_rows(dev(A, dt), dev(Wt, dt), geom, zero_pads=True)
-    assert float(oz[~real.cuda()].float().abs().sum()) == 0.0 if int((~real).sum()) else True
-    check(oz[real.cuda()], ref[real], dt, "token rows, zero pads")
-
-
-@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("C", [96, 192, 384])
 def test_layernorm_plain_and_embed_post(dt, C):
     ops = _ops()
