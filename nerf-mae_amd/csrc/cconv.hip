@@ -430,11 +430,11 @@ int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int
   static const int dbg = getenv("NMH_CCONV_DBG") ? atoi(getenv("NMH_CCONV_DBG")) : 0;
 #define CC_LAUNCH(D)                                                                                                              \
   {                                                                                                                               \
-    static bool attr = false;                                                                                                     \
-    if (!attr) {                                                                                                                  \
+    static NmhPerDeviceOnce attr;                                                                                                     \
+    if (attr.need()) {                                                                                                                  \
       hipError_t e = hipFuncSetAttribute((const void*)cconv_fwd_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
       if (e != hipSuccess) return (int)e;                                                                                         \
-      attr = true;                                                                                                                \
+      attr.set();                                                                                                                \
     }                                                                                                                             \
     hipLaunchKernelGGL(cconv_fwd_kernel<D>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);                                     \
   }
@@ -1019,11 +1019,11 @@ int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* 
     wg += s;
   }
   if (wg > 256) return -2;
-  static bool attr = false;
-  if (!attr) {
+  static NmhPerDeviceOnce attr;
+  if (attr.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)cconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.set();
   }
   if (phase != 2) {
     hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)wg), dim3(768), LDS_BYTES, st, a);
@@ -1318,11 +1318,11 @@ int k_cconv_dgrad(const void* dY, const void* Wdp, const void* add, void* DX, in
   if (a.total >= (1L << 31) || (long)B * 64 * v * v * v * 48 >= (1L << 40)) return -2;
   long nb = (a.total + 7) / 8 * 8;      // (rounded up: see k_cconv_fwd)
   if (nb > 256) nb = 256;
-  static bool attr = false;
-  if (!attr) {
+  static NmhPerDeviceOnce attr;
+  if (attr.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)cconv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CD_RING * WHALF);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.set();
   }
   hipLaunchKernelGGL(cconv_dgrad_kernel, dim3((unsigned)nb), dim3(512), 2 * CD_RING * WHALF, st, a);
   NMH_CHECK_LAUNCH();

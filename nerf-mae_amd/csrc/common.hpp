@@ -175,6 +175,14 @@ __device__ __forceinline__ float gelu_grad_fast_f(float x) {   // Phi(x) + x phi
   return 0.5f * (1.0f + er) + x * 0.39894228040143268f * e;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: a launcher's "done once" flag is kept per device, so that a process driving several
+// GPUs (or a second device selected later) opts every one of them in.  (Idempotent, so a benign race between two host threads only repeats the call.)
+struct NmhPerDeviceOnce {
+  bool done[64] = {};
+  static int dev() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0; return d; }
+  bool need() const { return !done[dev()]; }
+  void set() { done[dev()] = true; }
+};
 // Small accumulators are cleared by a kernel instead of hipMemsetAsync: inside a captured graph a memset node costs 20-30 us on the
 // dependent chain (rocprofv3: __amd_rocclr_fillBufferAligned, 2-3 workgroups), a kernel node ~5 us.  bytes must be a multiple of 4.
 #ifdef __HIPCC__

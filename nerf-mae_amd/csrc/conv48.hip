@@ -466,11 +466,11 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
     hipError_t e = nmh_zero_async(stats_acc, sizeof(double) * 2 * 48 * B, st);
     if (e != hipSuccess) return (int)e;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   long nb = a.total < 256 ? ((a.total + 7) / 8 * 8) : 256;
   if (dbg) {  // timing decomposition only: results are wrong by construction
@@ -485,11 +485,11 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
     return 0;
   }
   if (Y1) {
-    static bool attr_rb = false;
-    if (!attr_rb) {
+    static NmhPerDeviceOnce attr_rb;
+    if (attr_rb.need()) {
       hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
       if (e != hipSuccess) return (int)e;
-      attr_rb = true;
+      attr_rb.set();
     }
     hipLaunchKernelGGL((conv48_kernel<0, false, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
     NMH_CHECK_LAUNCH();
@@ -519,11 +519,11 @@ int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int
   a.stats_acc = nullptr;
   a.ncib = Cin / 48; a.ncob = Cout / 48; a.ldx = Cin; a.ldy = Cout;
   a.cosplit = (a.total < 256 && a.ncob > 1) ? 1 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   const long units = a.cosplit ? a.total * a.ncob : a.total;
   const long nb = units < 256 ? ((units + 7) / 8 * 8) : 256;
@@ -780,12 +780,12 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
   a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
   a.ldx = Cin; a.ldy = Cout; a.nci = Cin / 48;
   const int nsub = (Cin / 48) * (Cout / 48);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv48_wgrad_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   int nb;
   if (nsub == 1) nb = a.total < 256 ? (int)((a.total + 7) / 8 * 8) : 256;   // 8 XCD-contiguous tile ranges

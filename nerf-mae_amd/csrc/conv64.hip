@@ -307,11 +307,11 @@ int k_conv64(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
     hipError_t e = nmh_zero_async(stats_acc, sizeof(double) * 2 * Cout * B, st);
     if (e != hipSuccess) return (int)e;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   long nb = a.total < 256 ? ((a.total + 7) / 8 * 8) : 256;
   hipLaunchKernelGGL(conv64_kernel, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
@@ -535,11 +535,11 @@ int k_conv64_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, i
   if (a.total >= (1L << 31)) return -2;
   a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
   a.ldx = Cin; a.ldy = Cout; a.nci = Cin / 64;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)conv64_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   int nb = 256 / (2 * nsub);                 // <= 512 workgroups in total (two per CU never co-reside: 145 KB of LDS each)
   if (nb < 1) nb = 1;

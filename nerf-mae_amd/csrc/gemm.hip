@@ -471,11 +471,11 @@ static int launch_nt_dma(const ADirect<bf16_t>& al, const void* Bw, long ldb, in
   constexpr int lds_main = ST * (BM + BNP) * 128, lds_epi = 4 * 16 * (BN + 4) * 4;
   constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
   dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<MT, NT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((gemm_nt_dma_kernel<MT, NT, ST>), grid, dim3(256), lds, st, al.A, al.lda, al.rows_per_z, (const bf16_t*)Bw, ldb, M, N, K, ep);
   NMH_CHECK_LAUNCH();
@@ -512,11 +512,11 @@ static int launch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K
     if (try_dma<T, MT, NT, AL>(al, Bw, ldb, M, N, K, batch, ep, st, &rc)) return rc;
   }
   dim3 grid((M + BM - 1) / BM, (N + BN - 1) / BN, batch * (ep.ksplit > 1 ? ep.ksplit : 1));
-  static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;  // > 64 KiB of dynamic LDS must be opted into once per kernel
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, MT, NT, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((gemm_nt_kernel<T, MT, NT, AL>), grid, dim3(256), lds, st, al, (const T*)Bw, ldb, M, N, K, ep);
   NMH_CHECK_LAUNCH();
@@ -1069,11 +1069,11 @@ static int launch_tn_dma(const void* A, long lda, const void* Bm, const BL& bl, 
   int gx = (N + 95) / 96, gy = (K + 95) / 96, gz = (int)((Mtot + mps - 1) / mps);
   TnGeom gm = gm0;
   gm.part = (gm.ws && gz > 1 && gz <= tn_ws_max_splits() && (long)gz * N * (K + 1) <= gm.ws_floats) ? gm.ws : nullptr;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<BL, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   hipLaunchKernelGGL((gemm_tn_dma_kernel<BL, ST>), dim3(gx, gy, gz), dim3(256), lds, st, (const bf16_t*)A, lda, (const bf16_t*)Bm, bl, Out, Mtot, N, K, (int)mps, rs, rps, gm);
   NMH_CHECK_LAUNCH();

@@ -848,11 +848,11 @@ __global__ __launch_bounds__(256) void mlp96_bwd_kernel(MlpBwdArgs a) {
 
 template <int MT> int launch96_fwd(const MlpFwdArgs& a, hipStream_t st) {
   constexpr int lds = 2 * W96_BYTES;
-  static bool attr = false;
-  if (!attr) {
+  static NmhPerDeviceOnce attr;
+  if (attr.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp96_fwd_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.set();
   }
   long nb = (a.M + 8 * 16 * MT - 1) / (8 * 16 * MT);
   static const long cap = getenv("NMH_MLP96_WGS") ? atol(getenv("NMH_MLP96_WGS")) : 256;   // persistent workgroups (one per CU: 144 KB of LDS each)
@@ -863,11 +863,11 @@ template <int MT> int launch96_fwd(const MlpFwdArgs& a, hipStream_t st) {
 }
 template <int MT> int launch96_bwd(const MlpBwdArgs& a, hipStream_t st) {
   constexpr int lds = 2 * W96_BYTES + 4 * 4096;
-  static bool attr = false;
-  if (!attr) {
+  static NmhPerDeviceOnce attr;
+  if (attr.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp96_bwd_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.set();
   }
   long nb = (a.M + 4 * 16 * MT - 1) / (4 * 16 * MT);
   static const long cap = getenv("NMH_MLP96_WGS") ? atol(getenv("NMH_MLP96_WGS")) : 256;
@@ -885,11 +885,11 @@ template <int C, int MT, int HC> constexpr int mlp_bwd_lds() {
 
 template <int C, int MT, int HC> int launch_fwd(const MlpFwdArgs& a, hipStream_t st) {
   constexpr int lds = mlp_fwd_lds<C, MT, HC>();
-  static bool attr = false;
-  if (!attr) {
+  static NmhPerDeviceOnce attr;
+  if (attr.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_fwd_kernel<C, MT, HC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.set();
   }
   const long nb = (a.M + 64 * MT - 1) / (64 * MT);
   hipLaunchKernelGGL((mlp_fwd_kernel<C, MT, HC>), dim3((unsigned)nb), dim3(256), lds, st, a);
@@ -898,11 +898,11 @@ template <int C, int MT, int HC> int launch_fwd(const MlpFwdArgs& a, hipStream_t
 }
 template <int C, int MT, int HC> int launch_bwd(const MlpBwdArgs& a, hipStream_t st) {
   constexpr int lds = mlp_bwd_lds<C, MT, HC>();
-  static bool attr = false;
-  if (!attr) {
+  static NmhPerDeviceOnce attr;
+  if (attr.need()) {
     hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_kernel<C, MT, HC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.set();
   }
   const long nb = (a.M + 64 * MT - 1) / (64 * MT);
   hipLaunchKernelGGL((mlp_bwd_kernel<C, MT, HC>), dim3((unsigned)nb), dim3(256), lds, st, a);

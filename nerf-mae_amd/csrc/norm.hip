@@ -1462,12 +1462,12 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
       return 0;
     }
     const size_t lds = 64 * 256 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NmhPerDeviceOnce attr_set;
+    if (attr_set.need()) {
       e = hipFuncSetAttribute((const void*)tail_fwd_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tail_fwd_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
-      attr_set = true;
+      attr_set.set();
     }
     if (a.dt == NMH_DT_BF16) hipLaunchKernelGGL((tail_fwd_kernel<bf16_t, true>), grid, dim3(256), lds, st, (const bf16_t*)x, stats, (const bf16_t*)r, (bf16_t*)out, a, V, C, slope, vpb);
     else hipLaunchKernelGGL((tail_fwd_kernel<float, true>), grid, dim3(256), lds, st, (const float*)x, stats, (const float*)r, (float*)out, a, V, C, slope, vpb);

@@ -327,8 +327,8 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args g
 // host side: chunk the problem list into launches of <= 16 problems, decide the contraction splits per launch
 int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground) {
   using namespace tng;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipSuccess;
     auto setattr = [&](const void* f, int bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
     setattr((const void*)gemm_tn_grouped_kernel<false, false, false>, LDS_BYTES);
@@ -338,7 +338,7 @@ int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_
     setattr((const void*)gemm_tn_grouped_kernel<false, true, true>, 2 * 4 * TILE);
     setattr((const void*)gemm_tn_grouped_kernel<true, true, true>, 2 * 4 * TILE);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.set();
   }
   // workgroups a split launch aims at.  Round 3: 256 instead of 640 -- the launches run on the side stream UNDER the input-gradient chain (since
   // the queues really overlap), where fewer, longer workgroups take less from the chain's latency-bound kernels: 8 grids 51.1-51.2 -> 50.6-50.8 ms,

@@ -214,6 +214,7 @@ class Prefetcher:
         self.q = queue.Queue(maxsize=depth - 1 if depth > 1 else 1)
         self.batches = batches
         self.err = None
+        self._stop = False                              # close(): the producer leaves its wait loops and exits
         # the producer re-acquires the GIL after every C call (host copy, H2D, kernel launch: ~25 per batch); with CPython's default 5 ms
         # switch interval each hand-over from a busy consumer thread can take that long (measured: a 66 MB host copy 0.07 ms alone, 11 ms
         # next to a spinning Python thread) -- 0.2 ms keeps the producer's latency per call small against a 13-60 ms step
@@ -235,8 +236,10 @@ class Prefetcher:
                 flags = [draw_augmentation(self.b.flip_prob, self.b.rotate_prob, self.rng) for _ in scenes]
                 t1 = time.perf_counter()
                 with self._handback:                     # handed out before: wait until the consumer has given it back (done(j)) ...
-                    while self.free[j] is Prefetcher._PENDING:
+                    while self.free[j] is Prefetcher._PENDING and not self._stop:
                         self._handback.wait(0.05)
+                if self._stop:
+                    return
                 if self.free[j] is not None:
                     _wait_event(self.free[j])           # ... and until its last read of the buffer has executed
                 t2 = time.perf_counter()
@@ -246,7 +249,14 @@ class Prefetcher:
                     ev.record(self.stream)
                 t3 = time.perf_counter()
                 self.free[j] = Prefetcher._PENDING
-                self.q.put((j, xb, ext, ev))
+                while not self._stop:                   # (a bounded put: a consumer that went away must not park the thread for good)
+                    try:
+                        self.q.put((j, xb, ext, ev), timeout=0.05)
+                        break
+                    except Exception:                    # queue.Full
+                        continue
+                if self._stop:
+                    return
                 t4 = time.perf_counter()
                 st["batches"] += 1; st["load_s"] += t1 - t0; st["wait_free_s"] += t2 - t1; st["prepare_s"] += t3 - t2; st["put_s"] += t4 - t3
             self.q.put(None)
@@ -255,13 +265,33 @@ class Prefetcher:
             self.q.put(None)
 
     def __iter__(self):
-        while True:
-            item = self.q.get()
-            if item is None:
-                if self.err is not None:
-                    raise self.err
-                return
-            yield item
+        try:
+            while True:
+                item = self.q.get()
+                if item is None:
+                    if self.err is not None:
+                        raise self.err
+                    return
+                yield item
+        finally:
+            self.close()                                 # a consumer that leaves early (exception, break) releases the producer thread
+
+    def close(self):
+        """stop the producer (idempotent): it leaves its wait loops within 50 ms and drops its references to the staged batches"""
+        self._stop = True
+        with self._handback:
+            self._handback.notify_all()
+        try:
+            while True:
+                self.q.get_nowait()
+        except Exception:                                # queue.Empty
+            pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def done(self, j: int, stream=None):
         """the consumer has queued its last read of buffer j on `stream`"""

@@ -159,6 +159,27 @@ def test_prefetcher_never_overwrites_a_buffer_before_done_with_a_device_backlog(
         assert torch.equal(a, b), f"batch {n} was overwritten before its read executed"
 
 
+@pytest.mark.gpu
+def test_prefetcher_thread_ends_when_the_consumer_leaves_early():
+    """a consumer that stops iterating (exception in the step, `break`) without handing its buffers back must not leave the producer thread spinning on
+    them: leaving the iterator closes the prefetcher, and the thread is gone shortly after"""
+    import time
+    import numpy as np
+    from nerf_mae_amd import data
+    R = 32
+    scenes = [data.synthetic_scene((32, 32, 30), seed=70 + i, dtype=np.uint8) for i in range(16)]
+    batches = [scenes[2 * b:2 * b + 2] for b in range(8)]
+    pf = data.Prefetcher(data.GridBatcher(R, "cuda", normalize_density=True), batches, 2, depth=2)
+    for j, xb, ext, ev in pf:
+        torch.cuda.current_stream().wait_event(ev)
+        break                                  # no done(j): the buffer is never handed back
+    t0 = time.time()
+    while pf.t.is_alive() and time.time() - t0 < 5.0:
+        time.sleep(0.05)
+    assert not pf.t.is_alive(), "the producer thread survived its consumer"
+    pf.close()                                 # idempotent
+
+
 def test_prefetcher_uses_a_private_rng():
     """augmentation flags come from the prefetcher's own generator: drawing them leaves the global `random` stream (the training
     thread's block masks) untouched, and equal seeds give equal flags whatever else runs"""
