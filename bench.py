@@ -363,28 +363,9 @@ def main():
             # HBM traffic of this kernel comes from separate rocprofv3 --pmc passes (counters cannot be read in-process): the committed
             # summary is quoted only when it was taken on THIS kernel source (sha256 of conv48.hip) at the same shape
             try:
-                import glob
-                sha = hashlib.sha256(open(os.path.join(ROOT, "nerf-mae_amd", "csrc", "conv48.hip"), "rb").read()).hexdigest()
-                stale = []
-                for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*conv48_pmc.json")))[::-1]:
-                    pm = json.load(open(f))
-                    if key[0] != "conv3d_k3_c48" or pm.get("resolution") != R:
-                        continue
-                    if pm.get("conv48_hip_sha256") != sha:
-                        stale.append(os.path.basename(f))
-                        continue
-                    per_grid = pm["hbm_bytes_per_launch"] / pm["batch_per_gpu"]
-                    out["roofline"]["traffic"] = per_grid * Bg
-                    out["roofline"]["traffic_source"] = "%s (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes at %d grids per launch, scaled per grid; kernel source hash matches)" % (
-                        os.path.basename(f), pm["batch_per_gpu"])
-                    if pm.get("mfma_busy_frac"):
-                        out["roofline"]["mfma_busy_frac_pmc"] = round(pm["mfma_busy_frac"], 4)
-                    if pm.get("rocm_smi_raw"):
-                        out["roofline"]["rocm_smi_raw"] = "profiles/" + pm["rocm_smi_raw"]
-                    break
-                else:
-                    if stale:
-                        out["roofline"]["traffic_refused"] = "PMC summaries %s were taken on a different conv48.hip" % stale[:3]
+                tr = pmc_family_traffic("conv48", ("conv48_kernel<0, false, ",), Bg, R) if key[0] == "conv3d_k3_c48" else None
+                if tr is not None:
+                    out["roofline"].update(tr)
             except Exception as e:  # noqa: BLE001
                 out["roofline"]["traffic_error"] = repr(e)
         # HBM-bound kernels: achieved GB/s of algorithmic bytes (ops.PROFILE_BYTES) against the 8 TB/s peak
@@ -401,23 +382,19 @@ def main():
         # rocprofv3-reported HBM bytes of the same kernels (separate --pmc passes, tools/pmc_step.sh), quoted only when they were taken
         # on this source of csrc/norm.hip at the same per-GPU batch
         try:
-            import glob
-            shan = hashlib.sha256(open(os.path.join(ROOT, "nerf-mae_amd", "csrc", "norm.hip"), "rb").read()).hexdigest()
-            kmap = {"mae_tail_fwd": "tail_fwd", "mae_tail_bwd": "tail_bwd_kernel", "instnorm_apply": "in_apply_kernel", "instnorm_bwd_apply": "in_bwd_apply_kernel",
-                    "instnorm_bwd_reduce": "in_reduce_kernel"}
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_kernels_pmc.json")))[::-1]:
-                pm = json.load(open(f))
-                if pm.get("norm_hip_sha256") != shan or pm.get("batch_per_gpu") != Bg:
+            kmap = {"mae_tail_fwd": ("tail_fwd",), "mae_tail_bwd": ("tail_bwd_kernel",), "instnorm_apply": ("in_apply_kernel",), "instnorm_bwd_apply": ("in_bwd_apply_kernel",),
+                    "instnorm_bwd_reduce": ("in_reduce_kernel",)}
+            for h in hb:
+                pref = kmap.get(h["kernel"].split(":")[0])
+                if not pref:
                     continue
-                for h in hb:
-                    kn = kmap.get(h["kernel"].split(":")[0])
-                    cands = [v for k, v in pm["kernels"].items() if kn and k.startswith(kn)]
-                    if cands:
-                        tot_b = sum(c["hbm_bytes_per_launch"] for c in cands) if kn == "tail_bwd_kernel" else max(c["hbm_bytes_per_launch"] for c in cands)
-                        h["pmc_hbm_bytes_per_launch"] = tot_b
-                        h["pmc_GBs"] = round(tot_b / (h["avg_launch_ms"] * 1e-3) / 1e9, 1)
-                        h["pmc_source"] = os.path.basename(f)
-                break
+                for fam in ("norm_streaming", "misc_streaming", "hbm_kernels"):
+                    tr = pmc_family_traffic(fam, pref, Bg, R, pick="max")
+                    if tr is not None and tr.get("traffic"):
+                        h["pmc_hbm_bytes_per_launch"] = tr["traffic"]
+                        h["pmc_GBs"] = round(tr["traffic"] / (h["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                        h["pmc_source"] = tr["traffic_source"]
+                        break
         except Exception as e:  # noqa: BLE001
             out.setdefault("roofline", {})["hbm_pmc_error"] = repr(e)
         if "roofline" in out:
@@ -619,6 +596,65 @@ def e2e_leg(model, args, R, sweep):
         del tr
         torch.cuda.empty_cache()
     return res
+
+
+def pmc_family_traffic(family, prefixes, Bg, R, pick="weighted"):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summaries (profiles/*_<family>_pmc.json, written by tools/pmc_families.py /
+    tools/pmc_kernel.sh on the GPU box: counters cannot be read in-process).  A summary is quoted only when the sha256 it carries matches the kernel source
+    in this tree; bytes = 2 x FETCH_SIZE + WRITE_SIZE (the gfx950 correction of MI355X_MICROARCH.md), scaled from the grids per launch of the PMC run to Bg.
+    Two formats: per-family files {source_file, source_sha256, grids_per_launch?, kernels{name: {hbm_bytes_per_launch, dispatches, mfma_busy_frac}}} (rounds 4+)
+    and the flat round-2 files {conv48_hip_sha256 | norm_hip_sha256, batch_per_gpu, resolution, hbm_bytes_per_launch | kernels{}}.
+    pick: "weighted" = dispatch-weighted mean over the matching kernels at full size, "max" = the largest (the 160^3 instantiation of a streaming kernel)."""
+    import glob
+    import re as _re
+    stale = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s_pmc.json" % family)), key=os.path.getmtime)[::-1]:
+        pm = json.load(open(f))
+        srcf = pm.get("source_file")
+        if srcf:
+            want = pm.get("source_sha256")
+        else:   # round-2 format
+            srcf = "nerf-mae_amd/csrc/conv48.hip" if "conv48_hip_sha256" in pm else "nerf-mae_amd/csrc/norm.hip"
+            want = pm.get("conv48_hip_sha256") or pm.get("norm_hip_sha256")
+            if pm.get("resolution") not in (None, R):
+                continue
+        try:
+            have = hashlib.sha256(open(os.path.join(ROOT, srcf), "rb").read()).hexdigest()
+        except OSError:
+            continue
+        if have != want:
+            stale.append(os.path.basename(f))
+            continue
+        g = pm.get("grids_per_launch") or pm.get("batch_per_gpu")
+        if not g:
+            m = _re.search(r"at (\d+) grids", pm.get("source", ""))
+            g = int(m.group(1)) if m else None
+        if not g:
+            continue
+        ks = pm.get("kernels") or {}
+        hits = [(k, v) for k, v in ks.items() if any(k.startswith(p) for p in prefixes) and v.get("hbm_bytes_per_launch")]
+        if not hits and "hbm_bytes_per_launch" in pm and family == "conv48":
+            hits = [("conv48_kernel", pm)]
+        if not hits:
+            continue
+        big = max(v["hbm_bytes_per_launch"] for _, v in hits)
+        hits = [(k, v) for k, v in hits if v["hbm_bytes_per_launch"] > 0.25 * big]   # the full-size launches of the family (small decoder levels share the kernel)
+        if pick == "max":
+            per_launch, busy = big, None
+        else:
+            w = sum(v.get("dispatches", 1) for _, v in hits)
+            per_launch = sum(v["hbm_bytes_per_launch"] * v.get("dispatches", 1) for _, v in hits) / w
+            busy = [v["mfma_busy_frac"] * v.get("dispatches", 1) for _, v in hits if v.get("mfma_busy_frac")]
+            busy = sum(busy) / w if busy else None
+        res = {"traffic": per_launch / g * Bg,
+               "traffic_source": "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes at %d grids per launch, scaled per grid; sha256 of %s matches this tree; kernels %s)" % (
+                   os.path.basename(f), g, os.path.basename(srcf), [k for k, _ in hits][:3])}
+        if busy:
+            res["mfma_busy_frac_pmc"] = round(busy, 4)
+        return res
+    if stale:
+        return {"traffic": None, "traffic_refused": "PMC summaries %s were taken on a different kernel source" % stale[:3]}
+    return None
 
 
 def cpu_baseline(args, R, exts):

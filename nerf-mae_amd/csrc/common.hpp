@@ -143,6 +143,27 @@ __device__ __forceinline__ Frag<float> lds_frag_t(const char* tile, int RS, int 
   return f;
 }
 
+// ---- raw transpose reads for LDS-DMA pipelines ----------------------------------------------------
+// hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of a `__builtin_amdgcn_ds_read_tr16_b64` whenever an LDS-DMA (`global_load_lds`) may be in flight: its
+// wait-count pass cannot tell the ring slot being read from the slot being filled.  In a ring with counted `vmcnt(N)` waits that turns every step into a
+// synchronous load (round 5: every contraction-major LDS-DMA kernel of rounds 2-4 ran that way -- tools/scan_vmcnt0.py).  Inline-asm reads are invisible to
+// that pass; the caller orders them: tr_read_raw ... (all reads of a step), tr_wait(), tr_pin(f) on every fragment (an empty volatile asm that redefines the
+// registers behind the wait, so that no consumer can be scheduled above it), then tr_frag(f) as the MFMA operand.
+struct TrFrag { bf16x4 lo, hi; };
+__device__ __forceinline__ unsigned lds_addr_u(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+template <int HI_OFF, int OFF0 = 0> __device__ __forceinline__ void tr_read_raw(TrFrag& f, unsigned addr) {   // HI_OFF: byte distance of contraction rows m + 16 (16 x row stride); OFF0: immediate added to both
+  static_assert(OFF0 >= 0 && OFF0 + HI_OFF < 65536, "ds offset field");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(addr), "n"(OFF0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(OFF0 + HI_OFF));
+}
+__device__ __forceinline__ void tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void tr_pin(TrFrag& f) { asm volatile("" : "+v"(f.lo), "+v"(f.hi)); }
+__device__ __forceinline__ Frag<bf16_t> tr_frag(const TrFrag& f) {
+  Frag<bf16_t> r;
+  r.v = __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return r;
+}
+
 // ---- misc ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -576,7 +576,14 @@ __device__ __forceinline__ void w48_tile_origin(const W48Args& a, long t, int& b
   x0 = __builtin_amdgcn_readfirstlane((int)xt * w48::TX);
 }
 
-template <int NW, int DBG = 0>  // waves per workgroup: 16 (<=128 VGPRs, 5 blocks/wave) or 8 (<=256 VGPRs, 10 blocks/wave)
+template <int N, int I = 0, class F> __device__ __forceinline__ void w48_static_for(F&& f) {   // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    w48_static_for<N, I + 1>(f);
+  }
+}
+
+template <int NW, int DBG = 0, bool RAW = false>  // waves per workgroup: 16 (<=128 VGPRs, 5 blocks/wave) or 8 (<=256 VGPRs, 10 blocks/wave); RAW: inline-asm transpose reads
 __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   using namespace w48;
   constexpr int NT = 64 * NW, HREG = (HCH + NT - 1) / NT, UPW = NUNIT / NW;
@@ -656,6 +663,10 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   const int xoff = 2 * PLANE + 2 * LINE + 2 * 96 + 2 * 32;
   const bool has_x = wave >= 1 && wave <= 3;
   const int lane_off = (4 * g + (p >> 2)) * 96 + (p & 3) * 8;  // row (x) and 8-byte column piece supplied by this lane
+  const unsigned halo_u = lds_addr_u(halo), dyb_u = lds_addr_u(dyb), dy_lane_off = (unsigned)lane_off;   // (RAW: the dY tile has the same 96-byte rows)
+  unsigned u_ad[UPW], x_ad = halo_u + (unsigned)(lane_off + xoff);
+#pragma unroll
+  for (int i = 0; i < UPW; ++i) u_ad[i] = halo_u + (unsigned)(lane_off + uoff[i]);
 
   long t = tbeg + jb;
   int cur = 0;
@@ -681,10 +692,14 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
     if (has_next) w48_tile_origin(a, tn, nb, nz0, ny0, nx0);
     stamp(0);
     const char* dyc = dyb + cur * DYT;
+    unsigned dy_ad[3];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int c = 0; c < 3; ++c) dy_ad[c] = dyb_u + (unsigned)(cur * DYT + c * 32) + dy_lane_off;
+    w48_static_for<8>([&](auto KS) __attribute__((always_inline)) {
+      constexpr int ks = decltype(KS)::value;
       // lines 2ks, 2ks+1 of the tile: (z_l, y_l) = (ks>>1, (ks&1)*2) and y_l+1
       const int lbase = (ks >> 1) * PLANE + ((ks & 1) * 2) * LINE + lane_off;
+      if constexpr (!RAW) {
       Frag<bf16_t> af[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) af[c] = lds_frag_t(dyc, 96, ks * 32, c * 16, lane, (bf16_t*)nullptr);
@@ -716,7 +731,60 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
         else if (wave == 2) mma(accx, af[1], bfr);
         else mma(accx, af[2], bfr);
       }
-    }
+      } else {
+      // RAW (round 5): the builtin transpose read is ordered behind EVERY pending vector-memory operation (`s_waitcnt vmcnt(0)`: hipcc cannot tell the dY
+      // buffer / halo being read from the dY buffer being filled by LDS-DMA) -- i.e. behind the next tile's DMA and halo requests issued one k-step earlier,
+      // the prefetch this loop exists to hide.  Raw reads (common.hpp), software-pipelined by hand: the operands of unit pair j + 1 are requested before the
+      // MFMAs of pair j; lgkmcnt(0) only (scalar loads the compiler may have in flight return out of order, so a counted wait would not be safe).
+      constexpr int GU = 2, NG = (UPW + GU - 1) / GU;
+      // (the k-step's tile offsets go into the instructions' immediate field: the address registers -- one per unit, three for dY -- are the same in all 8 steps)
+      constexpr int LB = (ks >> 1) * PLANE + ((ks & 1) * 2) * LINE, DB = ks * 32 * 96;
+      TrFrag fa[3], fb[2][GU], fx;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tr_read_raw<16 * 96, DB>(fa[c], dy_ad[c]);
+#pragma unroll
+      for (int u = 0; u < GU; ++u) tr_read_raw<LINE, LB>(fb[0][u], u_ad[u]);
+      if (ks < NDMA) dy_dma_one(ks, nb, nz0, ny0, nx0, cur ^ 1, has_next);
+      {
+        constexpr int h8[9] = {0, 1, 2, 3, 5, 7, 8, 8, 8}, h4[9] = {0, 1, 2, 3, 4, 4, 4, 4, 4};
+        const int h0 = HREG == 8 ? h8[ks] : h4[ks], h1 = HREG == 8 ? h8[ks + 1] : h4[ks + 1];
+#pragma unroll
+        for (int i = 0; i < HREG; ++i)
+          if (i >= h0 && i < h1) halo_gload_one(i, nb, nz0, ny0, nx0, has_next);
+      }
+#pragma unroll
+      for (int j = 0; j < NG; ++j) {
+        tr_wait();
+        if (j == 0) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) tr_pin(fa[c]);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          if (j * GU + u < UPW) tr_pin(fb[j & 1][u]);
+        if (j + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < GU; ++u)
+            if ((j + 1) * GU + u < UPW) tr_read_raw<LINE, LB>(fb[(j + 1) & 1][u], u_ad[(j + 1) * GU + u]);
+        } else if (has_x) tr_read_raw<LINE, LB>(fx, x_ad);
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          if (j * GU + u < UPW) {
+            const Frag<bf16_t> bfr = tr_frag(fb[j & 1][u]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mma(acc[j * GU + u][c], tr_frag(fa[c]), bfr);
+          }
+      }
+      if (has_x) {
+        tr_wait();
+        tr_pin(fx);
+        const Frag<bf16_t> bfr = tr_frag(fx);
+        if (wave == 1) mma(accx, tr_frag(fa[0]), bfr);
+        else if (wave == 2) mma(accx, tr_frag(fa[1]), bfr);
+        else mma(accx, tr_frag(fa[2]), bfr);
+      }
+      }
+    });
     stamp(1);
     __syncthreads();  // everyone is done with halo / dY[cur]; the barrier also drains this wave's DMA + prefetch loads
     stamp(2);
@@ -804,7 +872,16 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
     NMH_CHECK_LAUNCH();
     return 0;
   }
-  if (nw == 8) hipLaunchKernelGGL(conv48_wgrad_kernel<8>, dim3(nb, nsub), dim3(512), LDS_BYTES, st, a);
+  static const int raw = getenv("NMH_W48_RAW") ? atoi(getenv("NMH_W48_RAW")) : 1;
+  if (nw == 8 && raw) {
+    static NmhPerDeviceOnce raw_set;
+    if (raw_set.need()) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv48_wgrad_kernel<8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+      raw_set.set();
+    }
+    hipLaunchKernelGGL((conv48_wgrad_kernel<8, 0, true>), dim3(nb, nsub), dim3(512), LDS_BYTES, st, a);
+  } else if (nw == 8) hipLaunchKernelGGL(conv48_wgrad_kernel<8>, dim3(nb, nsub), dim3(512), LDS_BYTES, st, a);
   else hipLaunchKernelGGL(conv48_wgrad_kernel<16>, dim3(nb, nsub), dim3(1024), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   hipLaunchKernelGGL(conv48_wgrad_reduce_kernel, dim3((PARTIAL + 255) / 256, nsub), dim3(256), 0, st, ws, dW, nb, a.nci, Cin);

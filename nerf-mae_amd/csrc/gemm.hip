@@ -170,12 +170,12 @@ template <typename T> __device__ __forceinline__ void epilogue8(const EpiParams&
 }
 
 // epilogue shared by the NT kernels: per wave, one 16-row m-tile at a time through a private LDS slab (16-byte row stores)
+// (mw0, n0: first row / column of this wave's (16 MT) x (16 NT) sub-tile; `wave` picks the wave's private slab)
 template <typename T, int MT, int NT>
-__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, const EpiParams& ep, int m0, int n0, int M, int N, int wave, int lane, int zb = -1) {
+__device__ __forceinline__ void nt_epilogue_w(f32x4 (&acc)[MT][NT], char* smem, const EpiParams& ep, int mw0, int n0, int M, int N, int wave, int lane, long zrow) {
   constexpr int BN = 16 * NT, SLD = BN + 4;
   const int g = lane >> 4, li = lane & 15;
   float* stg = reinterpret_cast<float*>(smem) + wave * 16 * SLD;
-  const long zrow = (long)(zb < 0 ? (int)blockIdx.z : zb) * M;
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
 #pragma unroll
@@ -186,7 +186,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, co
     __builtin_amdgcn_wave_barrier();
     for (int it = lane; it < 16 * (BN / 8); it += 64) {
       const int row = it / (BN / 8), cc = it - row * (BN / 8);
-      const int grow = m0 + wave * 16 * MT + a * 16 + row, gcol = n0 + cc * 8;
+      const int grow = mw0 + a * 16 + row, gcol = n0 + cc * 8;
       if (grow < M && gcol < N) {
         float v[8];
         float4 x0 = *reinterpret_cast<const float4*>(stg + row * SLD + cc * 8);
@@ -198,6 +198,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+}
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[MT][NT], char* smem, const EpiParams& ep, int m0, int n0, int M, int N, int wave, int lane, int zb = -1) {
+  nt_epilogue_w<T, MT, NT>(acc, smem, ep, m0 + wave * 16 * MT, n0, M, N, wave, lane, (long)(zb < 0 ? (int)blockIdx.z : zb) * M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,6 +485,122 @@ static int launch_nt_dma(const ADirect<bf16_t>& al, const void* Bw, long ldb, in
   NMH_CHECK_LAUNCH();
   return 0;
 }
+// ------------------------------------------------------------------------------------------------
+// gemm_nt, LDS-DMA ring, waves as a 2 x 2 grid (round 5).  The kernels above stack their four waves along M, so every wave reads the
+// workgroup's whole B tile: a 64 x 96 tile costs 1.17 KB of LDS fragment reads per MFMA -- more than the 1 KB per MFMA the LDS can
+// deliver at the matrix peak -- and fetches 160 operand rows per 6144 outputs.  Here a wave owns a (16 MT) x (16 NT) quadrant of a
+// (32 MT) x (32 NT) workgroup tile (128 x 128: 0.5 KB of fragment reads per MFMA, 256 operand rows per 16384 outputs); tiles, swizzle,
+// DMA image, counted-vmcnt ring and epilogue slabs are those of gemm_nt_dma_kernel.  1-D grid: XCD x takes a contiguous range of work
+// items with the N tiles of one row panel adjacent, so an A panel is pulled into one L2 once.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NT, int ST>
+__global__ __launch_bounds__(256) void gemm_nt_w22_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bw, long ldb, int M, int N, int K, int ntn,
+                                                          EpiParams ep) {
+  using T = bf16_t;
+  constexpr int BM = 32 * MT, BN = 32 * NT, KT = 64, PCS = MT + NT, STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = (int)blockIdx.x;
+  {
+    const int G = (int)gridDim.x, x = bid & 7, q = G >> 3, rem = G & 7;
+    bid = x * q + (x < rem ? x : rem) + (bid >> 3);
+  }
+  const int mt = bid / ntn, nt = bid - mt * ntn;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int lrow = lane >> 3, row8 = 8 * wave + lrow;
+  const int kc = ((lane & 7) ^ ((row8 >> 1) & 7)) * 8;   // logical k offset (elements) this lane fetches in every piece
+  const T* asrc[MT];
+  const T* bsrc[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int m = m0 + 32 * i + row8;
+    if (m > M - 1) m = M - 1;                              // clamped rows are computed but never stored
+    asrc[i] = A + (long)m * lda + kc;
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    int n = n0 + 32 * i + row8;
+    if (n > N - 1) n = N - 1;
+    bsrc[i] = Bw + (long)n * ldb + kc;
+  }
+  const int nk = (K + KT - 1) / KT;
+  unsigned long long zpage = (unsigned long long)(const void*)g_zero16_nt;
+  asm volatile("" : "+v"(zpage));
+  auto issue = [&](int kt) {
+    char* slot = smem + (kt % ST) * STAGE + wave * 1024;
+    const bool ok = kt * KT + kc < K;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const void* src = (const void*)(ok ? (unsigned long long)(asrc[i] + kt * KT) : zpage);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + i * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const void* src = (const void*)(ok ? (unsigned long long)(bsrc[i] + kt * KT) : zpage);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + BM * 128 + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (s < nk) issue(s);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (nk - 1 - kt >= ST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PCS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's pieces of stage kt are visible; everyone is done reading stage kt-1
+    if (kt + ST - 1 < nk) issue(kt + ST - 1);   // refills the slot of stage kt-1
+    const char* As = smem + (kt % ST) * STAGE + wm * (16 * MT * 128);
+    const char* Bs = smem + (kt % ST) * STAGE + BM * 128 + wn * (16 * NT * 128);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> bf[NT];
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bf[b] = lds_frag(Bs, b * 16 + li, s, g, (T*)nullptr);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        Frag<T> af = lds_frag(As, a * 16 + li, s, g, (T*)nullptr);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) mma(acc[a][b], bf[b], af);   // transposed product: lane (m = li, g) holds columns 16 b + 4 g + r of row m
+      }
+    }
+  }
+  __syncthreads();   // the epilogue reuses the ring as staging space
+  nt_epilogue_w<T, MT, NT>(acc, smem, ep, m0 + wm * 16 * MT, n0 + wn * 16 * NT, M, N, wave, lane, 0L);
+}
+
+template <int MT, int NT, int ST>
+static int launch_nt_w22(const bf16_t* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st) {
+  constexpr int BM = 32 * MT, BN = 32 * NT;
+  constexpr int lds_main = ST * (BM + BN) * 128, lds_epi = 4 * 16 * (16 * NT + 4) * 4;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  const int mtiles = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_w22_kernel<MT, NT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set.set();
+  }
+  hipLaunchKernelGGL((gemm_nt_w22_kernel<MT, NT, ST>), dim3(mtiles * ntn), dim3(256), lds, st, A, lda, (const bf16_t*)Bw, ldb, M, N, K, ntn, ep);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+// cfg = MT * 100 + NT * 10 + ST
+static int launch_nt_w22_cfg(int cfg, const bf16_t* A, long lda, const void* Bw, long ldb, int M, int N, int K, const EpiParams& ep, hipStream_t st) {
+  switch (cfg) {
+#define W22(mt, nt, s) case mt * 100 + nt * 10 + s: return launch_nt_w22<mt, nt, s>(A, lda, Bw, ldb, M, N, K, ep, st)
+    W22(4, 4, 2); W22(4, 4, 3); W22(4, 3, 2); W22(4, 3, 3); W22(2, 4, 2); W22(2, 4, 3); W22(2, 4, 4); W22(2, 3, 3); W22(2, 3, 4); W22(2, 2, 4); W22(4, 2, 3); W22(4, 2, 4);
+#undef W22
+  }
+  return -2;
+}
+
 // The pipelined kernel pays off where few workgroups exist to hide a global-load latency per k-tile (measured, M <= 8192:
 // fc2 4000x384x1536 21.9 -> 15.2 us, 500x768x3072 34.6 -> 24.5 us; with K = 384 the 4-deep ring holds most of the contraction at once:
 // whole step at 1 grid/GPU 13.75 -> 13.35 ms with the threshold lowered from K >= 1024 to K >= 384); with >= 1000 workgroups the
@@ -523,10 +643,25 @@ static int launch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K
   return 0;
 }
 
+// which launches take the 2 x 2-wave kernel, and with which tile (0: none).  NMH_GEMM_W22=<cfg> forces one tile everywhere it applies (tools/bench_nt_w22.py),
+// NMH_GEMM_W22=0 disables.
+static int w22_config(int M, int N, int K, const EpiParams& ep) {
+  const char* e = getenv("NMH_GEMM_W22");   // (read per dispatch: the tile sweep changes it inside one process)
+  const int forced = e ? atoi(e) : -1;
+  if (forced >= 0) return (K >= 64 && N >= 64) ? forced : 0;
+  return 0;
+}
+
 template <typename T, class AL>
 static int dispatch_nt(const AL& al, const void* Bw, long ldb, int M, int N, int K, int batch, const EpiParams& ep, hipStream_t st) {
   if (N % 8 != 0 || K % 8 != 0) return -2;
   const int t16 = (N + 15) / 16;
+  if constexpr (std::is_same<AL, ADirect<bf16_t>>::value) {
+    if (batch == 1 && ep.ksplit <= 1 && !ep.up_k && lda_ok(al.lda, ldb)) {
+      const int cfg = w22_config(M, N, K, ep);
+      if (cfg > 0) return launch_nt_w22_cfg(cfg, al.A, al.lda, Bw, ldb, M, N, K, ep, st);
+    }
+  }
   if (const char* ov = getenv("NMH_GEMM_CFG")) {  // tuning override "MT,NT"
     int mt = ov[0] - '0', nt = atoi(ov + 2);
     if (mt == 1 && nt == 2) return launch_nt<T, 1, 2, AL>(al, Bw, ldb, M, N, K, batch, ep, st);
@@ -953,6 +1088,15 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
   for (int j = 0; j < 8; ++j) ones.v[j] = (short)0x3F80;
 
   const int nc = mbeg < mend ? (int)((mend - mbeg + CH - 1) / CH) : 0;
+  unsigned aofs[NTW], bofs[KTW];   // per-lane fragment offsets inside a tile (lds_frag_t_sw's address)
+  {
+    const int fg = lane >> 4, fp = lane & 15, frow = 4 * fg + (fp >> 2);
+#pragma unroll
+    for (int a = 0; a < NTW; ++a) aofs[a] = (unsigned)(frow * RS + (((((wn * NTW + a) * 16) >> 2) + (fp & 3)) ^ (((frow >> 2) & 1) << 2)) * 8);
+#pragma unroll
+    for (int b = 0; b < KTW; ++b) bofs[b] = (unsigned)(frow * RS + (((((wk * KTW + b) * 16) >> 2) + (fp & 3)) ^ (((frow >> 2) & 1) << 2)) * 8);
+  }
+  const unsigned smem_u = lds_addr_u(smem);
 #pragma unroll
   for (int s = 0; s < ST - 1; ++s)
     if (s < nc) issue(s);
@@ -961,18 +1105,32 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const bf16_t* __restri
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (c + ST - 1 < nc) issue(c + ST - 1);
-    const char* sA = smem + (c % ST) * STAGE;
-    const char* sB = sA + TILE;
+    // raw transpose reads (common.hpp): the compiler-visible builtin is ordered behind EVERY pending LDS-DMA (`s_waitcnt vmcnt(0)`), the chunks just requested
+    // included, which made this ring a synchronous load
+    const unsigned st_u = smem_u + (unsigned)((c % ST) * STAGE);
+    TrFrag fa[CH / 32][NTW], fb[CH / 32][KTW];
 #pragma unroll
     for (int s = 0; s < CH / 32; ++s) {
-      Frag<T> bf[KTW];
 #pragma unroll
-      for (int b = 0; b < KTW; ++b) bf[b] = lds_frag_t_sw(sB, s * 32, (wk * KTW + b) * 16, lane);
+      for (int b = 0; b < KTW; ++b) tr_read_raw<16 * RS>(fb[s][b], st_u + TILE + bofs[b] + s * 32 * RS);
+#pragma unroll
+      for (int a = 0; a < NTW; ++a) tr_read_raw<16 * RS>(fa[s][a], st_u + aofs[a] + s * 32 * RS);
+    }
+    tr_wait();
+#pragma unroll
+    for (int s = 0; s < CH / 32; ++s) {
+#pragma unroll
+      for (int b = 0; b < KTW; ++b) tr_pin(fb[s][b]);
+#pragma unroll
+      for (int a = 0; a < NTW; ++a) tr_pin(fa[s][a]);
+    }
+#pragma unroll
+    for (int s = 0; s < CH / 32; ++s) {
 #pragma unroll
       for (int a = 0; a < NTW; ++a) {
-        Frag<T> af = lds_frag_t_sw(sA, s * 32, (wn * NTW + a) * 16, lane);
+        const Frag<T> af = tr_frag(fa[s][a]);
 #pragma unroll
-        for (int b = 0; b < KTW; ++b) mma(acc[a][b], af, bf[b]);
+        for (int b = 0; b < KTW; ++b) mma(acc[a][b], af, tr_frag(fb[s][b]));
         if (want_bias) mma(bacc[a], af, ones);
       }
     }

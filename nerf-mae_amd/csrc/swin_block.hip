@@ -1407,15 +1407,22 @@ __global__ __launch_bounds__(64 * NW) void swin_qkv_bwd_kernel(QkvBwdArgs a) {
 // launchers
 // ------------------------------------------------------------------------------------------------
 namespace {
+// The "attribute set" flag is keyed on (device, kernel ADDRESS): K is only the function-pointer type, which every instantiation of a kernel family
+// shares, so a flag per K would skip the opt-in of all instantiations but the first one launched.
 template <class K> int set_lds(K kernel, int bytes) {   // per device: a second GPU driven from the same process needs its own attribute
-  static bool done[64] = {};
+  constexpr int SLOTS = 64;
+  static const void* seen[64][SLOTS] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!done[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return (int)e;
-    done[dev] = true;
+  const void* key = (const void*)kernel;
+  int free_slot = -1;
+  for (int i = 0; i < SLOTS; ++i) {
+    if (seen[dev][i] == key) return 0;
+    if (!seen[dev][i]) { free_slot = i; break; }
   }
+  hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  if (free_slot >= 0) seen[dev][free_slot] = key;   // (table full: the idempotent call is simply repeated)
   return 0;
 }
 constexpr int RING_A = 4;

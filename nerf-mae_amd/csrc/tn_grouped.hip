@@ -74,6 +74,14 @@ __device__ __forceinline__ Frag<bf16_t> tng_frag(const char* tile, int m0, int c
   return f;
 }
 
+// byte offset (inside a tile of dense 192-byte rows) of this lane's transpose-read address for contraction rows m0.. and columns col0..col0+15: tng_frag's address
+__device__ __forceinline__ unsigned tng_frag_ofs(int m0, int col0, int lane) {
+  const int g = lane >> 4, p = lane & 15;
+  const int row = m0 + 4 * g + (p >> 2);
+  const int ch = ((col0 >> 2) + (p & 3)) ^ (((row >> 2) & 1) << 2);
+  return (unsigned)(row * tng::RS + ch * 8);
+}
+
 // BIG: 192x192 output tile, 8 waves (one workgroup per CU, LDS ring 3 x 48 KB).  The 96x96 kernel moves 24 KB into LDS per 1.18 MFLOP
 // and, with two chunks per workgroup in flight, is bound by the bytes it can keep in flight (measured ~8 TB/s of L2->LDS traffic at
 // 0.3-0.4 PF); the large tile halves the bytes per FLOP at the same bytes in flight.  The LDS image stays a set of 64-row x 96-column
@@ -198,20 +206,57 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
   for (int j = 0; j < 8; ++j) ones.v[j] = (short)0x3F80;
   const bool scaled = RSC && P.rowscale != nullptr;
 
+  // fragment addresses: per-lane offsets inside a stage, fixed for the kernel (the DMA variant reads them with raw ds_read_b64_tr_b16: common.hpp)
+  unsigned aofs[3], bofs[NB];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) aofs[a] = (unsigned)(sa * TILE) + tng_frag_ofs(0, acol0 + a * 16, lane);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) bofs[b] = (unsigned)((NSUB / 2 + sb) * TILE) + tng_frag_ofs(0, bcol0 + b * 16, lane);
+  const unsigned smem_u = lds_addr_u(smem);
   auto compute = [&](const char* stage) {
-    const char* sA = stage + sa * TILE;
-    const char* sB = stage + (NSUB / 2 + sb) * TILE;
+    if constexpr (REG) {   // (no LDS-DMA in flight: compiler-visible reads)
+      const char* sA = stage + sa * TILE;
+      const char* sB = stage + (NSUB / 2 + sb) * TILE;
 #pragma unroll
-    for (int s = 0; s < CH / 32; ++s) {
-      Frag<bf16_t> bf[NB];
+      for (int s = 0; s < CH / 32; ++s) {
+        Frag<bf16_t> bf[NB];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) bf[b] = tng_frag(sB, s * 32, bcol0 + b * 16, lane);
+        for (int b = 0; b < NB; ++b) bf[b] = tng_frag(sB, s * 32, bcol0 + b * 16, lane);
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        Frag<bf16_t> af = tng_frag(sA, s * 32, acol0 + a * 16, lane);
+        for (int a = 0; a < 3; ++a) {
+          Frag<bf16_t> af = tng_frag(sA, s * 32, acol0 + a * 16, lane);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) mma(acc[a][b], af, bf[b]);
-        if (want_bias) mma(bacc[a], af, ones);
+          for (int b = 0; b < NB; ++b) mma(acc[a][b], af, bf[b]);
+          if (want_bias) mma(bacc[a], af, ones);
+        }
+      }
+    } else {
+      const unsigned st_u = smem_u + (unsigned)(stage - smem);
+      TrFrag fb[2][NB], fa[2][3];
+#pragma unroll
+      for (int s = 0; s < CH / 32; ++s) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tr_read_raw<16 * RS>(fb[s][b], st_u + bofs[b] + s * 32 * RS);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tr_read_raw<16 * RS>(fa[s][a], st_u + aofs[a] + s * 32 * RS);
+      }
+      tr_wait();
+#pragma unroll
+      for (int s = 0; s < CH / 32; ++s) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tr_pin(fb[s][b]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tr_pin(fa[s][a]);
+      }
+#pragma unroll
+      for (int s = 0; s < CH / 32; ++s) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const Frag<bf16_t> af = tr_frag(fa[s][a]);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) mma(acc[a][b], af, tr_frag(fb[s][b]));
+          if (want_bias) mma(bacc[a], af, ones);
+        }
       }
     }
   };
@@ -293,9 +338,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
   }
 }
 
-// sums the split partials of every split problem of the group into dW / dbias: 256 threads x 4 consecutive elements per workgroup
+// sums the split partials of every split problem of the group into dW / dbias.  A workgroup: 64 items (four consecutive output elements, or one bias entry)
+// x 4 interleaved shares of the splits (thread = item + 64 * share), combined through LDS in a fixed order -- four times the loads in flight of the
+// one-thread-per-item form, whose 27-63 workgroups walked 100+ slabs as one dependent-latency chain each (28-66 us per reduce behind the streaming launches)
+constexpr int TNG_RED_ITEMS = 64;
 __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args ga) {
   using namespace tng;
+  __shared__ float4 red[3][TNG_RED_ITEMS];
   int pi = -1;
 #pragma unroll 1
   for (int i = 0; i < ga.nprob; ++i)
@@ -304,28 +353,377 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args g
   const Prob& P = ga.p[pi];
   const float* const ppart = ga.ws + P.partoff;
   const long NK = (long)P.N * P.K, NK4 = NK >> 2;   // K % 8 == 0
-  const long i4 = (long)((int)blockIdx.x - P.rbegin) * 256 + threadIdx.x;
-  if (i4 < NK4) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < P.zs; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(ppart + (long)z * NK + i4 * 4);
+  const int item = threadIdx.x & (TNG_RED_ITEMS - 1), share = threadIdx.x >> 6;
+  const long i4 = (long)((int)blockIdx.x - P.rbegin) * TNG_RED_ITEMS + item;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool is_w = i4 < NK4, is_b = !is_w && P.dbias && i4 < NK4 + P.N;
+  if (is_w) {
+    const float* src = ppart + i4 * 4;
+    int z = share;
+    for (; z + 12 < P.zs; z += 16) {   // four slabs of this share in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(src + (long)z * NK), v1 = *reinterpret_cast<const float4*>(src + (long)(z + 4) * NK);
+      const float4 v2 = *reinterpret_cast<const float4*>(src + (long)(z + 8) * NK), v3 = *reinterpret_cast<const float4*>(src + (long)(z + 12) * NK);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y); s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; z < P.zs; z += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)z * NK);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  } else if (is_b) {
+    const int n = (int)(i4 - NK4);
+    for (int z = share; z < P.zs; z += 4) s.x += ppart[(long)P.zs * NK + (long)z * P.N + n];
+  }
+  if (share) red[share - 1][item] = s;
+  __syncthreads();
+  if (share) return;
+  {
+    const float4 a = red[0][item], b = red[1][item], c = red[2][item];
+    s.x = (s.x + a.x) + (b.x + c.x); s.y = (s.y + a.y) + (b.y + c.y); s.z = (s.z + a.z) + (b.z + c.z); s.w = (s.w + a.w) + (b.w + c.w);
+  }
+  if (is_w) {
     const long i = i4 * 4;
     const int n = (int)(i / P.K), k = (int)(i - (long)n * P.K);
     float* o = P.Out + P.out_off(n, k);
     o[0] += s.x; o[P.sok] += s.y; o[2 * P.sok] += s.z; o[3 * P.sok] += s.w;
-  } else if (P.dbias && i4 < NK4 + P.N) {
+  } else if (is_b) {
     const int n = (int)(i4 - NK4);
-    float s = 0.f;
-    for (int z = 0; z < P.zs; ++z) s += ppart[(long)P.zs * NK + (long)z * P.N + n];
-    if (P.bias_atomic()) atomicAdd(P.dbias + P.bias_col(n), s);
-    else P.dbias[P.bias_col(n)] += s;
+    if (P.bias_atomic()) atomicAdd(P.dbias + P.bias_col(n), s.x);
+    else P.dbias[P.bias_col(n)] += s.x;
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming variant for LONG contractions with a SMALL output (round 5): the stage-0/1 Linear gradients (64 k - 512 k rows, 96..768 x 96..768
+// outputs), the patch-merging reduction and the decoder-1 transpose-conv gradient (512 k coarse voxels x 16 problems of 192 x 96).  With 96x96 output tiles
+// those problems have 1-32 tiles: each tile's workgroups re-read the B panel once per N tile and fetch 192-byte slices of 768-byte A rows, and the
+// launch ran at 1.3-2.0 TB/s of HBM traffic (2.35 ms for the transpose-conv gradient's 3.15 GB).  They are HBM-bound by two orders of magnitude
+// (48-96 FLOP per operand byte at full-output blocks, MFMA busy < 10 %), so here a workgroup owns a ROW RANGE and a whole output block of up to
+// 384 x 192 (8 waves x up to 36 accumulator tiles): every operand byte is fetched once, in full rows, through a ring of 32-row chunks with
+// ST-1 chunks (54-108 KB per CU) in flight; the partial blocks go to the launch workspace and the grouped reduce launch sums them (the
+// same [split][N][K] layout as the split path above).  A workgroup's rows lie inside one sample, so the stochastic-depth factor is one multiply
+// at the end.
+//   NA / NB: 96-column sub-tiles of the A / B operand per stage; WN x WK = 8: wave grid over the (6 NA) x (6 NB) accumulator tiles.
+// ------------------------------------------------------------------------------------------------
+namespace tns {
+constexpr int CH = 32, SUB = CH * tng::RS;   // one sub-tile: 32 rows x 96 columns = 6 x 1 KB DMA pieces
+}
+template <int NA, int NB, int WN, int WK, int ST, bool UP>   // UP: the launch's A operands are pixel-shuffled views (ConvTranspose3d backward)
+__global__ __launch_bounds__(512) void gemm_tn_stream_kernel(tng::Args ga) {
+  using namespace tng;
+  constexpr int NS = NA + NB, PIECES = NS * 6, NPW = (PIECES + 7) / 8, STG = NPW * 8 * 1024;   // (stage stride: whole pieces per wave; the surplus is a trash area)
+  constexpr int TN = 6 * NA / WN, TK = 6 * NB / WK;
+  static_assert(WN * WK == 8 && (6 * NA) % WN == 0 && (6 * NB) % WK == 0, "wave grid");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wn = wave / WK, wk = wave - wn * WK, g = lane >> 4, li = lane & 15;
+  const int bid = (int)blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAXP; ++i)
+    if (bid >= ga.wbegin[i]) pi = i;
+  const Prob& P = ga.p[pi];
+  const int lw = bid - ga.wbegin[pi];
+  const int N = P.N, K = P.K;
+  const int nblk = (N + 96 * NA - 1) / (96 * NA), kblk = (K + 96 * NB - 1) / (96 * NB);
+  const int z = lw / (nblk * kblk), t = lw - z * (nblk * kblk);
+  const int nb = t / kblk, kb = t - nb * kblk;
+  const int n0 = nb * 96 * NA, k0 = kb * 96 * NB;
+  // rows: split sj of sample sb takes the 32-row chunks sj, sj + sub, sj + 2 sub, ... of the sample: the workgroups of a problem stream ADJACENT chunks at
+  // any moment (a grid-stride loop) rather than row ranges a fixed multi-MB stride apart
+  const int sb = z / P.sub, sj = z - sb * P.sub, psub = P.sub;
+  const int seglen = P.rps;
+  const long segbase = (long)sb * P.rps;
+  const int tc = (seglen + tns::CH - 1) / tns::CH;
+  const int nc = tc > sj ? (tc - sj + psub - 1) / psub : 0;
+  const long lda = P.lda, ldb = P.ldb;
+  const int up_k = P.up_k(), up_v = P.up_v();
+  const float up_rcp = UP ? 1.0f / (float)up_v : 0.f;
+
+  // DMA piece i of this wave: 1-KB piece q = wave + 8 i of the stage image (sub-tile q / 6, piece q % 6); q >= PIECES: zero page -> trash.
+  // The issue path is one pointer bump per piece and chunk (first version: ~150 instructions of 64-bit address arithmetic and branches per piece -- 1.2 us
+  // per chunk and wave, the whole HBM budget of a 30-KB chunk; 2.5 TB/s).  pptr: source of the piece in the split's first chunk; pstep: bytes per chunk step.
+  unsigned long long zpage = (unsigned long long)(const void*)g_zero16_tng;
+  asm volatile("" : "+v"(zpage));
+  unsigned long long pptr[NPW];
+  int prow[NPW];
+  bool pok[NPW], pisA[NPW];
+  const long stepA = (long)psub * tns::CH * lda * 2, stepB = (long)psub * tns::CH * ldb * 2;
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    const int q = wave + 8 * i, sub = q / 6, off = 1024 * (q - sub * 6) + 16 * lane;
+    const int row = off / RS, u = (off - row * RS) >> 4;
+    prow[i] = row;
+    pisA[i] = sub < NA;
+    const int c = (u ^ (((row >> 2) & 1) << 1)) * 8 + (pisA[i] ? sub : sub - NA) * 96;
+    const int col = pisA[i] ? n0 + c : k0 + c;
+    pok[i] = q < PIECES && (pisA[i] ? col < N : col < K);
+    const long r = segbase + (long)sj * tns::CH + row;
+    if (pisA[i]) {
+      if (UP) {   // the column part of the folded tap row: column n = (tx, co) sits at fine row arow + tx, channel co (arow: per chunk, below)
+        long cofs = col;
+        if (P.ncol2) { const int ni = P.ncol2 & 0xffff, q1 = col / ni; cofs = (long)q1 * lda + (col - q1 * ni); }
+        pptr[i] = (unsigned long long)(P.A + cofs);
+      } else pptr[i] = (unsigned long long)(P.A + r * lda + col);
+    } else pptr[i] = (unsigned long long)(P.B + r * ldb + col);
+  }
+  int ichunk = 0, islot = 0;
+  auto issue = [&]() {
+    const int r0 = (sj + ichunk * psub) * tns::CH;
+    const bool full = r0 + tns::CH <= seglen;   // (wave-uniform) every row of the chunk exists
+    char* slot = smem + islot * STG;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      unsigned long long src = pptr[i];
+      if (UP && pisA[i]) {   // pixel-shuffled view: coarse voxel m -> the fine row of this problem's tap row
+        const unsigned vv = (unsigned)up_v, kk = (unsigned)up_k, m = (unsigned)(segbase + r0 + prow[i]);
+        // m < 2^24: floor(m / vv) from the float reciprocal, corrected by one step either way
+        auto divv = [&](unsigned a, unsigned& qo, unsigned& ro) {
+          unsigned qq = (unsigned)((float)a * up_rcp);
+          int rr = (int)(a - qq * vv);
+          if (rr < 0) { --qq; rr += (int)vv; }
+          if (rr >= (int)vv) { ++qq; rr -= (int)vv; }
+          qo = qq; ro = (unsigned)rr;
+        };
+        unsigned q1, x, q2, y, bb, zq;
+        divv(m, q1, x); divv(q1, q2, y); divv(q2, bb, zq);
+        const long Vf = (long)vv * kk;
+        const long arow = (((long)bb * Vf + zq * kk) * Vf + y * kk) * Vf + x * kk;
+        src += (unsigned long long)(arow * lda * 2);
+      } else pptr[i] += (unsigned long long)(pisA[i] ? stepA : stepB);
+      const bool ok = pok[i] && (full || r0 + prow[i] < seglen);
+      src = ok ? src : zpage;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+    ++ichunk;
+    if (++islot == ST) islot = 0;
+  };
+
+  f32x4 acc[TN][TK], bacc[TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < TK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_bias = P.dbias != nullptr && kb == 0 && wk == 0;
+  Frag<bf16_t> ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones.v[j] = (short)0x3F80;
+
+  // fragment addresses (raw transpose reads, common.hpp): per-lane offsets inside a stage
+  unsigned aofs[TN], bofs[TK];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) { const int tn = wn * TN + a; aofs[a] = (unsigned)((tn / 6) * tns::SUB) + tng_frag_ofs(0, (tn % 6) * 16, lane); }
+#pragma unroll
+  for (int b = 0; b < TK; ++b) { const int tk = wk * TK + b; bofs[b] = (unsigned)((NA + tk / 6) * tns::SUB) + tng_frag_ofs(0, (tk % 6) * 16, lane); }
+  const unsigned smem_u = lds_addr_u(smem);
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (s < nc) issue();
+  int cslot = 0;
+  for (int c = 0; c < nc; ++c) {
+    if (nc - 1 - c >= ST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // chunk c is visible to everyone; everyone is done reading chunk c-1 (whose slot the next issue refills)
+    if (c + ST - 1 < nc) issue();
+    const unsigned st_u = smem_u + (unsigned)(cslot * STG);
+    if (++cslot == ST) cslot = 0;
+    TrFrag fa[TN], fb[TK];
+#pragma unroll
+    for (int b = 0; b < TK; ++b) tr_read_raw<16 * RS>(fb[b], st_u + bofs[b]);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) tr_read_raw<16 * RS>(fa[a], st_u + aofs[a]);
+    tr_wait();
+#pragma unroll
+    for (int b = 0; b < TK; ++b) tr_pin(fb[b]);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) tr_pin(fa[a]);
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      const Frag<bf16_t> af = tr_frag(fa[a]);
+#pragma unroll
+      for (int b = 0; b < TK; ++b) mma(acc[a][b], af, tr_frag(fb[b]));
+      if (want_bias) mma(bacc[a], af, ones);
+    }
+  }
+  // acc[a][b][r]: row n = n0 + (wn TN + a) 16 + 4 g + r, column k = k0 + (wk TK + b) 16 + li  ->  this split's partial slab
+  const float sc = P.rowscale ? P.rowscale[sb] : 1.f;
+  float* const ppart = ga.ws + P.partoff;
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wn * TN + a) * 16 + 4 * g + r, k = k0 + (wk * TK + b) * 16 + li;
+        if (n < N && k < K) ppart[((long)z * N + n) * K + k] = sc * acc[a][b][r];
+      }
+  if (want_bias && li == 0) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (wn * TN + a) * 16 + 4 * g + r;
+        if (n < N) ppart[(long)P.zs * N * K + (long)z * N + n] = sc * bacc[a][r];
+      }
+  }
+}
+
+namespace tns {
+struct Cfg { int NA, NB; };
+// output-block shapes on offer (columns of A x columns of B per workgroup): {192,96} {384,96} {96,384} {384,192} {192,384} {192,192}
+static const Cfg kCfg[] = {{2, 1}, {4, 1}, {1, 4}, {4, 2}, {2, 4}, {2, 2}};
+constexpr int NCFG = 6;
+// the block shape a problem takes: the one that covers [N, K] with the fewest operand re-reads (blocks along N re-read B, blocks along K re-read A),
+// then the least padding
+static int pick_cfg(int N, int K) {
+  int best = -1;
+  double bestcost = 1e30;
+  for (int c = 0; c < NCFG; ++c) {
+    const int bn = 96 * kCfg[c].NA, bk = 96 * kCfg[c].NB;
+    const int nblk = (N + bn - 1) / bn, kblk = (K + bk - 1) / bk;
+    const double bytes = (double)N * kblk + (double)K * nblk;                    // operand columns fetched per row
+    const double pad = (double)nblk * bn * kblk * bk / ((double)N * K);           // MFMA / DMA-issue work relative to the useful part
+    const double cost = bytes * (1.0 + 0.02 * pad);
+    if (cost < bestcost) { bestcost = cost; best = c; }
+  }
+  return best;
+}
+template <int NA, int NB, int WN, int WK, int ST, bool UP> static int launch(const tng::Args& ga, int wgs, hipStream_t st) {
+  constexpr int lds = ST * ((((NA + NB) * 6 + 7) / 8) * 8 * 1024);
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_stream_kernel<NA, NB, WN, WK, ST, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set.set();
+  }
+  hipLaunchKernelGGL((gemm_tn_stream_kernel<NA, NB, WN, WK, ST, UP>), dim3(wgs), dim3(512), lds, st, ga);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+template <bool UP> static int launch_cfg(int c, const tng::Args& ga, int wgs, hipStream_t st) {
+  switch (c) {
+    case 0: return launch<2, 1, 4, 2, 4, UP>(ga, wgs, st);
+    case 1: return launch<4, 1, 8, 1, 4, UP>(ga, wgs, st);
+    case 2: return launch<1, 4, 1, 8, 4, UP>(ga, wgs, st);
+    case 3: return launch<4, 2, 4, 2, 3, UP>(ga, wgs, st);
+    case 4: return launch<2, 4, 2, 4, 3, UP>(ga, wgs, st);
+    case 5: return launch<2, 2, 4, 2, 4, UP>(ga, wgs, st);
+  }
+  return -2;
+}
+}  // namespace tns
+
+// the streaming launches of a grouped call: problems -> (block shape) groups -> one launch each + one grouped reduce.  Returns the number of problems taken
+// (they are removed from `rest`), or a negative error.
+static int tn_stream_launches(const TnProblemHost* probs, int nprob, std::vector<int>& rest, float* ws, long ws_floats, hipStream_t st, bool foreground) {
+  using namespace tng;
+  const char* e_on = getenv("NMH_TNS");   // (read per call: tools/bench_tns.py and the parity tests switch it inside one process)
+  const int on = e_on ? atoi(e_on) : 1;
+  static const long min_m = getenv("NMH_TNS_MINM") ? atol(getenv("NMH_TNS_MINM")) : 32768;
+  const char* e_ratio = getenv("NMH_TNS_RATIO");   // (per call, like NMH_TNS: the parity tests force the streaming path at small sizes with 0)
+  const double ratio = e_ratio ? atof(e_ratio) : 6.0;
+  static const int target_bg = getenv("NMH_TNS_TARGET") ? atoi(getenv("NMH_TNS_TARGET")) : 256;
+  (void)foreground;
+  rest.clear();
+  std::vector<int> take[2 * tns::NCFG];   // [block shape][plain | pixel-shuffled A]
+  for (int i = 0; i < nprob; ++i) {
+    const TnProblemHost& h = probs[i];
+    bool ok = on && ws && h.M >= min_m && h.rows_per_sample >= 2048 && h.M % h.rows_per_sample == 0 && (long)h.N * h.K <= 768L * 768 &&
+              h.K % 8 == 0 && h.lda % 8 == 0 && h.ldb % 8 == 0 && h.N % 8 == 0 && h.A && h.B && h.dW;
+    if (ok && h.n_inner > 0 && (h.N % h.n_inner || h.n_inner % 8 || h.n_inner > 65535 || h.stride_n2 < 0 || h.stride_n2 > 32767)) ok = false;
+    if (ok && h.up_k > 0 && (h.up_v <= 0 || h.up_k > 255 || h.up_v > 65535 || h.rows_per_sample != (long)h.up_v * h.up_v * h.up_v)) ok = false;
+    if (ok && (h.lda >= (1L << 31) || h.ldb >= (1L << 31) || h.ldo >= (1L << 31) || h.stride_k >= (1L << 31))) ok = false;
+    if (ok && h.up_k > 0 && h.M >= (1L << 24)) ok = false;   // (the kernel's float-reciprocal row decomposition)
+    int cfg = -1;
+    if (ok) {
+      // worth it only while the partial blocks (one per workgroup, written and read back by the reduce) stay small against the operands: the stage-1 problems
+      // (64 k rows, 768 x 192 outputs) measured 302 us here against 200 us with the tile kernels, stage 0 and the transpose conv (512 k rows) 1.2-2x faster
+      cfg = tns::pick_cfg(h.N, h.K);
+      const int bn = 96 * tns::kCfg[cfg].NA, bk = 96 * tns::kCfg[cfg].NB;
+      const int nblk = (h.N + bn - 1) / bn, kblk = (h.K + bk - 1) / bk;
+      const double operand = (double)h.M * ((double)h.N * kblk + (double)h.K * nblk) * 2.0 / (nblk * kblk);
+      const double partial = (double)target_bg * std::min(h.N, bn) * std::min(h.K, bk) * 4.0;
+      if (operand < ratio * partial) ok = false;
+    }
+    if (ok) take[2 * cfg + (h.up_k > 0 ? 1 : 0)].push_back(i);
+    else rest.push_back(i);
+  }
+  int ntaken = 0;
+  for (int cu = 0; cu < 2 * tns::NCFG; ++cu) {
+    const int c = cu >> 1;
+    std::vector<int>& idx = take[cu];
+    for (size_t base = 0; base < idx.size(); base += MAXP) {
+      const int np = (int)std::min((size_t)MAXP, idx.size() - base);
+      Args ga{};
+      ga.nprob = np; ga.ws = ws; ga.xcd = 0;
+      for (int i = 0; i < MAXP; ++i) ga.wbegin[i] = 0x7fffffff;
+      const int bn = 96 * tns::kCfg[c].NA, bk = 96 * tns::kCfg[c].NB;
+      double bytes_tot = 0.0;
+      std::vector<double> bytes(np);
+      for (int i = 0; i < np; ++i) {
+        const TnProblemHost& h = probs[idx[base + i]];
+        const int nblk = (h.N + bn - 1) / bn, kblk = (h.K + bk - 1) / bk;
+        bytes[i] = (double)h.M * ((double)h.N * kblk + (double)h.K * nblk);
+        bytes_tot += bytes[i];
+      }
+      // every launch is followed by its own reduce on the same stream, so each launch has the whole workspace
+      long wsoff = 0;
+      int w = 0, rb = 0;
+      bool fits = true;
+      for (int i = 0; i < np && fits; ++i) {
+        const TnProblemHost& h = probs[idx[base + i]];
+        Prob& p = ga.p[i];
+        p.A = (const bf16_t*)h.A; p.B = (const bf16_t*)h.B; p.Out = h.dW; p.dbias = h.dbias; p.rowscale = h.rowscale;
+        p.lda = (int)h.lda; p.ldb = (int)h.ldb; p.N = h.N; p.K = h.K;
+        p.son = (int)h.ldo; p.sok = h.stride_k > 0 ? (int)h.stride_k : 1;
+        p.ncol2 = h.n_inner > 0 ? (h.n_inner | ((int)h.stride_n2 << 16)) : 0;
+        p.upflags = (h.up_k & 0xff) | ((h.bias_atomic || h.n_inner > 0 ? 1 : 0) << 8) | (h.up_k > 0 ? (h.up_v << 16) : 0);
+        p.rps = h.rows_per_sample; p.nsamp = (int)(h.M / h.rows_per_sample);
+        const int nblk = (h.N + bn - 1) / bn, kblk = (h.K + bk - 1) / bk;
+        // this problem's share of the launch's workgroups -> row splits per sample (>= 1024 rows each; at least 2 splits in all: the reduce path)
+        const double share = target_bg * bytes[i] / bytes_tot / (double)(nblk * kblk);
+        int sub = (int)(share / p.nsamp + 0.5);
+        sub = std::max(1, std::min(sub, std::max(1, p.rps / 1024)));
+        if (p.nsamp * sub < 2) sub = 2;
+        long need = (long)p.nsamp * sub * p.N * (p.K + 1);
+        while (sub > 1 && p.nsamp * (sub - 1) >= 2 && (wsoff + need > ws_floats || wsoff + need >= (1L << 31))) { --sub; need = (long)p.nsamp * sub * p.N * (p.K + 1); }
+        if (wsoff + need > ws_floats || wsoff + need >= (1L << 31)) { fits = false; break; }
+        p.sub = sub; p.zs = p.nsamp * sub;
+        p.partoff = (int)wsoff;
+        wsoff += (need + 3) / 4 * 4;
+        ga.wbegin[i] = w;
+        w += p.zs * nblk * kblk;
+        p.rbegin = rb;
+        rb += (int)(((long)p.N * p.K / 4 + (p.dbias ? p.N : 0) + TNG_RED_ITEMS - 1) / TNG_RED_ITEMS);
+      }
+      if (!fits) {   // workspace too small for this launch: its problems take the tile kernels
+        for (int i = 0; i < np; ++i) rest.push_back(idx[base + i]);
+        continue;
+      }
+      if (int e = (cu & 1) ? tns::launch_cfg<true>(c, ga, w, st) : tns::launch_cfg<false>(c, ga, w, st)) return e;
+      hipLaunchKernelGGL(gemm_tn_grouped_reduce_kernel, dim3(rb), dim3(256), 0, st, ga);
+      NMH_CHECK_LAUNCH();
+      ntaken += np;
+    }
+  }
+  return ntaken;
+}
+
 // host side: chunk the problem list into launches of <= 16 problems, decide the contraction splits per launch
+static int k_gemm_tn_grouped_tiles(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground);
 int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground) {
+  // long contractions with small outputs take the streaming kernel (each workgroup: a row range x a whole output block), everything else the tile kernels
+  std::vector<int> rest;
+  const int taken = tn_stream_launches(probs, nprob, rest, ws, ws_floats, st, foreground);
+  if (taken < 0) return taken;
+  if (taken == 0) return k_gemm_tn_grouped_tiles(probs, nprob, ws, ws_floats, st, foreground);
+  if (rest.empty()) return 0;
+  std::vector<TnProblemHost> r(rest.size());
+  for (size_t i = 0; i < rest.size(); ++i) r[i] = probs[rest[i]];
+  // (the two paths share the workspace: the tile launches follow the streaming launches and their reduce on the same stream)
+  return k_gemm_tn_grouped_tiles(r.data(), (int)r.size(), ws, ws_floats, st, foreground);
+}
+static int k_gemm_tn_grouped_tiles(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground) {
   using namespace tng;
   static NmhPerDeviceOnce attr_set;
   if (attr_set.need()) {
@@ -415,7 +813,7 @@ int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_
       ga.wbegin[i] = w;
       w += p.ntile(bt) * p.zs;
       p.rbegin = rb;
-      if (p.zs > 1) rb += (int)(((long)p.N * p.K / 4 + (p.dbias ? p.N : 0) + 255) / 256);
+      if (p.zs > 1) rb += (int)(((long)p.N * p.K / 4 + (p.dbias ? p.N : 0) + TNG_RED_ITEMS - 1) / TNG_RED_ITEMS);
     }
     // Measured (tools/bench_tng.py, 16-40 stage-2 problems per launch): LDS-DMA 96x96 0.30-0.40 PF, register-staged 96x96 0.33-0.40 PF,
     // 192x192 0.38-0.50 PF; PMC: L2 hit rate 86 %, no LDS bank conflicts, waves parked in s_waitcnt / s_barrier 55-63 % of their cycles

@@ -33,7 +33,7 @@ def dev(t, dt=None):
     return (t if dt is None else t.to(dt)).cuda().contiguous()
 
 
-from tests._metrics import assert_close, relerr  # noqa: E402
+from tests._metrics import assert_close, rel_l2, relerr  # noqa: E402
 
 
 def check(a, b, dt, name="", mult=1.0, elem_mult=1.0):
@@ -864,6 +864,87 @@ def test_gemm_tn_grouped(case, variant, monkeypatch):
         assert relerr(dW, rW) < 2e-3, (case, i, specs[i], relerr(dW, rW))    # bf16 operands, fp32 accumulation: only summation order differs
         if db is not None:
             assert relerr(db, rb) < 2e-3, (case, i, "bias", relerr(db, rb))
+
+
+@pytest.mark.parametrize("case", ["stage0", "stage1", "ragged_widths", "tile_fallback_mix"])
+def test_gemm_tn_grouped_streaming(case, monkeypatch):
+    """The streaming weight-gradient kernel (csrc/tn_grouped.hip: gemm_tn_stream_kernel; contractions of >= 32768 rows with outputs up to 768 x 768: a
+    workgroup owns a row range inside one sample and a whole output block) behind nmh_gemm_tn_grouped: every block shape on offer, several blocks along N and
+    along K, widths that are not multiples of 96, rows per sample that are not a multiple of the 32-row chunk, stochastic-depth row scales, fused bias
+    gradients, accumulation into dW -- against fp32 matmuls on the bf16-rounded operands, and against the tile kernels (NMH_TNS=0) on the same inputs."""
+    ops = _ops()
+    dt = torch.bfloat16
+    if case == "stage0":       # qkv / proj / fc1 / fc2 of a 96-channel block: blocks {384,96} {192,96} {96,384}
+        specs = [(4, 8200, 288, 96, False, True), (4, 8200, 96, 96, True, True), (4, 8200, 384, 96, False, True), (4, 8200, 96, 384, True, True)]
+    elif case == "stage1":     # 192 channels + the patch-merging reduction: {384,192} x 2 blocks, {192,192}, {192,384} x 2 blocks along K
+        specs = [(2, 16400, 576, 192, False, True), (2, 16400, 192, 192, True, True), (2, 16400, 768, 192, False, True), (2, 16400, 192, 768, True, True),
+                 (2, 16400, 192, 768, False, False)]
+    elif case == "ragged_widths":
+        specs = [(3, 11000, 200, 104, True, True), (3, 11000, 40, 640, False, True), (1, 33000, 104, 200, True, False), (5, 7000, 768, 768, False, True)]
+    else:                      # one launch mixes streaming problems with problems the tile kernels keep (few rows; an output beyond 768 x 768)
+        specs = [(4, 8200, 384, 96, False, True), (4, 500, 384, 1536, True, True), (4, 8200, 96, 384, True, True), (2, 20000, 1152, 768, False, True)]
+    results = {}
+    monkeypatch.setenv("NMH_TNS_RATIO", "0")   # (the dispatch takes the streaming kernel only where the operands dwarf the partial blocks: forced here at test sizes)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NMH_TNS", mode)
+        q_ = ops.WgradQueue()
+        refs, outs = [], []
+        for i, (nsamp, rps, N, K, scaled, bias) in enumerate(specs):
+            M = nsamp * rps
+            A, Bm = q(rnd(M, N, seed=3 * i), dt), q(rnd(M, K, seed=3 * i + 1), dt)
+            rs = (torch.rand(nsamp, generator=torch.Generator().manual_seed(i)) > 0.3).float() / 0.7 if scaled else None
+            dW0 = rnd(N, K, seed=3 * i + 2)
+            db0 = rnd(N, seed=i + 50)
+            As = A if rs is None else A * rs.repeat_interleave(rps)[:, None]
+            refs.append((dW0 + As.T @ Bm, db0 + As.sum(0)))
+            dW, db = dev(dW0), dev(db0) if bias else None
+            outs.append((dW, db))
+            q_.pending.append((dev(A, dt), dev(Bm, dt), dW, db, None if rs is None else dev(rs), rps))
+        q_.flush()
+        q_.join()
+        torch.cuda.synchronize()
+        for i, ((dW, db), (rW, rb)) in enumerate(zip(outs, refs)):
+            assert relerr(dW, rW) < 2e-3, (case, mode, i, specs[i], relerr(dW, rW))    # bf16 operands, fp32 accumulation: only summation order differs
+            assert rel_l2(dW, rW) < 2e-3, (case, mode, i, specs[i], rel_l2(dW, rW))
+            if db is not None:
+                assert relerr(db, rb) < 2e-3, (case, mode, i, "bias", relerr(db, rb))
+        results[mode] = outs
+    for (w1, _), (w0, _) in zip(results["1"], results["0"]):
+        assert relerr(w1, w0) < 1e-3
+
+
+@pytest.mark.parametrize("B,v,k,Cin,Cout,skip", [(2, 32, 2, 96, 48, False), (1, 32, 2, 48, 24, True), (1, 20, 4, 96, 48, False)])
+def test_upconv_wgrad_grouped_streaming(B, v, k, Cin, Cout, skip, monkeypatch):
+    """The transpose-conv weight / bias gradient (k^2 folded problems over the pixel-shuffled view of the fine gradient, contiguous runs without a skip half and
+    k strided pieces with one) through the streaming kernel (>= 32768 coarse voxels per sample... the decoder-1 shape class) against autograd of
+    F.conv_transpose3d on the bf16-rounded operands and against the tile kernels."""
+    ops = _ops()
+    dt = torch.bfloat16
+    x = q(rnd(B, Cin, v, v, v), dt)
+    w = q(rnd(Cin, Cout, k, k, k, seed=1, scale=Cin ** -0.5), dt)
+    b = rnd(Cout, seed=2, scale=0.1)
+    V = v * k
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.conv_transpose3d(xr, wr, br, stride=k)
+    dy = q(rnd(*y.shape, seed=4), dt)
+    y.backward(dy)
+    Cc = 2 * Cout if skip else Cout
+    dc = torch.zeros(B * V ** 3, Cc, dtype=dt, device="cuda")
+    dc[:, :Cout] = dev(dy.permute(0, 2, 3, 4, 1).reshape(-1, Cout), dt)
+    if skip:
+        dc[:, Cout:] = 7.0    # the skip half's gradient must not leak into the transpose conv's
+    xcl = dev(x.permute(0, 2, 3, 4, 1).reshape(-1, Cin), dt)
+    outs = {}
+    monkeypatch.setenv("NMH_TNS_RATIO", "0")
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NMH_TNS", mode)
+        dW, db = torch.zeros(Cin, Cout, k, k, k, device="cuda"), torch.zeros(Cout, device="cuda")
+        ops.upconv_wgrad_grouped(dc, xcl, dW, db, B, v, k, Cin, Cout)
+        torch.cuda.synchronize()
+        check(dW, wr.grad, dt, f"grouped upconv dW NMH_TNS={mode}", 2)
+        check(db, br.grad, dt, f"grouped upconv dbias NMH_TNS={mode}", 2)
+        outs[mode] = dW
+    assert relerr(outs["1"], outs["0"]) < 1e-3
 
 
 def test_grad_bucket_casts():

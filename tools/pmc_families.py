@@ -1,11 +1,12 @@
 """gpurun_out/<tag>/pmc_* (the rocprofv3 --pmc passes of tools/pmc_kernel.sh over ONE eager training step) -> one summary per kernel family, each with the sha256
 of the source file its kernels live in: gpurun_out/<tag>_<family>_pmc.json (copy to profiles/).  Per-dispatch means; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE
 (KB; the gfx950 correction of MI355X_MICROARCH.md), MFMA-busy fraction of the chip, wave-cycle split.
-usage: python tools/pmc_families.py gpurun_out/<tag> <tag>"""
+usage: python tools/pmc_families.py gpurun_out/<tag> <tag> [grids per launch = 8]"""
 import collections, csv, glob, hashlib, json, os, re, sys
 src, tag = sys.argv[1:3]
+grids = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAM = [("swin_block", r"^sw::", "swin_block.hip"), ("mlp96", r"^mlp96_|^mlp_(fwd|bwd)_kernel", "mlp_fused.hip"), ("norm_streaming", r"^(tail_|in_|ln_)", "norm.hip"),
+FAM = [("swin_block", r"^sw::", "swin_block.hip"), ("mlp96", r"^mlp96_|^mlp_(fwd|bwd)_kernel", "mlp_fused.hip"), ("norm_streaming", r"^(in_|ln_)", "norm.hip"), ("misc_streaming", r"^tail_", "misc.hip"),
        ("conv48", r"^conv48_", "conv48.hip"), ("cconv", r"^(cconv_|upconv4_)", "cconv.hip"), ("gemm_tn_grouped", r"^gemm_tn_grouped", "tn_grouped.hip"),
        ("gemm", r"^gemm_(nt|tn)_", "gemm.hip"), ("attn", r"^attn_", "attn.hip")]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -14,7 +15,7 @@ for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         agg[name[:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for fam, rx, fn in FAM:
-    out = {"source": "rocprofv3 --pmc, one counter group per pass (tools/pmc_kernel.sh) over one eager training step at 8 grids; per-dispatch means",
+    out = {"source": "rocprofv3 --pmc, one counter group per pass (tools/pmc_kernel.sh) over one eager training step at %d grids; per-dispatch means" % grids, "grids_per_launch": grids,
            "source_file": "nerf-mae_amd/csrc/" + fn, "source_sha256": hashlib.sha256(open(os.path.join(root, "nerf-mae_amd/csrc", fn), "rb").read()).hexdigest(), "kernels": {}}
     for k, d in sorted(agg.items()):
         if not re.search(rx, k) or (fam == "gemm" and k.startswith("gemm_tn_grouped")):
