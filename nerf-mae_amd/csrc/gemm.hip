@@ -649,6 +649,15 @@ static int w22_config(int M, int N, int K, const EpiParams& ep) {
   const char* e = getenv("NMH_GEMM_W22");   // (read per dispatch: the tile sweep changes it inside one process)
   const int forced = e ? atoi(e) : -1;
   if (forced >= 0) return (K >= 64 && N >= 64) ? forced : 0;
+  // measured (tools/bench_nt_w22.py, graph replay, 8 grids; default dispatch -> this kernel): stage-2 Linears on 8000 rows 384 x 1536: 21.4 -> 17.3 us,
+  // 384 x 1152: 17.1 -> 14.2, 384 x 384: 10.0 -> 9.2 (64 x 96 tiles, ring of 3: 60 KB), 1536 x 384 + GELU' epilogue: 31.1 -> 24.9 (64 x 128, ring of 2: 48 KB);
+  // stage-1 Linears on 64000 rows 192 x 768: 49.7 -> 40.4, 192 x 576: 37.8 -> 34.0 (128 x 128, ring of 2).  4000 rows: 15.0 -> 13.9; 1000 rows lose (8.1 -> 12).
+  if (ep.win_on) return 0;
+  if (M >= 2048 && M <= 16384 && K >= 384) {
+    if (N % 96 == 0 && N <= 768) return 233;
+    if (N % 128 == 0) return 242;
+  }
+  if (M >= 32768 && N == 192 && K >= 576) return 442;
   return 0;
 }
 

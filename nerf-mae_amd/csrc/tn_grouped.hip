@@ -338,13 +338,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
   }
 }
 
-// sums the split partials of every split problem of the group into dW / dbias.  A workgroup: 64 items (four consecutive output elements, or one bias entry)
-// x 4 interleaved shares of the splits (thread = item + 64 * share), combined through LDS in a fixed order -- four times the loads in flight of the
-// one-thread-per-item form, whose 27-63 workgroups walked 100+ slabs as one dependent-latency chain each (28-66 us per reduce behind the streaming launches)
-constexpr int TNG_RED_ITEMS = 64;
+// sums the split partials of every split problem of the group into dW / dbias.  A wave: 16 items (four consecutive output elements, or one bias entry)
+// x 4 interleaved shares of the splits (lane = item + 16 * share), combined by two cross-lane adds in a fixed order -- four times the loads in flight of the
+// one-thread-per-item form, whose 27-63 workgroups walked 100+ slabs as one dependent-latency chain each (28-66 us per reduce behind the streaming launches).
+// No LDS, no barrier: the launch has to fit beside whatever persistent kernel owns the CUs' LDS at that moment.
+constexpr int TNG_RED_ITEMS = 64;   // items per 256-thread workgroup
 __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args ga) {
   using namespace tng;
-  __shared__ float4 red[3][TNG_RED_ITEMS];
   int pi = -1;
 #pragma unroll 1
   for (int i = 0; i < ga.nprob; ++i)
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args g
   const Prob& P = ga.p[pi];
   const float* const ppart = ga.ws + P.partoff;
   const long NK = (long)P.N * P.K, NK4 = NK >> 2;   // K % 8 == 0
-  const int item = threadIdx.x & (TNG_RED_ITEMS - 1), share = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, item = wave * 16 + (lane & 15), share = lane >> 4;
   const long i4 = (long)((int)blockIdx.x - P.rbegin) * TNG_RED_ITEMS + item;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool is_w = i4 < NK4, is_b = !is_w && P.dbias && i4 < NK4 + P.N;
@@ -373,13 +373,10 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_reduce_kernel(tng::Args g
     const int n = (int)(i4 - NK4);
     for (int z = share; z < P.zs; z += 4) s.x += ppart[(long)P.zs * NK + (long)z * P.N + n];
   }
-  if (share) red[share - 1][item] = s;
-  __syncthreads();
+  // shares 0+1, 2+3, then the two pairs (the same order for every item: results do not depend on the launch shape)
+  s.x += __shfl_xor(s.x, 16, 64); s.y += __shfl_xor(s.y, 16, 64); s.z += __shfl_xor(s.z, 16, 64); s.w += __shfl_xor(s.w, 16, 64);
+  s.x += __shfl_xor(s.x, 32, 64); s.y += __shfl_xor(s.y, 32, 64); s.z += __shfl_xor(s.z, 32, 64); s.w += __shfl_xor(s.w, 32, 64);
   if (share) return;
-  {
-    const float4 a = red[0][item], b = red[1][item], c = red[2][item];
-    s.x = (s.x + a.x) + (b.x + c.x); s.y = (s.y + a.y) + (b.y + c.y); s.z = (s.z + a.z) + (b.z + c.z); s.w = (s.w + a.w) + (b.w + c.w);
-  }
   if (is_w) {
     const long i = i4 * 4;
     const int n = (int)(i / P.K), k = (int)(i - (long)n * P.K);
@@ -602,12 +599,14 @@ template <int NA, int NB, int WN, int WK, int ST, bool UP> static int launch(con
 }
 template <bool UP> static int launch_cfg(int c, const tng::Args& ga, int wgs, hipStream_t st) {
   switch (c) {
-    case 0: return launch<2, 1, 4, 2, 4, UP>(ga, wgs, st);
-    case 1: return launch<4, 1, 8, 1, 4, UP>(ga, wgs, st);
-    case 2: return launch<1, 4, 1, 8, 4, UP>(ga, wgs, st);
-    case 3: return launch<4, 2, 4, 2, 3, UP>(ga, wgs, st);
-    case 4: return launch<2, 4, 2, 4, 3, UP>(ga, wgs, st);
-    case 5: return launch<2, 2, 4, 2, 4, UP>(ga, wgs, st);
+    // ring of ST = 2 stages (48-80 KB of LDS): the probe (tools/probes/ldsdma_stream_probe.hip) reads 6.2-6.3 TB/s with any ring of 32-KB stages, and the launches
+    // run on the side stream under the input-gradient chain, whose GEMM workgroups need 40-80 KB of the same CUs' LDS (with 4 stages the chain stood still)
+    case 0: return launch<2, 1, 4, 2, 2, UP>(ga, wgs, st);
+    case 1: return launch<4, 1, 8, 1, 2, UP>(ga, wgs, st);
+    case 2: return launch<1, 4, 1, 8, 2, UP>(ga, wgs, st);
+    case 3: return launch<4, 2, 4, 2, 2, UP>(ga, wgs, st);
+    case 4: return launch<2, 4, 2, 4, 2, UP>(ga, wgs, st);
+    case 5: return launch<2, 2, 4, 2, 2, UP>(ga, wgs, st);
   }
   return -2;
 }
@@ -622,8 +621,11 @@ static int tn_stream_launches(const TnProblemHost* probs, int nprob, std::vector
   static const long min_m = getenv("NMH_TNS_MINM") ? atol(getenv("NMH_TNS_MINM")) : 32768;
   const char* e_ratio = getenv("NMH_TNS_RATIO");   // (per call, like NMH_TNS: the parity tests force the streaming path at small sizes with 0)
   const double ratio = e_ratio ? atof(e_ratio) : 6.0;
-  static const int target_bg = getenv("NMH_TNS_TARGET") ? atoi(getenv("NMH_TNS_TARGET")) : 256;
-  (void)foreground;
+  // workgroups per launch.  Background (the side stream under the input-gradient chain): 192 -- a persistent 512-thread workgroup per CU leaves the chain's
+  // small kernels waiting for a CU, a quarter of the chip stays theirs; foreground (the last flushes of a backward pass): one per CU
+  static const int target_b = getenv("NMH_TNS_TARGET") ? atoi(getenv("NMH_TNS_TARGET")) : 192;
+  static const int target_f = getenv("NMH_TNS_TARGET_FG") ? atoi(getenv("NMH_TNS_TARGET_FG")) : 256;
+  const int target_bg = foreground ? target_f : target_b;
   rest.clear();
   std::vector<int> take[2 * tns::NCFG];   // [block shape][plain | pixel-shuffled A]
   for (int i = 0; i < nprob; ++i) {
@@ -783,7 +785,9 @@ static int k_gemm_tn_grouped_tiles(const TnProblemHost* probs, int nprob, float*
     //  large tile's halved L2->LDS traffic shows in the step: 8 grids 49.74 -> 49.27 ms, 4 grids 28.05 -> 27.81, 2 grids 16.95 -> 16.80, 1 grid
     //  11.15 -> 11.11 (64: the same within noise); a timing-only run without ANY grouped launch reads 45.4 ms at 8 grids -- 4.4 ms of the step is what
     //  these "background" launches still cost the input-gradient chain)
-    const int big_min = getenv("NMH_TNG_BIG") ? atoi(getenv("NMH_TNG_BIG")) : 256;
+    //  Round 5: 0 (off).  With the ring actually pipelined (raw transpose reads) the 96x96 tiles -- 48 KB of LDS, shorter-lived workgroups that let the
+    //  input-gradient chain's kernels onto the CUs -- measure 46.49-46.57 ms against 46.67-46.89 with the large tiles (same box, two alternating runs))
+    const int big_min = getenv("NMH_TNG_BIG") ? atoi(getenv("NMH_TNG_BIG")) : 0;
     const bool big = big_min > 0 && all192 && tiles_big >= big_min;
     const int bt = big ? 192 : 96;
     if (big) tiles = tiles_big;

@@ -249,20 +249,25 @@ class Prefetcher:
                     ev.record(self.stream)
                 t3 = time.perf_counter()
                 self.free[j] = Prefetcher._PENDING
-                while not self._stop:                   # (a bounded put: a consumer that went away must not park the thread for good)
-                    try:
-                        self.q.put((j, xb, ext, ev), timeout=0.05)
-                        break
-                    except Exception:                    # queue.Full
-                        continue
-                if self._stop:
+                if not self._put((j, xb, ext, ev)):
                     return
                 t4 = time.perf_counter()
                 st["batches"] += 1; st["load_s"] += t1 - t0; st["wait_free_s"] += t2 - t1; st["prepare_s"] += t3 - t2; st["put_s"] += t4 - t3
-            self.q.put(None)
+            self._put(None)
         except BaseException as e:  # noqa: BLE001
             self.err = e
-            self.q.put(None)
+            self._put(None)
+
+    def _put(self, item) -> bool:
+        """bounded put: a consumer that went away must not park the thread for good (also for the terminating None).  False: stopped, `item` was dropped"""
+        import queue
+        while not self._stop:
+            try:
+                self.q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def __iter__(self):
         try:
@@ -278,14 +283,25 @@ class Prefetcher:
 
     def close(self):
         """stop the producer (idempotent): it leaves its wait loops within 50 ms and drops its references to the staged batches"""
+        import queue
+        import threading
         self._stop = True
         with self._handback:
             self._handback.notify_all()
-        try:
-            while True:
-                self.q.get_nowait()
-        except Exception:                                # queue.Empty
-            pass
+
+        def drain():
+            try:
+                while True:
+                    self.q.get_nowait()
+            except queue.Empty:
+                pass
+        drain()
+        # the producer may have passed its `_stop` check just before the drain and still put one more staged batch: wait for it to exit (it leaves every
+        # wait loop within 50 ms), then drain again so that no batch -- and no device buffer -- stays referenced by the queue
+        t = getattr(self, "t", None)
+        if t is not None and t.is_alive() and t is not threading.current_thread():
+            t.join(timeout=1.0)
+        drain()
 
     def __del__(self):
         try:

@@ -272,11 +272,18 @@ class _BlockFn(torch.autograd.Function):
         sw = getattr(b, "_sw", None)
         # token-ordered backward (padded stages: 10^3 tokens in 12^3 window rows): window order stays inside the attention kernels, the Linear layers of the
         # attention branch see the real tokens only in the backward pass -- the forward then saves LN1(x) and o in token order
-        fused_attn = sw is not None and ops.swin_attn_ok(x, C, geom)
+        # (the fused kernels are built for heads = C / 32 and a hidden width of 4 C: anything else keeps the unfused chain)
+        swin_shape = heads * 32 == C and b.mlp[0].out_features == 4 * C
+        fused_attn = sw is not None and swin_shape and ops.swin_attn_ok(x, C, geom)
+        # the dispatch decisions are taken ONCE, here, and kept on ctx: the layout of the saved tensors depends on them, and the thresholds / switches they
+        # are derived from are module globals that a test (or a caller) may change between forward and backward
+        ctx.fused_attn = fused_attn
+        ctx.sw_attn_bwd = bool(fused_attn and ops.SWIN_ATTN_BWD in sw)
+        ctx.sw_qkv_bwd = bool(fused_attn and ops.SWIN_QKV_BWD in sw)
         no_sw_bwd = sw is None or (ops.SWIN_ATTN_BWD not in sw and ops.SWIN_QKV_BWD not in sw and ops.SWIN_MLP_BWD not in sw)
         ctx.tok_bwd = bool(ops.TOKEN_BWD and geom.rows != geom.tokens and ctx.needs_input_grad[0] and no_sw_bwd and not ops.mlp_fused_ok(x, C, T)
                            and (fused_attn or ops.TOKEN_BWD_UNFUSED))
-        if sw is not None and ops.swin_attn_ok(x, C, geom):
+        if fused_attn:
             # LN1 -> QKV -> window attention -> proj -> row scale -> + residual in ONE launch (csrc/swin_block.hip); saves the same tensors
             x1, xnw, mean1, rstd1, qkv, o, lse = ops.swin_attn_fwd(x, b.norm1.weight, b.norm1.bias, sw[ops.SWIN_ATTN_FWD], b.attn.qkv.bias,
                                                                    b.attn.relative_position_bias_table, b.attn.proj.bias, geom, rowscale=sd1, rows_per_scale=tps,
@@ -305,7 +312,7 @@ class _BlockFn(torch.autograd.Function):
             ops.gemm_nt_window_scatter(o, pk[key + "proj.w"].view(C, C), x1, x, b.attn.proj.bias, sd1, tps, geom)
         ctx.mlp_fused = ops.mlp_fused_ok(x, C, T)
         ctx.sw_mlp_bwd = False
-        if not ctx.mlp_fused and sw is not None and ops.swin_mlp_ok(x, C, T):
+        if not ctx.mlp_fused and sw is not None and swin_shape and ops.swin_mlp_ok(x, C, T):
             # LN2 -> fc1 -> GELU -> fc2 -> row scale -> + residual in one launch; keeps what the backward reads (gelu(hp) only for the unfused one)
             ctx.sw_mlp_bwd = ops.SWIN_MLP_BWD in sw
             if ctx.sw_mlp_bwd:
@@ -367,6 +374,10 @@ class _BlockFn(torch.autograd.Function):
                                                     rowscale=sd2, rows_per_scale=tps, dyw=dyw, dyw_scale=sd1, geom=geom)
             wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
             wgrad(dh, x1n, b.mlp[0])
+            if q is not None and ops.EARLY_MLP_WGRAD:
+                # stage 0 (the end of the backward pass): the MLP pair's gradients -- 10 of the block's 16 operand passes -- start under the block's own
+                # attention-branch chain instead of waiting for the stage flush (block 0's would run exposed behind the last input-gradient kernel)
+                q.flush()
         else:
             dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
             wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
@@ -376,7 +387,6 @@ class _BlockFn(torch.autograd.Function):
             ops.layernorm_bwd(dx1n, x1, b.norm2.weight, mean2, rstd2, dx1, _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias), T, C, dres=dx2,
                               geom=None if tok_bwd else geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=None if tok_bwd else sd1, wq=q)   # (dgamma / dbeta: partial sums now, reduced with the stage's weight gradients)
         # ---- attention branch
-        fused_ok = sw is not None and ops.swin_attn_ok(x, C, geom)
         if tok_bwd:
             # xnw / o hold LN1(x) / the attention output in TOKEN order here; every GEMM below has T rows
             dtab = _gradbuf(b.attn.relative_position_bias_table)
@@ -395,7 +405,7 @@ class _BlockFn(torch.autograd.Function):
                     ops.window_pad_rows_colsum(dq_pad, g_qb, geom)
             dx = torch.empty_like(x)
             ops.layernorm_bwd(dxn, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, dres=dx1, wq=q)
-        elif fused_ok and ops.SWIN_ATTN_BWD in sw:
+        elif ctx.sw_attn_bwd:
             dqkv = ops.swin_attn_bwd(dyw, qkv, b.attn.relative_position_bias_table, lse, sw[ops.SWIN_ATTN_BWD], _gradbuf(b.attn.relative_position_bias_table), geom)
             wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
         else:
@@ -405,7 +415,7 @@ class _BlockFn(torch.autograd.Function):
             ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
         if tok_bwd:
             pass
-        elif fused_ok and ops.SWIN_QKV_BWD in sw:
+        elif ctx.sw_qkv_bwd:
             dx = ops.swin_qkv_bwd(dqkv, x, dx1, mean1, rstd1, b.norm1.weight, sw[ops.SWIN_QKV_BWD], _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), geom)
             wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
         else:
@@ -1067,6 +1077,13 @@ class SwinTransformer_MAE3D_New(nn.Module):
             self._packer.wait_late()
         grouped = ops.GROUPED_WGRAD and self.compute_dtype == torch.bfloat16 and torch.is_grad_enabled() and x.requires_grad
         groups = red.chunk_groups if (red is not None and si == getattr(red, "chunk_stage", -1) and red.chunk_groups) else [list(self.stages[si])]
+        if red is None and grouped and ops.STAGE_FLUSH_BLOCKS > 0 and len(groups) == 1:
+            # a long stage (stage 2: 18 blocks) flushes its queued weight gradients every STAGE_FLUSH_BLOCKS blocks: flushed once at the stage's end they all
+            # run under stage 1 / stage 0, while the side stream idles for the last two thirds of the stage's own input-gradient chain (round-5 trace)
+            nblk = sum(1 for mod in groups[0] if isinstance(mod, SwinBlock3D))
+            if nblk > ops.STAGE_FLUSH_BLOCKS:
+                from .dist import stage_chunk_groups
+                groups = stage_chunk_groups(self, si, -(-nblk // ops.STAGE_FLUSH_BLOCKS))
         if red is None and si == 0 and grouped and ops.STAGE0_BLOCK_FLUSH and len(groups) == 1 and len(groups[0]) > 1:
             # stage 0 is the END of the backward pass: flushed as a whole, all of its weight gradients run exposed after the last input-gradient
             # kernel; per block, the second block's run under the first block's chain

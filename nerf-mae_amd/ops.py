@@ -58,7 +58,8 @@ class side_stream:
             return self
         dev = torch.cuda.current_device()
         if dev not in side_stream._streams:
-            side_stream._streams[dev] = torch.cuda.Stream(device=dev)
+            prio = __import__("os").environ.get("NMH_SIDE_PRIORITY")   # (experiment: HIP stream priority of the side queue; larger = lower)
+            side_stream._streams[dev] = torch.cuda.Stream(device=dev) if prio is None else torch.cuda.Stream(device=dev, priority=int(prio))
         self.s = side_stream._streams[dev]
         self.s.wait_stream(torch.cuda.current_stream())
         self.ctx = torch.cuda.stream(self.s)
@@ -168,6 +169,8 @@ STAGE0_BLOCK_FLUSH = __import__("os").environ.get("NMH_STAGE0_BLOCK_FLUSH", "0")
 
 
 TNG_FOREGROUND = __import__("os").environ.get("NMH_TNG_FOREGROUND", "1") != "0"
+EARLY_MLP_WGRAD = __import__("os").environ.get("NMH_EARLY_MLP_WGRAD", "0") == "1"   # stage-0 blocks flush the MLP pair's weight gradients right behind the fused MLP backward
+STAGE_FLUSH_BLOCKS = int(__import__("os").environ.get("NMH_STAGE_FLUSH_BLOCKS", "0"))   # single GPU: encoder stages longer than this flush their queued weight gradients in groups of this many blocks (0: once per stage)
 
 
 class _LnReduceItem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_ln_reduce_item
@@ -176,12 +179,27 @@ class _LnReduceItem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_ln_reduce_
 
 
 def ln_param_grad_reduce(items):
-    """items: [(partials, partial_rows, C, dgamma, dbeta)] -> one launch (nmh_layernorm_param_grad_reduce)"""
-    arr = (_LnReduceItem * len(items))()
-    for i, (part, nb, C, dg, db) in enumerate(items):
-        _chk(part, dg, db)
-        arr[i] = _LnReduceItem(part.data_ptr(), dg.data_ptr(), db.data_ptr(), nb, C, 0)
-    lib().call("nmh_layernorm_param_grad_reduce", arr, len(items), _st())
+    """items: [(partials, partial_rows, C, dgamma, dbeta)] -> one launch (nmh_layernorm_param_grad_reduce).  The items of a launch run as independent
+    workgroups that ADD into dgamma / dbeta with plain read-modify-writes: the same parameter twice in one flush (two forward passes before one
+    backward) is split over consecutive launches, like WgradQueue.flush does for a repeated dW"""
+    group, seen = [], set()
+
+    def launch(g):
+        if not g:
+            return
+        arr = (_LnReduceItem * len(g))()
+        for i, (part, nb, C, dg, db) in enumerate(g):
+            _chk(part, dg, db)
+            arr[i] = _LnReduceItem(part.data_ptr(), dg.data_ptr(), db.data_ptr(), nb, C, 0)
+        lib().call("nmh_layernorm_param_grad_reduce", arr, len(g), _st())
+
+    for it in items:
+        if it[3].data_ptr() in seen:
+            launch(group)
+            group, seen = [], set()
+        group.append(it)
+        seen.add(it[3].data_ptr())
+    launch(group)
 
 
 class WgradQueue:
@@ -708,13 +726,22 @@ _SPLIT_WS = {}
 
 
 def swin_mlp_split_ws(M, C, device):
-    """the zero-initialised workspace of the two-workgroups-per-tile MLP forward (None: this shape runs one workgroup per tile); one per shape and
-    device, shared by the blocks of a stage (their launches are ordered on the stream and each leaves the counters zero)"""
-    key = (device.index, M, C)
+    """the zero-initialised workspace of the two-workgroups-per-tile MLP forward (None: this shape runs one workgroup per tile); one per shape, device AND
+    stream: the blocks of a stage share it (their launches are ordered on the stream and each leaves the arrival counters zero), launches of the same shape on
+    another stream -- a second model instance, a standalone stage -- get their own, so that they cannot corrupt each other's counters and partial sums.
+    (A launch that aborts half-way leaves non-zero counters behind: swin_mlp_split_ws_reset() clears them.)"""
+    key = (device.index, M, C, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SPLIT_WS:
         n = int(lib().call("nmh_swin_mlp_split_ws_bytes", M, C))
         _SPLIT_WS[key] = torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
     return _SPLIT_WS[key]
+
+
+def swin_mlp_split_ws_reset():
+    """zero every split-MLP workspace (after a failed / aborted launch: the arrival counters must be zero before the next launch)"""
+    for ws in _SPLIT_WS.values():
+        if ws is not None:
+            ws.zero_()
 
 
 def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale=1, eps=1e-5, want_hact=False, split=None):
