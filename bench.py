@@ -174,8 +174,11 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(nb, steps, warmup, use_reducer=True):
-        """`steps` timed steps at nb grids per GPU -> (seconds [max over ranks], last loss, exposed comm ms per step or None)"""
+    comm_events = {}
+
+    def run_leg(nb, steps, warmup, use_reducer=True, comm_timing_key=None):
+        """`steps` timed steps at nb grids per GPU -> (seconds [max over ranks], last loss).  comm_timing_key: HIP events around every gradient exchange
+        (comm stream) and at the join (compute stream) during the timed steps -> comm_events[key] (per-range all-reduce ms, exposed ms from timestamps)"""
         grids = grids_all[:nb]
         graphed = None
         red = reducer if use_reducer else None
@@ -203,11 +206,15 @@ def main():
         for _ in range(warmup):
             loss = step()
         barrier()
+        if comm_timing_key is not None and red is not None:
+            red.timing_begin()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
         barrier()
         dt = time.perf_counter() - t0
+        if comm_timing_key is not None and red is not None:
+            comm_events[comm_timing_key] = red.timing_report(steps)
         if world > 1:
             t = torch.tensor([dt], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -230,6 +237,8 @@ def main():
         dt_local, _ = run_leg(Bg, args.steps, args.warmup, use_reducer=False)
         comm_exposed = round(1e3 * (dt - dt_local) / args.steps, 3)
         broadcast_parameters(model)
+        # a third, short leg with HIP events on the comm stream: per-range all-reduce times and the exposed part from stream timestamps
+        run_leg(Bg, max(3, min(args.steps, 5)), 2, comm_timing_key="%d_grids_per_gpu" % Bg)
 
     sweep = {}
     for nb in sweep_sizes:
@@ -241,6 +250,7 @@ def main():
             d3, _ = run_leg(nb, ks, 3, use_reducer=False)
             broadcast_parameters(model)
             sweep["%d_grids_per_gpu" % nb].update({"scaling": "weak", "global_batch": nb * world, "comm_ms_exposed": round(1e3 * (d2 - d3) / ks, 3)})
+            run_leg(nb, 3, 2, comm_timing_key="%d_grids_per_gpu" % nb)
     sweep["%d_grids_per_gpu" % Bg] = {"grids_per_s": round(grids_per_s, 3), "ms_per_step": round(1e3 * dt / args.steps, 3),
                                       "whole_step_mfma_frac": frac(grids_per_s / world)}
     if world > 1:
@@ -288,6 +298,13 @@ def main():
         out["config"]["collective_ranks_verified"] = rccl_ranks
         out["config"]["comm_ms_exposed"] = comm_exposed
         out["config"]["grad_comm_dtype"] = "bf16" if (reducer is not None and reducer.comm_dtype == torch.bfloat16) else "fp32"
+        # one record for the scaling run: `value` / config.sweep[<Bg>] = the strong leg (global batch 8 over N ranks), config.sweep["8_grids_per_gpu"] /
+        # ["1_grids_per_gpu"] = the weak legs; comm_ms_exposed = step time with minus without the exchange (same K steps), comm_events = HIP-event
+        # timestamps of a short extra leg: every range's all-reduce on the comm stream and what the compute stream waited for at the join
+        out["config"]["comm_ms_exposed_method"] = "K timed steps with the gradient exchange minus the same K steps on local gradients"
+        out["config"]["comm_events"] = comm_events
+        out["config"]["legs"] = {"strong": "%d_grids_per_gpu" % Bg if scaling == "strong" else None,
+                                 "weak": [k for k, v in sweep.items() if v.get("scaling") == "weak"]}
 
     if rank == 0 and prof:
         # dominant kernel: implicit-GEMM 3x3x3 conv at R^3 with Cin=Cout=E/2 (decoder1 fwd + dgrad launches share one kernel)

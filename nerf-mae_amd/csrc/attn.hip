@@ -500,7 +500,7 @@ int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   if ((long)wm.PH * wm.PW * wm.PD == (long)wm.H * wm.W * wm.D) return 0;   // no pad rows
   if (N > 4096) return -2;   // (one chunk per thread: N / 8 <= 512)
-  const unsigned nb = (unsigned)(nwin < 128 ? nwin : 128);
+  const unsigned nb = (unsigned)(nwin < 256 ? nwin : 256);   // (one window per workgroup at 8 grids of stage 2: 216 windows)
   if (dt == NMH_DT_BF16) hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<bf16_t>, dim3(nb), dim3(512), N * sizeof(float), st, (const bf16_t*)x, N, wm, nwin, out);
   else hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<float>, dim3(nb), dim3(512), N * sizeof(float), st, (const float*)x, N, wm, nwin, out);
   NMH_CHECK_LAUNCH();

@@ -17,6 +17,7 @@
 // 8 waves: wave w owns x-lines (z = w>>1, y = 2(w&1) + i), i = 0,1, all four co-tiles: 8 MFMAs per k-step from 2 A + 4 B fragments.
 // LDS: 82,944 + 73,728 + 1,024 = 157,696 B of 163,840.
 #include "common.hpp"
+#include <type_traits>
 #include "kernels.hpp"
 #include <cstdlib>
 
@@ -342,6 +343,12 @@ static_assert(HREG == 11 && NDMA == 4, "request schedule");
 }  // namespace w64
 
 __device__ uint4 g_zero16_w64[4];
+template <int N, int I = 0, class F> __device__ __forceinline__ void w64_static_for(F&& f) {   // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    w64_static_for<N, I + 1>(f);
+  }
+}
 
 struct W64Args {
   const bf16_t* X; const bf16_t* dY; float* ws;
@@ -436,6 +443,10 @@ __global__ __launch_bounds__(512) void conv64_wgrad_kernel(W64Args a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) offA[c] = xr * 128 + (((c ^ ((xr >> 1) & 3)) << 5) + ((p & 3) << 3));
 
+  const unsigned halo_u = lds_addr_u(halo), dyb_u = lds_addr_u(dyb);
+  unsigned u_ad[UPW];
+#pragma unroll
+  for (int i = 0; i < UPW; ++i) u_ad[i] = halo_u + (unsigned)uoff[i];
   const int nbx = gridDim.x;
   long t = blockIdx.x;
   int cur = 0;
@@ -455,17 +466,22 @@ __global__ __launch_bounds__(512) void conv64_wgrad_kernel(W64Args a) {
     int nb = 0, nz0 = 0, ny0 = 0, nx0 = 0;
     if (has_next) tile_origin(tn, nb, nz0, ny0, nx0);
     const char* dyc = dyb + cur * DYT;
+    // Raw transpose reads (common.hpp; round 5, as conv48_wgrad_kernel): the builtin read is ordered behind EVERY pending vector-memory operation
+    // (`s_waitcnt vmcnt(0)`), i.e. behind the next tile's dY DMA and halo requests issued one k-step earlier -- the prefetch this loop exists to hide.
+    // The k-step's tile offsets are instruction immediates; the operands of unit pair j + 1 are requested before the MFMAs of pair j.
+    unsigned dy_ad[4];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int c = 0; c < 4; ++c) dy_ad[c] = dyb_u + (unsigned)(cur * DYT + offA[c]);
+    w64_static_for<8>([&](auto KS) __attribute__((always_inline)) {
+      constexpr int ks = decltype(KS)::value;
       // lines 2ks, 2ks+1 of the tile: (z_l, y_l) = (ks>>1, (ks&1)*2) and y_l+1
-      const int lbase = (ks >> 1) * PLANE + ((ks & 1) * 2) * LINE;
-      Frag<bf16_t> af[4];
+      constexpr int LB = (ks >> 1) * PLANE + ((ks & 1) * 2) * LINE, DB = ks * 32 * 128;
+      constexpr int GU = 2, NG = (UPW + GU - 1) / GU;
+      TrFrag fa[4], fb[2][GU];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const char* pa = dyc + ks * 32 * 128 + offA[c];
-        bf16x4 lo = ds_read_tr16(pa), hi = ds_read_tr16(pa + 16 * 128);
-        af[c].v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-      }
+      for (int c = 0; c < 4; ++c) tr_read_raw<16 * 128, DB>(fa[c], dy_ad[c]);
+#pragma unroll
+      for (int u = 0; u < GU; ++u) tr_read_raw<LINE, LB>(fb[0][u], u_ad[u]);
       if (ks < NDMA) dy_dma_one(ks, nb, nz0, ny0, nx0, cur ^ 1, has_next);
       {
         constexpr int hs[9] = {0, 2, 4, 6, 8, 10, 11, 11, 11};
@@ -474,15 +490,29 @@ __global__ __launch_bounds__(512) void conv64_wgrad_kernel(W64Args a) {
           if (i >= hs[ks] && i < hs[ks + 1]) halo_gload_one(i, nb, nz0, ny0, nx0, has_next);
       }
 #pragma unroll
-      for (int i = 0; i < UPW; ++i) {
-        const char* pb = halo + lbase + uoff[i];
-        bf16x4 lo = ds_read_tr16(pb), hi = ds_read_tr16(pb + LINE);
-        Frag<bf16_t> bfr;
-        bfr.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      for (int j = 0; j < NG; ++j) {
+        tr_wait();
+        if (j == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mma(acc[i][c], af[c], bfr);
+          for (int c = 0; c < 4; ++c) tr_pin(fa[c]);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          if (j * GU + u < UPW) tr_pin(fb[j & 1][u]);
+        if (j + 1 < NG) {
+#pragma unroll
+          for (int u = 0; u < GU; ++u)
+            if ((j + 1) * GU + u < UPW) tr_read_raw<LINE, LB>(fb[(j + 1) & 1][u], u_ad[(j + 1) * GU + u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+          if (j * GU + u < UPW) {
+            const Frag<bf16_t> bfr = tr_frag(fb[j & 1][u]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mma(acc[j * GU + u][c], tr_frag(fa[c]), bfr);
+          }
       }
-    }
+    });
     __syncthreads();  // everyone is done with halo / dY[cur]; the barrier also drains this wave's DMA + prefetch loads
     if (has_next) halo_sstore();
     __syncthreads();

@@ -640,6 +640,9 @@ static int tn_stream_launches(const TnProblemHost* probs, int nprob, std::vector
     if (ok) {
       // worth it only while the partial blocks (one per workgroup, written and read back by the reduce) stay small against the operands: the stage-1 problems
       // (64 k rows, 768 x 192 outputs) measured 302 us here against 200 us with the tile kernels, stage 0 and the transpose conv (512 k rows) 1.2-2x faster
+      // (Also measured and dropped: 384 x 192 blocks for the stage-2 problems -- 8000 rows as one range split two ways.  1353 us for 18 blocks against
+      //  1129 us with the 96 x 96 tiles, +1.4 ms in the step: one 8-wave workgroup per CU with a two-stage ring cannot hide the chunk latency that three
+      //  co-resident tile workgroups hide for each other.  profiles/r5a_ab_tns_mid_class.txt)
       cfg = tns::pick_cfg(h.N, h.K);
       const int bn = 96 * tns::kCfg[cfg].NA, bk = 96 * tns::kCfg[cfg].NB;
       const int nblk = (h.N + bn - 1) / bn, kblk = (h.K + bk - 1) / bk;
@@ -647,10 +650,17 @@ static int tn_stream_launches(const TnProblemHost* probs, int nprob, std::vector
       const double partial = (double)target_bg * std::min(h.N, bn) * std::min(h.K, bk) * 4.0;
       if (operand < ratio * partial) ok = false;
     }
-    if (ok) take[2 * cfg + (h.up_k > 0 ? 1 : 0)].push_back(i);
-    else rest.push_back(i);
+    if (ok) { take[2 * cfg + (h.up_k > 0 ? 1 : 0)].push_back(i); continue; }
+    rest.push_back(i);
   }
   int ntaken = 0;
+  auto fill = [](tng::Prob& p, const TnProblemHost& h) {
+    p.A = (const bf16_t*)h.A; p.B = (const bf16_t*)h.B; p.Out = h.dW; p.dbias = h.dbias; p.rowscale = h.rowscale;
+    p.lda = (int)h.lda; p.ldb = (int)h.ldb; p.N = h.N; p.K = h.K;
+    p.son = (int)h.ldo; p.sok = h.stride_k > 0 ? (int)h.stride_k : 1;
+    p.ncol2 = h.n_inner > 0 ? (h.n_inner | ((int)h.stride_n2 << 16)) : 0;
+    p.upflags = (h.up_k & 0xff) | ((h.bias_atomic || h.n_inner > 0 ? 1 : 0) << 8) | (h.up_k > 0 ? (h.up_v << 16) : 0);
+  };
   for (int cu = 0; cu < 2 * tns::NCFG; ++cu) {
     const int c = cu >> 1;
     std::vector<int>& idx = take[cu];
@@ -675,11 +685,7 @@ static int tn_stream_launches(const TnProblemHost* probs, int nprob, std::vector
       for (int i = 0; i < np && fits; ++i) {
         const TnProblemHost& h = probs[idx[base + i]];
         Prob& p = ga.p[i];
-        p.A = (const bf16_t*)h.A; p.B = (const bf16_t*)h.B; p.Out = h.dW; p.dbias = h.dbias; p.rowscale = h.rowscale;
-        p.lda = (int)h.lda; p.ldb = (int)h.ldb; p.N = h.N; p.K = h.K;
-        p.son = (int)h.ldo; p.sok = h.stride_k > 0 ? (int)h.stride_k : 1;
-        p.ncol2 = h.n_inner > 0 ? (h.n_inner | ((int)h.stride_n2 << 16)) : 0;
-        p.upflags = (h.up_k & 0xff) | ((h.bias_atomic || h.n_inner > 0 ? 1 : 0) << 8) | (h.up_k > 0 ? (h.up_v << 16) : 0);
+        fill(p, h);
         p.rps = h.rows_per_sample; p.nsamp = (int)(h.M / h.rows_per_sample);
         const int nblk = (h.N + bn - 1) / bn, kblk = (h.K + bk - 1) / bk;
         // this problem's share of the launch's workgroups -> row splits per sample (>= 1024 rows each; at least 2 splits in all: the reduce path)

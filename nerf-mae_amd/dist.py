@@ -79,6 +79,7 @@ class GradReducer:
         self.on_gpu = model._flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if (self.active and self.on_gpu) else None
         self.pending: List = []
+        self.timing = None            # timing_begin(): {"ranges": [(lo, hi, ev0, ev1)], "joins": [(ev_main, ev_comm_end)]} -- HIP events on the comm / main stream
         self.comm_dtype = comm_dtype
         self.staging = torch.empty(n, dtype=comm_dtype, device=model._flat_grad.device) if (comm_dtype and self.active) else None
 
@@ -126,13 +127,44 @@ class GradReducer:
         if overlap and self.comm_stream is not None and dist.get_backend(self.group) == "nccl":
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
+                if self.timing is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.comm_stream)
                 self._exchange(lo, hi)
+                if self.timing is not None:
+                    e1.record(self.comm_stream)
+                    self.timing["ranges"].append((lo, hi, e0, e1))
         else:
             self._exchange(lo, hi)
 
     def wait(self):
         if self.comm_stream is not None:
+            if self.timing is not None and self.timing["ranges"]:
+                # what the compute stream really waits for: the end of the last exchange on the comm stream against the moment the compute stream gets here
+                em = torch.cuda.Event(enable_timing=True)
+                em.record(torch.cuda.current_stream())
+                self.timing["joins"].append((em, self.timing["ranges"][-1][3]))
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def timing_begin(self):
+        """record HIP events around every overlapped exchange (comm stream) and at every join (compute stream) until timing_report()"""
+        self.timing = {"ranges": [], "joins": []}
+
+    def timing_report(self, steps: int):
+        """-> {"ranges": [{"lo", "hi", "bytes_on_the_wire", "ms"}...] (mean per step, in issue order), "comm_ms_exposed_events": mean per step of
+        max(0, end of the last exchange - arrival of the compute stream at the join)}; call after torch.cuda.synchronize()"""
+        t, self.timing = self.timing, None
+        if not t or not t["ranges"] or steps <= 0:
+            return None
+        per = max(1, len(t["ranges"]) // steps)
+        esz = 2 if self.comm_dtype == torch.bfloat16 else 4
+        out = []
+        for k in range(per):
+            rs = t["ranges"][k::per]
+            lo, hi = rs[0][0], rs[0][1]
+            out.append({"lo": lo, "hi": hi, "bytes_on_the_wire": (hi - lo) * esz, "ms": round(sum(a.elapsed_time(b) for _, _, a, b in rs) / len(rs), 4)})
+        exposed = sum(max(0.0, em.elapsed_time(ec)) for em, ec in t["joins"]) / steps
+        return {"ranges": out, "comm_ms_exposed_events": round(exposed, 4), "joins_per_step": len(t["joins"]) // steps}
 
     def launch(self, seg: int):
         if not self.active:

@@ -645,7 +645,11 @@ class _UpBlockFn(torch.autograd.Function):
         defer = ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None and not (ctx.c48 or ctx.c64)
 
         def side(fn):
-            if defer:
+            if defer and ops.DEC_WGRAD_NOW:
+                # issued right away on the forked side stream (no join before the end of the backward pass): the small decoder levels' input-gradient chain
+                # is a string of latency-bound launches that leaves most of the chip idle, the side stream has nothing else to do there
+                m._wq.launch_now(fn)
+            elif defer:
                 m._wq.defer(fn)
             else:
                 with ops.side_stream(enable=not (ctx.c48 or ctx.c64)):
@@ -681,7 +685,7 @@ class _UpBlockFn(torch.autograd.Function):
             ops.gemm_nt(dy3, pk[key + "c3.wT"].view(Cc, Cout), out=dcat, accumulate=True)
             g_c3 = _gradbuf(m.conv_block.conv3.weight)
             if defer:
-                m._wq.defer(lambda: ops.gemm_tn(dy3, cat, g_c3))
+                (m._wq.launch_now if ops.DEC_WGRAD_NOW else m._wq.defer)(lambda: ops.gemm_tn(dy3, cat, g_c3))
             else:
                 with ops.side_stream():
                     ops.gemm_tn(dy3, cat, g_c3)
@@ -699,7 +703,7 @@ class _UpBlockFn(torch.autograd.Function):
             # encoder's on the side stream, which is busy from the stage-3 flush to the end of the step; issued here it runs under the small decoder levels
             m._wq.launch_now(lambda: ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout))
         elif defer or (ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None):
-            m._wq.defer(lambda: ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout))
+            (m._wq.launch_now if ops.DEC_WGRAD_NOW else m._wq.defer)(lambda: ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout))
         else:
             with ops.side_stream():
                 ops.upconv_wgrad(dcat, x, g_tw, g_tb, B, v, k, Cin, Cout)

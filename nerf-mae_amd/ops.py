@@ -163,6 +163,7 @@ class _TnProblem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_tn_problem
 
 GROUPED_WGRAD = __import__("os").environ.get("NMH_TNG", "1") != "0"
 DEFER_DECODER_WGRAD = __import__("os").environ.get("NMH_DEFER_DEC", "1") == "1"
+DEC_WGRAD_NOW = __import__("os").environ.get("NMH_DEC_WGRAD_NOW", "0") == "1"   # small decoder levels: weight gradients issued on the side stream as soon as their operands exist instead of with the stage-3 flush
 UPW_EARLY = __import__("os").environ.get("NMH_UPW_EARLY", "0") == "1"   # decoder1 transpose-conv weight gradient on the side stream at the end of its block instead of queued (measured 51.1 / 51.0 vs 50.9 / 51.0 ms: off)
 WQ_LATE_JOIN = __import__("os").environ.get("NMH_WQ_LATE_JOIN", "1") == "1"   # weight-gradient queue: join only at the end of the backward pass
 STAGE0_BLOCK_FLUSH = __import__("os").environ.get("NMH_STAGE0_BLOCK_FLUSH", "0") == "1"   # stage 0 flushes its queued weight gradients per block (measured 52.2-52.4 vs 52.0 ms at 8 grids: off)

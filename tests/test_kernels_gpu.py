@@ -866,7 +866,7 @@ def test_gemm_tn_grouped(case, variant, monkeypatch):
             assert relerr(db, rb) < 2e-3, (case, i, "bias", relerr(db, rb))
 
 
-@pytest.mark.parametrize("case", ["stage0", "stage1", "ragged_widths", "tile_fallback_mix"])
+@pytest.mark.parametrize("case", ["stage0", "stage1", "ragged_widths", "tile_fallback_mix", "stage2_rows"])
 def test_gemm_tn_grouped_streaming(case, monkeypatch):
     """The streaming weight-gradient kernel (csrc/tn_grouped.hip: gemm_tn_stream_kernel; contractions of >= 32768 rows with outputs up to 768 x 768: a
     workgroup owns a row range inside one sample and a whole output block) behind nmh_gemm_tn_grouped: every block shape on offer, several blocks along N and
@@ -881,6 +881,9 @@ def test_gemm_tn_grouped_streaming(case, monkeypatch):
                  (2, 16400, 192, 768, False, False)]
     elif case == "ragged_widths":
         specs = [(3, 11000, 200, 104, True, True), (3, 11000, 40, 640, False, True), (1, 33000, 104, 200, True, False), (5, 7000, 768, 768, False, True)]
+    elif case == "stage2_rows":  # stage-2 shapes (8000 rows): below the streaming threshold in the product, forced through the streaming blocks here (NMH_TNS_RATIO=0)
+        specs = [(8, 1000, 1152, 384, False, True), (8, 1000, 1536, 384, False, True), (8, 1000, 384, 1536, False, False), (8, 1000, 384, 1536, True, True),
+                 (4, 1000, 576, 192, False, True), (2, 1030, 384, 384, False, True)]
     else:                      # one launch mixes streaming problems with problems the tile kernels keep (few rows; an output beyond 768 x 768)
         specs = [(4, 8200, 384, 96, False, True), (4, 500, 384, 1536, True, True), (4, 8200, 96, 384, True, True), (2, 20000, 1152, 768, False, True)]
     results = {}
