@@ -542,7 +542,7 @@ def roofline_families(trace, cfg, R, Bg):
         ("decoder convs at the 10^3..40^3 levels, fwd+dgrad+wgrad (conv48_kernel<0,true>, AConv3, BConv3TN, small conv48_wgrad launches)",
          r"conv48_kernel<0, true, false>|AConv3|BConv3TN|conv48_wgrad_reduce", 3 * conv_small),
         ("fused Swin-block forward kernels: LN1+QKV+window attention+proj+residual per window, LN2+fc1+GELU+fc2+residual per 64 tokens "
-         "(swin_attn_fwd_kernel, swin_mlp_fwd_kernel; the backward kernels when NMH_SWIN_BWD enables them) + their weight-stream pack", r"sw::swin_",
+         "(swin_attn_fwd_kernel, swin_mlp_fwd_kernel) + their weight-stream pack", r"sw::swin_",
          (sw_lin + sw_attn) if has_sw else None),
         ("encoder Linear / patch-embed / merge / transpose-conv / 1x1 GEMMs fwd+dgrad (gemm_nt*, fused MLP)", r"gemm_nt|mlp96_|mlp_fwd_kernel|mlp_bwd_kernel|nt_ksplit|upconv4_fwd",
          2 * (lin + merge + up + c3) + embed - sw_lin),

@@ -196,18 +196,18 @@ NMH_API int nmh_mlp_fused_fwd(const void* x1, const float* gamma, const float* b
 NMH_API int nmh_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2T, const float* rowscale, int rows_per_scale, void* dx1, void* x1n, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm, int64_t M, int C, float eps, void* stream);
 /* Fused Swin-block kernels, bf16, widths C = 96 NW with NW in {1, 2, 4} (stages 0-2 of swin_t / swin_s); SURVEY 2a K1 + K2:
  * `x = x + stochastic_depth(attn(norm1(x)))`, `x = x + stochastic_depth(mlp(norm2(x)))` (swin_mae3d.py:366-369) with
- * shifted_window_attention (swin_mae3d.py:27-197) and the torchvision MLP (swin_mae3d.py:352-358) each in ONE launch per direction.
+ * shifted_window_attention (swin_mae3d.py:27-197) and the torchvision MLP (swin_mae3d.py:352-358) each in ONE forward launch (the backward is the
+ * unfused chain: nmh_gemm_nt, nmh_window_attn_bwd(_tokens), nmh_layernorm_bwd(_deferred), nmh_gemm_tn_grouped).
  * A workgroup owns 64 token rows (a 4x4x4 window / 64 consecutive tokens) and keeps them in registers as MFMA operand fragments; every one
  * of its NW waves owns a slice of the output features of every product and streams ITS weights -- a private, linear, pre-packed sequence of
  * 1-KB fragment images -- through an LDS ring with LDS-DMA (csrc/swin_block.hip).
  *   nmh_swin_pack: builds weight streams from the fp32 master parameters (once per optimizer step).  type 0: attention forward
- *     (w0 = qkv.weight [3C][C], w1 = proj.weight [C][C]); 1: MLP forward (w0 = mlp.0.weight [4C][C], w1 = mlp.3.weight [C][4C]);
- *     2: MLP backward (w0 = mlp.3.weight, w1 = mlp.0.weight); 3: attention backward, dO = dy Wproj (w0 = proj.weight); 4: QKV backward,
- *     dxn = dqkv Wqkv (w0 = qkv.weight).  dst: nmh_swin_stream_numel(type, C) bf16 elements.  Up to any number of items per call.
+ *     (w0 = qkv.weight [3C][C], w1 = proj.weight [C][C]); 1: MLP forward (w0 = mlp.0.weight [4C][C], w1 = mlp.3.weight [C][4C]).
+ *     dst: nmh_swin_stream_numel(type, C) bf16 elements.  Up to any number of items per call.
  *   nmh_swin_attn_fwd: x [T][C] token order -> x1[tok] = x[tok] + rowscale[tok / rows_per_scale] * (proj(attn(LN1(x))) + bproj); pad -> roll ->
  *     window partition and their inverses are address arithmetic (wm as for nmh_layernorm_fwd).  Also writes, in the layouts of the unfused
  *     kernels (nmh_layernorm_fwd src_mode 1, nmh_gemm_nt, nmh_window_attn_fwd): xnw [rows][C] = LN1(x) in window order (pad rows zero), mean / rstd
- *     [T], qkv [rows][3C], o [rows][C], lse [rows * heads] -- the operands of the weight gradients and of the backward kernels.
+ *     [T], qkv [rows][3C], o [rows][C], lse [rows * heads] -- the operands of the weight gradients and of the backward chain.
  *     token_saves != 0: xnw and o are written in TOKEN order instead ([T][C]; pad rows, which are zero / carry no gradient, are dropped): the operands of
  *     weight gradients that run on the real tokens only (with nmh_window_attn_bwd_tokens).
  *   nmh_swin_mlp_fwd: x2[row] = x1[row] + rowscale[..] * (gelu(LN2(x1) W1^T + b1) W2^T + b2); also writes x1n = LN2(x1) [M][C], the fc1
@@ -215,16 +215,7 @@ NMH_API int nmh_mlp_fused_bwd(const void* x1, const void* dx2, const float* gamm
  *     split_ws (optional): nmh_swin_mlp_split_ws_bytes(M, C) bytes, zero before the first call and left zero by every call (calls that share it
  *     must be ordered on one stream).  When that size is > 0 (C = 384 and <= 128 row tiles: fewer workgroups than half of the CUs) and the workspace
  *     is given, two workgroups share a row tile -- half of the hidden units each, fp32 partial sums added by whichever finishes last; the sum of two
- *     terms does not depend on the arrival order, so results are reproducible.
- *   nmh_swin_mlp_bwd: from dy = dL/dx2 and the saved x1, hp, mean / rstd: hact = gelu(hp) and dh = rowscale (dy W2) gelu'(hp) [M][4C] (written: the
- *     operands of the two weight gradients, which stay nmh_gemm_tn(_grouped) calls on (dy, hact, rowscale) and (dh, x1n)), dx1 = dy + LN2_backward(dh W1),
- *     dgamma / dbeta accumulated (fp32 atomics) and, with dyw != NULL, dx1 in window order times dyw_scale[row / rows_per_scale] (pad rows zeroed).
- *     Replaces 2 x nmh_gemm_nt + nmh_layernorm_bwd.
- *   nmh_swin_attn_bwd: dyw [rows][C] (the window-ordered incoming gradient) -> dO = dyw Wproj and, per (window, head), the backward of
- *     softmax(q k^T / sqrt(32) + bias + mask) v from the saved qkv and lse -> dqkv [rows][3C], d(bias table) accumulated.  Replaces nmh_gemm_nt +
- *     nmh_window_attn_bwd.
- *   nmh_swin_qkv_bwd: dx[tok] = dres[tok] + LN1_backward(dqkv Wqkv)[tok] (window rows scattered back to tokens, pad rows dropped), dgamma / dbeta
- *     accumulated.  Replaces nmh_gemm_nt + nmh_layernorm_bwd(src_mode 1). */
+ *     terms does not depend on the arrival order, so results are reproducible. */
 typedef struct nmh_swin_pack_item { const float* w0; const float* w1; void* dst; int type; int C; } nmh_swin_pack_item;
 NMH_API int nmh_swin_supported(int C);
 NMH_API int64_t nmh_swin_stream_numel(int type, int C);
@@ -232,9 +223,6 @@ NMH_API int nmh_swin_pack(const nmh_swin_pack_item* items, int n, void* stream);
 NMH_API int nmh_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const void* wstream, const float* bqkv, const float* bias_table, const float* bproj, const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1, const int* wm, int C, float eps, int token_saves, void* stream);
 NMH_API int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, const void* wstream, const float* b1, const float* b2, const float* rowscale, int rows_per_scale, void* x2, void* x1n, void* hp, void* hact, float* mean, float* rstd, int64_t M, int C, float eps, void* split_ws, int64_t split_ws_bytes, void* stream);
 NMH_API int64_t nmh_swin_mlp_split_ws_bytes(int64_t M, int C);
-NMH_API int nmh_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale, int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm, int64_t M, int C, void* stream);
-NMH_API int nmh_swin_attn_bwd(const void* dyw, const void* qkv, const float* bias_table, const float* lse, const void* wstream, void* dqkv, float* dbias_table, const int* wm, int C, void* stream);
-NMH_API int nmh_swin_qkv_bwd(const void* dqkv, const void* x, const void* dres, const float* mean, const float* rstd, const float* gamma, const void* wstream, void* dx, float* dgamma, float* dbeta, const int* wm, int C, void* stream);
 /* out[tok] = x[tok] + rowscale[b]*yw[window_row(tok)]: window reverse + un-roll + un-pad (:176-196) + residual + stochastic depth */
 NMH_API int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream);
 /* dyw[window_row] = rowscale[b]*dx[tok] (0 for pad rows): adjoint of the above */

@@ -290,29 +290,6 @@ int nmh_swin_mlp_fwd(const void* x1, const float* gamma, const float* beta, cons
   return k_swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale, rows_per_scale, x2, x1n, hp, hact, mean, rstd, (long)M, C, eps, split_ws, (long)split_ws_bytes, ST);
 }
 int64_t nmh_swin_mlp_split_ws_bytes(int64_t M, int C) { return k_swin_mlp_split_ws_bytes((long)M, C); }
-int nmh_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale,
-                     int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const int* wm, int64_t M, int C,
-                     void* stream) {
-  CLR();
-  REQ(dy, x1, hp, mean, rstd, gamma, wstream, dx1, hact, dh, dgamma, dbeta);
-  if (M <= 0) return 0;
-  if (dyw && !wm) return -4;
-  if ((long)M * 4 * C >= (1L << 31)) return -2;
-  const WinMap w = to_wm(wm);
-  return k_swin_mlp_bwd(dy, x1, hp, mean, rstd, gamma, wstream, rowscale, rows_per_scale, dx1, hact, dh, dgamma, dbeta, dyw, dyw_scale, wm ? &w : nullptr, (long)M, C, ST);
-}
-int nmh_swin_attn_bwd(const void* dyw, const void* qkv, const float* bias_table, const float* lse, const void* wstream, void* dqkv, float* dbias_table, const int* wm, int C,
-                      void* stream) {
-  CLR();
-  REQ(dyw, qkv, bias_table, lse, wstream, dqkv, dbias_table, wm);
-  return k_swin_attn_bwd(dyw, qkv, bias_table, lse, wstream, dqkv, dbias_table, to_wm(wm), C, ST);
-}
-int nmh_swin_qkv_bwd(const void* dqkv, const void* x, const void* dres, const float* mean, const float* rstd, const float* gamma, const void* wstream, void* dx,
-                     float* dgamma, float* dbeta, const int* wm, int C, void* stream) {
-  CLR();
-  REQ(dqkv, x, dres, mean, rstd, gamma, wstream, dx, dgamma, dbeta, wm);
-  return k_swin_qkv_bwd(dqkv, x, dres, mean, rstd, gamma, wstream, dx, dgamma, dbeta, to_wm(wm), C, ST);
-}
 int nmh_window_scatter_residual(int dt, const void* yw, const void* x, void* out, const float* rowscale, int C, const int* wm, void* stream) {
   CLR();
   return k_window_scatter_residual(dt, yw, x, out, rowscale, C, to_wm(wm), ST);

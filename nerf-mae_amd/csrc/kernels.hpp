@@ -198,14 +198,6 @@ int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const 
                     const float* rowscale, int rows_per_scale, void* xnw, float* mean, float* rstd, void* qkv, void* o, float* lse, void* x1,
                     const WinMap& wm, int C, float eps, int token_saves, hipStream_t st);
 
-int k_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale,
-                   int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const WinMap* wm, long M, int C,
-                   hipStream_t st);
-int k_swin_attn_bwd(const void* dyw, const void* qkv, const float* table, const float* lse, const void* wstream, void* dqkv, float* dtable, const WinMap& wm, int C,
-                    hipStream_t st);
-int k_swin_qkv_bwd(const void* dqkv, const void* x, const void* dres, const float* mean, const float* rstd, const float* gamma, const void* wstream, void* dx,
-                   float* dgamma, float* dbeta, const WinMap& wm, int C, hipStream_t st);
-
 // instance norm over channels-last [B, V, C]; stats[b][c] = {mean, rstd}
 int k_in_stats(int dt, const void* x, float* stats, double* scratch, int B, long V, int C, float eps, hipStream_t st);
 // out = lrelu( IN(x) [+ r | + IN(r)] ); rmode 0 none, 1 plain residual, 2 normalized residual (stats_r)

@@ -21,10 +21,8 @@
 //                          unfused path (the weight gradients stay on the grouped path and read them).
 //   swin_mlp_fwd_kernel    per 64 tokens: LN2 -> fc1 -> GELU (hidden slices exchanged through LDS, one barrier per 32 NW hidden units) -> fc2
 //                          -> row scale -> + residual.  Saves x1n, the fc1 pre-activation, mean2 / rstd2.
-//   swin_mlp_bwd_kernel    per 64 tokens: dh = s (dy W2) gelu'(hp), hact = gelu(hp) (operands of the two weight gradients), dx1n = dh W1,
-//                          LayerNorm backward, dx1 (+ its window-ordered, row-scaled copy), dgamma / dbeta.
-//   swin_attn_bwd_kernel   per window: dO = dyw Wproj, attention backward per head in the wave that owns it -> dqkv, d(bias table).
-//   swin_qkv_bwd_kernel    per window: dxn = dqkv Wqkv (both operands streamed), LayerNorm-1 backward, + residual gradient -> dx, dgamma / dbeta.
+// (Round 4 also built the backward of both branches on this scheme -- one wave per SIMD, all 64 rows in registers; each of the three kernels made the
+// step slower (+2.5 ... +6.5 ms, DESIGN_HISTORY.md section 11) and round 5 removed them: the backward is the unfused, token-ordered chain of model._BlockFn.)
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
@@ -150,7 +148,7 @@ template <int A, int DBG = 0> struct WStream {
 // ------------------------------------------------------------------------------------------------
 // weight streams from the fp32 masters
 // ------------------------------------------------------------------------------------------------
-enum { ST_ATTN_FWD = 0, ST_MLP_FWD = 1, ST_MLP_BWD = 2, ST_ATTN_BWD = 3, ST_QKV_BWD = 4 };
+enum { ST_ATTN_FWD = 0, ST_MLP_FWD = 1 };
 
 struct PackDesc { const float* w0; const float* w1; bf16_t* dst; int type, NW; };
 constexpr int MAX_PACK = 96;
@@ -160,9 +158,7 @@ __host__ __device__ inline int stream_steps(int type, int NW) {
   const int KS = 3 * NW;
   switch (type) {
     case ST_ATTN_FWD: return 4 * KS;
-    case ST_MLP_FWD: case ST_MLP_BWD: return 2 * MLP_ROUNDS * NW;
-    case ST_ATTN_BWD: return KS;
-    case ST_QKV_BWD: return 3 * KS;
+    case ST_MLP_FWD: return 2 * MLP_ROUNDS * NW;
   }
   return 0;
 }
@@ -180,19 +176,15 @@ __global__ __launch_bounds__(256) void swin_pack_kernel(PackArgs pa) {
     const int s = (int)(q % steps);
     const int w = (int)(q / steps);
     const int li = lane & 15, g = lane >> 4, t = i & 1, p = i >> 1;
-    const float* base = nullptr; long idx0 = 0, stride = 1;
+    const float* base = nullptr; long idx0 = 0;
     if (d.type == ST_ATTN_FWD) {
       const int seg = s / KS, ks = s - seg * KS;
       if (seg < 3) { const int h = 3 * w + seg; base = d.w0; idx0 = (long)(p * C + 32 * h + np_row(t, li)) * C + 32 * ks + 8 * g; }          // qkv.weight [3C][C]: part p (Q, K, V)
       else { base = d.w1; idx0 = (long)(96 * w + 32 * p + np_row(t, li)) * C + 32 * ks + 8 * g; }                                          // proj.weight [C][C]
-    } else if (d.type == ST_ATTN_BWD) {   // dO[f] = sum_c dyw[c] proj.weight[c][f]
-      base = d.w0; idx0 = (long)(32 * s + 8 * g) * C + 96 * w + 32 * p + np_row(t, li); stride = C;
-    } else if (d.type == ST_QKV_BWD) {    // dxn[n] = sum_kf dqkv[kf] qkv.weight[kf][n]
-      base = d.w0; idx0 = (long)(32 * s + 8 * g) * C + 96 * w + 32 * p + np_row(t, li); stride = C;
     } else {
       // step order within a segment of R rounds: fc1(0) | { fc1(c + 1), fc2(c) } for c = 0 .. R - 2 | fc2(R - 1); every part NW steps
       // (one segment of 12 rounds, or mlp_segments(NW) of them for the forward stream)
-      const int NSEG = d.type == ST_MLP_FWD ? mlp_segments(NW) : 1, R = MLP_ROUNDS / NSEG, per = 2 * R * NW;
+      const int NSEG = mlp_segments(NW), R = MLP_ROUNDS / NSEG, per = 2 * R * NW;
       const int sg = s / per, sl = s - sg * per;
       int c, kind, u;   // kind 0: first product of round c (rows = hidden), 1: second product of round c (rows = channels)
       if (sl < NW) { c = 0; kind = 0; u = sl; }
@@ -205,17 +197,15 @@ __global__ __launch_bounds__(256) void swin_pack_kernel(PackArgs pa) {
       const int H = 4 * C;
       if (kind == 0) {      // fragment i: k-step 3 u + (i >> 1), tile t = i & 1 of the wave's hidden pair of the round
         const int hid = 32 * (NW * c + w) + np_row(t, li), k0 = 32 * (3 * u + p) + 8 * g;
-        if (d.type == ST_MLP_FWD) { base = d.w0; idx0 = (long)hid * C + k0; }               // fc1.weight [4C][C]
-        else { base = d.w0; idx0 = (long)k0 * H + hid; stride = H; }                         // fc2.weight [C][4C] read as [hidden][channel]
+        base = d.w0; idx0 = (long)hid * C + k0;                                              // fc1.weight [4C][C]
       } else {              // fragment i: channel pair p, tile t; k-step = the 32 hidden units of wave u in round c
         const int ch = 96 * w + 32 * p + np_row(t, li), h0 = 32 * (NW * c + u) + 8 * g;
-        if (d.type == ST_MLP_FWD) { base = d.w1; idx0 = (long)ch * H + h0; }                // fc2.weight [C][4C]
-        else { base = d.w1; idx0 = (long)h0 * C + ch; stride = C; }                          // fc1.weight [4C][C] read as [channel][hidden]
+        base = d.w1; idx0 = (long)ch * H + h0;                                               // fc2.weight [C][4C]
       }
     }
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = base[idx0 + j * stride];
+    for (int j = 0; j < 8; ++j) v[j] = base[idx0 + j];
     *reinterpret_cast<bf16x8*>(d.dst + id * 8) = pack8(v);
   }
 }
@@ -807,600 +797,6 @@ __global__ __launch_bounds__(64 * NW) void swin_attn_fwd_kernel(AttnFwdArgs a) {
 }
 
 
-// ================================================================================================
-// shared tail of the two backward kernels: LayerNorm backward on acc = dL/d(LN output) in the accumulator layout
-//   (token li of row tile m, channels 96 w + 32 (n >> 1) + 8 g + 4 (n & 1) + r), plus the residual gradient:
-//   dx[row] = dres[row] + rstd (g - mean_c(g) - xhat mean_c(g xhat)),  g = acc * gamma;   dgamma += sum_rows acc xhat;  dbeta += sum_rows acc
-// rows[m] < 0: no such row.  The row sums over the C channels are completed across the NW waves through `red` (LDS, [NW][64][2] floats).
-// dyw (optional): second copy of dx at window row tok_to_win(row), times dyw_scale[row / rows_per_scale].
-// Call with the weight stream drained (plain LDS accesses and __syncthreads() below).  Every global load is requested before the first is used.
-// ================================================================================================
-template <int NW>
-__device__ __forceinline__ void ln_bwd_tail(f32x4 (&acc)[6][4], const long (&rows)[4], const bf16_t* __restrict__ x, const float* __restrict__ mean,
-                                            const float* __restrict__ rstd, const float* __restrict__ gamma, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-                                            bf16_t* __restrict__ dyw, const float* __restrict__ dyw_scale, int rows_per_scale, const WinMap& wm,
-                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* red, int wave, int lane) {
-  constexpr int C = 96 * NW;
-  const int g = lane >> 4, li = lane & 15;
-  float4 gmv[6];
-  uint4 xraw[4][3], draw[4][3];
-  float mu[4], rs_[4], dsc[4];
-#pragma unroll
-  for (int n = 0; n < 6; ++n) gmv[n] = *reinterpret_cast<const float4*>(gamma + 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1));
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const long row = rows[m] < 0 ? 0 : rows[m];
-    mu[m] = mean[row];
-    rs_[m] = rstd[row];
-    dsc[m] = (dyw && dyw_scale) ? dyw_scale[row / rows_per_scale] : 1.0f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      xraw[m][p] = *reinterpret_cast<const uint4*>(x + row * C + 96 * wave + 32 * p + 8 * g);
-      draw[m][p] = *reinterpret_cast<const uint4*>(dres + row * C + 96 * wave + 32 * p + 8 * g);
-    }
-  }
-  float pg[6][4], pb[6][4];
-#pragma unroll
-  for (int n = 0; n < 6; ++n)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { pg[n][r] = 0.f; pb[n][r] = 0.f; }
-  float xh[6][4][4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const bool ok = rows[m] >= 0;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      float xv[8];
-      unpack8(xraw[m][p], xv);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int n = 2 * p + t;
-        const float gm[4] = {gmv[n].x, gmv[n].y, gmv[n].z, gmv[n].w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = ok ? acc[n][m][r] : 0.f;
-          const float h = (xv[4 * t + r] - mu[m]) * rs_[m];
-          xh[n][m][r] = h;
-          pg[n][r] += d * h;
-          pb[n][r] += d;
-          const float gg = d * gm[r];
-          acc[n][m][r] = gg;
-          s1 += gg;
-          s2 += gg * h;
-        }
-      }
-    }
-    s1 = quad_row_sum(s1);
-    s2 = quad_row_sum(s2);
-    if (g == 0) { red[(wave * 64 + 16 * m + li) * 2] = s1; red[(wave * 64 + 16 * m + li) * 2 + 1] = s2; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    if (rows[m] < 0) continue;
-    const long row = rows[m];
-    float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { m1 += red[(w * 64 + 16 * m + li) * 2]; m2 += red[(w * 64 + 16 * m + li) * 2 + 1]; }
-    m1 *= (1.0f / C); m2 *= (1.0f / C);
-    const long wrow = dyw ? tok_to_win(wm, row) : 0;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      float rv[8];
-      unpack8(draw[m][p], rv);
-      f32x4 v0, v1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v0[r] = rs_[m] * (acc[2 * p][m][r] - m1 - xh[2 * p][m][r] * m2) + rv[r];
-        v1[r] = rs_[m] * (acc[2 * p + 1][m][r] - m1 - xh[2 * p + 1][m][r] * m2) + rv[4 + r];
-      }
-      *reinterpret_cast<bf16x8*>(dx + row * C + 96 * wave + 32 * p + 8 * g) = pack_tr(v0, v1).v;
-      if (dyw) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v0[r] *= dsc[m]; v1[r] *= dsc[m]; }
-        *reinterpret_cast<bf16x8*>(dyw + wrow * C + 96 * wave + 32 * p + 8 * g) = pack_tr(v0, v1).v;
-      }
-    }
-  }
-  // column sums over the 64 rows: butterfly over the 16 token lanes; lane li == 0 of group g owns channels 96 w + 32 p + 8 g + 4 t + r (no other wave does)
-#pragma unroll
-  for (int n = 0; n < 6; ++n)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float vg = pg[n][r], vb = pb[n][r];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { vg += __shfl_xor(vg, o, 64); vb += __shfl_xor(vb, o, 64); }
-      if (li == 0) {
-        const int col = 96 * wave + 32 * (n >> 1) + 8 * g + 4 * (n & 1) + r;
-        atomicAdd(dgamma + col, vg);
-        atomicAdd(dbeta + col, vb);
-      }
-    }
-}
-
-// ================================================================================================
-// MLP branch, backward.  Given dy = dL/dx2:
-//   hact = gelu(hp)                                          [M][4C]  (written: B operand of dW2 = (s dy)^T hact)
-//   dh   = s_row (dy W2) gelu'(hp)                           [M][4C]  (written: A operand of dW1 = dh^T x1n)
-//   dx1  = dy + LN2_backward(dh W1);  dgamma2 / dbeta2;  dyw = window-ordered copy of dx1 times dyw_scale (the attention branch's incoming gradient)
-// Same round structure as the forward: the first product of round c + 1 (dy W2 for the wave's 32 hidden units) carries the elementwise part of
-// round c tile by tile; the pre-activation of a round is requested a round ahead (a load consumed where it is requested waits for the whole
-// weight prefetch: vector-memory operations retire in order).
-// ================================================================================================
-struct MlpBwdArgs {
-  const bf16_t* dy; const bf16_t* x1; const bf16_t* hp; const float* mean; const float* rstd; const float* gamma; const char* wstream;
-  const float* rowscale; int rows_per_scale;
-  bf16_t* dx1; bf16_t* hact; bf16_t* dh; float* dgamma; float* dbeta;
-  bf16_t* dyw; const float* dyw_scale; WinMap wm; int dyw_pads;
-  long M;
-};
-
-template <int NW, int A> constexpr int mlp_bwd_lds() { return NW * A * STEP_BYTES + 2 * NW * 4096 + NW * 64 * 2 * 4; }
-
-template <int NW, int A>
-__global__ __launch_bounds__(64 * NW) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
-  constexpr int KS = 3 * NW, C = 32 * KS, H = 4 * C, TPS = 4 / NW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
-  char* exch = smem + NW * A * STEP_BYTES;
-  float* red = reinterpret_cast<float*>(exch + 2 * NW * 4096);
-  const unsigned exch_a = lds_addr(exch);
-  const long rbase = (long)blockIdx.x * 64;
-
-  WStream<A> ws;
-  ws.init(a.wstream + (long)wave * (2 * MLP_ROUNDS * NW) * STEP_BYTES, smem + wave * A * STEP_BYTES, 2 * MLP_ROUNDS * NW);
-  Frag<bf16_t> wf[G];
-  ws.start(wf, lane);
-
-  if (a.dyw && a.dyw_pads) {   // pad rows of the window-ordered output receive no token: zeroed here
-    const long wrows = (long)a.wm.B * a.wm.PH * a.wm.PW * a.wm.PD;
-    for (long i = (long)blockIdx.x * (64 * NW) + tid; i < wrows * (C / 8); i += (long)gridDim.x * (64 * NW)) {
-      const unsigned m = (unsigned)i / (unsigned)(C / 8), c = (unsigned)i - m * (unsigned)(C / 8);
-      if (win_to_tok(a.wm, (long)m) < 0) *reinterpret_cast<uint4*>(a.dyw + (long)m * C + c * 8) = make_uint4(0, 0, 0, 0);
-    }
-  }
-
-  Frag<bf16_t> df[4][KS];
-  long rows[4];
-  float sc[4];
-  const bf16_t* hprow[4];
-  long hoff[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const long row = rbase + 16 * m + li;
-    rows[m] = row < a.M ? row : -1;
-    const long lr = row < a.M ? row : a.M - 1;
-    sc[m] = a.rowscale ? a.rowscale[lr / a.rows_per_scale] : 1.0f;
-    hoff[m] = lr * H + 32 * wave + 8 * g;
-    hprow[m] = a.hp + hoff[m];
-#pragma unroll
-    for (int k = 0; k < KS; ++k) df[m][k].v = *reinterpret_cast<const bf16x8*>(a.dy + lr * C + 32 * k + 8 * g);
-  }
-
-  f32x4 acc[6][4];
-#pragma unroll
-  for (int n = 0; n < 6; ++n)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 hcur[2][4], hnxt[2][4];
-  uint4 hpc[4], hpn[4];
-
-  auto hp_load = [&](int c, uint4 (&q)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) q[m] = *reinterpret_cast<const uint4*>(hprow[m] + 32 * NW * c);
-  };
-  // elementwise part of round c, row tile m: hact, dh (stored: 16 bytes each), dh as the operand fragment of the second product
-  auto act_tile = [&](int c, f32x4 (&h)[2][4], int m, const uint4 (&q)[4]) __attribute__((always_inline)) {
-    float xv[8];
-    unpack8(q[m], xv);
-    f32x4 ha[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float xx = xv[4 * t + r];
-        float er, e;
-        erf_as_parts(xx * 0.70710678118654752f, er, e);
-        const float cdf = 0.5f * (1.0f + er);
-        ha[t][r] = xx * cdf;
-        h[t][m][r] = h[t][m][r] * (cdf + xx * 0.39894228040143268f * e) * sc[m];
-      }
-    const Frag<bf16_t> hf = pack_tr(h[0][m], h[1][m]);
-    if (rows[m] >= 0) {
-      *reinterpret_cast<bf16x8*>(a.hact + hoff[m] + 32 * NW * c) = pack_tr(ha[0], ha[1]).v;
-      *reinterpret_cast<bf16x8*>(a.dh + hoff[m] + 32 * NW * c) = hf.v;
-    }
-    lds_write16(exch_a + ((c & 1) * NW + wave) * 4096 + m * 1024 + lane * 16, hf.v);
-  };
-  auto dha = [&](f32x4 (&h)[2][4], auto with_act, int c_act, f32x4 (&hp)[2][4], const uint4 (&q)[4]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) h[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < NW; ++u)
-      ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) mma(h[t][m], w[2 * qq + t], df[m][3 * u + qq]);
-        if (decltype(with_act)::value) {
-#pragma unroll
-          for (int mm = 0; mm < TPS; ++mm) act_tile(c_act, hp, u * TPS + mm, q);
-        }
-      });
-  };
-  auto dxn = [&](int c) __attribute__((always_inline)) {
-    Frag<bf16_t> hf[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) hf[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW) * 4096 + m * 1024 + lane * 16);
-#pragma unroll
-    for (int u = 0; u < NW; ++u)
-      ws.step(wf, lane, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
-        Frag<bf16_t> hn[4];
-        if (u + 1 < NW) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) hn[m].v = *reinterpret_cast<const bf16x8*>(exch + ((c & 1) * NW + u + 1) * 4096 + m * 1024 + lane * 16);
-        }
-#pragma unroll
-        for (int n = 0; n < 6; ++n)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) mma(acc[n][m], w[n], hf[m]);
-        if (u + 1 < NW) {
-#pragma unroll
-          for (int m = 0; m < 4; ++m) hf[m] = hn[m];
-        }
-      });
-  };
-
-  hp_load(0, hpc);
-  dha(hcur, std::false_type{}, 0, hcur, hpc);
-#pragma unroll 1
-  for (int c = 0; c < MLP_ROUNDS - 1; ++c) {
-    hp_load(c + 1, hpn);
-    dha(hnxt, std::true_type{}, c, hcur, hpc);
-    wg_barrier();
-    dxn(c);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { hpc[m] = hpn[m]; hcur[0][m] = hnxt[0][m]; hcur[1][m] = hnxt[1][m]; }
-  }
-#pragma unroll
-  for (int m = 0; m < 4; ++m) act_tile(MLP_ROUNDS - 1, hcur, m, hpc);
-  wg_barrier();
-  dxn(MLP_ROUNDS - 1);
-  ws.drain();
-  ln_bwd_tail<NW>(acc, rows, a.x1, a.mean, a.rstd, a.gamma, a.dy, a.dx1, a.dyw, a.dyw_scale, a.rows_per_scale, a.wm, a.dgamma, a.dbeta, red, wave, lane);
-}
-
-// ================================================================================================
-// attention branch, backward, first half: dO = dyw Wproj, then per head (in the wave that owns it) the backward of
-// softmax(q k^T / sqrt(32) + bias + mask) v from the saved qkv and log-sum-exp -> dqkv (layout of the unfused path), d(bias table).
-//   phase A (S^T layout, lane <-> query): P, dP -> D_i = sum_j P dP, dS, d(bias), dQ = dS K
-//   phase B (S layout,   lane <-> key)  : P, dS recomputed -> dV = P^T dO, dK = dS^T Q        (the algorithm of csrc/attn.hip attn_bwd_kernel)
-// ================================================================================================
-struct AttnBwdArgs {
-  const bf16_t* dyw; const bf16_t* qkv; const float* table; const float* lse; const char* wstream;
-  bf16_t* dqkv; float* dtable; WinMap wm;
-};
-
-constexpr int ARS = 96;   // row stride of the [64][32] LDS tiles
-template <int NW, int A> constexpr int attn_bwd_lds() {
-  return NW * A * STEP_BYTES + NW * (2 * 64 * ARS + 344 * 4 + 64 * 4 + 64 * 4 + 64) + 3 * NW * 344 * 4;
-}
-__device__ __forceinline__ Frag<bf16_t> gfrag16(const bf16_t* base, long ld, int row, int g) {
-  Frag<bf16_t> f;
-  f.v = *reinterpret_cast<const bf16x8*>(base + row * ld + 8 * g);
-  return f;
-}
-__device__ __forceinline__ Frag<bf16_t> lds_row_frag(const char* tile, int row, int g) {
-  Frag<bf16_t> f;
-  f.v = *reinterpret_cast<const bf16x8*>(tile + row * ARS + 16 * g);
-  return f;
-}
-__device__ __forceinline__ void store4s(bf16_t* p, const f32x4& v, float s) {
-  *reinterpret_cast<uint2*>(p) = make_uint2(pk_bf16(v[0] * s, v[1] * s), pk_bf16(v[2] * s, v[3] * s));
-}
-
-template <int NW, int A>
-__global__ __launch_bounds__(64 * NW) void swin_attn_bwd_kernel(AttnBwdArgs a) {
-  constexpr int KS = 3 * NW, C = 32 * KS, HEADS = KS;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* wscr = smem + NW * A * STEP_BYTES + wave * (2 * 64 * ARS + 344 * 4 + 64 * 4 + 64 * 4 + 64);
-  char* tA = wscr;                                     // K tile (phase A), then Q tile (phase B)
-  char* tO = wscr + 64 * ARS;                          // dO tile
-  float* sDB = reinterpret_cast<float*>(wscr + 2 * 64 * ARS);        // [344] d(bias) of the current head
-  float* sD = sDB + 344;                               // [64]
-  float* sL = sD + 64;                                 // [64]
-  unsigned char* sRb = reinterpret_cast<unsigned char*>(sL + 64);   // [64] region ids
-  float* sTab = reinterpret_cast<float*>(smem + NW * A * STEP_BYTES + NW * (2 * 64 * ARS + 344 * 4 + 64 * 4 + 64 * 4 + 64));   // [HEADS][344]
-  const long win = blockIdx.x;
-  const int nW = (a.wm.PH >> 2) * (a.wm.PW >> 2) * (a.wm.PD >> 2);
-  const bool shifted = (a.wm.s0 + a.wm.s1 + a.wm.s2) > 0;
-  const float scale = 0.17677669529663689f;
-
-  for (int i = tid; i < HEADS * 343; i += 64 * NW) { const int t = i / HEADS, h = i - t * HEADS; sTab[h * 344 + t] = a.table[i]; }
-  for (int t = lane0; t < 344; t += 64) sDB[t] = 0.f;
-  sRb[lane0] = shifted ? (unsigned char)token_region(a.wm, (int)(win % nW), lane0) : 0;
-  __syncthreads();
-
-  WStream<A> ws;
-  ws.init(a.wstream + (long)wave * KS * STEP_BYTES, smem + wave * A * STEP_BYTES, KS);
-  Frag<bf16_t> wf[G];
-  ws.start(wf, lane0);
-
-  // ---- dO^T for this wave's three heads: rows = head features (natural order after packing), columns = tokens
-  Frag<bf16_t> dof[3][4];
-  {
-    const int g = lane0 >> 4, li = lane0 & 15;
-    Frag<bf16_t> dfw[4][KS];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int k = 0; k < KS; ++k) dfw[m][k].v = *reinterpret_cast<const bf16x8*>(a.dyw + (win * 64 + 16 * m + li) * C + 32 * k + 8 * g);
-    f32x4 acc[6][4];
-#pragma unroll
-    for (int n = 0; n < 6; ++n)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < KS; ++k)
-      ws.step(wf, lane0, [&](const Frag<bf16_t> (&w)[G]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int n = 0; n < 6; ++n)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) mma(acc[n][m], w[n], dfw[m][k]);
-      });
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) dof[p][m] = pack_tr(acc[2 * p][m], acc[2 * p + 1][m]);
-  }
-  ws.drain();   // (the stream is through: plain LDS accesses below)
-
-  const long ld = 3L * C;
-#pragma unroll 1
-  for (int j = 0; j < 3; ++j) {
-    const int h = 3 * wave + j;
-    const float* sB = sTab + h * 344;
-    const bf16_t* qb = a.qkv + win * 64 * ld + h * 32;
-    const bf16_t* kb = qb + C;
-    const bf16_t* vb = qb + 2 * C;
-    bf16_t* dqb = a.dqkv + win * 64 * ld + h * 32;
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));     // opaque: what derives from it is loop-invariant and would be hoisted into ~200 registers (attn.hip)
-    const int g = lane >> 4, li = lane & 15;
-    const int c1 = (li >> 2) - g, c2 = li & 3;
-    const int binA = (c1 + 3) * 7 + c2 + 3;  // phase A (i = 16it+li, j = 16jt+4g+r): binA + (it-jt+3)*49 - r
-    const int binB = (3 - c1) * 7 + 3 - c2;  // phase B (i = 16it+4g+r, j = 16jt+li): binB + (it-jt+3)*49 + r
-    float dsacc[7][4];
-#pragma unroll
-    for (int q = 0; q < 7; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dsacc[q][r] = 0.f;
-    Frag<bf16_t> kf[4], qf[4], vf[4], df[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      kf[t] = gfrag16(kb, ld, t * 16 + li, g); qf[t] = gfrag16(qb, ld, t * 16 + li, g); vf[t] = gfrag16(vb, ld, t * 16 + li, g);
-      if (j == 0) df[t] = dof[0][t]; else if (j == 1) df[t] = dof[1][t]; else df[t] = dof[2][t];
-    }
-    sL[lane] = a.lse[(win * HEADS + h) * 64 + lane];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      *reinterpret_cast<bf16x8*>(tA + (t * 16 + li) * ARS + 16 * g) = kf[t].v;
-      *reinterpret_cast<bf16x8*>(tO + (t * 16 + li) * ARS + 16 * g) = df[t].v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---------------- phase A ----------------
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      f32x4 p[4], dp[4];
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        p[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[jt], kf[jt], qf[it]);
-        dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[jt], vf[jt], df[it]);
-      }
-      const int i = 16 * it + li;
-      const unsigned ri = shifted ? sRb[i] : 0u;
-      const float L = sL[i];
-      float dsum = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const unsigned rw = shifted ? *reinterpret_cast<const unsigned*>(sRb + 16 * jt + 4 * g) : 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = p[jt][r] * scale + sB[binA + (it - jt + 3) * 49 - r];
-          if (shifted && ((rw >> (8 * r)) & 255u) != ri) v += -100.0f;
-          const float e = __expf(v - L);
-          p[jt][r] = e;
-          dsum += e * dp[jt][r];
-        }
-      }
-      dsum = quad_row_sum(dsum);
-      if (g == 0) sD[i] = dsum;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ds = p[jt][r] * (dp[jt][r] - dsum);
-          dp[jt][r] = ds;
-          dsacc[it - jt + 3][r] += ds;
-        }
-      // dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]
-      f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const Frag<bf16_t> pa = pack_tr(dp[2 * ks], dp[2 * ks + 1]);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const Frag<bf16_t> b = lds_frag_t(tA, ARS, ks * 32, dt * 16, lane, (bf16_t*)nullptr);
-          mma(o[dt], b, pa);
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) store4s(dqb + (long)i * ld + 16 * dt + 4 * g, o[dt], scale);
-      __builtin_amdgcn_sched_barrier(0);   // keeps the query tiles sequential (interleaved, they need 4x the registers)
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(tA + (t * 16 + li) * ARS + 16 * g) = qf[t].v;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---------------- phase B ----------------
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-      f32x4 p[4], dp[4];  // [it]: query i = 16it+4g+r, key j = 16jt+li
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        p[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[it], qf[it], kf[jt]);
-        dp[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[it], df[it], vf[jt]);
-      }
-      const int jj = 16 * jt + li;
-      const unsigned rj = shifted ? sRb[jj] : 0u;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const unsigned rw = shifted ? *reinterpret_cast<const unsigned*>(sRb + 16 * it + 4 * g) : 0u;
-        const float4 L4 = *reinterpret_cast<const float4*>(&sL[16 * it + 4 * g]);
-        const float4 D4 = *reinterpret_cast<const float4*>(&sD[16 * it + 4 * g]);
-        const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = p[it][r] * scale + sB[binB + (it - jt + 3) * 49 + r];
-          if (shifted && ((rw >> (8 * r)) & 255u) != rj) v += -100.0f;
-          const float e = __expf(v - Lr[r]);
-          p[it][r] = e;
-          dp[it][r] = e * (dp[it][r] - Dr[r]);
-        }
-      }
-      // dV^T[d][j] = sum_i dO[i][d] P[i][j];  dK^T[d][j] = sum_i Q[i][d] dS[i][j]
-      f32x4 ov[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, ok[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const Frag<bf16_t> ap = pack_tr(p[2 * ks], p[2 * ks + 1]);
-        const Frag<bf16_t> ad = pack_tr(dp[2 * ks], dp[2 * ks + 1]);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const Frag<bf16_t> bo = lds_frag_t(tO, ARS, ks * 32, dt * 16, lane, (bf16_t*)nullptr);
-          mma(ov[dt], bo, ap);
-          const Frag<bf16_t> bq = lds_frag_t(tA, ARS, ks * 32, dt * 16, lane, (bf16_t*)nullptr);
-          mma(ok[dt], bq, ad);
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        store4s(dqb + (long)jj * ld + 2 * C + 16 * dt + 4 * g, ov[dt], 1.0f);
-        store4s(dqb + (long)jj * ld + C + 16 * dt + 4 * g, ok[dt], scale);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // d(bias) of this (window, head): lanes of one 16-lane group hit 16 distinct bins, lanes of different groups may share one -- one group at a time
-#pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-      if (g == ph) {
-#pragma unroll
-        for (int q = 0; q < 7; ++q)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(&sDB[binA + q * 49 - r], dsacc[q][r]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    for (int t = lane; t < 343; t += 64) { atomicAdd(a.dtable + t * HEADS + h, sDB[t]); sDB[t] = 0.f; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ================================================================================================
-// attention branch, backward, second half (per window): dxn = dqkv Wqkv -- BOTH operands streamed, the 64 dqkv rows as four more 1-KB
-// pieces per step through the same ring (per-lane source addresses land them as lane-linear fragment images) -- then LayerNorm-1 backward and
-// the residual: dx[tok] = dres[tok] + LN1_backward(dxn)[tok];  dgamma1 / dbeta1.
-// ================================================================================================
-struct QkvBwdArgs {
-  const bf16_t* dqkv; const bf16_t* x; const bf16_t* dres; const float* mean; const float* rstd; const float* gamma; const char* wstream;
-  bf16_t* dx; float* dgamma; float* dbeta; WinMap wm;
-};
-constexpr int QB_STEP = (G + 4) * 1024;
-template <int NW, int A> constexpr int qkv_bwd_lds() { return NW * A * QB_STEP + NW * 64 * 2 * 4; }
-
-template <int NW, int A>
-__global__ __launch_bounds__(64 * NW) void swin_qkv_bwd_kernel(QkvBwdArgs a) {
-  constexpr int KS = 3 * NW, C = 32 * KS, NSTEP = 3 * KS;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, li = lane & 15;
-  char* ring = smem + wave * A * QB_STEP;
-  float* red = reinterpret_cast<float*>(smem + NW * A * QB_STEP);
-  const long win = blockIdx.x;
-  const char* wsrc = a.wstream + (long)wave * NSTEP * STEP_BYTES;
-  const char* rowp[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) rowp[m] = reinterpret_cast<const char*>(a.dqkv + (win * 64 + 16 * m + li) * (3L * C) + 8 * g);
-
-  int is_step = 0, is_slot = 0, rd_slot = 0;
-  auto issue = [&]() __attribute__((always_inline)) {
-    int lv = lane;
-    asm volatile("" : "+v"(lv));
-    const char* s = wsrc + (long)is_step * STEP_BYTES + lv * 16;
-    char* d = ring + is_slot * QB_STEP;
-    dma16<0>(s, d); dma16<1024>(s, d); dma16<2048>(s, d); dma16<3072>(s, d);
-    dma16<0>(s + 4096, d + 4096); dma16<1024>(s + 4096, d + 4096);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) dma16<0>(rowp[m] + is_step * 64, d + (G + m) * 1024);
-    is_step = is_step + 1 == NSTEP ? 0 : is_step + 1;
-    is_slot = is_slot + 1 == A ? 0 : is_slot + 1;
-  };
-  auto wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A - 1) * (G + 4)) : "memory"); };
-  auto read = [&](Frag<bf16_t> (&f)[G + 4]) __attribute__((always_inline)) {
-    const unsigned ad = lds_addr(ring) + (unsigned)(rd_slot * QB_STEP + lane * 16);
-#pragma unroll
-    for (int i = 0; i < G + 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[i].v) : "v"(ad), "n"(i * 1024));
-    rd_slot = rd_slot + 1 == A ? 0 : rd_slot + 1;
-  };
-  auto settle = [&](Frag<bf16_t> (&f)[G + 4]) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0].v), "+v"(f[1].v), "+v"(f[2].v), "+v"(f[3].v), "+v"(f[4].v), "+v"(f[5].v), "+v"(f[6].v), "+v"(f[7].v), "+v"(f[8].v), "+v"(f[9].v)::"memory");
-  };
-
-  Frag<bf16_t> cur[G + 4];
-#pragma unroll
-  for (int k = 0; k < A; ++k) issue();
-  wait();
-  read(cur);
-  settle(cur);
-  issue();
-
-  f32x4 acc[6][4];
-#pragma unroll
-  for (int n = 0; n < 6; ++n)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int s = 0; s < NSTEP; ++s) {
-    Frag<bf16_t> nx[G + 4];
-    wait();
-    read(nx);
-#pragma unroll
-    for (int n = 0; n < 6; ++n)
-#pragma unroll
-      for (int m = 0; m < 4; ++m) mma(acc[n][m], cur[n], cur[G + m]);
-    settle(nx);
-    issue();
-#pragma unroll
-    for (int i = 0; i < G + 4; ++i) cur[i] = nx[i];
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  long tok[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) tok[m] = win_to_tok(a.wm, win * 64 + 16 * m + li);
-  ln_bwd_tail<NW>(acc, tok, a.x, a.mean, a.rstd, a.gamma, a.dres, a.dx, nullptr, nullptr, 1, a.wm, a.dgamma, a.dbeta, red, wave, lane);
-}
-
 }  // namespace sw
 
 // ------------------------------------------------------------------------------------------------
@@ -1451,7 +847,7 @@ int k_swin_pack(const SwinPackItem* items, int n, hipStream_t st) {
     long maxthr = 0;
     for (int i = 0; i < cnt; ++i) {
       const SwinPackItem& it = items[base + i];
-      if (!k_swin_supported(it.C) || it.type < 0 || it.type > 4 || !it.w0 || !it.dst) return -4;
+      if (!k_swin_supported(it.C) || it.type < 0 || it.type > 1 || !it.w0 || !it.dst) return -4;
       const int NW = it.C / 96;
       pa.d[i] = sw::PackDesc{it.w0, it.w1, (bf16_t*)it.dst, it.type, NW};
       const long thr = (long)NW * sw::stream_steps(it.type, NW) * sw::G * 64;
@@ -1557,76 +953,6 @@ int k_swin_attn_fwd(const void* x, const float* gamma, const float* beta, const 
     case 96: return launch_attn_fwd<1>(a, nwin, st);
     case 192: return launch_attn_fwd<2>(a, nwin, st);
     case 384: return launch_attn_fwd<4>(a, nwin, st);
-  }
-  return -1;
-}
-
-template <int NW> static int launch_mlp_bwd(const sw::MlpBwdArgs& a, hipStream_t st) {
-  constexpr int lds = sw::mlp_bwd_lds<NW, RING_A>();
-  if (int e = set_lds(sw::swin_mlp_bwd_kernel<NW, RING_A>, lds)) return e;
-  hipLaunchKernelGGL((sw::swin_mlp_bwd_kernel<NW, RING_A>), dim3((unsigned)((a.M + 63) / 64)), dim3(64 * NW), lds, st, a);
-  NMH_CHECK_LAUNCH();
-  return 0;
-}
-int k_swin_mlp_bwd(const void* dy, const void* x1, const void* hp, const float* mean, const float* rstd, const float* gamma, const void* wstream, const float* rowscale,
-                   int rows_per_scale, void* dx1, void* hact, void* dh, float* dgamma, float* dbeta, void* dyw, const float* dyw_scale, const WinMap* wm, long M, int C,
-                   hipStream_t st) {
-  sw::MlpBwdArgs a{(const bf16_t*)dy, (const bf16_t*)x1, (const bf16_t*)hp, mean, rstd, gamma, (const char*)wstream, rowscale, rows_per_scale > 0 ? rows_per_scale : 1,
-                   (bf16_t*)dx1, (bf16_t*)hact, (bf16_t*)dh, dgamma, dbeta, (bf16_t*)dyw, dyw_scale, WinMap{}, 0, M};
-  if (dyw) {
-    if (!wm) return -4;
-    a.wm = *wm;
-    if ((long)wm->B * wm->PH * wm->PW * wm->PD * (C / 8) >= (1L << 32)) return -2;
-    a.dyw_pads = (long)wm->PH * wm->PW * wm->PD != (long)wm->H * wm->W * wm->D;
-  }
-  switch (C) {
-    case 96: return launch_mlp_bwd<1>(a, st);
-    case 192: return launch_mlp_bwd<2>(a, st);
-    case 384: return launch_mlp_bwd<4>(a, st);
-  }
-  return -1;
-}
-
-template <int NW> static int launch_attn_bwd(const sw::AttnBwdArgs& a, long nwin, hipStream_t st) {
-  constexpr int A = 3;
-  constexpr int lds = sw::attn_bwd_lds<NW, A>();
-  if (int e = set_lds(sw::swin_attn_bwd_kernel<NW, A>, lds)) return e;
-  hipLaunchKernelGGL((sw::swin_attn_bwd_kernel<NW, A>), dim3((unsigned)nwin), dim3(64 * NW), lds, st, a);
-  NMH_CHECK_LAUNCH();
-  return 0;
-}
-int k_swin_attn_bwd(const void* dyw, const void* qkv, const float* table, const float* lse, const void* wstream, void* dqkv, float* dtable, const WinMap& wm, int C,
-                    hipStream_t st) {
-  sw::AttnBwdArgs a{(const bf16_t*)dyw, (const bf16_t*)qkv, table, lse, (const char*)wstream, (bf16_t*)dqkv, dtable, wm};
-  const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
-  if (nwin <= 0) return 0;
-  if (nwin * 64 >= (1L << 31)) return -2;
-  switch (C) {
-    case 96: return launch_attn_bwd<1>(a, nwin, st);
-    case 192: return launch_attn_bwd<2>(a, nwin, st);
-    case 384: return launch_attn_bwd<4>(a, nwin, st);
-  }
-  return -1;
-}
-
-template <int NW> static int launch_qkv_bwd(const sw::QkvBwdArgs& a, long nwin, hipStream_t st) {
-  constexpr int A = 3;
-  constexpr int lds = sw::qkv_bwd_lds<NW, A>();
-  if (int e = set_lds(sw::swin_qkv_bwd_kernel<NW, A>, lds)) return e;
-  hipLaunchKernelGGL((sw::swin_qkv_bwd_kernel<NW, A>), dim3((unsigned)nwin), dim3(64 * NW), lds, st, a);
-  NMH_CHECK_LAUNCH();
-  return 0;
-}
-int k_swin_qkv_bwd(const void* dqkv, const void* x, const void* dres, const float* mean, const float* rstd, const float* gamma, const void* wstream, void* dx,
-                   float* dgamma, float* dbeta, const WinMap& wm, int C, hipStream_t st) {
-  sw::QkvBwdArgs a{(const bf16_t*)dqkv, (const bf16_t*)x, (const bf16_t*)dres, mean, rstd, gamma, (const char*)wstream, (bf16_t*)dx, dgamma, dbeta, wm};
-  const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
-  if (nwin <= 0) return 0;
-  if (nwin * 64 >= (1L << 31)) return -2;
-  switch (C) {
-    case 96: return launch_qkv_bwd<1>(a, nwin, st);
-    case 192: return launch_qkv_bwd<2>(a, nwin, st);
-    case 384: return launch_qkv_bwd<4>(a, nwin, st);
   }
   return -1;
 }

@@ -278,10 +278,7 @@ class _BlockFn(torch.autograd.Function):
         # the dispatch decisions are taken ONCE, here, and kept on ctx: the layout of the saved tensors depends on them, and the thresholds / switches they
         # are derived from are module globals that a test (or a caller) may change between forward and backward
         ctx.fused_attn = fused_attn
-        ctx.sw_attn_bwd = bool(fused_attn and ops.SWIN_ATTN_BWD in sw)
-        ctx.sw_qkv_bwd = bool(fused_attn and ops.SWIN_QKV_BWD in sw)
-        no_sw_bwd = sw is None or (ops.SWIN_ATTN_BWD not in sw and ops.SWIN_QKV_BWD not in sw and ops.SWIN_MLP_BWD not in sw)
-        ctx.tok_bwd = bool(ops.TOKEN_BWD and geom.rows != geom.tokens and ctx.needs_input_grad[0] and no_sw_bwd and not ops.mlp_fused_ok(x, C, T)
+        ctx.tok_bwd = bool(ops.TOKEN_BWD and geom.rows != geom.tokens and ctx.needs_input_grad[0] and not ops.mlp_fused_ok(x, C, T)
                            and (fused_attn or ops.TOKEN_BWD_UNFUSED))
         if fused_attn:
             # LN1 -> QKV -> window attention -> proj -> row scale -> + residual in ONE launch (csrc/swin_block.hip); saves the same tensors
@@ -311,17 +308,10 @@ class _BlockFn(torch.autograd.Function):
             x1 = torch.empty_like(x)   # x1 = x + sd1 * window_reverse(proj(o)): the reverse + residual are the GEMM's store
             ops.gemm_nt_window_scatter(o, pk[key + "proj.w"].view(C, C), x1, x, b.attn.proj.bias, sd1, tps, geom)
         ctx.mlp_fused = ops.mlp_fused_ok(x, C, T)
-        ctx.sw_mlp_bwd = False
         if not ctx.mlp_fused and sw is not None and swin_shape and ops.swin_mlp_ok(x, C, T):
-            # LN2 -> fc1 -> GELU -> fc2 -> row scale -> + residual in one launch; keeps what the backward reads (gelu(hp) only for the unfused one)
-            ctx.sw_mlp_bwd = ops.SWIN_MLP_BWD in sw
-            if ctx.sw_mlp_bwd:
-                x2, x1n, h_pre, mean2, rstd2 = ops.swin_mlp_fwd(x1, b.norm2.weight, b.norm2.bias, sw[ops.SWIN_MLP_FWD], b.mlp[0].bias, b.mlp[3].bias,
-                                                               rowscale=sd2, rows_per_scale=tps)
-                h_act = None
-            else:
-                x2, x1n, h_pre, mean2, rstd2, h_act = ops.swin_mlp_fwd(x1, b.norm2.weight, b.norm2.bias, sw[ops.SWIN_MLP_FWD], b.mlp[0].bias, b.mlp[3].bias,
-                                                                      rowscale=sd2, rows_per_scale=tps, want_hact=True)
+            # LN2 -> fc1 -> GELU -> fc2 -> row scale -> + residual in one launch; keeps what the (unfused) backward reads, gelu(hp) included
+            x2, x1n, h_pre, mean2, rstd2, h_act = ops.swin_mlp_fwd(x1, b.norm2.weight, b.norm2.bias, sw[ops.SWIN_MLP_FWD], b.mlp[0].bias, b.mlp[3].bias,
+                                                                  rowscale=sd2, rows_per_scale=tps, want_hact=True)
         elif ctx.mlp_fused:
             # LN2 -> fc1 -> GELU -> fc2 -> row scale -> + residual in one launch; nothing but x1 is kept for the backward (csrc/mlp_fused.hip)
             x2 = ops.mlp_fused_fwd(x1, b.norm2.weight, b.norm2.bias, pk[key + "fc1.w"].view(4 * C, C), b.mlp[0].bias, pk[key + "fc2.wT"].view(4 * C, C),
@@ -360,14 +350,7 @@ class _BlockFn(torch.autograd.Function):
         tok_bwd = ctx.tok_bwd
         # = sd1 * dx1 in window order (adjoint of the window reverse), second output of the LN backward; not formed by the token-ordered backward
         dyw = None if tok_bwd else torch.empty_like(xnw)
-        sw = getattr(b, "_sw", None)
-        if ctx.sw_mlp_bwd:
-            # one launch: hact / dh (operands of the two weight gradients), dx1 and its window-ordered copy, dgamma / dbeta (csrc/swin_block.hip)
-            dx1, h_act, dh, _ = ops.swin_mlp_bwd(dx2, x1, h_pre, mean2, rstd2, b.norm2.weight, sw[ops.SWIN_MLP_BWD], _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias),
-                                                 geom, rowscale=sd2, rows_per_scale=tps, dyw=dyw, dyw_scale=sd1)
-            wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
-            wgrad(dh, x1n, b.mlp[0])
-        elif ctx.mlp_fused:
+        if ctx.mlp_fused:
             # one launch: recomputes LN2 / the hidden activations, writes the operands of the two weight gradients and dx1 (+ its window-ordered copy)
             dx1, x1n, h_act, dh = ops.mlp_fused_bwd(x1, dx2, b.norm2.weight, b.norm2.bias, pk[key + "fc1.w"].view(4 * C, C), b.mlp[0].bias,
                                                     pk[key + "fc2.wT"].view(4 * C, C), _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias),
@@ -405,20 +388,12 @@ class _BlockFn(torch.autograd.Function):
                     ops.window_pad_rows_colsum(dq_pad, g_qb, geom)
             dx = torch.empty_like(x)
             ops.layernorm_bwd(dxn, x, b.norm1.weight, mean1, rstd1, dx, _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), T, C, dres=dx1, wq=q)
-        elif ctx.sw_attn_bwd:
-            dqkv = ops.swin_attn_bwd(dyw, qkv, b.attn.relative_position_bias_table, lse, sw[ops.SWIN_ATTN_BWD], _gradbuf(b.attn.relative_position_bias_table), geom)
-            wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
         else:
             do = ops.gemm_nt(dyw, pk[key + "proj.wT"].view(C, C))
             wgrad(dyw, o, b.attn.proj, rps=geom.rows // geom.B)
             dqkv = torch.empty_like(qkv)
             ops.window_attn_bwd(qkv, b.attn.relative_position_bias_table, do, lse, dqkv, _gradbuf(b.attn.relative_position_bias_table), heads, C, geom)
-        if tok_bwd:
-            pass
-        elif ctx.sw_qkv_bwd:
-            dx = ops.swin_qkv_bwd(dqkv, x, dx1, mean1, rstd1, b.norm1.weight, sw[ops.SWIN_QKV_BWD], _gradbuf(b.norm1.weight), _gradbuf(b.norm1.bias), geom)
-            wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
-        else:
+        if not tok_bwd:
             dxnw = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
             wgrad(dqkv, xnw, b.attn.qkv, rps=geom.rows // geom.B)
             dx = torch.empty_like(x)
@@ -1007,11 +982,8 @@ class SwinTransformer_MAE3D_New(nn.Module):
         the fp32 masters by one launch per group (stages < / >= LATE_STAGE, like the other encoder layouts)"""
         if not (ops.SWIN_FUSED and self.compute_dtype == torch.bfloat16):
             return
-        kinds = [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD] + ([ops.SWIN_MLP_BWD] if "mlp" in ops.SWIN_BWD else []) + ([ops.SWIN_ATTN_BWD] if "attn" in ops.SWIN_BWD else []) + \
-                ([ops.SWIN_QKV_BWD] if "qkv" in ops.SWIN_BWD else [])
-        src = {ops.SWIN_ATTN_FWD: lambda b: (b.attn.qkv.weight, b.attn.proj.weight), ops.SWIN_MLP_FWD: lambda b: (b.mlp[0].weight, b.mlp[3].weight),
-               ops.SWIN_MLP_BWD: lambda b: (b.mlp[3].weight, b.mlp[0].weight), ops.SWIN_ATTN_BWD: lambda b: (b.attn.proj.weight, None),
-               ops.SWIN_QKV_BWD: lambda b: (b.attn.qkv.weight, None)}
+        kinds = [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD]
+        src = {ops.SWIN_ATTN_FWD: lambda b: (b.attn.qkv.weight, b.attn.proj.weight), ops.SWIN_MLP_FWD: lambda b: (b.mlp[0].weight, b.mlp[3].weight)}
         blocks = [(s, b) for s, st in enumerate(self.stages) for b in st if isinstance(b, SwinBlock3D) and ops.swin_supported(b.dim)]
         total = sum((ops.swin_stream_numel(k, b.dim) + 63) // 64 * 64 for _, b in blocks for k in kinds)
         if not total:

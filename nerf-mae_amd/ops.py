@@ -652,7 +652,7 @@ def mlp_fused_bwd(x1, dx2, gamma, beta, W1, b1, W2T, dgamma, dbeta, rowscale=Non
 
 
 # ---- fused Swin-block kernels (csrc/swin_block.hip): bf16, C = 96 * {1, 2, 4} ----
-SWIN_ATTN_FWD, SWIN_MLP_FWD, SWIN_MLP_BWD, SWIN_ATTN_BWD, SWIN_QKV_BWD = range(5)
+SWIN_ATTN_FWD, SWIN_MLP_FWD = range(2)   # weight-stream kinds (nmh_swin_pack)
 
 
 class _SwinPackItem(ctypes.Structure):   # include/nerfmae_hip.h: nmh_swin_pack_item
@@ -666,10 +666,6 @@ SWIN_ATTN_MIN_WINDOWS = int(__import__("os").environ.get("NMH_SWIN_ATTN_MIN_WIN"
 SWIN_MLP_MIN_ROWS = int(__import__("os").environ.get("NMH_SWIN_MLP_MIN_ROWS", "6000"))
 SWIN_MLP_WIDTHS = tuple(int(v) for v in __import__("os").environ.get("NMH_SWIN_MLP_WIDTHS", "192,384").split(",") if v)   # C = 96 keeps csrc/mlp_fused.hip (weights resident in LDS)
 SWIN_ATTN_WIDTHS = tuple(int(v) for v in __import__("os").environ.get("NMH_SWIN_ATTN_WIDTHS", "96,192,384").split(",") if v)
-
-
-# backward kernels taken by default ("mlp", "attn", "qkv"; measured in the replayed step): NMH_SWIN_BWD=mlp,attn,qkv to force
-SWIN_BWD = tuple(v for v in __import__("os").environ.get("NMH_SWIN_BWD", "").split(",") if v)
 
 
 def swin_attn_ok(x, C: int, geom) -> bool:
@@ -762,46 +758,6 @@ def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return (x2, x1n, hp, mean, rstd, hact) if want_hact else (x2, x1n, hp, mean, rstd)
-
-
-def swin_mlp_bwd(dy, x1, hp, mean, rstd, gamma, wstream, dgamma, dbeta, geom: Optional[WinGeom] = None, rowscale=None, rows_per_scale=1, dyw=None, dyw_scale=None):
-    """-> (dx1, hact, dh[, dyw]); dgamma / dbeta accumulated.  dyw (with geom): dx1 in window order times dyw_scale[sample] -- allocated here when geom is given"""
-    _chk(dy, x1, hp, mean, rstd, gamma, wstream, dgamma, dbeta, rowscale, dyw, dyw_scale)
-    M, C = x1.shape
-    dx1 = torch.empty_like(x1)
-    hact, dh = torch.empty_like(hp), torch.empty_like(hp)
-    if dyw is None and geom is not None:
-        dyw = torch.empty((geom.rows, C), dtype=x1.dtype, device=x1.device)
-    ev = _prof(("swin_mlp_bwd", M, C))
-    lib().call("nmh_swin_mlp_bwd", dy, x1, hp, mean, rstd, gamma, wstream, rowscale, rows_per_scale, dx1, hact, dh, dgamma, dbeta, dyw, dyw_scale,
-               geom.carr if geom is not None else None, M, C, _st())
-    if ev is not None:
-        ev.record(torch.cuda.current_stream())
-    return (dx1, hact, dh, dyw) if dyw is not None else (dx1, hact, dh)
-
-
-def swin_attn_bwd(dyw, qkv, table, lse, wstream, dtable, geom: WinGeom):
-    """-> dqkv [rows, 3C]; dtable accumulated"""
-    _chk(dyw, qkv, table, lse, wstream, dtable)
-    C = dyw.shape[1]
-    dqkv = torch.empty_like(qkv)
-    ev = _prof(("swin_attn_bwd", geom.rows, C))
-    lib().call("nmh_swin_attn_bwd", dyw, qkv, table, lse, wstream, dqkv, dtable, geom.carr, C, _st())
-    if ev is not None:
-        ev.record(torch.cuda.current_stream())
-    return dqkv
-
-
-def swin_qkv_bwd(dqkv, x, dres, mean, rstd, gamma, wstream, dgamma, dbeta, geom: WinGeom):
-    """-> dx [T, C] = dres + LN1_backward(dqkv @ Wqkv) scattered from window order; dgamma / dbeta accumulated"""
-    _chk(dqkv, x, dres, mean, rstd, gamma, wstream, dgamma, dbeta)
-    C = x.shape[1]
-    dx = torch.empty_like(x)
-    ev = _prof(("swin_qkv_bwd", geom.rows, C))
-    lib().call("nmh_swin_qkv_bwd", dqkv, x, dres, mean, rstd, gamma, wstream, dx, dgamma, dbeta, geom.carr, C, _st())
-    if ev is not None:
-        ev.record(torch.cuda.current_stream())
-    return dx
 
 
 def window_scatter_residual(yw, x, out, rowscale, C, geom: WinGeom):

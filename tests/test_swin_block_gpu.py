@@ -55,7 +55,7 @@ def make_block(C, shift, seed=0):
 def streams(ops, blk, C, kinds):
     """weight streams of the requested kinds from the block's fp32 parameters"""
     w = {"qkv": dev(blk.attn.qkv.weight.float()), "proj": dev(blk.attn.proj.weight.float()), "fc1": dev(blk.mlp[0].weight.float()), "fc2": dev(blk.mlp[3].weight.float())}
-    src = {ops.SWIN_ATTN_FWD: ("qkv", "proj"), ops.SWIN_MLP_FWD: ("fc1", "fc2"), ops.SWIN_MLP_BWD: ("fc2", "fc1"), ops.SWIN_ATTN_BWD: ("proj", None), ops.SWIN_QKV_BWD: ("qkv", None)}
+    src = {ops.SWIN_ATTN_FWD: ("qkv", "proj"), ops.SWIN_MLP_FWD: ("fc1", "fc2")}
     out, items = {}, []
     for k in kinds:
         out[k] = torch.empty(ops.swin_stream_numel(k, C), dtype=BF, device="cuda")
@@ -144,9 +144,9 @@ def test_swin_block_forward(C, shape, shift):
 @pytest.mark.parametrize("C", WIDTHS)
 @pytest.mark.parametrize("shape,shift", GEOMS)
 def test_swin_block_backward(C, shape, shift):
-    """the three backward kernels chained (nmh_swin_mlp_bwd -> nmh_swin_attn_bwd -> nmh_swin_qkv_bwd) on the fused forward's saved tensors: the input gradient,
-    every LayerNorm / bias-table gradient and -- through plain matmuls of the operands the kernels write -- every Linear weight / bias gradient
-    against fp64 autograd of the oracle block; the attention half also against the unfused HIP kernels"""
+    """the product's backward of a block behind the fused forward: the unfused chain (nmh_gemm_nt with the GELU' epilogue, nmh_layernorm_bwd with the
+    window-ordered second output, nmh_window_attn_bwd, ...) run on the tensors the FUSED forward kernels saved -- the input gradient, every LayerNorm /
+    bias-table gradient and, through plain matmuls of the operands the kernels write, every Linear weight / bias gradient against fp64 autograd of the oracle block"""
     ops = _ops()
     B, H, W, D = shape
     geom = ops.WinGeom(B, H, W, D, [shift] * 3)
@@ -161,17 +161,21 @@ def test_swin_block_backward(C, shape, shift):
     x1_ref, x2_ref = reference(blk, xr, sd1, sd2)
     x1_ref.retain_grad()
     x2_ref.backward(dy.double())
-    st, w = streams(ops, blk, C, [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD, ops.SWIN_MLP_BWD, ops.SWIN_ATTN_BWD, ops.SWIN_QKV_BWD])
+    st, w = streams(ops, blk, C, [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD])
     f = lambda p: dev(p.detach().float())
     xd, dyd = dev(x.view(T, C), BF), dev(dy.view(T, C), BF)
     sd1d, sd2d = dev(sd1), dev(sd2)
     g1, b1n, g2, b2n, tab = f(blk.norm1.weight), f(blk.norm1.bias), f(blk.norm2.weight), f(blk.norm2.bias), f(blk.attn.relative_position_bias_table)
     x1, xnw, mean1, rstd1, qkv, o, lse = ops.swin_attn_fwd(xd, g1, b1n, st[ops.SWIN_ATTN_FWD], f(blk.attn.qkv.bias), tab, f(blk.attn.proj.bias), geom, rowscale=sd1d, rows_per_scale=tps)
-    x2, x1n, hp, mean2, rstd2 = ops.swin_mlp_fwd(x1, g2, b2n, st[ops.SWIN_MLP_FWD], f(blk.mlp[0].bias), f(blk.mlp[3].bias), rowscale=sd2d, rows_per_scale=tps)
+    x2, x1n, hp, mean2, rstd2, hact = ops.swin_mlp_fwd(x1, g2, b2n, st[ops.SWIN_MLP_FWD], f(blk.mlp[0].bias), f(blk.mlp[3].bias), rowscale=sd2d, rows_per_scale=tps,
+                                                      want_hact=True)
     z = lambda *s: torch.zeros(*s, device="cuda")
     # ---- MLP branch
     dg2, db2 = z(C), z(C)
-    dx1, hact, dh, dyw = ops.swin_mlp_bwd(dyd, x1, hp, mean2, rstd2, g2, st[ops.SWIN_MLP_BWD], dg2, db2, geom, rowscale=sd2d, rows_per_scale=tps, dyw_scale=sd1d)
+    dh = ops.gemm_nt(dyd, dev(w["fc2"].T.contiguous(), BF), act=2, C2=hp, rowscale=sd2d, rows_per_scale=tps)
+    dx1n = ops.gemm_nt(dh, dev(w["fc1"].T.contiguous(), BF))
+    dx1, dyw = torch.empty_like(x1), torch.empty(geom.rows, C, dtype=BF, device="cuda")
+    ops.layernorm_bwd(dx1n, x1, g2, mean2, rstd2, dx1, dg2, db2, T, C, dres=dyd, geom=geom, tokens_per_sample=tps, dyw=dyw, dyw_scale=sd1d)
     torch.cuda.synchronize()
     assert_close(hact, torch.nn.functional.gelu(hp.float().cpu().double()), 1e-2, "hact")
     assert_close(dx1, x1_ref.grad.view(T, C), TOL, "dx1", elem_mult=2.0)
@@ -187,13 +191,10 @@ def test_swin_block_backward(C, shape, shift):
     assert_close((rs2 * dyf).T @ hactf, blk.mlp[3].weight.grad, 2 * TOL, "fc2 weight gradient from (dy, hact)")
     # ---- attention branch: dO + attention core
     dtab = z(343, heads)
-    dqkv = ops.swin_attn_bwd(dyw, qkv, tab, lse, st[ops.SWIN_ATTN_BWD], dtab, geom)
-    torch.cuda.synchronize()
     do_u = ops.gemm_nt(dyw, dev(w["proj"].T.contiguous(), BF))
-    dqkv_u, dtab_u = torch.empty_like(dqkv), z(343, heads)
-    ops.window_attn_bwd(qkv, tab, do_u, lse, dqkv_u, dtab_u, heads, C, geom)
-    assert_close(dqkv, dqkv_u.float().cpu(), TOL, "dqkv vs the unfused kernels")
-    assert_close(dtab, dtab_u.cpu(), TOL, "d(bias table) vs the unfused kernels")
+    dqkv = torch.empty_like(qkv)
+    ops.window_attn_bwd(qkv, tab, do_u, lse, dqkv, dtab, heads, C, geom)
+    torch.cuda.synchronize()
     assert_close(dtab, blk.attn.relative_position_bias_table.grad, 2 * TOL, "d(bias table) vs autograd")
     dywf, of, dqf, xnwf = dyw.float().cpu().double(), o.float().cpu().double(), dqkv.float().cpu().double(), xnw.float().cpu().double()
     assert_close(dywf.T @ of, blk.attn.proj.weight.grad, 2 * TOL, "proj weight gradient from (dyw, o)")
@@ -201,14 +202,10 @@ def test_swin_block_backward(C, shape, shift):
     assert_close(dqf.sum(0), blk.attn.qkv.bias.grad, 2 * TOL, "qkv bias gradient", elem_mult=2.0)
     # ---- QKV + LayerNorm-1 backward
     dg1, db1 = z(C), z(C)
-    dx = ops.swin_qkv_bwd(dqkv, xd, dx1, mean1, rstd1, g1, st[ops.SWIN_QKV_BWD], dg1, db1, geom)
+    dxnw = ops.gemm_nt(dqkv, dev(w["qkv"].T.contiguous(), BF))
+    dx = torch.empty_like(xd)
+    ops.layernorm_bwd(dxnw, xd, g1, mean1, rstd1, dx, dg1, db1, T, C, src_mode=1, geom=geom, dres=dx1)
     torch.cuda.synchronize()
-    dxnw_u = ops.gemm_nt(dqkv, dev(w["qkv"].T.contiguous(), BF))
-    dx_u, dg1u, db1u = torch.empty_like(dx), z(C), z(C)
-    ops.layernorm_bwd(dxnw_u, xd, g1, mean1, rstd1, dx_u, dg1u, db1u, T, C, src_mode=1, geom=geom, dres=dx1)
-    assert_close(dx, dx_u.float().cpu(), TOL, "dx vs the unfused kernels")
-    assert_close(dg1, dg1u.cpu(), TOL, "dgamma1 vs the unfused kernels")
-    assert_close(db1, db1u.cpu(), TOL, "dbeta1 vs the unfused kernels")
     assert_close(dx, xr.grad.view(T, C), 2 * TOL, "dx vs autograd", elem_mult=2.0)
     assert_close(dg1, blk.norm1.weight.grad, 2 * TOL, "dgamma1 vs autograd")
     assert_close(db1, blk.norm1.bias.grad, 2 * TOL, "dbeta1 vs autograd")

@@ -43,8 +43,8 @@ for C in widths:
     table = torch.randn(343, heads, device=dev) * 0.02
     rs = torch.ones(grids, device=dev)
     geom = ops.WinGeom(grids, s, s, s, [2, 2, 2])
-    kinds = [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD] + ([ops.SWIN_MLP_BWD, ops.SWIN_ATTN_BWD, ops.SWIN_QKV_BWD] if hasattr(ops, "swin_mlp_bwd") else [])
-    src = {ops.SWIN_ATTN_FWD: (Wqkv, Wp), ops.SWIN_MLP_FWD: (W1, W2), ops.SWIN_MLP_BWD: (W2, W1), ops.SWIN_ATTN_BWD: (Wp, None), ops.SWIN_QKV_BWD: (Wqkv, None)}
+    kinds = [ops.SWIN_ATTN_FWD, ops.SWIN_MLP_FWD]
+    src = {ops.SWIN_ATTN_FWD: (Wqkv, Wp), ops.SWIN_MLP_FWD: (W1, W2)}
     st = {k: torch.empty(ops.swin_stream_numel(k, C), dtype=dt, device=dev) for k in kinds}
     arr = ops.swin_pack_items([(src[k][0], src[k][1], st[k], k, C) for k in kinds])
     res = {"pack": bench(lambda: ops.swin_pack(arr))}
@@ -74,7 +74,7 @@ for C in widths:
         res["fused mlp fwd, one workgroup per tile"] = bench(lambda: ops.swin_mlp_fwd(x, gam, bet, st[ops.SWIN_MLP_FWD], b1, b2, rowscale=rs, rows_per_scale=tps, split=False))
         res["fused mlp fwd + hact"] = bench(lambda: ops.swin_mlp_fwd(x, gam, bet, st[ops.SWIN_MLP_FWD], b1, b2, rowscale=rs, rows_per_scale=tps, want_hact=True))
         res["fused mlp fwd + hact, one workgroup per tile"] = bench(lambda: ops.swin_mlp_fwd(x, gam, bet, st[ops.SWIN_MLP_FWD], b1, b2, rowscale=rs, rows_per_scale=tps, want_hact=True, split=False))
-    if hasattr(ops, "swin_mlp_bwd"):
+    if True:   # the unfused backward chains (the fused backward kernels of round 4 were removed in round 5)
         dh = torch.empty_like(hpre); dxn = torch.empty_like(x); dx1 = torch.empty_like(x); dx = torch.empty_like(x)
         dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
         dyw = torch.empty(geom.rows, C, dtype=dt, device=dev); do = torch.empty_like(dyw); dqkv = torch.empty_like(qkv); dxnw = torch.empty_like(dyw)
@@ -93,11 +93,8 @@ for C in widths:
             ops.layernorm_bwd(dxnw, x, gam, mean, rstd, dx, dg, db, M, C, src_mode=1, geom=geom, dres=dx1)
 
         res["unfused mlp bwd"] = bench(unf_mlp_bwd)
-        res["fused mlp bwd"] = bench(lambda: ops.swin_mlp_bwd(dy, x, hpre, mean, rstd, gam, st[ops.SWIN_MLP_BWD], dg, db, geom, rowscale=rs, rows_per_scale=tps, dyw_scale=rs))
         res["unfused attn bwd"] = bench(unf_attn_bwd)
 
         res["unfused proj-dgrad + attn core bwd"] = bench(lambda: (ops.gemm_nt(dyw, WpT_b, out=do), ops.window_attn_bwd(qkv, table, do, lse, dqkv, dtab, heads, C, geom)))
-        res["fused attn bwd (dO + core)"] = bench(lambda: ops.swin_attn_bwd(dyw, qkv, table, lse, st[ops.SWIN_ATTN_BWD], dtab, geom))
         res["unfused qkv-dgrad + LN1 bwd"] = bench(lambda: (ops.gemm_nt(dqkv, WqkvT_b, out=dxnw), ops.layernorm_bwd(dxnw, x, gam, mean, rstd, dx, dg, db, M, C, src_mode=1, geom=geom, dres=dx1)))
-        res["fused qkv bwd"] = bench(lambda: ops.swin_qkv_bwd(dqkv, x, dx1, mean, rstd, gam, st[ops.SWIN_QKV_BWD], dg, db, geom))
     print(f"C={C} grids={grids} rows={M} window rows={geom.rows}: " + "  ".join(f"{k} {v:.1f} us" for k, v in res.items()), flush=True)

@@ -6,7 +6,7 @@ import collections, csv, glob, hashlib, json, os, re, sys
 src, tag = sys.argv[1:3]
 grids = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAM = [("swin_block", r"^sw::", "swin_block.hip"), ("mlp96", r"^mlp96_|^mlp_(fwd|bwd)_kernel", "mlp_fused.hip"), ("norm_streaming", r"^(in_|ln_)", "norm.hip"), ("misc_streaming", r"^tail_", "misc.hip"),
+FAM = [("swin_block", r"^sw::", "swin_block.hip"), ("mlp96", r"^mlp96_|^mlp_(fwd|bwd)_kernel", "mlp_fused.hip"), ("norm_streaming", r"^(tail_|in_|ln_)", "norm.hip"),
        ("conv48", r"^conv48_", "conv48.hip"), ("cconv", r"^(cconv_|upconv4_)", "cconv.hip"), ("gemm_tn_grouped", r"^gemm_tn_grouped", "tn_grouped.hip"),
        ("gemm", r"^gemm_(nt|tn)_", "gemm.hip"), ("attn", r"^attn_", "attn.hip")]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
