@@ -244,6 +244,9 @@ NMH_API int nmh_layernorm_fwd_window_tokens(int dt, const void* x, void* out_win
 NMH_API int nmh_window_attn_fwd_tokens(int dt, const void* qkv, const float* bias_table, void* out_tok, float* lse, int heads, int C, const int* wm, void* stream);
 NMH_API int nmh_window_attn_bwd_tokens(int dt, const void* qkv, const float* bias_table, const void* dout_tok, const float* lse, void* dqkv_tok, void* dqkv_pad, float* dbias_table, int heads, int C, const int* wm, void* stream);
 NMH_API int nmh_window_pad_rows_colsum(int dt, const void* x, int N, const int* wm, float* out, void* stream);
+/* the same for n buffers of one geometry in ONE launch (xs / outs: HOST arrays of n device pointers, copied into the kernel arguments): the blocks of an
+ * encoder stage, issued with the stage's grouped weight gradients */
+NMH_API int nmh_window_pad_rows_colsum_grouped(int dt, const void* const* xs, float* const* outs, int n, int N, const int* wm, void* stream);
 
 /* InstanceNorm3d (eps, no affine, biased var) + LeakyReLU(slope) + residual over channels-last [B][V][C] (unetr_block.py:57-71).
  * stats[b][c] = {mean, rstd}; scratch/sums: fp64 [B][C][2].  rmode 0: lrelu(IN(x)); 1: lrelu(IN(x)+r); 2: lrelu(IN(x)+IN(r)). */

@@ -449,8 +449,14 @@ int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, co
 // out[n] += sum over the PAD rows (window rows without a token) of x[row][n]: the part of the qkv bias gradient that the token-ordered weight-gradient
 // GEMM does not see (pad tokens enter the attention as keys / values with q = k = v = bias, swin_mae3d.py:62-112, so their d(qkv) is not zero).
 // A workgroup walks every gridDim.x-th window: thread = (8-column chunk, row slice); the window's pad rows are listed once per window (wave ballot).
+// Grouped form: blockIdx.y = item (one Swin block's buffer and bias gradient).  A stage's blocks share the launch: as one launch per block the 18 stage-2 items
+// were 18 nodes on the side branch of the captured step, and at 1 grid per GPU the host-driven graph launch left the chip idle between them (0.8 ms of an 11-ms step).
+constexpr int PADSUM_MAX = 24;
+struct PadSumArgs { const void* x[PADSUM_MAX]; float* out[PADSUM_MAX]; };
 template <typename T>
-__global__ __launch_bounds__(512) void attn_pad_rows_colsum_kernel(const T* __restrict__ x, int N, WinMap wm, long nwin, float* __restrict__ out) {
+__global__ __launch_bounds__(512) void attn_pad_rows_colsum_kernel(PadSumArgs pa, int N, WinMap wm, long nwin) {
+  const T* __restrict__ x = reinterpret_cast<const T*>(pa.x[blockIdx.y]);
+  float* __restrict__ out = pa.out[blockIdx.y];
   extern __shared__ float ssum[];   // [N]
   __shared__ unsigned char list[64];   // the window's pad rows, compacted
   __shared__ int npad;
@@ -495,14 +501,25 @@ __global__ __launch_bounds__(512) void attn_pad_rows_colsum_kernel(const T* __re
   __syncthreads();
   for (int i = threadIdx.x; i < N; i += 512) atomicAdd(out + i, ssum[i]);
 }
-int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float* out, hipStream_t st) {
-  if (N % 8) return -2;
+int k_attn_pad_rows_colsum_grouped(int dt, const void* const* xs, float* const* outs, int n, int N, const WinMap& wm, hipStream_t st) {
+  if (N % 8 || n < 0) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
   if ((long)wm.PH * wm.PW * wm.PD == (long)wm.H * wm.W * wm.D) return 0;   // no pad rows
   if (N > 4096) return -2;   // (one chunk per thread: N / 8 <= 512)
   const unsigned nb = (unsigned)(nwin < 256 ? nwin : 256);   // (one window per workgroup at 8 grids of stage 2: 216 windows)
-  if (dt == NMH_DT_BF16) hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<bf16_t>, dim3(nb), dim3(512), N * sizeof(float), st, (const bf16_t*)x, N, wm, nwin, out);
-  else hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<float>, dim3(nb), dim3(512), N * sizeof(float), st, (const float*)x, N, wm, nwin, out);
-  NMH_CHECK_LAUNCH();
+  for (int base = 0; base < n; base += PADSUM_MAX) {
+    const int cnt = n - base < PADSUM_MAX ? n - base : PADSUM_MAX;
+    PadSumArgs pa{};
+    for (int i = 0; i < cnt; ++i) {
+      if (!xs[base + i] || !outs[base + i]) return -4;
+      pa.x[i] = xs[base + i]; pa.out[i] = outs[base + i];
+    }
+    if (dt == NMH_DT_BF16) hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<bf16_t>, dim3(nb, cnt), dim3(512), N * sizeof(float), st, pa, N, wm, nwin);
+    else hipLaunchKernelGGL(attn_pad_rows_colsum_kernel<float>, dim3(nb, cnt), dim3(512), N * sizeof(float), st, pa, N, wm, nwin);
+    NMH_CHECK_LAUNCH();
+  }
   return 0;
+}
+int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float* out, hipStream_t st) {
+  return k_attn_pad_rows_colsum_grouped(dt, &x, &out, 1, N, wm, st);
 }

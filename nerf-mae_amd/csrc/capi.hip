@@ -323,6 +323,11 @@ int nmh_window_pad_rows_colsum(int dt, const void* x, int N, const int* wm, floa
   REQ(x, wm, out);
   return k_attn_pad_rows_colsum(dt, x, N, to_wm(wm), out, ST);
 }
+int nmh_window_pad_rows_colsum_grouped(int dt, const void* const* xs, float* const* outs, int n, int N, const int* wm, void* stream) {
+  CLR();
+  REQ(xs, outs, wm);
+  return k_attn_pad_rows_colsum_grouped(dt, xs, outs, n, N, to_wm(wm), ST);
+}
 int nmh_instnorm_stats(int dt, const void* x, float* stats, double* scratch, int B, int64_t V, int C, float eps, void* stream) {
   CLR();
   return k_in_stats(dt, x, stats, scratch, B, (long)V, C, eps, ST);

@@ -213,6 +213,7 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
 int k_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st, int tok_out = 0);
 int k_attn_bwd(int dt, const void* qkv, const float* bias_table, const void* dout, const float* lse, void* dqkv, float* dbias_table, int heads, int C, const WinMap& wm, hipStream_t st, void* dqkv_tok = nullptr);
 int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float* out, hipStream_t st);
+int k_attn_pad_rows_colsum_grouped(int dt, const void* const* xs, float* const* outs, int n, int N, const WinMap& wm, hipStream_t st);
 
 // ---- misc.hip ----
 int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st);

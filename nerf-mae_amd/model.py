@@ -381,8 +381,8 @@ class _BlockFn(torch.autograd.Function):
             dxn = ops.gemm_nt(dqkv, pk[key + "qkv.wT"].view(C, 3 * C))
             wgrad(dqkv, xnw, b.attn.qkv)
             g_qb = _gradbuf(b.attn.qkv.bias)
-            if q is not None:   # the pad rows' share of the qkv bias gradient, with the stage's weight gradients
-                q.defer(lambda: ops.window_pad_rows_colsum(dq_pad, g_qb, geom))
+            if q is not None:   # the pad rows' share of the qkv bias gradient, with the stage's weight gradients (one launch for all blocks of the flush)
+                q.add_pad_colsum(dq_pad, g_qb, geom)
             else:
                 with ops.side_stream():
                     ops.window_pad_rows_colsum(dq_pad, g_qb, geom)

@@ -212,6 +212,7 @@ class WgradQueue:
     def __init__(self):
         self.pending, self.inflight, self._cb, self.sync_after_flush = [], [], False, False
         self.ln_items = []   # LayerNorm parameter-gradient partials of the current flush group (add_ln_partials)
+        self.pad_items = {}  # pad-row column sums of the current flush group, by (geometry, width, dtype) (add_pad_colsum)
         self.deferred = []   # closures (other weight-gradient launches) to issue with the next flush, inside the same fork
 
     def reset(self):
@@ -220,7 +221,7 @@ class WgradQueue:
         if self.pending or self.deferred or self.inflight or self._cb:
             join_side()
             self.pending, self.deferred, self.inflight, self._cb = [], [], [], False
-            self.ln_items = []
+            self.ln_items, self.pad_items = [], {}
 
     def defer(self, fn):
         """queue an arbitrary weight-gradient launch (a closure that keeps its operands alive) for the next flush: the decoder's small-level
@@ -236,6 +237,15 @@ class WgradQueue:
             items = self.ln_items = []
             self.defer(lambda: ln_param_grad_reduce(items))   # (the list object: filled until the flush runs the closure)
         self.ln_items.append((part, nb, C, dgamma, dbeta))
+
+    def add_pad_colsum(self, x, out, geom):
+        """the pad rows' share of a qkv bias gradient (ops.window_pad_rows_colsum): all of a flush with the same geometry go out as ONE launch"""
+        key = (tuple(geom.carr), x.shape[1], x.dtype)
+        groups = self.pad_items
+        if key not in groups:
+            lst = groups[key] = []
+            self.defer(lambda: window_pad_rows_colsum_grouped(lst, geom))   # (the list object: filled until the flush runs the closure)
+        groups[key].append((x, out))
 
     def launch_now(self, fn):
         """issue a weight-gradient launch on the forked side stream right away (no join: the closure keeps its operands alive until the end-of-backward
@@ -276,7 +286,7 @@ class WgradQueue:
             return
         todo, self.pending = self.pending, []
         fns, self.deferred = self.deferred, []
-        self.ln_items = []   # (the queued closure holds the list it reduces)
+        self.ln_items, self.pad_items = [], {}   # (the queued closures hold the lists they work on)
         with side_stream():
             for fn in fns:
                 fn()
@@ -808,6 +818,21 @@ def window_pad_rows_colsum(x, out, geom: WinGeom):
     """out[n] += sum of x[row][n] over the window rows that hold no token"""
     _chk(x, out)
     lib().call("nmh_window_pad_rows_colsum", dt_of(x), x, x.shape[1], geom.carr, out, _st())
+
+
+def window_pad_rows_colsum_grouped(items, geom: WinGeom):
+    """items: [(x, out)] of one geometry and width -> one launch (nmh_window_pad_rows_colsum_grouped)"""
+    if not items:
+        return
+    n = len(items)
+    xs, outs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    N, dt = items[0][0].shape[1], dt_of(items[0][0])
+    for i, (x, out) in enumerate(items):
+        _chk(x, out)
+        if x.shape[1] != N or dt_of(x) != dt:
+            raise ValueError("window_pad_rows_colsum_grouped: one width / dtype per call")
+        xs[i], outs[i] = x.data_ptr(), out.data_ptr()
+    lib().call("nmh_window_pad_rows_colsum_grouped", dt, xs, outs, n, N, geom.carr, _st())
 
 
 def instnorm_stats(x, stats, scratch, B, V, C, eps=1e-5):

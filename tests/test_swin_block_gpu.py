@@ -313,6 +313,14 @@ def test_token_ordered_attention_backward(C, shape, shift):
     ops.window_pad_rows_colsum(dq_pad, dbq, geom)
     ref_pad = dq_pad[~real].float().sum(0).cpu() if int((~real).sum()) else torch.zeros(3 * C)
     assert_close(dbq, ref_pad, 1e-3, "pad rows' column sums")
+    # the grouped entry (all blocks of a stage in one launch): three buffers -> three accumulators, each += its own pad-row sums
+    bufs = [dq_pad, (dq_pad.float() * 2).to(BF), (dq_pad.float() * -0.5).to(BF)]
+    accs = [z(3 * C), torch.full((3 * C,), 1.0, device="cuda"), z(3 * C)]
+    ops.window_pad_rows_colsum_grouped(list(zip(bufs, accs)), geom)
+    torch.cuda.synchronize()
+    assert_close(accs[0], ref_pad, 1e-3, "grouped pad-row sums, item 0")
+    assert_close(accs[1], 1.0 + 2 * ref_pad, 1e-2, "grouped pad-row sums, item 1 (accumulates)")
+    assert_close(accs[2], -0.5 * ref_pad, 1e-2, "grouped pad-row sums, item 2")
     dxn = ops.gemm_nt(dq_t, WqT)
     dx, dg1, db1 = torch.empty_like(xd), z(C), z(C)
     ops.layernorm_bwd(dxn, xd, g1, mean1, rstd1, dx, dg1, db1, T, C, dres=dx1)

@@ -4,7 +4,7 @@ OUT=$1; shift
 : > $OUT
 for rep in 1 2; do
   for e in "$@"; do
-    v=$(env $e python bench.py --no-cpu-baseline --no-sweep --no-kernel-timing --steps 20 --warmup 5 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*')
+    v=$(env $e python bench.py --no-cpu-baseline --no-sweep --no-kernel-timing --steps 20 --warmup 5 $BENCH_ARGS 2>/dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*')
     echo "rep $rep  [$e]  $v" >> $OUT
   done
 done
