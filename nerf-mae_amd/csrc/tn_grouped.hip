@@ -149,44 +149,12 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
   // issue stream state: (segment, chunk within segment) of the next chunk to request
   int iseg = s0, ilc = 0, islot = 0;
   uint4 stg[REG ? PCS : 1];
-  // Plain operands (everything but the pixel-shuffled views): a piece's source is ONE pointer bumped per chunk and re-based per segment.  Round 5: the
-  // general form below -- 64-bit row arithmetic, the shuffle's divisions and its branches, ~150 instructions per piece -- ran for every piece of every chunk:
-  // 900 VALU instructions per wave and chunk against 36 MFMAs (PMC: waves issuing 40-42 % of their cycles, MFMA busy 6-16 %).
-  unsigned long long pptr[PCS];
-  bool pcok[PCS];
-  const long stepA = (long)CH * lda * 2, stepB = (long)CH * ldb * 2;
-  auto seg_ptrs = [&](int seg) {
-    const long segbase = (long)seg * P.rps + sublo;
-#pragma unroll
-    for (int i = 0; i < PCS; ++i) {
-      const bool isA = BIG ? (psub[i] < NSUB / 2) : (i < 3);
-      pptr[i] = isA ? (unsigned long long)(A + (segbase + prow[i]) * lda + n0 + pcol[i]) : (unsigned long long)(Bm + (segbase + prow[i]) * ldb + k0 + pcol[i]);
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < PCS; ++i) {
-    const bool isA = BIG ? (psub[i] < NSUB / 2) : (i < 3);
-    pcok[i] = isA ? (n0 + pcol[i] < N) : (k0 + pcol[i] < K);
-  }
-  seg_ptrs(s0);
+  // (round 5: a pointer-bumped issue path as in gemm_tn_stream_kernel was measured here and dropped: 12 live 64-bit pointers took the rowscale variant
+  //  from 171 to 195 VGPRs = one workgroup less per CU, and its stage-1/2 launches ran 2x longer inside the step; profiles/r5c_step_kernels_by_shape_8grids.txt)
   auto issue = [&]() {
+    const long segbase = (long)iseg * P.rps + sublo;
     const int r0 = ilc * CH;
     char* slot = smem + islot * STG;
-    if (!up_k) {
-      const bool full = r0 + CH <= seglen;   // (wave-uniform) every row of the chunk exists
-#pragma unroll
-      for (int i = 0; i < PCS; ++i) {
-        const bool isA = BIG ? (psub[i] < NSUB / 2) : (i < 3);
-        unsigned long long src = pptr[i];
-        pptr[i] += (unsigned long long)(isA ? stepA : stepB);
-        const bool ok = pcok[i] && (full || r0 + prow[i] < seglen);
-        src = ok ? src : zpage;
-        const int q = wave + NW * i;
-        if constexpr (REG) stg[i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-        else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
-      }
-    } else {
-    const long segbase = (long)iseg * P.rps + sublo;
 #pragma unroll
     for (int i = 0; i < PCS; ++i) {
       const int r = r0 + prow[i];
@@ -196,13 +164,13 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
         const int n = n0 + pcol[i];
         if (r < seglen && n < N) {
           long arow = segbase + r;
-          {   // pixel-shuffled view (ConvTranspose3d k = stride backward): coarse voxel -> the fine row of this problem's tap
+          if (up_k) {   // pixel-shuffled view (ConvTranspose3d k = stride backward): coarse voxel -> the fine row of this problem's tap
             const unsigned vv = (unsigned)up_v, kk = (unsigned)up_k, m = (unsigned)arow;
             const unsigned q = m / vv, x = m - q * vv, q2 = q / vv, y = q - q2 * vv, bb = q2 / vv, zq = q2 - bb * vv;
             const long Vf = (long)vv * kk;
             arow = (((long)bb * Vf + zq * kk) * Vf + y * kk) * Vf + x * kk;
           }
-          if (P.ncol2) {   // folded tap row: column n = (tx, co) sits at fine row arow + tx, channel co (contiguous when lda == Cout)
+          if (up_k && P.ncol2) {   // folded tap row: column n = (tx, co) sits at fine row arow + tx, channel co (contiguous when lda == Cout)
             const int ni = P.ncol2 & 0xffff, q = n / ni;
             src = (unsigned long long)(A + (arow + q) * lda + (n - q * ni));
           } else src = (unsigned long long)(A + arow * lda + n);
@@ -215,8 +183,7 @@ __global__ __launch_bounds__(BIG ? 512 : 256) void gemm_tn_grouped_kernel(tng::A
       if constexpr (REG) stg[i] = src != zpage ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
       else __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
     }
-    }
-    if (++ilc == cps) { ilc = 0; ++iseg; if (!up_k) seg_ptrs(iseg); }
+    if (++ilc == cps) { ilc = 0; ++iseg; }
     if (!REG && ++islot == ST) islot = 0;
   };
   auto sstore = [&](int slotidx) {   // REG: the staged chunk -> LDS stage `slotidx` (same image as the DMA writes: piece q at q * 1024 + lane * 16)
