@@ -757,6 +757,206 @@ __global__ __launch_bounds__(768) void cconv_wgrad_kernel(CCWArgs a) {
           for (int r = 0; r < 4; ++r) out[((c * 6 + b6) * 96 + 48 * half + 16 * it + 4 * g + r) * 48 + 16 * ct + p] = acc[c][it][ct][r];
 }
 
+// ---- the same kernel with the stage filled by LDS-DMA (round 5) --------------------------------------------------------------------------
+// The register-staged version above spends a third of an iteration outside its MFMAs: every wave stalls on its five global loads, writes them
+// to LDS (the phase-major dy layout puts four consecutive voxels 3840 bytes = 0 banks apart: 21 % of the LDS cycles were conflicts) and meets
+// the others at the barrier -- all twelve waves in the same phase at the same time (PMC: MFMA busy 0.26, LDS busy 0.24, waves waiting 39 %).
+// Here a stage is a ring slot filled by global_load_lds: a wave-load covers 1 KB of CONSECUTIVE stage bytes and each lane's source is the global
+// chunk that belongs there (zero cells, rows of lines outside the volume and the padding come from a 16-byte zero page, so a slot needs no
+// initialisation and holds its own zero rows), one barrier per pair and no register staging; units with one neighbour line run a ring of three
+// slots (the wait leaves the youngest pair in flight), units with two a ring of two.  Both operands leave LDS by raw ds_read_b64_tr_b16 (the
+// builtin would be ordered behind every DMA in flight: DESIGN 3.2) at addresses computed once per kernel.
+namespace ccw2 {
+constexpr int DPH = 40 * 96, DLINE = 4 * DPH, DYB = 2 * DLINE;                 // dy: [line][a_x][cell][48 ch]                      30 wave-loads
+constexpr int XHALF = 42 * 96, XLINE = 2 * XHALF, XCOMB = 16384;               // x: [comb][line][ci half][cell + 1][48 ch] + 256 B  16 wave-loads per comb
+constexpr int ZROW = DYB + 2 * XLINE;                                          // the padding of comb 0 (comb 1: + XCOMB): always zeros
+constexpr int stage_bytes(int nc) { return DYB + nc * XCOMB; }
+constexpr int DUMP = 3 * stage_bytes(1) > 2 * stage_bytes(2) ? 3 * stage_bytes(1) : 2 * stage_bytes(2);   // target of the wave-loads past the stage
+constexpr int LDS_BYTES = DUMP + 1024;
+static_assert(LDS_BYTES <= 163840, "LDS budget");
+}  // namespace ccw2
+__device__ uint4 g_zero16_ccw[1];
+
+template <int NC, int KS>
+__device__ __forceinline__ void ccw2_body(const CCWArgs& a, const CCWUnit& U, char* smem) {
+  using namespace ccw2;
+  constexpr int NST = NC == 1 ? 3 : 2, STG = stage_bytes(NC), NGRP = STG / 1024, NG = (NGRP + 11) / 12;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, p = lane & 15;
+  const int slab = blockIdx.x - U.wg0, nslab = U.nslab;
+  const int v = a.v, F = 4 * v, hv = v >> 1;
+  const int b6 = wave >> 1, half = wave & 1, ax = cc::BLK_AX[b6], nx = cc::BLK_NX[b6] - 1;
+  unsigned long long zpage = (unsigned long long)(const void*)g_zero16_ccw;
+  asm volatile("" : "+v"(zpage));
+
+  // source of this lane's chunk in each of the wave's loads, one register: (16-byte units from the pair's dy / x base) * 32 + kind; kind 0: zero page,
+  // 1: dy, 2 + (dz + 1) * 8 + (dyl + 1): x with a plane / line shift (the chunk is zero when the shifted line is outside the volume)
+  int desc[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int gi = wave + 12 * i, q = gi * 64 + lane;
+    desc[i] = 0;
+    if (q < DYB / 16) {
+      const int line = q / 960, r = q - line * 960, axq = r / 240, r2 = r - axq * 240, cell = r2 / 6, c6 = r2 - cell * 6;
+      if (cell < v) desc[i] = ((line * 4 * F * 48 + (4 * cell + axq) * 48 + c6 * 8) >> 3) * 32 + 1;
+    } else if (gi < NGRP) {
+      const int k = q - DYB / 16, comb = k >> 10, r = k & 1023;
+      if (r < 1008) {
+        const int line = r / 504, r1 = r - line * 504, hf = r1 / 252, r2 = r1 - hf * 252, cellp = r2 / 6, c6 = r2 - cellp * 6, cell = cellp - 1;
+        const int dz = comb ? U.nz1 : U.nz0, dyl = line + (comb ? U.ny1 : U.ny0);
+        if (cell >= 0 && cell < v) desc[i] = ((((dz * v + dyl) * v + cell) * 96 + (hf * 6 + c6) * 8) >> 3) * 32 + 2 + (dz + 1) * 8 + (dyl + 1);
+      }
+    }
+  }
+  auto issue = [&](long pair, int stg) {
+    const bool live = pair < a.npair;
+    const unsigned pu = live ? (unsigned)pair : 0u;
+    const unsigned q1 = pu / (unsigned)hv, y2 = pu - q1 * (unsigned)hv, b = q1 / (unsigned)v, z = q1 - b * (unsigned)v;
+    const char* dyb = reinterpret_cast<const char*>(a.dY + ((((long)b * F + 4 * (long)z + U.az) * F + 4 * (long)(2 * y2) + U.ay) * F) * 48);
+    const char* xb = reinterpret_cast<const char*>(a.X + ((((long)b * v + z) * v + 2 * y2) * v) * 96);
+    // which (dz, dyl) shifts stay inside the volume for this pair: bit (dz + 1) * 8 + (dyl + 1) + 2; bit 1: dy; bit 0 (zero page) never
+    unsigned okm = 0u;
+    if (live) {
+      unsigned ym = 0u;
+#pragma unroll
+      for (int d = -1; d <= 2; ++d) ym |= ((unsigned)((int)(2 * y2) + d) < (unsigned)v ? 1u : 0u) << (d + 1);
+#pragma unroll
+      for (int d = -1; d <= 1; ++d)
+        if ((unsigned)((int)z + d) < (unsigned)v) okm |= ym << ((d + 1) * 8 + 2);
+      okm |= 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int gi = wave + 12 * i, kind = desc[i] & 31;
+      const long off = (long)(desc[i] >> 5) << 4;
+      const bool ok = (okm >> kind) & 1u;
+      const unsigned long long src = ok ? (unsigned long long)((kind == 1 ? dyb : xb) + off) : zpage;
+      char* dst = gi < NGRP ? smem + stg * STG + gi * 1024 : smem + DUMP;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // operand rows of this lane in the k-steps (stage-relative byte addresses; rows past the pair read the zero rows)
+  unsigned adx[KS][2], add[KS][2];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = 32 * t + 16 * h + 4 * g + (p >> 2);
+      const int line = i >= v, xi = i - line * v;
+      const bool ok = i < 2 * v;
+      adx[t][h] = (unsigned)((ok ? DYB + half * XHALF + line * XLINE + (xi + 1 + nx) * 96 : ZROW) + (p & 3) * 8);
+      add[t][h] = (unsigned)((ok ? ax * DPH + line * DLINE + xi * 96 : ZROW) + (p & 3) * 8);
+    }
+  const unsigned smem_u = lds_addr_u(smem);
+
+  f32x4 acc[NC][3][3];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads of k-step t: the dy tiles and the x tiles of neighbour line c; a set is requested one half-step ahead of its MFMAs
+  TrFrag df[2][3], xf[2][3];   // df: by parity of t; xf: NC == 2: by neighbour line, NC == 1: by parity of t
+  auto read_d = [&](TrFrag (&f)[3], unsigned sb, int t) {
+    const unsigned d0 = sb + add[t][0], d1 = sb + add[t][1];
+    tr_read1<0>(f[0].lo, d0); tr_read1<0>(f[0].hi, d1);
+    tr_read1<32>(f[1].lo, d0); tr_read1<32>(f[1].hi, d1);
+    tr_read1<64>(f[2].lo, d0); tr_read1<64>(f[2].hi, d1);
+  };
+  auto read_x0 = [&](TrFrag (&f)[3], unsigned sb, int t) {
+    const unsigned x0 = sb + adx[t][0], x1 = sb + adx[t][1];
+    tr_read1<0>(f[0].lo, x0); tr_read1<0>(f[0].hi, x1);
+    tr_read1<32>(f[1].lo, x0); tr_read1<32>(f[1].hi, x1);
+    tr_read1<64>(f[2].lo, x0); tr_read1<64>(f[2].hi, x1);
+  };
+  auto read_x1 = [&](TrFrag (&f)[3], unsigned sb, int t) {
+    const unsigned x0 = sb + adx[t][0], x1 = sb + adx[t][1];
+    tr_read1<XCOMB>(f[0].lo, x0); tr_read1<XCOMB>(f[0].hi, x1);
+    tr_read1<XCOMB + 32>(f[1].lo, x0); tr_read1<XCOMB + 32>(f[1].hi, x1);
+    tr_read1<XCOMB + 64>(f[2].lo, x0); tr_read1<XCOMB + 64>(f[2].hi, x1);
+  };
+  auto pin3 = [&](TrFrag (&f)[3]) { tr_pin(f[0]); tr_pin(f[1]); tr_pin(f[2]); };
+  auto mma9 = [&](f32x4 (&ac)[3][3], const TrFrag (&x)[3], const TrFrag (&d)[3]) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct) mma(ac[it][ct], tr_frag(x[it]), tr_frag(d[ct]));     // rows ci = 48 half + 16 it + 4 g + r, column c = 16 ct + p
+    // the nine products are issued before whatever follows (the wait for the next set)
+    asm volatile("" : "+v"(ac[0][0]), "+v"(ac[0][1]), "+v"(ac[0][2]), "+v"(ac[1][0]), "+v"(ac[1][1]), "+v"(ac[1][2]), "+v"(ac[2][0]), "+v"(ac[2][1]), "+v"(ac[2][2]));
+  };
+
+  long pair = slab;
+  int cur = 0;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue(pair + (long)s * nslab, s);
+  for (; pair < a.npair; pair += nslab) {
+    if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned sb = smem_u + (unsigned)(cur * STG);
+    read_d(df[0], sb, 0);
+    read_x0(xf[0], sb, 0);
+    {   // the next pair's loads: their address arithmetic runs under the latency of the first reads
+      int nxt = cur + NST - 1;
+      if (nxt >= NST) nxt -= NST;
+      issue(pair + (long)(NST - 1) * nslab, nxt);
+    }
+    tr_wait();
+    pin3(df[0]); pin3(xf[0]);
+    if constexpr (NC == 2) {
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        read_x1(xf[1], sb, t);
+        mma9(acc[0], xf[0], df[t & 1]);
+        tr_wait();
+        pin3(xf[1]);
+        if (t + 1 < KS) { read_d(df[(t + 1) & 1], sb, t + 1); read_x0(xf[0], sb, t + 1); }
+        mma9(acc[NC - 1], xf[1], df[t & 1]);
+        if (t + 1 < KS) { tr_wait(); pin3(df[(t + 1) & 1]); pin3(xf[0]); }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < KS; ++t) {
+        if (t + 1 < KS) { read_d(df[(t + 1) & 1], sb, t + 1); read_x0(xf[(t + 1) & 1], sb, t + 1); }
+        mma9(acc[0], xf[t & 1], df[t & 1]);
+        if (t + 1 < KS) { tr_wait(); pin3(df[(t + 1) & 1]); pin3(xf[(t + 1) & 1]); }
+      }
+    }
+    if (++cur == NST) cur = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (zero-page) loads
+  // partial blocks of this workgroup: part[wg][comb][b6][ci][c]
+  float* out = a.part + (long)blockIdx.x * (2 * 6 * 96 * 48);
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+      for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[((c * 6 + b6) * 96 + 48 * half + 16 * it + 4 * g + r) * 48 + 16 * ct + p] = acc[c][it][ct][r];
+}
+
+__global__ __launch_bounds__(768) void cconv_wgrad_dma_kernel(CCWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int ui = 0;
+  for (int i = 0; i < a.nunit; ++i)
+    if ((int)blockIdx.x >= a.u[i].wg0) ui = i;
+  const CCWUnit U = a.u[ui];
+  const int ks = (2 * a.v + 31) / 32;   // k-steps of a pair of lines (v a multiple of 8, <= 40: 1..3)
+  if (U.ncomb == 1) {
+    if (ks == 3) ccw2_body<1, 3>(a, U, smem);
+    else if (ks == 2) ccw2_body<1, 2>(a, U, smem);
+    else ccw2_body<1, 1>(a, U, smem);
+  } else {
+    if (ks == 3) ccw2_body<2, 3>(a, U, smem);
+    else if (ks == 2) ccw2_body<2, 2>(a, U, smem);
+    else ccw2_body<2, 1>(a, U, smem);
+  }
+}
+
 // G[block][ci][c] = sum over the slabs of the unit that owns the block (block = (group, neighbour line, (a_x, n_x)): the forward's order)
 __global__ void cconv_wgrad_reduce_kernel(CCWArgs a, float* __restrict__ G) {
   // grid = (unit, neighbour line of the unit, (a_x, n_x) block, 18 pieces of 256 elements)
@@ -989,7 +1189,9 @@ int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* 
   CCWArgs a{};
   a.X = (const bf16_t*)X; a.dY = (const bf16_t*)dY; a.part = ws; a.B = B; a.v = v;
   a.npair = (long)B * v * (v / 2);
-  // units: every (a_z, a_y) group with at most two of its neighbour lines; slabs in proportion to the bytes a unit streams per pair
+  // units: every (a_z, a_y) group with at most two of its neighbour lines; slabs in proportion to the time of a pair: wa + neighbour lines (the bytes a
+  // unit streams per pair would give 1.9 + lines; measured with the LDS-DMA kernel: tools/bench_ccw.py)
+  static const double wa = [] { const char* e = getenv("NMH_CCW_WA"); return e ? atof(e) : 1.9; }();
   int nu = 0, base = 0;
   double wsum = 0.0, wgt[MAXU];
   for (int gi = 0; gi < 16; ++gi) {
@@ -1003,17 +1205,33 @@ int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* 
       u.nz0 = (signed char)(fz + c0 / cy); u.ny0 = (signed char)(fy + c0 % cy);
       u.nz1 = (signed char)(fz + c1 / cy); u.ny1 = (signed char)(fy + c1 % cy);
       u.blk0 = base + c0; u.blk1 = base + c1;
-      wgt[nu] = 30.7 + 16.1 * u.ncomb;
+      wgt[nu] = wa + u.ncomb;
       wsum += wgt[nu];
       ++nu;
     }
     base += ncombs;
   }
   a.nunit = nu;
-  int wg = 0;
+  // slabs: largest-remainder shares of the part's 256 CUs (one workgroup per CU)
+  int wg = 0, ns[MAXU];
+  double fr[MAXU];
   for (int i = 0; i < nu; ++i) {
-    int s = (int)(248.0 * wgt[i] / wsum);
+    const double share = 256.0 * wgt[i] / wsum;
+    int s = (int)share;
     if (s < 1) s = 1;
+    fr[i] = share - s;
+    ns[i] = s;
+    wg += s;
+  }
+  while (wg < 256) {
+    int best = 0;
+    for (int i = 1; i < nu; ++i)
+      if (fr[i] > fr[best]) best = i;
+    ++ns[best]; fr[best] = -1.0; ++wg;
+  }
+  wg = 0;
+  for (int i = 0; i < nu; ++i) {
+    int s = ns[i];
     if ((long)s > a.npair) s = (int)a.npair;
     a.u[i].wg0 = wg; a.u[i].nslab = s;
     wg += s;
@@ -1025,8 +1243,16 @@ int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* 
     if (e != hipSuccess) return (int)e;
     attr.set();
   }
+  static NmhPerDeviceOnce attr2;
+  if (attr2.need()) {
+    hipError_t e = hipFuncSetAttribute((const void*)cconv_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ccw2::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr2.set();
+  }
+  static const int use_dma = [] { const char* e = getenv("NMH_CCW_DMA"); return e ? atoi(e) : 1; }();
   if (phase != 2) {
-    hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)wg), dim3(768), LDS_BYTES, st, a);
+    if (use_dma) hipLaunchKernelGGL(cconv_wgrad_dma_kernel, dim3((unsigned)wg), dim3(768), ccw2::LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(cconv_wgrad_kernel, dim3((unsigned)wg), dim3(768), LDS_BYTES, st, a);
     NMH_CHECK_LAUNCH();
   }
   if (phase == 1) return 0;

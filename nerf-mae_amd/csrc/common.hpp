@@ -156,6 +156,10 @@ template <int HI_OFF, int OFF0 = 0> __device__ __forceinline__ void tr_read_raw(
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(addr), "n"(OFF0));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(OFF0 + HI_OFF));
 }
+template <int OFF> __device__ __forceinline__ void tr_read1(bf16x4& d, unsigned addr) {   // one half of a fragment at its own address (rows of the two halves not a fixed distance apart)
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
 __device__ __forceinline__ void tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void tr_pin(TrFrag& f) { asm volatile("" : "+v"(f.lo), "+v"(f.hi)); }
 __device__ __forceinline__ Frag<bf16_t> tr_frag(const TrFrag& f) {
