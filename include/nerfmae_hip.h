@@ -254,6 +254,10 @@ NMH_API int nmh_instnorm_stats(int dt, const void* x, float* stats, double* scra
 NMH_API int nmh_instnorm_apply(int dt, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, void* out, int B, int64_t V, int C, float slope, void* stream);
 NMH_API int nmh_instnorm_bwd_reduce(int dt, const void* dout, const void* out, const void* x, const float* stats, const void* r, const float* stats_r, int rmode, double* sums, double* sums_r, int B, int64_t V, int C, float slope, void* stream);
 NMH_API int nmh_instnorm_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r, const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, int64_t V, int C, float slope, void* stream);
+/* the rmode-0 apply pass with the sign taken from x (out = NULL), bf16, C = 48, as a background launch: one persistent workgroup per CU with a footprint
+ * (<= 96 VGPRs, no dynamic LDS) that fits on a CU beside the persistent 48 -> 48 weight-gradient kernel -- decoder-1's InstanceNorm backward
+ * (unetr_block.py:57-63 backward) issued on a forked stream next to nmh_conv3d_k3_c48_wgrad.  Bit-identical to nmh_instnorm_bwd_apply. */
+NMH_API int nmh_instnorm_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, int64_t V, int C, float slope, void* stream);
 
 /* im2row of the 4x4x4 stride-4 patch conv input: x fp32 (B,4,R,R,R) -> A[(b,z,y,x)][256] (swin_mae3d.py:1120-1126) */
 NMH_API int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream);

@@ -346,6 +346,10 @@ int nmh_instnorm_bwd_apply(int dt, const void* dout, const void* out, const void
   CLR();
   return k_in_bwd_apply(dt, dout, out, x, stats, sums, r, stats_r, sums_r, rmode, dx, dr, dr_accumulate, B, (long)V, C, slope, ST);
 }
+int nmh_instnorm_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, int64_t V, int C, float slope, void* stream) {
+  CLR();
+  return k_in_bwd_apply_bg(dt, dout, x, stats, sums, dx, B, (long)V, C, slope, ST);
+}
 int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream) {
   CLR(); return k_embed_gather(dt, x, A, B, R, ST); }
 int nmh_upconv_shuffle_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, void* stream) {

@@ -208,6 +208,7 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
 // dx = rstd*(g - S1/V - xhat*S2/V); rmode 1: dr (+)= g ; rmode 2: dr = IN-bwd wrt r
 int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
                    const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st);
+int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, long V, int C, float slope, hipStream_t st);
 
 // ---- attn.hip ----
 int k_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st, int tok_out = 0);

@@ -737,6 +737,18 @@ int k_in_apply(int dt, const void* x, const float* stats, const void* r, const f
   return 0;
 }
 
+// the arithmetic of the apply pass, pinned (no compiler-chosen contraction) so that every kernel that runs it -- the general one and the background launch
+// below -- rounds the same way: g = dout * lrelu'(sign source), x-hat, dx = rstd * fma(-x-hat, S2/V, g - S1/V)
+__device__ __forceinline__ void in_bwd_terms(float dv, float sgn, float xv, float mu, float rs, float slope, float& g, float& xh) {
+#pragma clang fp contract(off)
+  g = dv * (sgn > 0.f ? 1.0f : slope);
+  xh = (xv - mu) * rs;
+}
+__device__ __forceinline__ float in_bwd_dx(float g, float xh, float rs, float m1, float m2) {
+#pragma clang fp contract(off)
+  return rs * __builtin_fmaf(-xh, m2, g - m1);
+}
+
 template <typename T, bool ST = false, bool NT = false>
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const T* outp, const T* x, const float* stats, const double* sums, const T* r, const float* stats_r,
                                                             const double* sums_r, int rmode, T* dx, T* dr, int dr_acc, long V, int C, float slope, long vpb) {
@@ -791,9 +803,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(const T* dout, const 
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float g = dv[j] * ((outp ? ov[j] : xv[j] - mu[j]) > 0.f ? 1.0f : slope);
-      const float xh = (xv[j] - mu[j]) * rs[j];
-      od[j] = rs[j] * (g - m1[j] - xh * m2[j]);
+      float g, xh;
+      in_bwd_terms(dv[j], outp ? ov[j] : xv[j] - mu[j], xv[j], mu[j], rs[j], slope, g, xh);
+      od[j] = in_bwd_dx(g, xh, rs[j], m1[j], m2[j]);
       if (rmode == 1) orr[j] = dr_acc ? orr[j] + g : g;
       else if (rmode == 2) {
         const float rh = (rv[j] - mur[j]) * rsr[j];
@@ -822,6 +834,77 @@ int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, con
   else
     hipLaunchKernelGGL(in_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)out, (const float*)x, stats, sums,
                        (const float*)r, stats_r, sums_r, rmode, (float*)dx, (float*)dr, dr_accumulate, V, C, slope, vpb);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- the apply pass as a BACKGROUND kernel (round 5; bf16, C = 48, rmode 0, sign from x: decoder-1's first InstanceNorm) -------------------------
+// In decoder-1's backward this pass (9.4 GB, HBM-bound, no matrix work) sits between two persistent MFMA kernels that leave HBM two-thirds idle; it
+// depends on conv2's input gradient only, conv2's weight gradient on neither.  One persistent 256-thread workgroup per CU with <= 96 VGPRs and no dynamic
+// LDS is the footprint that fits on a CU BESIDE conv48_wgrad_kernel's workgroup (8 waves x 208 VGPRs, 109 KB): issued on a forked stream next to it, the
+// pass streams under the weight gradient's MFMAs.  A workgroup owns one contiguous voxel range of one sample (constants loaded once); U iterations of
+// (dout, x) chunks are in flight per thread.  Same arithmetic, in the same order, as in_bwd_apply_kernel: bit-identical output.
+template <int U>
+__global__ __launch_bounds__(256) void in_bwd_apply_bg_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                               const double* __restrict__ sums, bf16_t* __restrict__ dx, long V, float slope, int wps) {
+  constexpr int C = 48, CL = 6, NV = 42;
+  const int b = blockIdx.x / wps, w = blockIdx.x - b * wps;
+  const int cl = threadIdx.x % CL, vl = threadIdx.x / CL;
+  if (vl >= NV) return;
+  const float invV = 1.0f / (float)V;
+  float mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long sc = ((long)b * C + cl * 8 + j) * 2;
+    mu[j] = stats[sc]; rs[j] = stats[sc + 1];
+    m1[j] = (float)sums[sc] * invV; m2[j] = (float)sums[sc + 1] * invV;
+  }
+  const long per = (V + wps - 1) / wps, v0 = (long)w * per;
+  long v1 = v0 + per;
+  if (v1 > V) v1 = V;
+  const bf16_t* const db = dout + (long)b * V * C + cl * 8;
+  const bf16_t* const xb = x + (long)b * V * C + cl * 8;
+  bf16_t* const ob = dx + (long)b * V * C + cl * 8;
+  for (long vb = v0 + vl; vb < v1; vb += (long)NV * U) {
+    u32x4 dw[U], xw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long v = vb + (long)u * NV;
+      if (v < v1) {
+        dw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(db + v * C));
+        xw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xb + v * C));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long v = vb + (long)u * NV;
+      if (v < v1) {
+        float od[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int j = 2 * i + h;
+            const float dv = __uint_as_float(h ? dw[u][i] & 0xffff0000u : dw[u][i] << 16), xv = __uint_as_float(h ? xw[u][i] & 0xffff0000u : xw[u][i] << 16);
+            float g, xh;
+            in_bwd_terms(dv, xv - mu[j], xv, mu[j], rs[j], slope, g, xh);
+            od[j] = in_bwd_dx(g, xh, rs[j], m1[j], m2[j]);
+          }
+        }
+        Vec8<bf16_t>::store_nt(ob + v * C, od);
+      }
+    }
+  }
+}
+int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, long V, int C, float slope, hipStream_t st) {
+  if (dt != NMH_DT_BF16 || C != 48 || B < 1 || V < 1) return -2;
+  int wps = 256 / B;
+  if (wps < 1) wps = 1;
+  static const int unroll = [] { const char* e = getenv("NMH_INBWD_BG_U"); return e ? atoi(e) : 5; }();   // 74 / 82 / 90 VGPRs: 96 are free beside the weight gradient
+  const dim3 grid((unsigned)(B * wps));
+  if (unroll <= 3) hipLaunchKernelGGL(in_bwd_apply_bg_kernel<3>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, stats, sums, (bf16_t*)dx, V, slope, wps);
+  else if (unroll == 4) hipLaunchKernelGGL(in_bwd_apply_bg_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, stats, sums, (bf16_t*)dx, V, slope, wps);
+  else hipLaunchKernelGGL(in_bwd_apply_bg_kernel<5>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, stats, sums, (bf16_t*)dx, V, slope, wps);
   NMH_CHECK_LAUNCH();
   return 0;
 }

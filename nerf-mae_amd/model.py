@@ -613,8 +613,9 @@ class _UpBlockFn(torch.autograd.Function):
         else:
             da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
         # Weight gradients run on the forked side stream -- except the persistent 160^3 kernels, which own every CU: overlapping
-        # them with the next MFMA kernel OR with the HBM-bound InstanceNorm passes measured slower (51.2 vs 50.4 ms at 4 grids,
-        # 34.8 vs 30.8 ms at 1), so they stay on the main stream.
+        # them with the next MFMA kernel OR with the HBM-bound InstanceNorm passes AS THEY ARE (100 k workgroups of 120 VGPRs) measured slower
+        # (51.2 vs 50.4 ms at 4 grids, 34.8 vs 30.8 ms at 1), so they stay on the main stream.  Round 5: the pass as ONE small workgroup per CU that
+        # fits beside the weight gradient's (`bg` below) does overlap.
         # small-level weight gradients: forked to the side stream -- or (NMH_DEFER_DEC) queued on the encoder's weight-gradient queue and issued
         # with its next flush, one fork for all of them
         defer = ops.DEFER_DECODER_WGRAD and getattr(m, "_wq", None) is not None and not (ctx.c48 or ctx.c64)
@@ -630,11 +631,21 @@ class _UpBlockFn(torch.autograd.Function):
                 with ops.side_stream(enable=not (ctx.c48 or ctx.c64)):
                     fn()
         g_c2, g_c1 = _gradbuf(m.conv_block.conv2.weight), _gradbuf(m.conv_block.conv1.weight)
+        dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
+        bg = ops.INBWD_BG and ctx.c48 and fused_red and Cout == 48 and dtype == torch.bfloat16 and ops.side_stream.enabled
+        if bg:
+            # decoder1: the HBM-bound InstanceNorm backward (needs conv2's input gradient only) streams on a forked stream UNDER conv2's weight gradient, as one
+            # small workgroup per CU beside the persistent kernel's (csrc/norm.hip: in_bwd_apply_bg_kernel); joined in front of its first consumer
+            # (the transpose conv's input gradient, a 4000-workgroup GEMM, does not ride along: one of its workgroups per CU at a time crawls -- 2.7 ms for 0.64)
+            with ops.side_stream():
+                ops.instnorm_bwd_apply_bg(da1, y1, st1, sums1, dy1, B, V, Cout)
         side(lambda: wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), g_c2))
         if not fused_red:
             ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
-        dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
-        ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
+        if bg:
+            ops.join_side()
+        else:
+            ops.instnorm_bwd_apply(da1, None, y1, st1, sums1, dy1, B, V, Cout, rmode=0)
         # decoder1 with the composed kernels: conv1's input gradient on the fine grid is never formed -- dx and the transpose conv's parameter gradients
         # take their conv1 part through the composition (cconv_dgrad below, cconv_wgrad's G blocks), dcat keeps the residual branch's gradient alone
         cdg = ctx.cc and pk.cconv[5] is not None

@@ -654,6 +654,26 @@ def test_instnorm_bwd_without_out(dt):
     check(res[1], res[0], dt, "dx without out", 1)
 
 
+@pytest.mark.parametrize("B,V", [(1, 4096), (3, 1500), (8, 64 ** 3), (2, 41)])
+def test_instnorm_bwd_apply_background_launch_is_bit_identical(B, V):
+    """nmh_instnorm_bwd_apply_bg (one persistent workgroup per CU, the footprint that runs beside the 48 -> 48 weight-gradient kernel in decoder-1's backward,
+    unetr_block.py:57-63 backward) == nmh_instnorm_bwd_apply(rmode 0, out = None), bit for bit; ragged voxel counts and fewer / more samples than workgroups."""
+    ops = _ops()
+    dt, C = torch.bfloat16, 48
+    x, dout = q(rnd(B, V, C) * 1.5 + 0.3, dt), q(rnd(B, V, C, seed=2), dt)
+    xd, dd = dev(x, dt), dev(dout, dt)
+    stats, scratch = torch.empty(B, C, 2, device="cuda"), torch.empty(B, C, 2, dtype=torch.float64, device="cuda")
+    ops.instnorm_stats(xd, stats, scratch, B, V, C)
+    sums = torch.empty(B, C, 2, dtype=torch.float64, device="cuda")
+    ops.instnorm_bwd_reduce(dd, None, xd, stats, sums, B, V, C)
+    ref = torch.empty(B, V, C, dtype=dt, device="cuda")
+    ops.instnorm_bwd_apply(dd, None, xd, stats, sums, ref, B, V, C)
+    got = torch.full((B, V, C), float("nan"), dtype=dt, device="cuda")
+    ops.instnorm_bwd_apply_bg(dd, xd, stats, sums, got, B, V, C)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_patch_embed_gather_and_bias_grad(dt):
     ops = _ops()
