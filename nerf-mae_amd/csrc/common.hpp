@@ -156,6 +156,12 @@ template <int HI_OFF, int OFF0 = 0> __device__ __forceinline__ void tr_read_raw(
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(addr), "n"(OFF0));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(addr), "n"(OFF0 + HI_OFF));
 }
+// a 16-byte LDS read the compiler does not see (it orders every LDS read it does see behind ALL LDS-DMAs in flight: s_waitcnt vmcnt(0)); own lgkmcnt wait
+__device__ __forceinline__ float4 lds_read_f4_raw(const float* p) {
+  float4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr_u(p)) : "memory");
+  return v;
+}
 template <int OFF> __device__ __forceinline__ void tr_read1(bf16x4& d, unsigned addr) {   // one half of a fragment at its own address (rows of the two halves not a fixed distance apart)
   static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));

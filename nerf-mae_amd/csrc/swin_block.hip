@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
     float4 bb[2];
     if (decltype(with_act)::value) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bb[t] = *reinterpret_cast<const float4*>(sB1 + 32 * (NW * c_act + wave) + 8 * g + 4 * t);
+      for (int t = 0; t < 2; ++t) bb[t] = lds_read_f4_raw(sB1 + 32 * (NW * c_act + wave) + 8 * g + 4 * t);   // (a compiler-visible LDS load here is preceded by vmcnt(0): it drained the weight stream every round)
     }
 #pragma unroll
     for (int u = 0; u < NW; ++u)
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(64 * NW) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
     {
       float4 bb[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bb[t] = *reinterpret_cast<const float4*>(sB1 + 32 * (NW * cl + wave) + 8 * g + 4 * t);
+      for (int t = 0; t < 2; ++t) bb[t] = lds_read_f4_raw(sB1 + 32 * (NW * cl + wave) + 8 * g + 4 * t);
 #pragma unroll
       for (int m = 0; m < 4; ++m) act_tile(cl, hcur, m, bb);
     }
