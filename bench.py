@@ -399,7 +399,8 @@ def main():
         # rocprofv3-reported HBM bytes of the same kernels (separate --pmc passes, tools/pmc_step.sh), quoted only when they were taken
         # on this source of csrc/norm.hip at the same per-GPU batch
         try:
-            kmap = {"mae_tail_fwd": ("tail_fwd",), "mae_tail_bwd": ("tail_bwd_kernel",), "instnorm_apply": ("in_apply_kernel",), "instnorm_bwd_apply": ("in_bwd_apply_kernel",),
+            kmap = {"mae_tail_fwd": ("tail_fwd",), "mae_tail_bwd": ("tail_bwd_kernel",), "instnorm_apply": ("in_apply_kernel",), "instnorm_bwd_apply": ("in_bwd_apply_kernel", "in_bwd_apply_bg_kernel"),   # (in the step: the background launch, same bytes)
+                    "instnorm_bwd_apply_bg": ("in_bwd_apply_bg_kernel",),
                     "instnorm_bwd_reduce": ("in_reduce_kernel",)}
             for h in hb:
                 pref = kmap.get(h["kernel"].split(":")[0])
