@@ -592,6 +592,7 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
   char* dyb = smem + HALO;
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, p = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (gridDim.y == 1) __builtin_amdgcn_s_setprio(3);   // decoder-1's launch: issue priority over the background pass sharing its CUs (csrc/norm.hip: in_bwd_apply_bg_kernel; same-box -0.4 ms)
 
   // one problem (decoder1): the tile range is cut into 8 XCD-contiguous parts; channel sub-problems: plain striding inside the slice
   const bool multi = gridDim.y > 1;
