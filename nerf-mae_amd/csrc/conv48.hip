@@ -859,7 +859,11 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
   int nb;
   if (nsub == 1) nb = a.total < 256 ? (int)((a.total + 7) / 8 * 8) : 256;   // 8 XCD-contiguous tile ranges
   else {
-    nb = 256 / nsub;
+    // the sub-problem launches are the small decoder levels, which run on the weight-gradient queue under the encoder's backward chain: 256 persistent
+    // workgroups hold every CU's LDS for the whole launch and stop the chain (a 30-us GEMM of the chain took 280-520 us); on HALF the CUs they take longer
+    // but the chain keeps moving -- same-box step 45.0 (256) / 44.9 (224) / 44.7 (192) / 44.5 (128) / 44.4 (96) / 44.9 ms (64 workgroups)
+    static const int side_wgs = [] { const char* e = getenv("NMH_W48_SIDE_WGS"); const int v = e ? atoi(e) : 128; return v < 1 ? 1 : (v > 256 ? 256 : v); }();
+    nb = side_wgs / nsub;
     if (nb < 1) nb = 1;
     if (nb > a.total) nb = (int)a.total;
   }
