@@ -1306,12 +1306,15 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
   __syncthreads();
   // channel chunks of this lane: sets 0 / 1 = channels 8g.. of tile 0 / 1, set 2 = channels 32 + 8(g&1).. of tile g>>1
   const int c0 = 8 * g, c1 = 32 + 8 * (g & 1), t2 = g >> 1;
-  float mu0[8], rs0[8], mu1[8], rs1[8];
+  typedef float tf2 __attribute__((ext_vector_type(2)));
+  typedef short ts2 __attribute__((ext_vector_type(2)));
+  tf2 mu0[4], rs0[4], mu1[4], rs1[4];   // channel pairs, mu* = MINUS the mean: the normalisation runs on packed fp32 (v_pk_add_f32 / v_pk_mul_f32)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    mu0[j] = stats[((long)b * C + c0 + j) * 2]; rs0[j] = stats[((long)b * C + c0 + j) * 2 + 1];
-    mu1[j] = stats[((long)b * C + c1 + j) * 2]; rs1[j] = stats[((long)b * C + c1 + j) * 2 + 1];
+    mu0[j >> 1][j & 1] = -stats[((long)b * C + c0 + j) * 2]; rs0[j >> 1][j & 1] = stats[((long)b * C + c0 + j) * 2 + 1];
+    mu1[j >> 1][j & 1] = -stats[((long)b * C + c1 + j) * 2]; rs1[j >> 1][j & 1] = stats[((long)b * C + c1 + j) * 2 + 1];
   }
+  const tf2 slope2 = {slope, slope};
   // head weight fragments (B operand: lane (o = vi, g), k-slot j = channel): k-step 0 = channels 8g + j; the shared chunk: tile 0 reads
   // lanes g < 2 (channels 32 + 8g + j), tile 1 lanes g >= 2 (channels 32 + 8(g-2) + j); hi + lo bf16 parts of the fp32 weights
   Frag<bf16_t> w0h, w0l, wah, wal, w1h, w1l, wbh, wbl;   // w0*/wa*: tile 0 (output o in lane vi = o); w1*/wb*: tile 1 (output o in lane vi = 4 + o)
@@ -1342,37 +1345,65 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
   if (v1 > V) v1 = V;
   const bf16_t* const xb = x + (long)b * V * C;
   const bf16_t* const rb = r + (long)b * V * C;
-  uint4 nx[3], nr[3];
-  auto issue = [&](long base) {   // base + 32 <= V (V is a multiple of 64: R is a multiple of 4)
-    const long o0 = (base + vi) * C + c0, o1 = (base + 16 + vi) * C + c0, o2 = (base + 16 * t2 + vi) * C + c1;
+  // Everything a step reads from global memory is requested one step ahead (round 5).  Before, the loss lanes loaded their targets and their token-mask
+  // byte inside the step: vector-memory loads return in order, so that wait also drained the x / r prefetch of the next step issued a moment earlier --
+  // every step stalled for a full memory latency (VALU active 0.44, 3.9 TB/s).
+  struct Ops { uint4 x[3], r[3]; float4 tg, t3; unsigned tm; int xk; };
+  Ops nxt;
+  const unsigned xoff = (unsigned)(vi * C + c0) * 2u, xoff2 = (unsigned)((16 * t2 + vi) * C + c1) * 2u;   // byte offsets inside a step's 32 voxel rows
+  const int tl_ = (vi >> 2) & 1, ol_ = vi & 3;   // the loss part runs on lanes vi < 8 (tile vi >> 2, output vi & 3); lanes vi >= 8 request the same words
+  auto issue = [&](long base, Ops& o) {   // base + 32 <= V (V is a multiple of 64: R is a multiple of 4)
+    const char* const xs_ = reinterpret_cast<const char*>(xb) + base * (C * 2);   // uniform part of the address: scalar registers
+    const char* const rs_ = reinterpret_cast<const char*>(rb) + base * (C * 2);
     if (NT) {   // one-pass operands far larger than the caches: non-temporal
-      auto ldn = [](const bf16_t* p) { const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); return make_uint4(w[0], w[1], w[2], w[3]); };
-      nx[0] = ldn(xb + o0); nr[0] = ldn(rb + o0); nx[1] = ldn(xb + o1); nr[1] = ldn(rb + o1); nx[2] = ldn(xb + o2); nr[2] = ldn(rb + o2);
+      auto ldn = [](const char* p) { const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); return make_uint4(w[0], w[1], w[2], w[3]); };
+      o.x[0] = ldn(xs_ + xoff); o.r[0] = ldn(rs_ + xoff); o.x[1] = ldn(xs_ + (xoff + 16u * C * 2u)); o.r[1] = ldn(rs_ + (xoff + 16u * C * 2u));
+      o.x[2] = ldn(xs_ + xoff2); o.r[2] = ldn(rs_ + xoff2);
     } else {
-      nx[0] = *reinterpret_cast<const uint4*>(xb + o0); nr[0] = *reinterpret_cast<const uint4*>(rb + o0);
-      nx[1] = *reinterpret_cast<const uint4*>(xb + o1); nr[1] = *reinterpret_cast<const uint4*>(rb + o1);
-      nx[2] = *reinterpret_cast<const uint4*>(xb + o2); nr[2] = *reinterpret_cast<const uint4*>(rb + o2);
+      o.x[0] = *reinterpret_cast<const uint4*>(xs_ + xoff); o.r[0] = *reinterpret_cast<const uint4*>(rs_ + xoff);
+      o.x[1] = *reinterpret_cast<const uint4*>(xs_ + (xoff + 16u * C * 2u)); o.r[1] = *reinterpret_cast<const uint4*>(rs_ + (xoff + 16u * C * 2u));
+      o.x[2] = *reinterpret_cast<const uint4*>(xs_ + xoff2); o.r[2] = *reinterpret_cast<const uint4*>(rs_ + xoff2);
     }
+    const long vq = base + 16 * tl_ + 4 * g;
+    const unsigned vox = (unsigned)vq, tq = vox / Ru, zq = tq / Ru;
+    const int x0 = (int)(vox - tq * Ru), yy = (int)(tq - zq * Ru), zz = (int)zq;
+    o.tg = *reinterpret_cast<const float4*>(a.target + ((long)b * 4 + ol_) * V + vq);
+    o.t3 = *reinterpret_cast<const float4*>(a.target + ((long)b * 4 + 3) * V + vq);
+    o.tm = a.tokmask[((zz >> 2) * gd + (yy >> 2)) * gd + (x0 >> 2)];
+    o.xk = (zz < e0 && yy < e1) ? x0 : (1 << 30);   // x0 + q < e2 fails for a row outside the sample's extent
   };
   // one chunk: x-hat, d0 (bf16), and the four packed operand rows for the reduction GEMMs
-  auto chunk = [&](const uint4& xw, const uint4& rw, const float (&mu)[8], const float (&rs)[8], uint4& ypk, uint4& mpk, uint4& mxpk, uint4& xpk, unsigned& bits) {
+  // (round 5: 40 -> 17 vector instructions per channel pair.  The arithmetic is packed fp32 with the expressions and roundings of before ((x - mean) * rstd,
+  //  + r, max(y, slope y)); inline asm because the compiler splits most of the packed operations again.  The three mask products no longer cost compares,
+  //  selects, multiplies and conversions per channel: [d0 > 0] of a PAIR is read off the packed bf16 d0 by two packed 16-bit integer instructions -- bf16
+  //  d0 > 0 <=> its bits as int16 > 0 <=> the saturating 0 - bits is negative -- and the 0xffff / 0 halves AND the bf16 constant 1.0, the packed x-hat and
+  //  the pair's two bits of the chunk's mask byte.  LeakyReLU keeps the sign (0 < slope < 1) and the sign of a bf16 rounding is that of the fp32 value.)
+  const unsigned sh15 = 0x000f000fu;
+  auto chunk = [&](const uint4& xw, const uint4& rw, const tf2 (&nmu)[4], const tf2 (&rs)[4], uint4& ypk, uint4& mpk, uint4& mxpk, uint4& xpk, unsigned& bits) {
     const unsigned xs[4] = {xw.x, xw.y, xw.z, xw.w}, rr[4] = {rw.x, rw.y, rw.z, rw.w};
     unsigned yo[4], mo[4], mxo[4], xo[4];
-    bits = 0u;
+    unsigned u = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float xa = (__uint_as_float(xs[i] << 16) - mu[2 * i]) * rs[2 * i], xc = (__uint_as_float(xs[i] & 0xffff0000u) - mu[2 * i + 1]) * rs[2 * i + 1];
-      float ya = xa + __uint_as_float(rr[i] << 16), yc = xc + __uint_as_float(rr[i] & 0xffff0000u);
-      // (the sign of the fp32 value is the sign of its bf16 rounding: same exponent range)
-      const float ma = ya > 0.f ? 1.0f : 0.0f, mc = yc > 0.f ? 1.0f : 0.0f;
-      bits |= (ya > 0.f ? 1u : 0u) << (2 * i) | (yc > 0.f ? 1u : 0u) << (2 * i + 1);
-      ya = fmaxf(ya, slope * ya); yc = fmaxf(yc, slope * yc);   // LeakyReLU, 0 < slope < 1
-      const unsigned yp = pk_bf16(ya, yc);
-      yo[i] = yp;
-      mo[i] = pk_bf16(ma, mc);
-      mxo[i] = pk_bf16(ma * xa, mc * xc);
-      xo[i] = pk_bf16(xa, xc);
+      const tf2 xv = {__uint_as_float(xs[i] << 16), __uint_as_float(xs[i] & 0xffff0000u)};
+      const tf2 rv = {__uint_as_float(rr[i] << 16), __uint_as_float(rr[i] & 0xffff0000u)};
+      tf2 xh, y, ys;
+      asm("v_pk_add_f32 %0, %1, %2" : "=v"(xh) : "v"(xv), "v"(nmu[i]));
+      asm("v_pk_mul_f32 %0, %1, %2" : "=v"(xh) : "v"(xh), "v"(rs[i]));
+      asm("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(xh), "v"(rv));
+      asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ys) : "v"(y), "v"(slope2));
+      float ya, yc;   // LeakyReLU, 0 < slope < 1 (asm: behind opaque operands the compiler would canonicalise both inputs of fmaxf first)
+      asm("v_max_f32 %0, %1, %2" : "=v"(ya) : "v"(y.x), "v"(ys.x));
+      asm("v_max_f32 %0, %1, %2" : "=v"(yc) : "v"(y.y), "v"(ys.y));
+      const unsigned yp = pk_bf16(ya, yc), xp = pk_bf16(xh.x, xh.y);
+      unsigned nm;
+      asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, %2, %0" : "=&v"(nm) : "v"(yp), "v"(sh15));   // 0xffff / 0 per half
+      yo[i] = yp; xo[i] = xp;
+      mo[i] = nm & 0x3f803f80u;   // bf16 1.0 / 0.0
+      mxo[i] = nm & xp;           // [d0 > 0] x-hat (the masked-out halves are +0)
+      u |= nm & (0x00010001u << (2 * i));
     }
+    bits = (u | (u >> 15)) & 0xffu;   // bit 2 i = low half of pair i, bit 2 i + 1 = high half
     ypk = make_uint4(yo[0], yo[1], yo[2], yo[3]); mpk = make_uint4(mo[0], mo[1], mo[2], mo[3]);
     mxpk = make_uint4(mxo[0], mxo[1], mxo[2], mxo[3]); xpk = make_uint4(xo[0], xo[1], xo[2], xo[3]);
   };
@@ -1384,18 +1415,16 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
     *reinterpret_cast<uint4*>(p + 3 * OPB) = ypk;
   };
   const long gstep = 4 * 32;
-  long base = v0 + wave * 32;
-  if (base < v1) issue(base);
-  for (; base < v1; base += gstep) {
-    uint4 cx[3], cr[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { cx[k] = nx[k]; cr[k] = nr[k]; }
-    if (base + gstep < v1) issue(base + gstep);
+  auto step = [&](long base) {
+    const Ops o = nxt;
+    if (base + gstep < v1) issue(base + gstep, nxt);
     uint4 y0, y1, y2, mp, mxp, xp;
     unsigned sb0, sb1, sb2;
-    chunk(cx[0], cr[0], mu0, rs0, y0, mp, mxp, xp, sb0); put(vi, c0, mp, mxp, xp, y0);
-    chunk(cx[1], cr[1], mu0, rs0, y1, mp, mxp, xp, sb1); put(16 + vi, c0, mp, mxp, xp, y1);
-    chunk(cx[2], cr[2], mu1, rs1, y2, mp, mxp, xp, sb2); put(16 * t2 + vi, c1, mp, mxp, xp, y2);
+    chunk(o.x[0], o.r[0], mu0, rs0, y0, mp, mxp, xp, sb0); put(vi, c0, mp, mxp, xp, y0);
+    chunk(o.x[1], o.r[1], mu0, rs0, y1, mp, mxp, xp, sb1); put(16 + vi, c0, mp, mxp, xp, y1);
+    chunk(o.x[2], o.r[2], mu1, rs1, y2, mp, mxp, xp, sb2); put(16 * t2 + vi, c1, mp, mxp, xp, y2);
+    const float4 tg = o.tg, t3 = o.t3;
+    const int xr = o.tm != 0u ? o.xk : (1 << 30);
     if (a.sign_mask) {   // [d0 > 0] of the lane's three chunks: byte c0 / 8 of voxels vi and 16 + vi, byte c1 / 8 of voxel 16 t2 + vi -- collected per
       //                    voxel in a wave-private LDS row of 8 bytes (6 used) and stored by lanes 0..31 behind the wave barrier below: 256 contiguous bytes
       //                    per step (single-byte global stores cost the pass 0.17 ms)
@@ -1417,11 +1446,6 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
     if (vi < 8) {
       const int tl = vi >> 2, ol = vi & 3;
       const long vq = base + 16 * tl + 4 * g;
-      const unsigned vox = (unsigned)vq, tq = vox / Ru, zq = tq / Ru;
-      const int x0 = (int)(vox - tq * Ru), yy = (int)(tq - zq * Ru), zz = (int)zq;
-      const float4 tg = *reinterpret_cast<const float4*>(a.target + ((long)b * 4 + ol) * V + vq);
-      const float4 t3 = *reinterpret_cast<const float4*>(a.target + ((long)b * 4 + 3) * V + vq);
-      const bool rowok = zz < e0 && yy < e1 && a.tokmask[((zz >> 2) * gd + (yy >> 2)) * gd + (x0 >> 2)] != 0;
       const float tv[4] = {tg.x, tg.y, tg.z, tg.w}, t3v[4] = {t3.x, t3.y, t3.z, t3.w};
       const bool alpha = ol == 3;
       float pv[4];
@@ -1429,7 +1453,7 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
       for (int q = 0; q < 4; ++q) {   // branch-free over the lane's output: RGB terms (o < 3) and the alpha term (o = 3) differ in selects only
         const float p = (tl ? P[1][q] : P[0][q]) + bias_l;
         pv[q] = p;
-        const bool on = alpha ? (rowok && x0 + q < e2) : (t3v[q] > 0.01f);
+        const bool on = alpha ? (xr + q < e2) : (t3v[q] > 0.01f);
         const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-p));
         const float val = alpha ? sg : p, df = val - tv[q];
         const float dfac = alpha ? 2.f * sg * (1.f - sg) : 2.f;
@@ -1465,6 +1489,11 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  };
+  {
+    long base = v0 + wave * 32;
+    if (base < v1) issue(base, nxt);
+    for (; base < v1; base += gstep) step(base);
   }
   // ---- block reduction: S[q][n][r] of lane (c = vi, g = tile) is that tile's sum for (operand q, output o = r, channel 16n + c) ---------
   __syncthreads();   // every wave is done with its operand images
