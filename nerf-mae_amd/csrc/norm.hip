@@ -915,7 +915,7 @@ int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stat
 // {sum g, sum g*xhat} with g = d(d0) * lrelu'(d0), plus the head weight gradient dW[o][c] = sum_v dp[v][o] d0[v][c];
 // pass 1 (APPLY=1): dx = rstd (g - S1/V - xhat S2/V), dr = g.  Same thread mapping as the InstanceNorm kernels above.
 template <typename T, int APPLY, bool ST = false, bool NT = false>
-__global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0, const T* __restrict__ rres, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dp,
+__global__ __launch_bounds__(256, ST ? 4 : 1) void tail_bwd_kernel(const T* __restrict__ d0, const T* __restrict__ rres, const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ dp,
                                                        const double* __restrict__ lsums, const float* __restrict__ Wout, double* in_sums, T* __restrict__ dx,
                                                        T* __restrict__ dr, float slope, float* dWout, float* dbout, long V, int C, long vpb,
                                                        const unsigned char* __restrict__ smask) {
@@ -968,27 +968,32 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
     if (v1 > V) v1 = V;
     constexpr int U = 2;
     for (long vb = v0 + vl; vb < v1; vb += (long)NV * U) {
-      float ov[U][8], xv[U][8];
+      float ov[ST ? 1 : U][8], xv[U][8];
+      unsigned mb[U];   // ST (the streaming apply pass, always with the sign mask): the mask byte stays packed -- 8 registers less per voxel row in flight, 128
+      //                   VGPRs = four waves per SIMD instead of three
       float4 dq[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long v = vb + (long)u * NV;
         if (v < v1) {
           const long o = ((long)b * V + v) * C + cl * 8;
-          if (APPLY && smask) {   // only the sign of d0 is needed (the sums came out of the forward pass): one byte instead of 16
+          if (ST) {
+            const uint2 mw = *reinterpret_cast<const uint2*>(smask + ((long)b * V + v) * 8);
+            mb[u] = ((cl < 4 ? mw.x : mw.y) >> (8 * (cl & 3))) & 0xffu;
+          } else if (APPLY && smask) {   // only the sign of d0 is needed (the sums came out of the forward pass): one byte instead of 16
             const uint2 mw = *reinterpret_cast<const uint2*>(smask + ((long)b * V + v) * 8);   // 8-byte rows (C = 48: 6 used), one load per voxel row
             const unsigned m8 = ((cl < 4 ? mw.x : mw.y) >> (8 * (cl & 3))) & 0xffu;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[u][j] = (m8 >> j) & 1u ? 1.0f : -1.0f;
-          } else Vec8<T>::load((d0 ? d0 : rres) + o, ov[u]);
+            for (int j = 0; j < 8; ++j) ov[ST ? 0 : u][j] = (m8 >> j) & 1u ? 1.0f : -1.0f;
+          } else Vec8<T>::load((d0 ? d0 : rres) + o, ov[ST ? 0 : u]);
           if (NT) Vec8<T>::load_nt(x + o, xv[u]); else Vec8<T>::load(x + o, xv[u]);
           dq[u] = *reinterpret_cast<const float4*>(dp + ((long)b * V + v) * 4);
-          if (!d0 && !(APPLY && smask)) {  // d0 was not stored by the forward: rebuild it bit-exactly (same fp32 expression, same rounding) from x and r
+          if (!ST && !d0 && !(APPLY && smask)) {  // d0 was not stored by the forward: rebuild it bit-exactly (same fp32 expression, same rounding) from x and r
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              float y = (xv[u][j] - mu[j]) * rs[j] + ov[u][j];
+              float y = (xv[u][j] - mu[j]) * rs[j] + ov[ST ? 0 : u][j];
               y = y > 0.f ? y : slope * y;
-              ov[u][j] = to_f<T>(from_f<T>(y));
+              ov[ST ? 0 : u][j] = to_f<T>(from_f<T>(y));
             }
           }
         }
@@ -1001,11 +1006,11 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const T* __restrict__ d0,
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float d = dq[u].x * w[0][j] + dq[u].y * w[1][j] + dq[u].z * w[2][j] + dq[u].w * w[3][j];
-            const float g = d * (ov[u][j] > 0.f ? 1.0f : slope);
+            const float g = d * ((ST ? ((mb[u] >> j) & 1u) != 0u : ov[ST ? 0 : u][j] > 0.f) ? 1.0f : slope);
             const float xh = (xv[u][j] - mu[j]) * rs[j];
             if (!APPLY) {
               u1[j] += g; u2[j] += g * xh;
-              wacc[0][j] += dq[u].x * ov[u][j]; wacc[1][j] += dq[u].y * ov[u][j]; wacc[2][j] += dq[u].z * ov[u][j]; wacc[3][j] += dq[u].w * ov[u][j];
+              wacc[0][j] += dq[u].x * ov[ST ? 0 : u][j]; wacc[1][j] += dq[u].y * ov[ST ? 0 : u][j]; wacc[2][j] += dq[u].z * ov[ST ? 0 : u][j]; wacc[3][j] += dq[u].w * ov[ST ? 0 : u][j];
             } else {
               gq[j] = g;
               od[j] = rs[j] * (g - u1[j] - xh * u2[j]);
@@ -1061,7 +1066,7 @@ int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const flo
   const long vpb = in_vox_per_block(V, B);
   const bool nt = bwd_sums && sign_mask && in_apply_streaming(V, B, C, dt);
   static const int tail_sv = getenv("NMH_TAIL_STREAM_VPB") ? atoi(getenv("NMH_TAIL_STREAM_VPB")) : 0;
-  const long vpa = nt && tail_sv > 0 ? tail_sv : in_apply_vpb(V, B, C, nt, 32);
+  const long vpa = nt && tail_sv > 0 ? tail_sv : in_apply_vpb(V, B, C, nt, 16);   // (round 5, four waves per SIMD: 1.93 ms with 16, 1.98 / 1.99 / 2.04 with 32 / 64 / 128)
   dim3 g0((unsigned)((V + vpb - 1) / vpb), B), g1((unsigned)((V + vpa - 1) / vpa), B);
   if (bwd_sums) {   // the reductions were taken by the forward pass: one apply pass is all that is left
     const int n = B * C + 4 * C + 4;
@@ -1554,7 +1559,7 @@ int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void*
   if (e != hipSuccess) return (int)e;
   long vpb = (V * a.B + 2047) / 2048;
   if (vpb < 160) vpb = 160;
-  if (vpb > 2048) vpb = 2048;
+  if (vpb > (a.bwd_sums ? 4096 : 2048)) vpb = a.bwd_sums ? 4096 : 2048;   // (matrix-core pass at 8 x 160^3: 1.89 / 1.58 / 1.54 / 1.55 ms with 1024 / 2048 / 4096 / 8192)
   static const int tf_vpb = getenv("NMH_TAIL_FWD_VPB") ? atoi(getenv("NMH_TAIL_FWD_VPB")) : 0;
   if (tf_vpb > 0 && a.bwd_sums) vpb = tf_vpb;
   dim3 grid((unsigned)((V + vpb - 1) / vpb), a.B);

@@ -355,6 +355,8 @@ class _BlockFn(torch.autograd.Function):
             dx1, x1n, h_act, dh = ops.mlp_fused_bwd(x1, dx2, b.norm2.weight, b.norm2.bias, pk[key + "fc1.w"].view(4 * C, C), b.mlp[0].bias,
                                                     pk[key + "fc2.wT"].view(4 * C, C), _gradbuf(b.norm2.weight), _gradbuf(b.norm2.bias),
                                                     rowscale=sd2, rows_per_scale=tps, dyw=dyw, dyw_scale=sd1, geom=geom)
+            if q is not None:
+                q.flush_due()   # the previous stage's weight gradients fork off BEHIND this stage's first input-gradient kernel (ops.WgradQueue.request_flush)
             wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
             wgrad(dh, x1n, b.mlp[0])
             if q is not None and ops.EARLY_MLP_WGRAD:
@@ -363,6 +365,8 @@ class _BlockFn(torch.autograd.Function):
                 q.flush()
         else:
             dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)
+            if q is not None:
+                q.flush_due()
             wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
             dx1n = ops.gemm_nt(dh, pk[key + "fc1.wT"].view(C, 4 * C))
             wgrad(dh, x1n, b.mlp[0])
@@ -423,7 +427,10 @@ class _StageFlushFn(torch.autograd.Function):
         # referenced by the queue until the end-of-backward join.
         if not ops.WQ_LATE_JOIN or ctx.wq.sync_after_flush:
             ctx.wq.join()     # the previous stage's launch (if any) has had a whole stage of input-gradient work to finish under
-        ctx.wq.flush(foreground=ctx.last)
+        if ops.WQ_FLUSH_AFTER_FIRST and not ctx.last and not ctx.wq.sync_after_flush:
+            ctx.wq.request_flush()   # issued by the next block's backward behind its first kernel
+        else:
+            ctx.wq.flush(foreground=ctx.last)
         if ctx.wq.sync_after_flush:
             ctx.wq.join()
         return g, None, None

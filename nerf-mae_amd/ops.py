@@ -166,6 +166,11 @@ DEFER_DECODER_WGRAD = __import__("os").environ.get("NMH_DEFER_DEC", "1") == "1"
 DEC_WGRAD_NOW = __import__("os").environ.get("NMH_DEC_WGRAD_NOW", "0") == "1"   # small decoder levels: weight gradients issued on the side stream as soon as their operands exist instead of with the stage-3 flush
 UPW_EARLY = __import__("os").environ.get("NMH_UPW_EARLY", "0") == "1"   # decoder1 transpose-conv weight gradient on the side stream at the end of its block instead of queued (measured 51.1 / 51.0 vs 50.9 / 51.0 ms: off)
 WQ_LATE_JOIN = __import__("os").environ.get("NMH_WQ_LATE_JOIN", "1") == "1"   # weight-gradient queue: join only at the end of the backward pass
+# A stage's flush forks off behind the FIRST input-gradient kernel of the next stage instead of in front of it (round 5).  In the captured graph both are
+# successors of the stage's last kernel; the HIP graph executor keeps the successor captured first on the predecessor's queue and gives the other one a new
+# queue plus a cross-queue wait -- and that wait was released only ~10 side kernels later (1 grid: 0.58 ms with the input-gradient queue idle at the
+# stage 3 -> 2 boundary, profiles/r5k_timeline_1grids.txt 6.86 -> 7.43 ms).  Captured first, the chain stays on its queue and the side launches take the wait.
+WQ_FLUSH_AFTER_FIRST = __import__("os").environ.get("NMH_WQ_FLUSH_AFTER_FIRST", "1") == "1"
 STAGE0_BLOCK_FLUSH = __import__("os").environ.get("NMH_STAGE0_BLOCK_FLUSH", "0") == "1"   # stage 0 flushes its queued weight gradients per block (measured 52.2-52.4 vs 52.0 ms at 8 grids: off)
 
 
@@ -214,13 +219,14 @@ class WgradQueue:
         self.ln_items = []   # LayerNorm parameter-gradient partials of the current flush group (add_ln_partials)
         self.pad_items = {}  # pad-row column sums of the current flush group, by (geometry, width, dtype) (add_pad_colsum)
         self.deferred = []   # closures (other weight-gradient launches) to issue with the next flush, inside the same fork
+        self._due = False    # a flush requested by a stage boundary, issued by the next block behind its first kernel (WQ_FLUSH_AFTER_FIRST)
 
     def reset(self):
         """start of a forward pass: nothing may be queued here -- unless a previous backward pass raised half-way, in which case its
         operands (whole 160^3 gradients) would stay referenced for good and `_cb` would never re-arm the end-of-backward callback"""
         if self.pending or self.deferred or self.inflight or self._cb:
             join_side()
-            self.pending, self.deferred, self.inflight, self._cb = [], [], [], False
+            self.pending, self.deferred, self.inflight, self._cb, self._due = [], [], [], False, False
             self.ln_items, self.pad_items = [], {}
 
     def defer(self, fn):
@@ -266,8 +272,20 @@ class WgradQueue:
             self._cb = True
             torch.autograd.Variable._execution_engine.queue_callback(self._final)
 
+    def request_flush(self):
+        self._due = True
+        if not self._cb:
+            self._cb = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._final)
+
+    def flush_due(self):
+        if self._due:
+            self._due = False
+            self.flush()
+
     def _final(self):
         self._cb = False
+        self._due = False
         self.flush()
         self.join()
 
