@@ -425,6 +425,10 @@ def main():
     if args.e2e and rank == 0 and world == 1:
         out["config"]["e2e"] = e2e_leg(model, args, R, sweep)
 
+    if rank == 0 and world == 1 and args.dtype == "bf16" and not (args.no_sweep or args.eager) and os.environ.get("NMH_BENCH_INNER") != "1":
+        fp = fp32_mode_leg(args)
+        if fp:
+            out["config"]["fp32_mode"] = fp
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, R, exts)
     if rank == 0:
@@ -541,7 +545,7 @@ def roofline_families(trace, cfg, R, Bg):
         ("conv %d->%d 3x3x3 @%d^3 weight gradient (conv48_wgrad_kernel, persistent launches)" % (E2, E2, R), r"conv48_wgrad_kernel|conv64_wgrad_kernel",
          (1 if has_cw else 2) * conv1),
         ("decoder convs at the 10^3..40^3 levels, fwd+dgrad+wgrad (conv48_kernel<0,true>, AConv3, BConv3TN, small conv48_wgrad launches)",
-         r"conv48_kernel<0, true, false>|AConv3|BConv3TN|conv48_wgrad_reduce", 3 * conv_small),
+         r"conv48_kernel<0, true, false>|AConv3|BConv3TN|conv48_wgrad_reduce|conv48_wgrad_kernel", 3 * conv_small),   # (the 160^3 wgrad launch is taken by the family above)
         ("fused Swin-block forward kernels: LN1+QKV+window attention+proj+residual per window, LN2+fc1+GELU+fc2+residual per 64 tokens "
          "(swin_attn_fwd_kernel, swin_mlp_fwd_kernel) + their weight-stream pack", r"sw::swin_",
          (sw_lin + sw_attn) if has_sw else None),
@@ -584,6 +588,22 @@ def roofline_families(trace, cfg, R, Bg):
     rest = sum(ns for key, (ns, cnt) in ks.items() if key not in used)
     out.append({"family": "everything else", "ms_per_step": round(rest / 1e6, 3), "launches_per_step": round(sum(c for k, (ns, c) in ks.items() if k not in used), 1)})
     return out
+
+def fp32_mode_leg(args):
+    """Informational: the same step in the exact-fp32 mode (the reference's own arithmetic, SURVEY fact 4: every GEMM / conv on v_mfma_f32_16x16x4_f32,
+    fp32 activations), 1 grid per step, from a short child run of this script.  Not the BASELINE metric (that is bf16) and never `value`."""
+    import subprocess
+    env = dict(os.environ, NMH_BENCH_INNER="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--batch-per-gpu", "1", "--backbone", args.backbone, "--resolution", str(args.resolution), "--dtype", "fp32",
+           "--no-cpu-baseline", "--no-kernel-timing", "--no-sweep", "--steps", "6", "--warmup", "2"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        return {"grids_per_s": d["value"], "ms_per_step": d["ms_per_step"], "grids_per_gpu": 1, "dtype": "fp32",
+                "note": "exact-fp32 mode of every kernel (parity mode; the reference trains in fp32), child run of this script; informational, not the BASELINE metric"}
+    except Exception:  # noqa: BLE001
+        return None
+
 
 def e2e_leg(model, args, R, sweep):
     """Trainer.fit on HOST-resident synthetic scenes (stored format, through the pinned ring / copy stream / grid_prepare kernel):
