@@ -228,7 +228,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
   __shared__ __attribute__((aligned(16))) float sD[NW][64];
   __shared__ __attribute__((aligned(16))) float sL[NW][64];
   __shared__ unsigned sR[NW][16];                                  // region id of the 64 tokens, one byte each
+  // bf16: the probabilities of phase A stay in LDS for phase B, transposed (key-major rows of 64 queries, 136-byte rows: conflict-free 2-byte writes, 8-byte
+  // reads) -- phase B then needs neither its 16 score MFMAs nor 64 bias reads, mask tests and exponentials per lane.  P is rounded to bf16 there, as it is
+  // for the dV product anyway; dS = P (dP - D) takes one extra rounding before its own.  8.5 KB per wave: six waves per CU instead of eight (measured equal).
+  constexpr bool PC = sizeof(T) == 2;
+  constexpr int PRS = 136;
+  __shared__ __attribute__((aligned(16))) char sP[PC ? NW : 1][PC ? 64 * PRS : 16];
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* const tP = sP[PC ? wave : 0];
   const int h = blockIdx.y;
   const int nW = (wm.PH >> 2) * (wm.PW >> 2) * (wm.PD >> 2);
   const bool shifted = (wm.s0 + wm.s1 + wm.s2) > 0;
@@ -315,6 +322,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
           dsum += e * dp[jt][r];
         }
       }
+      if constexpr (PC) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+          const unsigned w01 = pk_bf16(p[jt][0], p[jt][1]), w23 = pk_bf16(p[jt][2], p[jt][3]);
+          char* const q = tP + (16 * jt + 4 * g) * PRS + i * 2;
+          *reinterpret_cast<unsigned short*>(q) = (unsigned short)(w01 & 0xffffu);
+          *reinterpret_cast<unsigned short*>(q + PRS) = (unsigned short)(w01 >> 16);
+          *reinterpret_cast<unsigned short*>(q + 2 * PRS) = (unsigned short)(w23 & 0xffffu);
+          *reinterpret_cast<unsigned short*>(q + 3 * PRS) = (unsigned short)(w23 >> 16);
+        }
+      }
       dsum += __shfl_xor(dsum, 16, 64);
       dsum += __shfl_xor(dsum, 32, 64);
       if (g == 0) sD[wave][i] = dsum;
@@ -357,24 +375,32 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const Frag<T> dfi = lds_row_frag<T>(tO, RS, it * 16 + li, g);
-        p[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[it], qf[it], kf[jt]);
+        if constexpr (!PC) { p[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[it], qf[it], kf[jt]); }
         dp[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[it], dfi, vf[jt]);
       }
       const int j = 16 * jt + li;
       const unsigned rj = shifted ? sRb[j] : 0u;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const unsigned rw = shifted ? sR[wave][4 * it + g] : 0u;
-        const float4 L4 = *reinterpret_cast<const float4*>(&sL[wave][16 * it + 4 * g]);
         const float4 D4 = *reinterpret_cast<const float4*>(&sD[wave][16 * it + 4 * g]);
-        const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+        const float Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+        if constexpr (PC) {   // P[i = 16 it + 4 g + r][j] of phase A
+          const uint2 w = *reinterpret_cast<const uint2*>(tP + j * PRS + (16 * it + 4 * g) * 2);
+          const float e4[4] = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = p[it][r] * scale + sB[binB + (it - jt + 3) * 49 + r];
-          if (shifted && ((rw >> (8 * r)) & 255u) != rj) v += -100.0f;
-          const float e = __expf(v - Lr[r]);
-          p[it][r] = e;
-          dp[it][r] = e * (dp[it][r] - Dr[r]);
+          for (int r = 0; r < 4; ++r) { p[it][r] = e4[r]; dp[it][r] = e4[r] * (dp[it][r] - Dr[r]); }
+        } else {
+          const unsigned rw = shifted ? sR[wave][4 * it + g] : 0u;
+          const float4 L4 = *reinterpret_cast<const float4*>(&sL[wave][16 * it + 4 * g]);
+          const float Lr[4] = {L4.x, L4.y, L4.z, L4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = p[it][r] * scale + sB[binB + (it - jt + 3) * 49 + r];
+            if (shifted && ((rw >> (8 * r)) & 255u) != rj) v += -100.0f;
+            const float e = __expf(v - Lr[r]);
+            p[it][r] = e;
+            dp[it][r] = e * (dp[it][r] - Dr[r]);
+          }
         }
       }
       // dV^T[d][j] = sum_i dO[i][d] P[i][j];  dK^T[d][j] = sum_i Q[i][d] dS[i][j]
@@ -424,23 +450,18 @@ int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, co
                void* dqkv_tok) {
   if (C != heads * 32) return -2;
   const long nwin = (long)wm.B * (wm.PH / 4) * (wm.PW / 4) * (wm.PD / 4);
-  // one wave per (window, head); a wave loops over several windows only when there are more waves than the chip holds at once -- 8 per CU in
-  // bf16 (248 VGPRs, 28 KB of LDS per 2-wave workgroup), 6 in fp32: the grid is ONE round of resident workgroups (with the former cap of 12
-  // per CU, stage 2 at 8 grids was 2592 waves on 2048 slots: a full round plus a quarter-full one, 74 us instead of 47)
-  // waves per workgroup: every workgroup ends with 343 global atomics on the head's table gradient; with 4 waves there are half as many
-  // flushes (2592 pairs: 57 -> 50 us, 6000 pairs: 72 -> 70), but fewer, larger workgroups spread worse when the launch is small (324 pairs:
-  // 18.5 -> 21.3 us) or far larger than the chip (24000 pairs: 236 -> 243).  NMH_ATTN_BNW=2/4 forces.
-  const char* nw_s = getenv("NMH_ATTN_BNW");
-  const long npairs = nwin * heads;
-  const int nw = nw_s ? atoi(nw_s) : ((dt == NMH_DT_BF16 && npairs >= 2048 && npairs <= 8000) ? 4 : 2);
+  // one wave per (window, head); a wave loops over several windows only when there are more waves than the chip holds at once: the grid is ONE round of
+  // resident workgroups -- six waves per CU (248 VGPRs: two per SIMD by registers; 45 KB of LDS per 2-wave workgroup with the bf16 probability cache:
+  // three workgroups per CU).  Rounds 3-5 measured 8 waves per CU and 4-wave workgroups for mid-size launches: within 5 % of this everywhere
+  // (profiles/r5m_attn_bwd_waves_per_cu_sweep_not_kept.txt).
+  const int nw = 2;
   long gx = (nwin + nw - 1) / nw;
-  long cap = (256L * (dt == NMH_DT_BF16 ? 8 : 6) / nw) / heads;
+  long cap = (256L * 6 / nw) / heads;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   dim3 grid((unsigned)gx, heads);
   if (dt == NMH_DT_BF16) {
-    if (nw == 4) hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 4>), grid, dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
-    else hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
+    hipLaunchKernelGGL((attn_bwd_kernel<bf16_t, 2>), grid, dim3(128), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
   } else hipLaunchKernelGGL((attn_bwd_kernel<float, 2>), dim3((unsigned)gx, heads), dim3(128), 0, st, (const float*)qkv, table, (const float*)dout, lse, (float*)dqkv, dtable, heads, C, wm, nwin, (float*)dqkv_tok);
   NMH_CHECK_LAUNCH();
   return 0;
