@@ -147,6 +147,29 @@ def test_fused_and_unfused_decoder_tail_agree():
     assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.99999
 
 
+def test_stage_flush_behind_the_first_chain_kernel_changes_nothing(monkeypatch):
+    """ops.WQ_FLUSH_AFTER_FIRST only moves the POINT at which a stage's queued weight gradients fork off (behind the next stage's first input-gradient
+    kernel instead of in front of it): same launches, same operands -- every gradient but the few that end in order-dependent atomics is bit-identical."""
+    from nerf_mae_amd import ops
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(SWIN_T, torch.bfloat16, res=32, init="default")
+    xs = [O.synthetic_grid((32, 32, 32), 21).cuda(), O.synthetic_grid((32, 30, 27), 22).cuda()]
+    bm = O.draw_block_mask((8, 8, 8), ora.masking_prob, rng=random.Random(5))
+    grads = []
+    for flag in (False, True, False):
+        monkeypatch.setattr(ops, "WQ_FLUSH_AFTER_FIRST", flag)
+        hip.zero_grad()
+        out = hip(xs, block_mask=bm)
+        out[0].backward()
+        torch.cuda.synchronize()
+        assert not hip._wq._due and not hip._wq.pending and not hip._wq.deferred
+        grads.append((out[0].item(), hip._flat_grad.clone()))
+    noise = relerr(grads[0][1], grads[2][1])            # run-to-run difference of the same setting (atomics)
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[0][0])
+    assert relerr(grads[1][1], grads[0][1]) <= max(4 * noise, 1e-6), (relerr(grads[1][1], grads[0][1]), noise)
+    assert torch.isfinite(grads[1][1]).all()
+
+
 def test_bf16_close_to_oracle_and_eval_contract():
     from oracle import mae3d_oracle as O
     res = 96
