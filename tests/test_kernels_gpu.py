@@ -206,7 +206,7 @@ def test_layernorm_window_modes(dt, shape, shift, C):
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("C", [96, 192, 384])
+@pytest.mark.parametrize("C", [96, 192, 384, 128, 512, 1024])   # (128 / 512 / 1024: the 128-channel stem; 512 takes the 32-lanes-per-row backward instantiation)
 def test_layernorm_plain_and_embed_post(dt, C):
     ops = _ops()
     B, tps = 2, 130
@@ -252,7 +252,7 @@ class _Defer:
 
 
 @pytest.mark.parametrize("dt", DTS)
-@pytest.mark.parametrize("shape,C,shift", [((2, 8, 8, 8), 96, 2), ((1, 5, 5, 5), 192, 2), ((8, 10, 10, 10), 384, 2), ((2, 10, 10, 10), 384, 0), ((3, 40, 12, 40), 96, 2), ((1, 5, 5, 5), 768, 0)])
+@pytest.mark.parametrize("shape,C,shift", [((2, 8, 8, 8), 96, 2), ((1, 5, 5, 5), 192, 2), ((8, 10, 10, 10), 384, 2), ((2, 10, 10, 10), 384, 0), ((3, 40, 12, 40), 96, 2), ((1, 5, 5, 5), 768, 0), ((2, 10, 10, 10), 512, 2)])
 def test_layernorm_bwd_deferred_parameter_gradients(dt, shape, C, shift):
     """the parameter gradients as per-workgroup partial sums + a later column-sum launch (nmh_layernorm_bwd_deferred / _param_grad_reduce) against the
     atomic form of the same kernel: identical dx / dyw, dgamma / dbeta equal up to the fp32 summation order, accumulated INTO their buffers"""
