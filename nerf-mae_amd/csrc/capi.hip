@@ -348,6 +348,7 @@ int nmh_instnorm_bwd_apply(int dt, const void* dout, const void* out, const void
 }
 int nmh_instnorm_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, int64_t V, int C, float slope, void* stream) {
   CLR();
+  REQ(dout, x, stats, sums, dx);
   return k_in_bwd_apply_bg(dt, dout, x, stats, sums, dx, B, (long)V, C, slope, ST);
 }
 int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream) {

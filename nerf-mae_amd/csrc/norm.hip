@@ -900,7 +900,7 @@ int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stat
   if (dt != NMH_DT_BF16 || C != 48 || B < 1 || V < 1) return -2;
   int wps = 256 / B;
   if (wps < 1) wps = 1;
-  static const int unroll = [] { const char* e = getenv("NMH_INBWD_BG_U"); return e ? atoi(e) : 5; }();   // 74 / 82 / 90 VGPRs: 96 are free beside the weight gradient
+  static const int unroll = [] { const char* e = getenv("NMH_INBWD_BG_U"); const int u = e ? atoi(e) : 5; return u < 3 ? 3 : (u > 5 ? 5 : u); }();   // test-only override, clamped to {3, 4, 5}:   // 74 / 82 / 90 VGPRs: 96 are free beside the weight gradient
   const dim3 grid((unsigned)(B * wps));
   if (unroll <= 3) hipLaunchKernelGGL(in_bwd_apply_bg_kernel<3>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, stats, sums, (bf16_t*)dx, V, slope, wps);
   else if (unroll == 4) hipLaunchKernelGGL(in_bwd_apply_bg_kernel<4>, grid, dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, stats, sums, (bf16_t*)dx, V, slope, wps);

@@ -277,7 +277,6 @@ class _BlockFn(torch.autograd.Function):
         fused_attn = sw is not None and swin_shape and ops.swin_attn_ok(x, C, geom)
         # the dispatch decisions are taken ONCE, here, and kept on ctx: the layout of the saved tensors depends on them, and the thresholds / switches they
         # are derived from are module globals that a test (or a caller) may change between forward and backward
-        ctx.fused_attn = fused_attn
         ctx.tok_bwd = bool(ops.TOKEN_BWD and geom.rows != geom.tokens and ctx.needs_input_grad[0] and not ops.mlp_fused_ok(x, C, T)
                            and (fused_attn or ops.TOKEN_BWD_UNFUSED))
         if fused_attn:
@@ -360,8 +359,10 @@ class _BlockFn(torch.autograd.Function):
             wgrad(dx2, h_act, b.mlp[3], rowscale=sd2)
             wgrad(dh, x1n, b.mlp[0])
             if q is not None and ops.EARLY_MLP_WGRAD:
-                # stage 0 (the end of the backward pass): the MLP pair's gradients -- 10 of the block's 16 operand passes -- start under the block's own
-                # attention-branch chain instead of waiting for the stage flush (block 0's would run exposed behind the last input-gradient kernel)
+                # (NMH_EARLY_MLP_WGRAD=1, off by default) every block that takes the fused MLP backward -- with the default MLP_FUSED_WIDTHS = {96} that is
+                # stage 0, the end of the backward pass: the MLP pair's gradients -- 10 of the block's 16 operand passes -- start under the block's own
+                # attention-branch chain instead of waiting for the stage flush.  The flush is a background flush of EVERYTHING queued so far (LayerNorm /
+                # pad items included): it splits the stage's grouped launches per block
                 q.flush()
         else:
             dh = ops.gemm_nt(dx2, pk[key + "fc2.wT"].view(4 * C, C), act=2, C2=h_pre, rowscale=sd2, rows_per_scale=tps)

@@ -754,19 +754,33 @@ def swin_mlp_split_ws(M, C, device):
     """the zero-initialised workspace of the two-workgroups-per-tile MLP forward (None: this shape runs one workgroup per tile); one per shape, device AND
     stream: the blocks of a stage share it (their launches are ordered on the stream and each leaves the arrival counters zero), launches of the same shape on
     another stream -- a second model instance, a standalone stage -- get their own, so that they cannot corrupt each other's counters and partial sums.
+    A workspace is never allocated inside a stream capture (it would come from the graph's private pool and outlive the graph in this table): during a
+    capture the entry of the capture stream must already exist -- GraphedTrainStep warms up on the stream it then captures on -- and a missing one raises.
     (A launch that aborts half-way leaves non-zero counters behind: swin_mlp_split_ws_reset() clears them.)"""
     key = (device.index, M, C, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SPLIT_WS:
         n = int(lib().call("nmh_swin_mlp_split_ws_bytes", M, C))
+        if n > 0 and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("split-MLP workspace requested for the first time inside a stream capture: run one eager step on the capture stream first")
         _SPLIT_WS[key] = torch.zeros(n, dtype=torch.uint8, device=device) if n > 0 else None
     return _SPLIT_WS[key]
 
 
-def swin_mlp_split_ws_reset():
-    """zero every split-MLP workspace (after a failed / aborted launch: the arrival counters must be zero before the next launch)"""
+def swin_mlp_split_ws_reset(drop: bool = False):
+    """zero every split-MLP workspace (after a failed / aborted launch, and at the start of every graph capture: the arrival counters must be zero before the
+    next launch); drop=True releases them instead (trainer reset / a stream that is gone)"""
+    if drop:
+        _SPLIT_WS.clear()
+        return
     for ws in _SPLIT_WS.values():
         if ws is not None:
             ws.zero_()
+
+
+def swin_mlp_split_ws_drop_stream(stream_handle: int):
+    """release the workspaces keyed by a stream that is going away (a GraphedTrainStep being deleted)"""
+    for k in [k for k in _SPLIT_WS if k[3] == stream_handle]:
+        del _SPLIT_WS[k]
 
 
 def swin_mlp_fwd(x1, gamma, beta, wstream, b1, b2, rowscale=None, rows_per_scale=1, eps=1e-5, want_hact=False, split=None):

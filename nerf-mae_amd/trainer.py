@@ -148,6 +148,14 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep: the data-parallel step expects the gradient segments of a 4-stage encoder + decoder")
         self.comm_captured = False
 
+    def __del__(self):
+        st = getattr(self, "_capture_stream", None)
+        if st is not None:   # workspaces keyed by this step's capture stream go with it (ops.swin_mlp_split_ws)
+            try:
+                ops.swin_mlp_split_ws_drop_stream(st.cuda_stream)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
     def set_extents(self, ext):
         """valid extents [B][3] of the batch now in `self.x` (host list / tensor) -> static device buffer, through a pinned ring"""
         self._ext_host = [[int(v) for v in row] for row in (ext.tolist() if hasattr(ext, "tolist") else ext)]   # sent with the next step's parameters
@@ -178,8 +186,12 @@ class GraphedTrainStep:
         # split mode: the eager path's autograd triggers would issue collectives on the comm stream inside the capture, graph mode owns the
         # exchange (see __call__); captured mode: the triggers ARE the exchange
         self.model._reducer = self.reducer if self.comm_captured else None
+        # ONE stream for the warm-up and for every capture below: workspaces that are keyed by the launch stream (ops.swin_mlp_split_ws) are then
+        # allocated eagerly by the warm-up, never from a graph's private pool, and their arrival counters are cleared before the capture
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        ops.swin_mlp_split_ws_reset()
+        self._capture_stream = s
         with torch.cuda.stream(s):
             for _ in range(self._warm):
                 # warm-up touches no optimizer state (lazy kernel attributes / allocator pools only)
@@ -197,7 +209,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self._g1 = torch.cuda.CUDAGraph()
         if not split:
-            with torch.cuda.graph(self._g1, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(self._g1, stream=s, capture_error_mode=_CAPTURE_MODE):
                 out = self._fwd_bwd(zero=False)
                 if self.comm_captured:
                     self.reducer.finish()      # ranges whose trigger did not fire (the embed tail) + join of the comm stream
@@ -212,18 +224,18 @@ class GraphedTrainStep:
         #                  stage-2/3 parameters is in flight while two thirds of stage 2 are still in backward)
         #   gb[3] = backward of stages 1, 0, the embed                    -> all-reduce [mask token, embed, stage 0, stage 1]
         #   g2 = clip + AdamW
-        with torch.cuda.graph(self._g1, capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(self._g1, stream=s, capture_error_mode=_CAPTURE_MODE):
             out = self._split_a(zero=False)
             self.losses = torch.stack([o.detach() for o in out[:3]])
         pool = self._g1.pool()
         self._gb = []
         for k in range(len(self._pieces["back"])):
             gk = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gk, pool=pool, capture_error_mode=_CAPTURE_MODE):
+            with torch.cuda.graph(gk, pool=pool, stream=s, capture_error_mode=_CAPTURE_MODE):
                 self._split_back(k)
             self._gb.append(gk)
         self._g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g2, pool=pool, capture_error_mode=_CAPTURE_MODE):
+        with torch.cuda.graph(self._g2, pool=pool, stream=s, capture_error_mode=_CAPTURE_MODE):
             self.opt.launch()
         self._gb1 = self._gb[0]            # (kept for callers that test for the split mode)
         self._pieces = None

@@ -189,3 +189,57 @@ def test_skip_full_size_bf16_trains():
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
     # top-down pathway: level 3 feeds every finer level, so its lateral weights see gradient from all four outputs
     assert m.fpn_neck.lateral_convs[3].weight.grad.abs().sum() > 0
+
+
+_FULL = {}
+
+
+def _full_size_oracle():
+    """BASELINE config 5 at full size on the host: FPNSkipOracle(resolution=160) forward + backward on one synthetic grid, the reference's own initialisation
+    (+ small non-zero biases / bias tables, as test_skip_hip_bf16_close_to_oracle); computed once for the fp32 and the bf16 case"""
+    if not _FULL:
+        torch.manual_seed(11)
+        torch.set_num_threads(max(1, min(64, (torch.get_num_threads() or 1) * 4)))
+        ora = O.FPNSkipOracle(resolution=160)
+        with torch.no_grad():
+            for n, p in ora.named_parameters():
+                if p.requires_grad and (n.endswith("bias") or "relative_position_bias_table" in n):
+                    p.add_(0.02 * torch.randn_like(p))
+        ora.eval()
+        x = torch.stack([O.synthetic_grid((160, 160, 160), 5)])
+        yo = ora(x)
+        w = [torch.randn(y.shape, generator=torch.Generator().manual_seed(40 + i)) / y.numel() ** 0.5 for i, y in enumerate(yo)]
+        sum((y * wi).sum() for y, wi in zip(yo, w)).backward()
+        _FULL.update(sd={k: v.detach().clone() for k, v in ora.state_dict().items()}, x=x, w=w, y=[y.detach() for y in yo],
+                     g={n: p.grad.detach().clone() for n, p in ora.named_parameters() if p.grad is not None})
+    return _FULL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol,cos_all,cos_each", [(torch.float32, 1e-3, 0.9999, 0.999), (torch.bfloat16, 5e-2, 0.995, 0.9)], ids=["fp32", "bf16"])
+def test_skip_full_size_matches_oracle(dtype, tol, cos_all, cos_each):
+    """BASELINE config 5 at FULL size (feature_extractor.py:1176-1187, fpn.py:135-185): swin_s encoder + FPN(256) on one 160^3 grid against the oracle --
+    the four NCDHW maps (40^3 ... 5^3 x 256) to `tol` of their max-norm, every parameter gradient by cosine"""
+    from nerf_mae_amd.fpn import SwinTransformer_FPN_Pretrained_Skip
+    ref = _full_size_oracle()
+    m = SwinTransformer_FPN_Pretrained_Skip(resolution=160, is_eval=True, compute_dtype=dtype)
+    m.load_state_dict(ref["sd"], strict=True)
+    m = m.cuda().eval()
+    yh = m(ref["x"].cuda())
+    assert [tuple(y.shape) for y in yh] == [(1, 256, 40, 40, 40), (1, 256, 20, 20, 20), (1, 256, 10, 10, 10), (1, 256, 5, 5, 5)]
+    sum((y * wi.cuda()).sum() for y, wi in zip(yh, ref["w"])).backward()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(yh, ref["y"])):
+        assert relerr(a, b) < tol, ("map", i, relerr(a, b))
+    fa, fb, worst = [], [], (1.0, "")
+    for n, p in m.named_parameters():
+        if not p.requires_grad or n not in ref["g"]:
+            continue
+        a, b = p.grad.float().cpu().flatten(), ref["g"][n].flatten()
+        fa.append(a)
+        fb.append(b)
+        if b.norm() > 0:
+            worst = min(worst, ((torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item(), n))
+    fa, fb = torch.cat(fa), torch.cat(fb)
+    assert (torch.dot(fa, fb) / (fa.norm() * fb.norm())).item() > cos_all
+    assert worst[0] > cos_each, worst

@@ -17,9 +17,6 @@ done
 run "default, second run" 8 X=0
 run "one workgroup per row tile in the stage-2 MLP forward" 8 NMH_SWIN_SPLIT=0
 run "LayerNorm parameter gradients by atomics in the launch" 8 NMH_LN_DEFER=0
-run "fused MLP backward" 8 NMH_SWIN_BWD=mlp
-run "fused attention backward" 8 NMH_SWIN_BWD=attn
-run "fused qkv + LN1 backward" 8 NMH_SWIN_BWD=qkv
 run "window-ordered backward of the attention branch at stage 2" 8 NMH_TOKEN_BWD=0
 run "default, third run" 8 X=0
 NMH_SWIN_DBG=8 python tools/swin_phase_cycles.py 8 > gpurun_out/${T}_swin_phase_cycles.txt 2>&1
