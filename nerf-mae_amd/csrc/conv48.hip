@@ -26,11 +26,13 @@ constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
 constexpr int LINE = HX * 96 + 16, PLANE = HY * LINE + 16, HALO = (TZ + 2) * PLANE;
 constexpr int NSTEP = 41, CSTEPS = 9, WCHUNK = CSTEPS * 3 * 1024;
 constexpr int LDS_BYTES = HALO + 2 * WCHUNK + 2 * 96 * 4;  // halo, weight ring, statistics accumulators
+constexpr int AP_TAB = 6 * 64;                             // AP: (-mean, rstd) of the 48 input channels of one sample, [chunk c6][channel pair j]{-mu0, -mu1, rs0, rs1}
+constexpr int LDS_BYTES_AP = LDS_BYTES + AP_TAB;
 constexpr int HCH = (TZ + 2) * HY * HX * 6;  // 16-B chunks in the halo (6480)
 constexpr int HREG = (HCH + 511) / 512;      // 13
 static_assert(HREG == 13, "the halo request schedule (4+3+3+3 over weight chunks 0-3) assumes 13 loads per thread");
 static_assert(LINE % 32 == 16 && PLANE % 32 == 16, "bank-half alternation");
-static_assert(LDS_BYTES <= 163840, "LDS budget");
+static_assert(LDS_BYTES_AP <= 163840, "LDS budget");
 }  // namespace c48
 
 struct C48Args {
@@ -43,6 +45,10 @@ struct C48Args {
   // backward-reduce variant (RB: the launch is the input gradient of a conv whose INPUT was lrelu(InstanceNorm(Y1))): stats_acc receives the two
   // sums the InstanceNorm backward needs, sum g and sum g * yhat with g = out * lrelu'(Y1 - mean), yhat = (Y1 - mean) * rstd (nmh_instnorm_bwd_reduce)
   const bf16_t* Y1; const float* stats1; float slope;
+  // apply-on-load variant (AP: the launch is a conv whose INPUT is lrelu(InstanceNorm(X)), X = the raw output of the previous conv): the halo is normalised
+  // and activated in registers on its way to LDS (stats1 = (mean, rstd) pairs of X, [B][48][2]); A1 (optional) receives the normalised tensor -- the operand
+  // of this conv's weight gradient -- copied out of the LDS halo's interior under the k-loop.  Replaces the stand-alone nmh_instnorm_apply pass (6.3 GB at 8 x 160^3)
+  bf16_t* A1;
   // multi-block variant (MB): Cin = 48 ncib, Cout = 48 ncob; a work item is (tile, output block cob, input block cib), cib innermost:
   // the accumulators persist over cib, the epilogue runs after the last one; Wk holds one fragment-ordered image per (cob, cib)
   int ncib, ncob, ldx, ldy;    // ldx / ldy: channels per voxel of X / Y
@@ -66,9 +72,10 @@ __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b
 
 // DBG (diagnostic builds only, NMH_C48_DBG): 1 = no output stores, 2 = no halo prefetch / LDS refill, 4 = no weight DMA and no
 // chunk barriers, 8 = no MFMAs (operand traffic only), 16 = no operand reads in the k-loop (MFMAs only).  DBG = 0 is the product.
-template <int DBG, bool MB = false, bool RB = false>
+template <int DBG, bool MB = false, bool RB = false, bool AP = false>
 __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   using namespace c48;
+  static_assert(!AP || (!MB && !RB && DBG == 0), "apply-on-load: plain forward instantiation only");
   constexpr long WBLK = (long)NSTEP * 3 * 512;   // elements of one (cob, cib) weight image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
@@ -83,6 +90,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   const long tbeg = (long)xcd * per, tend = (tbeg + per < total) ? tbeg + per : total;
 
   uint4 hreg[HREG];
+  unsigned hokm = 0;   // AP: bit i = halo request i of the tile in flight lies inside the volume (outside, the conv pads the NORMALISED tensor with zeros)
   const unsigned vox_bytes = MB ? (unsigned)a.ldx * 2u : 96u;
   const unsigned sample_bytes = (unsigned)a.D * a.H * a.W * vox_bytes;  // one sample of X (< 4 GiB: checked at launch)
   // halo request i (of 13) of the tile at origin (b, z0, y0, x0): chunk id cid = tid + 512 i -> (line, within).  The requests of the
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     const bool ok = line < (TZ + 2) * HY && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
     const unsigned off = ok ? (unsigned)((z * a.H + y) * a.W + x) * vox_bytes + (unsigned)((MB ? cib * 96 : 0) + c6 * 16) : 0xFFFFFFF0u;
     hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    if constexpr (AP) hokm = i == 0 ? (ok ? 1u : 0u) : (hokm | (ok ? (1u << i) : 0u));
   };
   // LDS byte offset / 16 of halo request i (tile-invariant): two per VGPR.  Recomputing them per tile (two integer divisions by
   // multiply-shift, predication and a serial within/line update per store: ~17 VALU instructions of which two quarter-rate
@@ -114,15 +123,67 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     const int cid = tid + 512 * i;
     const int line = (cid * 4855) >> 19, within = cid - line * (HX * 6);
     const int hz = (line * 205) >> 11, hy = line - hz * HY;
-    const unsigned u = (unsigned)(hz * PLANE + hy * LINE + within * 16) >> 4;   // < 2^13 (garbage for cid >= HCH: never stored)
+    unsigned u = (unsigned)(hz * PLANE + hy * LINE + within * 16) >> 4;   // < 2^13 (garbage for cid >= HCH: never stored)
+    if constexpr (AP) { const int hx = (within * 43) >> 8; u = (u & 0x1fffu) | ((unsigned)(within - hx * 6) << 13); }   // + the chunk's 8-channel group c6 in bits 13-15
     if (i & 1) hoff[i >> 1] |= u << 16; else hoff[i >> 1] = u;
   }
   auto halo_sstore = [&]() {
 #pragma unroll
     for (int i = 0; i < HREG; ++i) {
-      const unsigned off = (i & 1) ? ((hoff[i >> 1] >> 12) & 0xFFFF0u) : ((hoff[i >> 1] << 4) & 0xFFFF0u);
+      const unsigned off = (i & 1) ? ((hoff[i >> 1] >> 12) & (AP ? 0x1FFF0u : 0xFFFF0u)) : ((hoff[i >> 1] << 4) & (AP ? 0x1FFF0u : 0xFFFF0u));
       if (i < HREG - 1 || tid < HCH - 512 * (HREG - 1)) *reinterpret_cast<uint4*>(halo + off) = hreg[i];
     }
+  };
+  // AP: halo request i, landed, -> lrelu((x - mean) * rstd) in place (the arithmetic of in_apply_kernel, csrc/norm.hip, operation for operation: same bits),
+  // zero outside the volume.  The sample's constants come from the LDS table (one 16-byte read per channel pair).
+  typedef float tf2 __attribute__((ext_vector_type(2)));
+  char* const aptab = smem + LDS_BYTES;
+  auto ap_transform = [&](int i) {
+    if constexpr (AP) {
+      const unsigned c6 = ((i & 1) ? (hoff[i >> 1] >> 29) : (hoff[i >> 1] >> 13)) & 7u;
+      const float4* tab = reinterpret_cast<const float4*>(aptab + c6 * 64);
+      const tf2 slope2 = {a.slope, a.slope};
+      unsigned w[4] = {hreg[i].x, hreg[i].y, hreg[i].z, hreg[i].w};
+      const bool ok = (hokm >> i) & 1u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 cst = tab[j];
+        const tf2 nmu = {cst.x, cst.y}, rs = {cst.z, cst.w};
+        const tf2 xv = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+        tf2 y, ys;
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(xv), "v"(nmu));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(y), "v"(rs));
+        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ys) : "v"(y), "v"(slope2));
+        const unsigned r = pk_bf16(fmaxf(y[0], ys[0]), fmaxf(y[1], ys[1]));   // 0 < slope < 1: max(y, slope y) == (y > 0 ? y : slope y)
+        w[j] = ok ? r : 0u;
+      }
+      hreg[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  };
+  // AP: the table of sample b (threads 0-47: one channel's (mean, rstd) pair each); visible after the next barrier
+  auto ap_table = [&](int b) {
+    if constexpr (AP) {
+      if (tid < 48) {
+        const float2 ms = reinterpret_cast<const float2*>(a.stats1)[(long)b * 48 + tid];
+        float* t = reinterpret_cast<float*>(aptab + (tid >> 3) * 64 + ((tid & 7) >> 1) * 16);
+        t[tid & 1] = -ms.x;
+        t[2 + (tid & 1)] = ms.y;
+      }
+    }
+  };
+  // AP: interior chunk j (of 6 per thread) of the CURRENT tile's halo -- the normalised input -- LDS -> A1
+  auto ap_copy_read = [&](int j) -> uint4 {
+    const int cid = tid + 512 * j, vox = (cid * 10923) >> 16, c6 = cid - vox * 6;   // / 6 (cid < 4096)
+    const int x = vox & 15, line = vox >> 4, y = line & 7, z = line >> 3;
+    return *reinterpret_cast<const uint4*>(halo + (z + 1) * PLANE + (y + 1) * LINE + (x + 1) * 96 + c6 * 16);
+  };
+  auto ap_copy_store = [&](int j, const uint4& v, int b, int z0, int y0, int x0) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    const int cid = tv + 512 * j, vox = (cid * 10923) >> 16, c6 = cid - vox * 6;
+    const int x = x0 + (vox & 15), line = vox >> 4, y = y0 + (line & 7), z = z0 + (line >> 3);
+    if (z < a.D && y < a.H && x < a.W)
+      *reinterpret_cast<uint4*>(a.A1 + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8) = v;
   };
   // weight chunk ck (steps [9ck, min(9ck+9,41))) -> LDS ring slot `buf` by LDS-DMA: the image is lane-linear
   // (dst = wave-uniform base + lane*16), so no VGPR staging and no ds_write pass; completes before the next barrier.
@@ -161,6 +222,13 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, cx0, sample_bytes, 0);
   w_dma(wfirst, 0, 0);
   if (DBG & 4) w_dma(wfirst, 1, 1);
+  int ap_b = cb;   // AP: sample whose constants the LDS table holds
+  if constexpr (AP) {
+    ap_table(cb);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < HREG; ++i) ap_transform(i);
+  }
   halo_sstore();
   __syncthreads();
   int wb = 0;  // LDS buffer holding chunk 0 of the current tile
@@ -227,6 +295,12 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     int nb = cb, nz0 = cz0, ny0 = cy0, nx0 = cx0;
     if (has_next && (!MB || tn != t)) c48_tile_origin(a, split ? tn / a.ncob : tn, nb, nz0, ny0, nx0);
     const unsigned nbytes = pf_next ? sample_bytes : 0u;
+    if constexpr (AP) {
+      // the next tile belongs to another sample: its constants replace the table now -- every transform of THIS tile's halo ran during the previous tile,
+      // the first one of the next tile's comes after the barrier that closes weight chunk 0
+      if (has_next && nb != ap_b) { ap_table(nb); ap_b = nb; }
+    }
+    uint4 cpv = make_uint4(0, 0, 0, 0);   // AP: interior chunk on its way LDS -> A1
     const bf16_t* const wcur = MB ? a.Wk + (long)(cob * a.ncib + cib) * WBLK : a.Wk;
     const bf16_t* const wnxt = MB ? a.Wk + (long)(nco * a.ncib + nci) * WBLK : a.Wk;
     if (!MB || cib == 0) {
@@ -279,6 +353,18 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
             // chunk 0: steps 4,5,6,8; chunks 1-3: steps 4,6,8
             const int k = (hcnt == 4) ? (sl == 4 ? 0 : sl == 5 ? 1 : sl == 6 ? 2 : sl == 8 ? 3 : -1) : (hcnt == 3) ? (sl == 4 ? 0 : sl == 6 ? 1 : sl == 8 ? 2 : -1) : -1;
             if (k >= 0) halo_gload_one(hbase + k, nb, nz0, ny0, nx0, nbytes, nci);
+          }
+          if constexpr (AP) {
+            // VALU / LDS work dealt over the k-steps like the requests: chunk 0 copies the six interior chunks of this tile's (normalised) halo out to A1 (read
+            // at step j, stored at step j + 1); chunks 1-4 normalise the requests issued during the previous chunk (4 + 3 + 3 + 3), one per step
+            if (ck == 0 && a.A1) {
+              if (sl >= 1 && sl <= 6) ap_copy_store(sl - 1, cpv, cb, cz0, cy0, cx0);
+              if (sl <= 5) cpv = ap_copy_read(sl);
+            }
+            if (ck >= 1) {
+              const int tb = ck == 1 ? 0 : 4 + 3 * (ck - 2), tn_ = ck == 1 ? 4 : 3;
+              if (sl < tn_ && pf_next) ap_transform(tb + sl);
+            }
           }
           if (DBG & 8) {
 #pragma unroll
@@ -447,11 +533,12 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 
 
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st,
-             const void* Y1, const float* stats1, float slope) {
+             const void* Y1, const float* stats1, float slope, int apply_on_load, void* A1) {
   using namespace c48;
   C48Args a;
-  a.Y1 = (const bf16_t*)Y1; a.stats1 = stats1; a.slope = slope;
+  a.Y1 = (const bf16_t*)Y1; a.stats1 = stats1; a.slope = slope; a.A1 = (bf16_t*)A1;
   if (Y1 && (!stats1 || !stats_acc || accumulate)) return -1;
+  if (apply_on_load && (Y1 || !stats1 || accumulate || !(slope > 0.f && slope < 1.f))) return -1;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
@@ -495,6 +582,17 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
     NMH_CHECK_LAUNCH();
     return 0;
   }
+  if (apply_on_load) {
+    static NmhPerDeviceOnce attr_ap;
+    if (attr_ap.need()) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_AP);
+      if (e != hipSuccess) return (int)e;
+      attr_ap.set();
+    }
+    hipLaunchKernelGGL((conv48_kernel<0, false, false, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES_AP, st, a);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(conv48_kernel<0>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
@@ -508,7 +606,7 @@ int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int
   if (Cin % 48 || Cout % 48 || Cin <= 0 || Cout <= 0) return -2;
   if ((long)D * H * W * Cin * 2 >= (1L << 32)) return -2;   // 32-bit buffer offsets inside one sample
   C48Args a;
-  a.Y1 = nullptr; a.stats1 = nullptr; a.slope = 0.f;
+  a.Y1 = nullptr; a.stats1 = nullptr; a.slope = 0.f; a.A1 = nullptr;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
