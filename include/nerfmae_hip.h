@@ -89,11 +89,6 @@ NMH_API int nmh_conv3d_k3_c48(const void* X, const void* Wk, void* Y, int B, int
  * sums [B][48][2] fp64 (zeroed here) = (sum g, sum g * yhat) with g = dX * lrelu'(Y1 - mean), yhat = (Y1 - mean) * rstd, stats1 = (mean, rstd) pairs
  * [B][48][2] -- what nmh_instnorm_bwd_reduce(dX, Y1, rmode 0) would produce in a separate pass over both tensors. */
 NMH_API int nmh_conv3d_k3_c48_bwd_reduce(const void* dY, const void* Wkd, void* dX, int B, int D, int H, int W, const void* Y1, const float* stats1, float slope, double* sums, void* stream);
-/* The forward launch of that kernel when the conv's INPUT is LeakyReLU(InstanceNorm3d(X)) with X the raw output of the previous conv (decoder1's
- * norm1 -> lrelu -> conv2, unetr_block.py:58-62): the normalisation and activation are applied to the halo in registers on its way to LDS, so the
- * stand-alone nmh_instnorm_apply pass over the 160^3 tensor is gone.  stats = (mean, rstd) pairs [B][48][2] of X (nmh_instnorm_finalize), 0 < slope < 1;
- * A (optional) receives lrelu(IN(X)) -- bit-identical to nmh_instnorm_apply's output -- for this conv's weight gradient; Y and stats_acc as nmh_conv3d_k3_c48. */
-NMH_API int nmh_conv3d_k3_c48_norm_in(const void* X, const float* stats, float slope, const void* Wk, void* Y, void* A, int B, int D, int H, int W, double* stats_acc, void* stream);
 /* The LDS-halo kernel on 48-channel blocks: Cin, Cout multiples of 48 (the 40^3 decoder level of swin_t/s: 96 / 192 channels;
  * UnetResBlock convs, unetr_block.py:35-44); Wk = one fragment-ordered image per (output block, input block), output-block-major
  * (pack modes 6 / 7 on a [Cout][Cin][27] weight).  No fused statistics. */

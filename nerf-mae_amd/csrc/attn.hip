@@ -446,223 +446,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_kernel(const T* __restric
   for (int t = threadIdx.x; t < 343; t += 64 * NW) atomicAdd(dtable + t * heads + h, sDB[t]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// bf16, round 6: FOUR waves per (window, head).  The one-wave kernel above is a single dependent chain of eight score tiles per wave at 248 VGPRs -- six waves
-// per CU, ~18 us of one SIMD per pair whatever the residency (profiles/r5m_attn_bwd_waves_per_cu_sweep_not_kept.txt).  Here a 256-thread workgroup owns the
-// pair: Q, K, V, dO rows are staged ONCE in LDS (each lane loads 16 bytes of one row per tensor), wave w runs query tile w of phase A and key tile w of phase B
-// against row fragments read from LDS, P^T and D cross the waves through LDS (the P cache of round 5), and two workgroup barriers replace the wave barriers.
-// A wave keeps one tile of state (<= 128 VGPRs: four waves per SIMD, sixteen per CU), its chain is a quarter as long, and the next window's rows are requested
-// before phase B.  Same arithmetic, operation for operation, as attn_bwd_kernel<bf16_t> (P rounded to bf16 for phase B): bit-identical dqkv, d(bias) up to
-// the order of its atomics.
-template <int DBG>   // DBG = 1 (NMH_ATTN_DBG, diagnostic builds only): per-phase s_memtime totals of wave 0 are added to dtable[0..7] instead of the bias gradient
-__global__ __launch_bounds__(256, 4) void attn_bwd4_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ table, const bf16_t* __restrict__ dout,
-                                                           const float* __restrict__ lse, bf16_t* __restrict__ dqkv, float* __restrict__ dtable, int heads, int C,
-                                                           WinMap wm, long nwin, bf16_t* __restrict__ dqkv_tok) {
-  typedef bf16_t T;
-  constexpr int RS = OddRS32<64>::v, PRS = 136;
-  __shared__ __attribute__((aligned(16))) char tK[64 * RS], tQ[64 * RS], tV[64 * RS], tO[64 * RS];
-  __shared__ __attribute__((aligned(16))) char tP[64 * PRS];
-  __shared__ float sB[344], sDB[344];
-  __shared__ __attribute__((aligned(16))) float sD[64];
-  __shared__ __attribute__((aligned(16))) float sL[64];
-  __shared__ unsigned sR[16];
-  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.y;
-  const int nW = (wm.PH >> 2) * (wm.PW >> 2) * (wm.PD >> 2);
-  const bool shifted = (wm.s0 + wm.s1 + wm.s2) > 0;
-  const long ld = 3L * C;
-  const float scale = 0.17677669529663689f;
-  for (int t = threadIdx.x; t < 344; t += 256) { sB[t] = t < 343 ? table[t * heads + h] : 0.f; sDB[t] = 0.f; }
-  float dsacc[4][4];   // [jt][r]: bin (wave - jt + 3) * 49 + binA - r
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dsacc[q][r] = 0.f;
-  const unsigned char* sRb = reinterpret_cast<const unsigned char*>(sR);
-
-  // this lane's share of a window: 16 bytes (head-dim slice 8 g .. 8 g + 7) of row 16 wave + li of Q, K, V and dO
-  Frag<T> nq, nk, nv, nd;
-  float nl = 0.f;
-  int ntk = 0;
-  auto request = [&](long win) {
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int g = lane >> 4, li = lane & 15, row = 16 * wave + li;
-    const T* qb = qkv + win * 64 * ld + h * 32;
-    nq = gfrag<T>(qb, ld, row, g); nk = gfrag<T>(qb + C, ld, row, g); nv = gfrag<T>(qb + 2 * C, ld, row, g);
-    ntk = dqkv_tok ? (int)win_to_tok(wm, win * 64 + row) : 0;
-    if (dqkv_tok) {
-      if (ntk >= 0) nd = gfrag<T>(dout + h * 32, (long)C, ntk, g);
-      else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) nd.v[j] = 0;
-      }
-    } else nd = gfrag<T>(dout + win * 64 * C + h * 32, (long)C, row, g);
-    if (wave == 0) nl = lse[(win * heads + h) * 64 + lane];
-  };
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-  auto stamp = [&](int slot) {
-    if (DBG & 1) { const long long now = (long long)__builtin_amdgcn_s_memtime(); ph[slot] += now - tlast; tlast = now; }
-  };
-  if (DBG & 1) tlast = (long long)__builtin_amdgcn_s_memtime();
-  long win = blockIdx.x;
-  if (win < nwin) request(win);
-  stamp(0);
-  for (; win < nwin; win += gridDim.x) {
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int g = lane >> 4, li = lane & 15;
-    const int c1 = (li >> 2) - g, c2 = li & 3;
-    const int binA = (c1 + 3) * 7 + c2 + 3;  // phase A (i = 16it+li, j = 16jt+4g+r): binA + (it-jt+3)*49 - r
-    const int tkw = ntk;                      // token of window row 16 wave + li (token mode), -1 = pad
-    T* const dqb = dqkv + win * 64 * ld + h * 32;
-    {
-      const int row = 16 * wave + li;
-      frag_to_lds<T>(tQ, RS, row, g, nq); frag_to_lds<T>(tK, RS, row, g, nk); frag_to_lds<T>(tV, RS, row, g, nv); frag_to_lds<T>(tO, RS, row, g, nd);
-      if (wave == 0) {
-        sL[lane] = nl;
-        if (shifted) reinterpret_cast<unsigned char*>(sR)[lane] = (unsigned char)token_region(wm, (int)(win % nW), lane);
-      }
-    }
-    stamp(1);
-    __syncthreads();
-    stamp(2);
-    // ---------------- phase A: query tile it = wave ----------------
-    {
-      const int it = wave;
-      f32x4 p[4], dp[4];
-      {
-        const Frag<T> dfi = lds_row_frag<T>(tO, RS, it * 16 + li, g), qfi = lds_row_frag<T>(tQ, RS, it * 16 + li, g);
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt) {
-          const Frag<T> kfj = lds_row_frag<T>(tK, RS, jt * 16 + li, g), vfj = lds_row_frag<T>(tV, RS, jt * 16 + li, g);
-          p[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(p[jt], kfj, qfi);
-          dp[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[jt], vfj, dfi);
-        }
-      }
-      const int i = 16 * it + li;
-      const unsigned ri = shifted ? sRb[i] : 0u;
-      const float L = sL[i];
-      float dsum = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const unsigned rw = shifted ? sR[4 * jt + g] : 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = p[jt][r] * scale + sB[binA + (it - jt + 3) * 49 - r];
-          if (shifted && ((rw >> (8 * r)) & 255u) != ri) v += -100.0f;
-          const float e = __expf(v - L);
-          p[jt][r] = e;
-          dsum += e * dp[jt][r];
-        }
-      }
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const unsigned w01 = pk_bf16(p[jt][0], p[jt][1]), w23 = pk_bf16(p[jt][2], p[jt][3]);
-        char* const q = tP + (16 * jt + 4 * g) * PRS + i * 2;
-        *reinterpret_cast<unsigned short*>(q) = (unsigned short)(w01 & 0xffffu);
-        *reinterpret_cast<unsigned short*>(q + PRS) = (unsigned short)(w01 >> 16);
-        *reinterpret_cast<unsigned short*>(q + 2 * PRS) = (unsigned short)(w23 & 0xffffu);
-        *reinterpret_cast<unsigned short*>(q + 3 * PRS) = (unsigned short)(w23 >> 16);
-      }
-      dsum += __shfl_xor(dsum, 16, 64);
-      dsum += __shfl_xor(dsum, 32, 64);
-      if (g == 0) sD[i] = dsum;
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ds = p[jt][r] * (dp[jt][r] - dsum);
-          dp[jt][r] = ds;
-          dsacc[jt][r] += ds;
-        }
-      // dQ^T[d][i] = sum_j K[j][d] dS^T[j][i]
-      f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const Frag<T> a = pack_frag(dp[2 * ks], dp[2 * ks + 1], (T*)nullptr);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const Frag<T> b = lds_frag_t(tK, RS, ks * 32, dt * 16, lane, (T*)nullptr);
-          mma(o[dt], b, a);
-        }
-      }
-      T* const rowp = (dqkv_tok && tkw >= 0) ? dqkv_tok + (long)tkw * ld + h * 32 : dqb + (long)i * ld;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) if (!(DBG & 2) || o[dt][0] == 123.456f) store4(rowp + 16 * dt + 4 * g, o[dt], scale);
-    }
-    stamp(3);
-    __syncthreads();
-    stamp(4);
-    // the next window's rows travel while phase B runs
-    if (win + gridDim.x < nwin && !(DBG & 4)) request(win + gridDim.x);
-    // ---------------- phase B: key tile jt = wave ----------------
-    {
-      const int jt = wave;
-      f32x4 p[4], dp[4];  // [it]: query i = 16it+4g+r, key j = 16jt+li
-      const Frag<T> vfj = lds_row_frag<T>(tV, RS, jt * 16 + li, g);
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const Frag<T> dfi = lds_row_frag<T>(tO, RS, it * 16 + li, g);
-        dp[it] = f32x4{0.f, 0.f, 0.f, 0.f}; mma(dp[it], dfi, vfj);
-      }
-      const int j = 16 * jt + li;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const float4 D4 = *reinterpret_cast<const float4*>(&sD[16 * it + 4 * g]);
-        const float Dr[4] = {D4.x, D4.y, D4.z, D4.w};
-        const uint2 w = *reinterpret_cast<const uint2*>(tP + j * PRS + (16 * it + 4 * g) * 2);   // P[i = 16 it + 4 g + r][j] of phase A
-        const float e4[4] = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { p[it][r] = e4[r]; dp[it][r] = e4[r] * (dp[it][r] - Dr[r]); }
-      }
-      // dV^T[d][j] = sum_i dO[i][d] P[i][j];  dK^T[d][j] = sum_i Q[i][d] dS[i][j]
-      f32x4 ov[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, ok[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const Frag<T> ap = pack_frag(p[2 * ks], p[2 * ks + 1], (T*)nullptr);
-        const Frag<T> ad = pack_frag(dp[2 * ks], dp[2 * ks + 1], (T*)nullptr);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const Frag<T> bo = lds_frag_t(tO, RS, ks * 32, dt * 16, lane, (T*)nullptr);
-          mma(ov[dt], bo, ap);
-          const Frag<T> bq = lds_frag_t(tQ, RS, ks * 32, dt * 16, lane, (T*)nullptr);
-          mma(ok[dt], bq, ad);
-        }
-      }
-      T* const rowp = (dqkv_tok && tkw >= 0) ? dqkv_tok + (long)tkw * ld + h * 32 : dqb + (long)j * ld;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) if (!(DBG & 2) || ov[dt][0] == 123.456f) {
-        store4(rowp + 2 * C + 16 * dt + 4 * g, ov[dt], 1.0f);
-        store4(rowp + C + 16 * dt + 4 * g, ok[dt], scale);
-      }
-    }
-    stamp(5);
-    __syncthreads();
-    stamp(6);
-  }
-  if (DBG & 1) {
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < 7; ++i) atomicAdd(dtable + i, (float)ph[i]);
-      atomicAdd(dtable + 7, 1.0f);
-    }
-    return;
-  }
-  const int binA0 = ((((lane0 & 15) >> 2) - (lane0 >> 4)) + 3) * 7 + (lane0 & 3) + 3;
-  // lanes of one 16-lane group hit 16 distinct bins, lanes of different groups may share one: one group at a time keeps the ds_add_f32 of a wave conflict-free
-#pragma unroll
-  for (int ph = 0; ph < 4; ++ph) {
-    if ((lane0 >> 4) == ph) {
-#pragma unroll
-      for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&sDB[binA0 + (wave - jt + 3) * 49 - r], dsacc[jt][r]);
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < 343; t += 256) atomicAdd(dtable + t * heads + h, sDB[t]);
-}
-
 int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, const float* lse, void* dqkv, float* dtable, int heads, int C, const WinMap& wm, hipStream_t st,
                void* dqkv_tok) {
   if (C != heads * 32) return -2;
@@ -671,23 +454,6 @@ int k_attn_bwd(int dt, const void* qkv, const float* table, const void* dout, co
   // resident workgroups -- six waves per CU (248 VGPRs: two per SIMD by registers; 45 KB of LDS per 2-wave workgroup with the bf16 probability cache:
   // three workgroups per CU).  Rounds 3-5 measured 8 waves per CU and 4-wave workgroups for mid-size launches: within 5 % of this everywhere
   // (profiles/r5m_attn_bwd_waves_per_cu_sweep_not_kept.txt).
-  static const int bwd4 = [] { const char* e = getenv("NMH_ATTN_BWD4"); return e ? atoi(e) : 0; }();   // off: measured equal to the one-wave kernel at every stage shape (profiles/r6c_*)
-  if (dt == NMH_DT_BF16 && bwd4) {
-    // four waves per (window, head): one round of resident workgroups (four per CU by registers and LDS), each looping over its windows
-    long cap4 = (256L * 4) / heads;
-    if (cap4 < 1) cap4 = 1;
-    const long gx4 = nwin < cap4 ? nwin : cap4;
-    static const int dbg4 = [] { const char* e = getenv("NMH_ATTN_DBG"); return e ? atoi(e) : 0; }();
-    if (dbg4 == 2) hipLaunchKernelGGL(attn_bwd4_kernel<2>, dim3((unsigned)gx4, heads), dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
-    else if (dbg4 == 4) hipLaunchKernelGGL(attn_bwd4_kernel<4>, dim3((unsigned)gx4, heads), dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
-    else if (dbg4 == 6) hipLaunchKernelGGL(attn_bwd4_kernel<6>, dim3((unsigned)gx4, heads), dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm, nwin, (bf16_t*)dqkv_tok);
-    else if (dbg4) hipLaunchKernelGGL(attn_bwd4_kernel<1>, dim3((unsigned)gx4, heads), dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm,
-                                 nwin, (bf16_t*)dqkv_tok);
-    else hipLaunchKernelGGL(attn_bwd4_kernel<0>, dim3((unsigned)gx4, heads), dim3(256), 0, st, (const bf16_t*)qkv, table, (const bf16_t*)dout, lse, (bf16_t*)dqkv, dtable, heads, C, wm,
-                            nwin, (bf16_t*)dqkv_tok);
-    NMH_CHECK_LAUNCH();
-    return 0;
-  }
   const int nw = 2;
   long gx = (nwin + nw - 1) / nw;
   long cap = (256L * 6 / nw) / heads;

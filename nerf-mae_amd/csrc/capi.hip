@@ -138,11 +138,6 @@ int nmh_conv3d_k3_c48_bwd_reduce(const void* dY, const void* Wkd, void* dX, int 
   REQ(dY, Wkd, dX, Y1, stats1, sums);
   return k_conv48(dY, Wkd, dX, B, D, H, W, 0, sums, ST, Y1, stats1, slope);
 }
-int nmh_conv3d_k3_c48_norm_in(const void* X, const float* stats, float slope, const void* Wk, void* Y, void* A, int B, int D, int H, int W, double* stats_acc, void* stream) {
-  CLR();
-  REQ(X, stats, Wk, Y);
-  return k_conv48(X, Wk, Y, B, D, H, W, 0, stats_acc, ST, nullptr, stats, slope, 1, A);
-}
 int nmh_conv3d_k3_c48mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
   CLR();
   if (!X || !Wk || !Y) return -4;

@@ -26,13 +26,12 @@ constexpr int TZ = 4, TY = 8, TX = 16, HY = TY + 2, HX = TX + 2;
 constexpr int LINE = HX * 96 + 16, PLANE = HY * LINE + 16, HALO = (TZ + 2) * PLANE;
 constexpr int NSTEP = 41, CSTEPS = 9, WCHUNK = CSTEPS * 3 * 1024;
 constexpr int LDS_BYTES = HALO + 2 * WCHUNK + 2 * 96 * 4;  // halo, weight ring, statistics accumulators
-constexpr int AP_TAB = 6 * 64;                             // AP: (-mean, rstd) of the 48 input channels of one sample, [chunk c6][channel pair j]{-mu0, -mu1, rs0, rs1}
-constexpr int LDS_BYTES_AP = LDS_BYTES + AP_TAB;
-constexpr int HCH = (TZ + 2) * HY * HX * 6;  // 16-B chunks in the halo (6480)
-constexpr int HREG = (HCH + 511) / 512;      // 13
-static_assert(HREG == 13, "the halo request schedule (4+3+3+3 over weight chunks 0-3) assumes 13 loads per thread");
+constexpr int NLINE = (TZ + 2) * HY;         // 60 x-lines in the halo, 108 16-B chunks each
+constexpr int LPW = (NLINE + 7) / 8;         // lines per wave (8 waves): 8
+constexpr int HREG = 2 * LPW;                // two requests per line: 16
+static_assert(HREG == 16 && HX * 6 > 64 && HX * 6 <= 128, "the halo request schedule (4 per weight chunk 0-3) assumes 16 loads per thread, two per line");
 static_assert(LINE % 32 == 16 && PLANE % 32 == 16, "bank-half alternation");
-static_assert(LDS_BYTES_AP <= 163840, "LDS budget");
+static_assert(LDS_BYTES <= 163840, "LDS budget");
 }  // namespace c48
 
 struct C48Args {
@@ -45,10 +44,6 @@ struct C48Args {
   // backward-reduce variant (RB: the launch is the input gradient of a conv whose INPUT was lrelu(InstanceNorm(Y1))): stats_acc receives the two
   // sums the InstanceNorm backward needs, sum g and sum g * yhat with g = out * lrelu'(Y1 - mean), yhat = (Y1 - mean) * rstd (nmh_instnorm_bwd_reduce)
   const bf16_t* Y1; const float* stats1; float slope;
-  // apply-on-load variant (AP: the launch is a conv whose INPUT is lrelu(InstanceNorm(X)), X = the raw output of the previous conv): the halo is normalised
-  // and activated in registers on its way to LDS (stats1 = (mean, rstd) pairs of X, [B][48][2]); A1 (optional) receives the normalised tensor -- the operand
-  // of this conv's weight gradient -- copied out of the LDS halo's interior under the k-loop.  Replaces the stand-alone nmh_instnorm_apply pass (6.3 GB at 8 x 160^3)
-  bf16_t* A1;
   // multi-block variant (MB): Cin = 48 ncib, Cout = 48 ncob; a work item is (tile, output block cob, input block cib), cib innermost:
   // the accumulators persist over cib, the epilogue runs after the last one; Wk holds one fragment-ordered image per (cob, cib)
   int ncib, ncob, ldx, ldy;    // ldx / ldy: channels per voxel of X / Y
@@ -72,10 +67,9 @@ __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b
 
 // DBG (diagnostic builds only, NMH_C48_DBG): 1 = no output stores, 2 = no halo prefetch / LDS refill, 4 = no weight DMA and no
 // chunk barriers, 8 = no MFMAs (operand traffic only), 16 = no operand reads in the k-loop (MFMAs only).  DBG = 0 is the product.
-template <int DBG, bool MB = false, bool RB = false, bool AP = false>
+template <int DBG, bool MB = false, bool RB = false>
 __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   using namespace c48;
-  static_assert(!AP || (!MB && !RB && DBG == 0), "apply-on-load: plain forward instantiation only");
   constexpr long WBLK = (long)NSTEP * 3 * 512;   // elements of one (cob, cib) weight image
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
@@ -90,100 +84,52 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   const long tbeg = (long)xcd * per, tend = (tbeg + per < total) ? tbeg + per : total;
 
   uint4 hreg[HREG];
-  unsigned hokm = 0;   // AP: bit i = halo request i of the tile in flight lies inside the volume (outside, the conv pads the NORMALISED tensor with zeros)
   const unsigned vox_bytes = MB ? (unsigned)a.ldx * 2u : 96u;
-  const unsigned sample_bytes = (unsigned)a.D * a.H * a.W * vox_bytes;  // one sample of X (< 4 GiB: checked at launch)
-  // halo request i (of 13) of the tile at origin (b, z0, y0, x0): chunk id cid = tid + 512 i -> (line, within).  The requests of the
-  // NEXT tile are dealt one at a time over the k-steps of the current tile (see the chunk loop): a burst of 13 x 8 wave-loads backs
-  // up the CU's vector-memory path (measured ~40-75 cycles per 1-KB wave-load, latency-bound misses) and every wave then sits at
-  // issue in front of its MFMAs; one request every few k-steps never queues.
-  // `bytes` = sample_bytes, or 0 when there is no next tile: the request is still issued (no branch inside the k-loop) but every lane
-  // is out of range and reads zero without touching memory
-  auto halo_gload_one = [&](int i, int b, int z0, int y0, int x0, unsigned bytes, int cib) {
-    int tv = tid;
-    asm volatile("" : "+v"(tv));  // opaque: keep the index math below inside the tile loop (no LICM -> no long-lived VGPRs)
-    // buffer resource over sample b: offsets are 32-bit, and an offset >= num_records reads as zero (the conv's zero padding)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * (sample_bytes / 2)), 0, (int)bytes, 0x00020000);
-    const int cid = tv + 512 * i;
-    const int line = (cid * 4855) >> 19, within = cid - line * (HX * 6);                                      // /108 by multiply-shift
-    const int hz = (line * 205) >> 11, hy = line - hz * HY, hx = (within * 43) >> 8, c6 = within - hx * 6;  // /10 and /6
-    const int z = z0 - 1 + hz, y = y0 - 1 + hy, x = x0 - 1 + hx;
-    const bool ok = line < (TZ + 2) * HY && (unsigned)z < (unsigned)a.D && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-    const unsigned off = ok ? (unsigned)((z * a.H + y) * a.W + x) * vox_bytes + (unsigned)((MB ? cib * 96 : 0) + c6 * 16) : 0xFFFFFFF0u;
-    hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
-    if constexpr (AP) hokm = i == 0 ? (ok ? 1u : 0u) : (hokm | (ok ? (1u << i) : 0u));
+  const unsigned sample_bytes = (unsigned)a.D * a.H * a.W * vox_bytes;  // one sample of X (< 2 GiB: checked at launch)
+  // The halo by LINES (round 6): its 60 x-lines of 18 voxels (1728 contiguous bytes = 108 16-byte chunks) are dealt to the waves, line l = wave + 8 j, and a
+  // wave fetches a line with two requests (lanes = chunks 0-63, chunks 64-107).  Everything that depends on the line -- its (z, y), the range test, the byte
+  // offset in the sample, its LDS row -- is wave-uniform and lives on the scalar unit (the line's offset is the buffer instruction's SGPR offset); the lane part
+  // (x range test, byte offset of the chunk in the line) is the same for every line of a tile: two VGPRs per tile.  The request costs no vector instruction,
+  // where the chunk-id mapping of rounds 2-5 (13 requests of tid + 512 i) spent ~18 per request on two divisions by multiply-shift, four multiplies and the
+  // range tests: ~230 VALU instructions per tile and wave in a kernel whose MFMA stream has no idle issue slots (NMH_C48_DBG=2: the prefetch cost 11 % of it).
+  // 16 requests instead of 13 (the second request of a line has 44 live lanes).  The requests of the NEXT tile are dealt one at a time over the k-steps of the
+  // current one (a burst backs up the CU's vector-memory path); `bytes` = 0 when there is no next tile: still issued (no branch in the k-loop), reads zero.
+  constexpr unsigned OOB = 0x80000000u;   // >= num_records with or without the SGPR offset added (samples are < 2 GiB)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  unsigned hv0 = OOB, hv1 = OOB;   // lane offsets of the two requests of a line of the tile IN FLIGHT (OOB: x outside the volume / lane beyond chunk 107)
+  auto halo_voff = [&](int x0, int cib) {
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int c1 = lv + 64;
+    const int hxa = (lv * 43) >> 8, hxb = (c1 * 43) >> 8;   // / 6
+    const int xa = x0 - 1 + hxa, xb = x0 - 1 + hxb;
+    const unsigned cofs = MB ? (unsigned)cib * 96u : 0u;
+    hv0 = (unsigned)xa < (unsigned)a.W ? (unsigned)xa * vox_bytes + (unsigned)(lv - hxa * 6) * 16u + cofs : OOB;
+    hv1 = (c1 < HX * 6 && (unsigned)xb < (unsigned)a.W) ? (unsigned)xb * vox_bytes + (unsigned)(c1 - hxb * 6) * 16u + cofs : OOB;
   };
-  // LDS byte offset / 16 of halo request i (tile-invariant): two per VGPR.  Recomputing them per tile (two integer divisions by
-  // multiply-shift, predication and a serial within/line update per store: ~17 VALU instructions of which two quarter-rate
-  // multiplies) made the refill phase VALU-bound -- ~95 cycles per store and wave, 2.6k cycles per tile with two waves per SIMD --
-  // although the 13 ds_write_b128 themselves need ~1.3k; 7 VGPRs buy that back.
-  unsigned hoff[(HREG + 1) / 2];
-#pragma unroll
-  for (int i = 0; i < HREG; ++i) {
-    const int cid = tid + 512 * i;
-    const int line = (cid * 4855) >> 19, within = cid - line * (HX * 6);
-    const int hz = (line * 205) >> 11, hy = line - hz * HY;
-    unsigned u = (unsigned)(hz * PLANE + hy * LINE + within * 16) >> 4;   // < 2^13 (garbage for cid >= HCH: never stored)
-    if constexpr (AP) { const int hx = (within * 43) >> 8; u = (u & 0x1fffu) | ((unsigned)(within - hx * 6) << 13); }   // + the chunk's 8-channel group c6 in bits 13-15
-    if (i & 1) hoff[i >> 1] |= u << 16; else hoff[i >> 1] = u;
-  }
+  auto halo_gload_one = [&](int i, int b, int z0, int y0, unsigned bytes) {
+    const int j = i >> 1, l = wv + 8 * j;
+    const int hz = (l * 205) >> 11, hy = l - hz * HY;   // / 10 (l < 64)
+    const int z = z0 - 1 + hz, y = y0 - 1 + hy;
+    // (bitwise, not short-circuit: the scalar unit then selects instead of branching -- a branch per request cut the k-loop into basic blocks)
+    const unsigned lok = (unsigned)(l < NLINE) & (unsigned)((unsigned)z < (unsigned)a.D) & (unsigned)((unsigned)y < (unsigned)a.H);
+    const unsigned lmask = 0u - lok;
+    // buffer resource over sample b; a line outside the volume (the conv's zero padding) gets an empty one: every lane reads zero without touching memory
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (long)b * (sample_bytes / 2)), 0, (int)(bytes & lmask), 0x00020000);
+    const unsigned soff = ((unsigned)((z * a.H + y) * a.W) * vox_bytes) & lmask;
+    hreg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((i & 1) ? hv1 : hv0), (int)soff, 0));
+  };
   auto halo_sstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < HREG; ++i) {
-      const unsigned off = (i & 1) ? ((hoff[i >> 1] >> 12) & (AP ? 0x1FFF0u : 0xFFFF0u)) : ((hoff[i >> 1] << 4) & (AP ? 0x1FFF0u : 0xFFFF0u));
-      if (i < HREG - 1 || tid < HCH - 512 * (HREG - 1)) *reinterpret_cast<uint4*>(halo + off) = hreg[i];
-    }
-  };
-  // AP: halo request i, landed, -> lrelu((x - mean) * rstd) in place (the arithmetic of in_apply_kernel, csrc/norm.hip, operation for operation: same bits),
-  // zero outside the volume.  The sample's constants come from the LDS table (one 16-byte read per channel pair).
-  typedef float tf2 __attribute__((ext_vector_type(2)));
-  char* const aptab = smem + LDS_BYTES;
-  auto ap_transform = [&](int i) {
-    if constexpr (AP) {
-      const unsigned c6 = ((i & 1) ? (hoff[i >> 1] >> 29) : (hoff[i >> 1] >> 13)) & 7u;
-      const float4* tab = reinterpret_cast<const float4*>(aptab + c6 * 64);
-      const tf2 slope2 = {a.slope, a.slope};
-      unsigned w[4] = {hreg[i].x, hreg[i].y, hreg[i].z, hreg[i].w};
-      const bool ok = (hokm >> i) & 1u;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 cst = tab[j];
-        const tf2 nmu = {cst.x, cst.y}, rs = {cst.z, cst.w};
-        const tf2 xv = {__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
-        tf2 y, ys;
-        asm("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(xv), "v"(nmu));
-        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(y) : "v"(y), "v"(rs));
-        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ys) : "v"(y), "v"(slope2));
-        const unsigned r = pk_bf16(fmaxf(y[0], ys[0]), fmaxf(y[1], ys[1]));   // 0 < slope < 1: max(y, slope y) == (y > 0 ? y : slope y)
-        w[j] = ok ? r : 0u;
-      }
-      hreg[i] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-  };
-  // AP: the table of sample b (threads 0-47: one channel's (mean, rstd) pair each); visible after the next barrier
-  auto ap_table = [&](int b) {
-    if constexpr (AP) {
-      if (tid < 48) {
-        const float2 ms = reinterpret_cast<const float2*>(a.stats1)[(long)b * 48 + tid];
-        float* t = reinterpret_cast<float*>(aptab + (tid >> 3) * 64 + ((tid & 7) >> 1) * 16);
-        t[tid & 1] = -ms.x;
-        t[2 + (tid & 1)] = ms.y;
+    for (int j = 0; j < LPW; ++j) {
+      const int l = wv + 8 * j;
+      if (l < NLINE) {
+        const int hz = (l * 205) >> 11, hy = l - hz * HY;
+        char* const p = halo + hz * PLANE + hy * LINE + lane * 16;
+        *reinterpret_cast<uint4*>(p) = hreg[2 * j];
+        if (lane < HX * 6 - 64) *reinterpret_cast<uint4*>(p + 1024) = hreg[2 * j + 1];
       }
     }
-  };
-  // AP: interior chunk j (of 6 per thread) of the CURRENT tile's halo -- the normalised input -- LDS -> A1
-  auto ap_copy_read = [&](int j) -> uint4 {
-    const int cid = tid + 512 * j, vox = (cid * 10923) >> 16, c6 = cid - vox * 6;   // / 6 (cid < 4096)
-    const int x = vox & 15, line = vox >> 4, y = line & 7, z = line >> 3;
-    return *reinterpret_cast<const uint4*>(halo + (z + 1) * PLANE + (y + 1) * LINE + (x + 1) * 96 + c6 * 16);
-  };
-  auto ap_copy_store = [&](int j, const uint4& v, int b, int z0, int y0, int x0) {
-    int tv = tid;
-    asm volatile("" : "+v"(tv));
-    const int cid = tv + 512 * j, vox = (cid * 10923) >> 16, c6 = cid - vox * 6;
-    const int x = x0 + (vox & 15), line = vox >> 4, y = y0 + (line & 7), z = z0 + (line >> 3);
-    if (z < a.D && y < a.H && x < a.W)
-      *reinterpret_cast<uint4*>(a.A1 + ((((long)b * a.D + z) * a.H + y) * a.W + x) * 48 + c6 * 8) = v;
   };
   // weight chunk ck (steps [9ck, min(9ck+9,41))) -> LDS ring slot `buf` by LDS-DMA: the image is lane-linear
   // (dst = wave-uniform base + lane*16), so no VGPR staging and no ds_write pass; completes before the next barrier.
@@ -218,17 +164,11 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   c48_tile_origin(a, split ? t / a.ncob : t, cb, cz0, cy0, cx0);
   int cob = split ? (int)(t % a.ncob) : 0, cib = 0;   // MB: output / input channel block of the current work item
   const bf16_t* const wfirst = MB ? a.Wk + (long)cob * a.ncib * ((long)NSTEP * 3 * 512) : a.Wk;
+  halo_voff(cx0, 0);
 #pragma unroll
-  for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, cx0, sample_bytes, 0);
+  for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, sample_bytes);
   w_dma(wfirst, 0, 0);
   if (DBG & 4) w_dma(wfirst, 1, 1);
-  int ap_b = cb;   // AP: sample whose constants the LDS table holds
-  if constexpr (AP) {
-    ap_table(cb);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < HREG; ++i) ap_transform(i);
-  }
   halo_sstore();
   __syncthreads();
   int wb = 0;  // LDS buffer holding chunk 0 of the current tile
@@ -295,12 +235,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     int nb = cb, nz0 = cz0, ny0 = cy0, nx0 = cx0;
     if (has_next && (!MB || tn != t)) c48_tile_origin(a, split ? tn / a.ncob : tn, nb, nz0, ny0, nx0);
     const unsigned nbytes = pf_next ? sample_bytes : 0u;
-    if constexpr (AP) {
-      // the next tile belongs to another sample: its constants replace the table now -- every transform of THIS tile's halo ran during the previous tile,
-      // the first one of the next tile's comes after the barrier that closes weight chunk 0
-      if (has_next && nb != ap_b) { ap_table(nb); ap_b = nb; }
-    }
-    uint4 cpv = make_uint4(0, 0, 0, 0);   // AP: interior chunk on its way LDS -> A1
+    halo_voff(nx0, nci);   // lane offsets of the next tile's requests
     const bf16_t* const wcur = MB ? a.Wk + (long)(cob * a.ncib + cib) * WBLK : a.Wk;
     const bf16_t* const wnxt = MB ? a.Wk + (long)(nco * a.ncib + nci) * WBLK : a.Wk;
     if (!MB || cib == 0) {
@@ -340,8 +275,8 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
       const char* wsrc = wbuf + ((wb + ck) & 1) * WCHUNK;
       constexpr int NST4 = NSTEP - 4 * CSTEPS;
       const int nst = (ck < 4) ? CSTEPS : NST4;
-      const int hbase = ck == 0 ? 0 : 4 + 3 * (ck - 1);  // first halo request index of this chunk
-      const int hcnt = ck == 0 ? 4 : (ck < 4 ? 3 : 0);
+      const int hbase = 4 * ck;          // first halo request index of this chunk
+      const int hcnt = ck < 4 ? 4 : 0;   // (16 = 4 + 4 + 4 + 4 over chunks 0-3)
       if (!(DBG & 16) || ck == 0) ld_frags(0, wsrc, 0, ck * CSTEPS);
       if ((DBG & 16) && ck == 0) ld_frags(1, wsrc, 1, 1);
 #pragma unroll
@@ -352,19 +287,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
           if (sl >= 4) {
             // chunk 0: steps 4,5,6,8; chunks 1-3: steps 4,6,8
             const int k = (hcnt == 4) ? (sl == 4 ? 0 : sl == 5 ? 1 : sl == 6 ? 2 : sl == 8 ? 3 : -1) : (hcnt == 3) ? (sl == 4 ? 0 : sl == 6 ? 1 : sl == 8 ? 2 : -1) : -1;
-            if (k >= 0) halo_gload_one(hbase + k, nb, nz0, ny0, nx0, nbytes, nci);
-          }
-          if constexpr (AP) {
-            // VALU / LDS work dealt over the k-steps like the requests: chunk 0 copies the six interior chunks of this tile's (normalised) halo out to A1 (read
-            // at step j, stored at step j + 1); chunks 1-4 normalise the requests issued during the previous chunk (4 + 3 + 3 + 3), one per step
-            if (ck == 0 && a.A1) {
-              if (sl >= 1 && sl <= 6) ap_copy_store(sl - 1, cpv, cb, cz0, cy0, cx0);
-              if (sl <= 5) cpv = ap_copy_read(sl);
-            }
-            if (ck >= 1) {
-              const int tb = ck == 1 ? 0 : 4 + 3 * (ck - 2), tn_ = ck == 1 ? 4 : 3;
-              if (sl < tn_ && pf_next) ap_transform(tb + sl);
-            }
+            if (k >= 0) halo_gload_one(hbase + k, nb, nz0, ny0, nbytes);
           }
           if (DBG & 8) {
 #pragma unroll
@@ -533,17 +456,16 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 
 
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st,
-             const void* Y1, const float* stats1, float slope, int apply_on_load, void* A1) {
+             const void* Y1, const float* stats1, float slope) {
   using namespace c48;
   C48Args a;
-  a.Y1 = (const bf16_t*)Y1; a.stats1 = stats1; a.slope = slope; a.A1 = (bf16_t*)A1;
+  a.Y1 = (const bf16_t*)Y1; a.stats1 = stats1; a.slope = slope;
   if (Y1 && (!stats1 || !stats_acc || accumulate)) return -1;
-  if (apply_on_load && (Y1 || !stats1 || accumulate || !(slope > 0.f && slope < 1.f))) return -1;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
   a.total = (long)B * a.tz * a.ty * a.tx;
-  if (a.total >= (1L << 31)) return -2;
+  if (a.total >= (1L << 31) || (long)D * H * W * 96 >= (1L << 31)) return -2;
   a.dtx = make_fdiv((unsigned)a.tx); a.dty = make_fdiv((unsigned)a.ty); a.dtz = make_fdiv((unsigned)a.tz);
   a.accumulate = accumulate;
   a.stats_acc = stats_acc;
@@ -582,17 +504,6 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
     NMH_CHECK_LAUNCH();
     return 0;
   }
-  if (apply_on_load) {
-    static NmhPerDeviceOnce attr_ap;
-    if (attr_ap.need()) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_AP);
-      if (e != hipSuccess) return (int)e;
-      attr_ap.set();
-    }
-    hipLaunchKernelGGL((conv48_kernel<0, false, false, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES_AP, st, a);
-    NMH_CHECK_LAUNCH();
-    return 0;
-  }
   hipLaunchKernelGGL(conv48_kernel<0>, dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
   return 0;
@@ -604,9 +515,9 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
 int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, hipStream_t st) {
   using namespace c48;
   if (Cin % 48 || Cout % 48 || Cin <= 0 || Cout <= 0) return -2;
-  if ((long)D * H * W * Cin * 2 >= (1L << 32)) return -2;   // 32-bit buffer offsets inside one sample
+  if ((long)D * H * W * Cin * 2 >= (1L << 31)) return -2;   // 32-bit buffer offsets inside one sample, below the out-of-range marker
   C48Args a;
-  a.Y1 = nullptr; a.stats1 = nullptr; a.slope = 0.f; a.A1 = nullptr;
+  a.Y1 = nullptr; a.stats1 = nullptr; a.slope = 0.f;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;

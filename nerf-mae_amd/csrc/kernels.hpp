@@ -113,7 +113,7 @@ struct TnProblemHost {
 };
 int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground = false);
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st,
-             const void* Y1 = nullptr, const float* stats1 = nullptr, float slope = 0.f, int apply_on_load = 0, void* A1 = nullptr);
+             const void* Y1 = nullptr, const float* stats1 = nullptr, float slope = 0.f);
 int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, hipStream_t st);
 int k_conv64(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, double* stats_acc, const float* bias, hipStream_t st);
 long k_conv64_pack_numel(int Cin, int Cout);

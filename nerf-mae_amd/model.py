@@ -541,15 +541,10 @@ class _UpBlockFn(torch.autograd.Function):
             y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout).view(B * V, Cout)
             ops.instnorm_stats(y1, st1, scratch, B, V, Cout)
         a1 = torch.empty_like(y1)
-        norm_in = c48 and ops.C48_NORM_IN   # decoder1: norm1 + LeakyReLU applied to conv2's halo on its way to LDS (a1 is written by the same launch, for the weight gradient)
-        if not norm_in:
-            ops.instnorm_apply(y1, st1, a1, B, V, Cout)
+        ops.instnorm_apply(y1, st1, a1, B, V, Cout)
         st2 = torch.empty((B, Cout, 2), device=dev)
         scratch = new_acc()
-        if norm_in:
-            y2 = ops.conv3d_k3_c48_norm_in(y1.view(B, S, S, S, Cout), st1, pk[key + "c2.wk"], a_out=a1.view(B, S, S, S, Cout), stats_acc=scratch).view(B * V, Cout)
-            ops.instnorm_finalize(scratch, st2, B, V, Cout)
-        elif halo_stats:
+        if halo_stats:
             y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st2, B, V, Cout)
         else:

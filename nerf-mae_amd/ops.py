@@ -357,27 +357,6 @@ def conv3d_k3_c48(X, Wk, out=None, accumulate=False, stats_acc=None):
     return out
 
 
-# decoder1 conv2 forward: InstanceNorm apply + LeakyReLU on the halo's way to LDS (no stand-alone apply pass).  Bit-identical, but OFF by default: round 6 measured the
-# launch at 4.94 ms against 3.54 + 1.06 ms for conv + stand-alone pass (the MFMA-bound kernel has no spare issue slots for the VALU work: profiles/r6b_*)
-C48_NORM_IN = __import__("os").environ.get("NMH_C48_NORM_IN", "0") == "1"
-
-
-def conv3d_k3_c48_norm_in(X, stats, Wk, out=None, a_out=None, stats_acc=None, slope=0.01):
-    """Y = conv(lrelu(IN(X))) with the normalisation applied on load (include/nerfmae_hip.h: nmh_conv3d_k3_c48_norm_in); stats = (mean, rstd) [B,48,2] of X;
-    a_out (optional, same shape as X) receives lrelu(IN(X)); stats_acc as conv3d_k3_c48"""
-    _chk(X, stats, Wk, out, a_out, stats_acc)
-    B, D, H, W, Cin = X.shape
-    if Cin != 48 or X.dtype != torch.bfloat16 or stats.dtype != torch.float32 or stats.numel() != B * 96:
-        raise RuntimeError("conv3d_k3_c48_norm_in needs bf16 activations with 48 channels and fp32 [B,48,2] statistics")
-    if out is None:
-        out = torch.empty((B, D, H, W, 48), dtype=X.dtype, device=X.device)
-    ev = _prof(("conv3d_k3_c48", B, D, 48, 48))
-    lib().call("nmh_conv3d_k3_c48_norm_in", X, stats, float(slope), Wk, out, a_out, B, D, H, W, stats_acc, _st())
-    if ev is not None:
-        ev.record(torch.cuda.current_stream())
-    return out
-
-
 TAIL_SIGN_MASK = __import__("os").environ.get("NMH_TAIL_SIGN_MASK", "1") != "0"   # tail backward reads [d0 > 0] bits written by the tail forward instead of the residual
 C48_BWD_REDUCE = __import__("os").environ.get("NMH_C48_BWD_REDUCE", "1") != "0"   # decoder1 conv2 input gradient: InstanceNorm-backward sums in the conv epilogue
 

@@ -1234,44 +1234,6 @@ def test_conv48_input_gradient_with_fused_instnorm_backward_sums(B, D, H, W):
     check(sums[:, :, 1].float(), (g * t * rstd[:, None, None, None, :]).sum(dim=(1, 2, 3)).float(), torch.float32, "fused IN-backward sum g yhat", 20)
 
 
-@pytest.mark.parametrize("B,D,H,W", [(1, 16, 16, 16), (2, 20, 24, 40), (3, 32, 32, 32), (1, 7, 9, 19), (9, 8, 16, 32), (2, 48, 40, 64)])
-@pytest.mark.parametrize("want_a", [True, False], ids=["a_out", "no_a_out"])
-def test_conv48_forward_with_instnorm_applied_on_load(B, D, H, W, want_a):
-    """nmh_conv3d_k3_c48_norm_in (decoder1: norm1 -> lrelu -> conv2, unetr_block.py:58-62): the halo is normalised in registers on its way to LDS.  Against the
-    two-launch path it replaces (nmh_instnorm_apply, then nmh_conv3d_k3_c48) BIT for bit -- the conv output, its fused InstanceNorm statistics and the
-    normalised tensor copied out for the weight gradient -- including partial tiles (zero padding of the NORMALISED tensor, not of the raw one), several
-    samples per workgroup (the per-sample constant table) and more samples than workgroups walk in one stretch; and against F.conv3d of the definition"""
-    ops = _ops()
-    dt = torch.bfloat16
-    w = rnd(48, 48, 3, 3, 3, seed=1, scale=(27 * 48) ** -0.5)
-    wk = _pack_via_kernel(w, 6, dt, 41 * 3 * 64 * 8)
-    # per-sample, per-channel offsets and scales: a wrong (sample, channel) constant must show
-    y1h = rnd(B, D, H, W, 48, seed=3) * (0.5 + rnd(B, 1, 1, 1, 48, seed=4).abs()) + 2.0 * rnd(B, 1, 1, 1, 48, seed=5)
-    y1 = dev(q(y1h, dt), dt)
-    V = D * H * W
-    st = torch.empty(B, 48, 2, device="cuda")
-    ops.instnorm_stats(y1.view(B * V, 48), st, ops.acc_zeros((B, 48, 2), "cuda"), B, V, 48)
-    a_ref = torch.empty_like(y1)
-    ops.instnorm_apply(y1.view(B * V, 48), st, a_ref.view(B * V, 48), B, V, 48)
-    acc_ref = torch.empty(B, 48, 2, dtype=torch.float64, device="cuda")
-    y_ref = ops.conv3d_k3_c48(a_ref, wk, stats_acc=acc_ref)
-    acc = torch.full((B, 48, 2), 7.0, dtype=torch.float64, device="cuda")
-    a_out = torch.full_like(y1, 3.0) if want_a else None
-    y = ops.conv3d_k3_c48_norm_in(y1, st, wk, a_out=a_out, stats_acc=acc)
-    torch.cuda.synchronize()
-    assert torch.equal(y, y_ref)
-    if want_a:
-        assert torch.equal(a_out, a_ref)
-    assert torch.allclose(acc, acc_ref, rtol=1e-6, atol=1e-6 * V)
-    # the definition: conv(lrelu(IN(y1))) in fp32 on the host
-    xin = F.leaky_relu(F.instance_norm(y1.float().cpu().permute(0, 4, 1, 2, 3), eps=1e-5), 0.01)
-    ref = F.conv3d(q(xin, dt), q(w, dt), padding=1)
-    check(y.permute(0, 4, 1, 2, 3), ref, dt, "conv48 norm-in vs definition", 2)
-    # without statistics
-    y_b = ops.conv3d_k3_c48_norm_in(y1, st, wk)
-    assert torch.equal(y_b, y_ref)
-
-
 @pytest.mark.parametrize("B,v", [(1, 8), (2, 8), (1, 16), (3, 24), (2, 40)])
 def test_upconv4_forward_matches_conv_transpose(B, v):
     """decoder1's transpose conv as the persistent register-fragment kernel (csrc/cconv.hip upconv4): against F.conv_transpose3d in fp32 on the

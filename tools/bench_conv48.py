@@ -16,8 +16,6 @@ fl = 2.0 * 27 * 48 * 48 * R ** 3 * B
 st = torch.empty(B, 48, 2, device='cuda'); sums = torch.zeros(B, 48, 2, dtype=torch.float64, device='cuda')
 ops.instnorm_stats(x.view(-1, 48), st, ops.acc_zeros((B, 48, 2), 'cuda'), B, R ** 3, 48)
 for name, fn in (("conv48 fwd", lambda: ops.conv3d_k3_c48(x, wk, out=y)), ("conv48 fwd + stats", lambda: ops.conv3d_k3_c48(x, wk, out=y, stats_acc=sums)),
-                 ("conv48 fwd + stats, InstanceNorm applied on load, a1 written", lambda: ops.conv3d_k3_c48_norm_in(x, st, wk, out=y, a_out=dy, stats_acc=sums)),
-                 ("conv48 fwd + stats, InstanceNorm applied on load, no a1", lambda: ops.conv3d_k3_c48_norm_in(x, st, wk, out=y, stats_acc=sums)),
                  ("stand-alone InstanceNorm apply", lambda: ops.instnorm_apply(x.view(-1, 48), st, dy.view(-1, 48), B, R ** 3, 48)),
                  ("conv48 dgrad + IN-backward sums", lambda: ops.conv3d_k3_c48_bwd_reduce(dy, wk, x, st, sums, out=y)),
                  ("separate IN-backward reduce", lambda: ops.instnorm_bwd_reduce(y.view(-1, 48), None, x.view(-1, 48), st, sums, B, R ** 3, 48, rmode=0)),
