@@ -261,6 +261,21 @@ NMH_API int nmh_instnorm_bwd_apply_bg(int dt, const void* dout, const void* x, c
 
 /* im2row of the 4x4x4 stride-4 patch conv input: x fp32 (B,4,R,R,R) -> A[(b,z,y,x)][256] (swin_mae3d.py:1120-1126) */
 NMH_API int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream);
+/* Patch embed of the KEPT tokens only (the embedding of a removed token is replaced by mask_token right after the LayerNorm, swin_mae3d.py:1375-1380: at
+ * mask_ratio 0.75 three quarters of the im2row, of the GEMM rows, of the LayerNorm rows and of the weight-gradient contraction are work on values nobody reads).
+ * nmh_patch_embed_kept_rows: token mask [n] (1 = removed) -> rowmap [n + 2]: the compact row of every kept token (raster order), -1 for a removed one;
+ *   rowmap[n] = kept count (<= cap), rowmap[n + 1] = 1 if kept tokens did not fit into cap rows (they read -1; the caller sizes cap from the mask it drew).
+ * nmh_patch_embed_gather_kept: as nmh_patch_embed_gather into A [B][cap_rows][256], rows behind the kept count zeroed.
+ * nmh_patch_embed_norm_fwd_kept / _bwd_kept: nmh_layernorm_fwd / _bwd (mode 0, with pos / mask / mask_token) reading y0 [B][cap_rows][C] through rowmap and
+ *   writing token rows [rows][C]; the backward writes d(y0) compact (rows behind the kept count zeroed) and adds the removed tokens' gradients to dmask_token. */
+NMH_API int nmh_patch_embed_kept_rows(const unsigned char* mask, int n, int cap, int* rowmap, void* stream);
+NMH_API int nmh_patch_embed_gather_kept(int dt, const float* x, void* A, int B, int R, const int* rowmap, int64_t cap_rows, void* stream);
+NMH_API int nmh_patch_embed_norm_fwd_kept(int dt, const void* y0, void* tok, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C,
+                                          const float* pos, const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, const int* rowmap, int64_t cap_rows,
+                                          void* stream);
+NMH_API int nmh_patch_embed_norm_bwd_kept(int dt, const void* dtok, const void* y0, const float* gamma, const float* mean, const float* rstd, void* dy0, float* dgamma, float* dbeta,
+                                          int64_t rows, int C, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, const int* rowmap, int64_t cap_rows,
+                                          void* stream);
 /* ConvTranspose3d(kernel = stride = k) (unetr_block.py:151-158,193-198) as GEMMs with the pixel shuffle folded into the addressing,
  * channels-last.  x [B*v^3][Cin] coarse grid; cat/dcat [B*(v*k)^3][ldc] fine grid, the transpose conv occupies columns [0,Cout)
  * (the skip connection, if any, the rest).  Wt packed [(tap,co)][ci], Wd packed [ci][(tap,co)], dW fp32 [Cin][Cout][k^3]. */

@@ -353,6 +353,35 @@ int nmh_instnorm_bwd_apply_bg(int dt, const void* dout, const void* x, const flo
 }
 int nmh_patch_embed_gather(int dt, const float* x, void* A, int B, int R, void* stream) {
   CLR(); return k_embed_gather(dt, x, A, B, R, ST); }
+int nmh_patch_embed_kept_rows(const unsigned char* mask, int n, int cap, int* rowmap, void* stream) {
+  CLR();
+  REQ(mask, rowmap);
+  return k_mask_rowmap(mask, n, cap, rowmap, ST);
+}
+int nmh_patch_embed_gather_kept(int dt, const float* x, void* A, int B, int R, const int* rowmap, int64_t cap_rows, void* stream) {
+  CLR();
+  REQ(x, A, rowmap);
+  return k_embed_gather(dt, x, A, B, R, ST, rowmap, (long)cap_rows);
+}
+int nmh_patch_embed_norm_fwd_kept(int dt, const void* y0, void* tok, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int64_t rows, int C, const float* pos,
+                                  const unsigned char* mask, const float* mask_token, int64_t tokens_per_sample, const int* rowmap, int64_t cap_rows, void* stream) {
+  CLR();
+  REQ(y0, tok, gamma, beta, mean, rstd, mask, mask_token, rowmap);
+  if (rows <= 0) return 0;
+  if (tokens_per_sample <= 0 || rows % tokens_per_sample || cap_rows <= 0) return -2;
+  LnArgs a{dt, 0, y0, tok, gamma, beta, eps, mean, rstd, (long)rows, C, WinMap{}, pos, mask, mask_token, (long)tokens_per_sample, nullptr, rowmap, (long)cap_rows};
+  return k_ln_fwd(a, ST);
+}
+int nmh_patch_embed_norm_bwd_kept(int dt, const void* dtok, const void* y0, const float* gamma, const float* mean, const float* rstd, void* dy0, float* dgamma, float* dbeta,
+                                  int64_t rows, int C, const unsigned char* mask, float* dmask_token, int64_t tokens_per_sample, const int* rowmap, int64_t cap_rows, void* stream) {
+  CLR();
+  REQ(dtok, y0, gamma, mean, rstd, dy0, dgamma, dbeta, mask, dmask_token, rowmap);
+  if (rows <= 0) return 0;
+  if (tokens_per_sample <= 0 || rows % tokens_per_sample || cap_rows <= 0) return -2;
+  LnBwdArgs a{dt, 0, dtok, y0, gamma, mean, rstd, nullptr, dy0, dgamma, dbeta, (long)rows, C, WinMap{}, mask, dmask_token, (long)tokens_per_sample, nullptr, nullptr, 0, nullptr,
+              rowmap, (long)cap_rows};
+  return k_ln_bwd(a, ST);
+}
 int nmh_upconv_shuffle_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, void* stream) {
   CLR();
   return k_up_cat_fwd(dt, upre, bias, skip, out, B, v, k, Cout, ST);

@@ -139,8 +139,14 @@ struct LnArgs {
   WinMap wm;                            // modes 1, 2 (mode 2 uses B,H,W,D as the *input* grid)
   const float* pos; const unsigned char* mask; const float* mask_token; long tokens_per_sample;  // patch-embed post-ops (mode 0)
   void* out_tok;                        // mode 1, optional: a second, TOKEN-ordered copy of the normalised rows [T,C] (operand of a token-ordered weight gradient)
+  // mode 0 with a mask, optional (patch embed of the KEPT tokens only, k_mask_rowmap): x holds the kept tokens of every sample in compact rows
+  // [B][cap_rows][C] -- token tl of sample b at row b * cap_rows + rowmap[tl]; masked tokens have no row and are not read
+  const int* rowmap; long cap_rows;
 };
 int k_ln_fwd(const LnArgs& a, hipStream_t st);
+// mask [n] (1 = removed) -> rowmap [n + 2]: rowmap[t] = number of kept tokens in front of token t (its compact row), -1 for a removed token (and for kept tokens
+// beyond cap rows: rowmap[n + 1] = 1 then); rowmap[n] = min(kept count, cap)
+int k_mask_rowmap(const unsigned char* mask, int n, int cap, int* rowmap, hipStream_t st);
 struct LnBwdArgs {
   int dt; int src_mode;
   const void* dy;                       // mode 0: [T,C]; mode 1: window-ordered [Tw,C]; mode 2: [rows, 8C]
@@ -154,6 +160,8 @@ struct LnBwdArgs {
   int dyw_pads;                         // set by k_ln_bwd: the window-ordered tensor has pad rows (no token) -- the kernel writes their zeros
   float* part;                          // optional [k_ln_bwd_blocks(rows, C)][2C]: every workgroup leaves its dgamma / dbeta sums here (plain stores) instead of adding
                                         // them to dgamma / dbeta with 2C same-address atomics; k_ln_param_reduce adds the column sums later, off the dependent chain
+  // mode 0 with a mask, optional (see LnArgs): x and dx are compact [B][cap_rows][C]; masked tokens write no row, the rows behind the kept count are zeroed
+  const int* rowmap; long cap_rows;
 };
 int k_ln_bwd(const LnBwdArgs& a, hipStream_t st);
 long k_ln_bwd_blocks(long rows, int C);
@@ -217,7 +225,7 @@ int k_attn_pad_rows_colsum(int dt, const void* x, int N, const WinMap& wm, float
 int k_attn_pad_rows_colsum_grouped(int dt, const void* const* xs, float* const* outs, int n, int N, const WinMap& wm, hipStream_t st);
 
 // ---- misc.hip ----
-int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st);
+int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st, const int* rowmap = nullptr, long cap_rows = 0);
 int k_up_cat_fwd(int dt, const void* upre, const float* bias, const void* skip, void* out, int B, int v, int k, int Cout, hipStream_t st);
 int k_up_cat_bwd(int dt, const void* dcat, void* dupre, void* dskip, float* dbias, int B, int v, int k, int Cout, int has_skip, hipStream_t st);
 struct LossArgs {

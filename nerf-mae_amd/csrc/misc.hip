@@ -33,9 +33,57 @@ template <typename T> __global__ __launch_bounds__(256) void embed_gather_kernel
     out[idx] = *reinterpret_cast<const unsigned long long*>(esm + tx * ROWB + c * 8);
   }
 }
-int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st) {
+// The KEPT tokens only (k_mask_rowmap), into the compact rows [b][rowmap[token]] of A [B][cap][256]: a removed token costs neither its 64 x 16 source bytes nor
+// its row (its embedding is replaced by the mask token, swin_mae3d.py:1375-1380).  One WAVE per run of four tokens along x: lane q = (ci, kz, ky) reads the run's
+// 64 contiguous source bytes of its row -- 16 per kept token -- and writes elements 4 q .. 4 q + 3 of each kept token's row: the 64 lanes complete the row (no LDS,
+// no barrier; the line-per-block kernel above was latency-bound once three quarters of its work were gone).  Every block also zeroes its share of the rows behind
+// the kept count, which stay operands of the GEMM and of the weight gradient.
+template <typename T> __global__ __launch_bounds__(256) void embed_gather_kept_kernel(const float* __restrict__ x, T* __restrict__ A, int B, int R, const int* __restrict__ rowmap, long cap) {
+  const int g = R >> 2, runs = (g + 3) >> 2, n = g * g * g;
+  const int q = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nrun = (long)B * g * g * runs;
+  constexpr int V8 = 256 * (int)sizeof(T) / 8;
+  for (long u = (long)blockIdx.x * 4 + wave; u < nrun; u += (long)gridDim.x * 4) {
+    const int rx = (int)(u % runs);
+    const long l = u / runs;
+    const int ty = (int)(l % g), tz = (int)((l / g) % g), b = (int)(l / ((long)g * g));
+    const int t0 = (tz * g + ty) * g + 4 * rx;
+    int r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = 4 * rx + j < g ? rowmap[t0 + j] : -1;
+    if ((r[0] & r[1] & r[2] & r[3]) < 0 && r[0] < 0 && r[1] < 0 && r[2] < 0 && r[3] < 0) continue;
+    const int ci = q >> 4, kz = (q >> 2) & 3, ky = q & 3;
+    const float* src = x + ((((long)b * 4 + ci) * R + 4 * tz + kz) * R + 4 * ty + ky) * (long)R + 16 * rx;
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (r[j] >= 0) v[j] = *reinterpret_cast<const float4*>(src + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (r[j] >= 0) {
+        T* o = A + ((long)b * cap + r[j]) * 256 + q * 4;
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(o) = make_uint2(pk_bf16(v[j].x, v[j].y), pk_bf16(v[j].z, v[j].w));
+        else *reinterpret_cast<float4*>(o) = v[j];
+      }
+  }
+  const int K = rowmap[n];
+  const long tail = cap - K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * tail * V8; i += (long)gridDim.x * 256) {
+    const long rr = i / V8, c = i - rr * V8, b = rr / tail;
+    reinterpret_cast<unsigned long long*>(A + (b * cap + K + (rr - b * tail)) * 256)[c] = 0ull;
+  }
+}
+int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st, const int* rowmap, long cap_rows) {
   const int g = R / 4;
-  if (R % 4 || g <= 0) return -2;
+  if (R % 4 || g <= 0 || (rowmap && cap_rows <= 0)) return -2;
+  if (rowmap) {
+    const long nrun = (long)B * g * g * ((g + 3) / 4);
+    long nb = (nrun + 3) / 4;
+    if (nb > 65536) nb = 65536;
+    if (dt == NMH_DT_BF16) hipLaunchKernelGGL(embed_gather_kept_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, x, (bf16_t*)A, B, R, rowmap, cap_rows);
+    else hipLaunchKernelGGL(embed_gather_kept_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, x, (float*)A, B, R, rowmap, cap_rows);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
   const long lines = (long)B * g * g;
   const size_t lds = (size_t)g * (256 * (dt == NMH_DT_BF16 ? 2 : 4) + 8);
   if (lds > 160 * 1024) return -2;
@@ -46,6 +94,59 @@ int k_embed_gather(int dt, const float* x, void* A, int B, int R, hipStream_t st
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)embed_gather_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(embed_gather_kernel<float>, dim3((unsigned)lines), dim3(256), lds, st, x, (float*)A, B, R);
   }
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- compact rows of the kept tokens: rowmap[t] = number of kept tokens in front of token t (raster order), -1 for a removed one -------------------------
+// One workgroup; thread i owns the tokens [i per, (i + 1) per).  rowmap[n] = kept count (clamped to cap), rowmap[n + 1] = 1 if kept tokens did not fit (their
+// rows read -1: memory-safe, and the host -- which drew the mask -- never lets that happen).
+__global__ __launch_bounds__(1024) void mask_rowmap_kernel(const unsigned char* __restrict__ mask, int n, int cap, int* __restrict__ rowmap) {
+  // wave w owns the contiguous tokens [w seg, (w + 1) seg), seg a multiple of 1024; per step a lane reads 16 consecutive mask bytes (one 16-byte load; the steps'
+  // loads are all in flight at once -- a serial per-token loop took 94 us for 64000 tokens, mostly load latency), counts its kept tokens and takes its place by a
+  // scan over the wave.  Segments longer than 8 steps (n > 131072) repeat the sweep.
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seg = ((n + 16 * 1024 - 1) / (16 * 1024)) * 1024, nstep = seg / 1024, t0 = wave * seg;
+  const bool vec = (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
+  auto load16 = [&](int t) -> unsigned {   // bit j = token t + j is kept
+    unsigned bits = 0;
+    if (vec && t + 16 <= n) {
+      const uint4 m = *reinterpret_cast<const uint4*>(mask + t);
+      const unsigned w[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bits |= (((w[j >> 2] >> (8 * (j & 3))) & 255u) == 0u ? 1u : 0u) << j;
+    } else {
+      for (int j = 0; j < 16; ++j) if (t + j < n && mask[t + j] == 0) bits |= 1u << j;
+    }
+    return bits;
+  };
+  int cnt = 0;
+  for (int s0 = 0; s0 < nstep; ++s0) cnt += __popc(load16(t0 + s0 * 1024 + lane * 16));
+  int wtot = cnt;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wtot += __shfl_xor(wtot, o, 64);
+  if (lane == 0) wsum[wave] = wtot;
+  __syncthreads();
+  int pos = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) pos += wsum[w]; tot += wsum[w]; }
+  for (int s0 = 0; s0 < nstep; ++s0) {
+    const int t = t0 + s0 * 1024 + lane * 16;
+    const unsigned bits = load16(t);
+    const int c = __popc(bits);
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    int r = pos + inc - c;
+    for (int j = 0; j < 16; ++j)
+      if (t + j < n) { const bool k = (bits >> j) & 1u; rowmap[t + j] = (k && r < cap) ? r : -1; r += k; }
+    pos += __shfl(inc, 63, 64);
+  }
+  if (tid == 0) { rowmap[n] = tot < cap ? tot : cap; rowmap[n + 1] = tot > cap ? 1 : 0; }
+}
+int k_mask_rowmap(const unsigned char* mask, int n, int cap, int* rowmap, hipStream_t st) {
+  if (n <= 0 || cap <= 0) return -2;
+  hipLaunchKernelGGL(mask_rowmap_kernel, dim3(1), dim3(1024), 0, st, mask, n, cap, rowmap);
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -51,6 +51,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
     long tok = row;
     bool valid = true;
     if (MODE == 1) { tok = win_to_tok(a.wm, row); valid = tok >= 0; }
+    bool masked = false;
+    long tl = 0, srow = tok;
+    if (MODE == 0 && a.mask) { tl = (long)((unsigned)row % (unsigned)a.tokens_per_sample); masked = a.mask[tl] != 0; }
+    if (MODE == 0 && a.rowmap) {   // compact rows of the kept tokens
+      const int rm = masked ? -1 : a.rowmap[tl];
+      srow = rm < 0 ? -1 : (long)((unsigned)row / (unsigned)a.tokens_per_sample) * a.cap_rows + rm;
+    }
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
@@ -58,10 +65,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
       const int c = sub + i * LPR;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
-      if (c < nch && valid) {
+      if (c < nch && valid && srow >= 0) {
         const T* p;
         if (MODE == 2) { long tk; p = merge_src<T>(x, a.wm, row, c * 8, Cin, &tk); }
-        else p = x + tok * C + c * 8;
+        else p = x + srow * C + c * 8;
         if (p) Vec8<T>::load(p, v[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[i][j];
@@ -75,9 +82,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { float d = v[i][j] - mean; q += d * d; }
     const float rstd = rsqrtf(group_sum<LPR>(q) * invC + a.eps);
-    bool masked = false;
-    long tl = 0;
-    if (MODE == 0 && a.mask) { tl = (long)((unsigned)row % (unsigned)a.tokens_per_sample); masked = a.mask[tl] != 0; }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = sub + i * LPR;
@@ -187,6 +191,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
       if (win_to_tok(a.wm, (long)m) < 0) { const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; Vec8<T>::store((T*)a.dyw + (long)m * C + c * 8, z8); }
     }
   }
+  if (MODE == 0 && a.rowmap) {   // compact dx: the rows behind the kept count are operands of the weight gradient -- zero
+    const long tps = a.tokens_per_sample, nsamp = a.rows / tps, K = a.rowmap[tps], tail = a.cap_rows - K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nsamp * tail * nch; i += (long)gridDim.x * 256) {
+      const long r = i / nch, c = i - r * nch, b = r / tail, rr = K + (r - b * tail);
+      const float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      Vec8<T>::store(dx + (b * a.cap_rows + rr) * C + c * 8, z8);
+    }
+  }
   // U consecutive rows per lane group and iteration: all of their loads are issued before the first row is reduced
   constexpr int U = (!FLUSH && MODE != 2 && NCH == 2) ? 2 : 1;   // measured: 64000 x 192 57 -> 52 us with 2; 512000 x 96 (NCH = 1) 118 -> 154 us with 4 (registers)
   for (long rowb = ((long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR) * U; rowb < a.rows; rowb += gstride * U) {   // U consecutive rows
@@ -194,11 +206,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     long toks[U][NCH];
     float mean[U], rstd[U];
     bool ok[U], maskedr[U];
+    long xrow[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long row = rowb + u;
       ok[u] = row < a.rows;
       maskedr[u] = false;
+      xrow[u] = row;
       mean[u] = 0.f; rstd[u] = 0.f;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
@@ -210,6 +224,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
       long dyrow = row;
       if (MODE == 1) dyrow = tok_to_win(a.wm, row);
       if (MODE == 0 && a.mask) maskedr[u] = a.mask[(unsigned)row % (unsigned)a.tokens_per_sample] != 0;
+      xrow[u] = row;
+      if (MODE == 0 && a.rowmap) {   // compact rows of the kept tokens (x and dx)
+        const int rm = maskedr[u] ? -1 : a.rowmap[(unsigned)row % (unsigned)a.tokens_per_sample];
+        if (rm < 0) maskedr[u] = true;   // (a kept token without a row: the host never lets the kept count exceed the capacity)
+        xrow[u] = rm < 0 ? -1 : (long)((unsigned)row / (unsigned)a.tokens_per_sample) * a.cap_rows + rm;
+      }
       mean[u] = a.mean[row]; rstd[u] = a.rstd[row];
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
           if (!maskedr[u]) {
             const T* p;
             if (MODE == 2) p = merge_src<T>(x, a.wm, row, c * 8, Cin, &toks[u][i]);
-            else p = x + row * C + c * 8;
+            else p = x + xrow[u] * C + c * 8;
             if (p) Vec8<T>::load(p, xr[u][i]);
           }
           if (MODE != 2 && a.dres) Vec8<T>::load((const T*)a.dres + row * C + c * 8, rv[u][i]);
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) o[j] += rv[u][i][j];
             }
-            Vec8<T>::store(dx + row * C + c * 8, o);
+            if (xrow[u] >= 0) Vec8<T>::store(dx + xrow[u] * C + c * 8, o);
             if (MODE == 0 && a.dyw) {   // adjoint of the window scatter fused here: dyw[win(row)] = s_b * dx[row] (pad rows pre-zeroed)
               const float sc = a.dyw_scale ? a.dyw_scale[(unsigned)row / (unsigned)a.tokens_per_sample] : 1.0f;
 #pragma unroll

@@ -50,13 +50,14 @@ class _FPNFn(torch.autograd.Function):
         fpn = ctx.fpn
         feats, lats = ctx.saved
         pk, Co, n = fpn._pk, fpn.out_channels, len(feats)
-        dlats = []
+        dlats, keep = [], []   # keep: tensors the forked side stream still reads -- referenced until the join (the caching allocator knows nothing of that stream)
         for i, (lat, g) in enumerate(zip(lats, douts)):
             B, D, H, W, _ = lat.shape
             if g is None:
                 dlats.append(torch.zeros_like(lat))
                 continue
             dy = ops.ncdhw_to_ndhwc(g, lat.dtype)
+            keep.append(dy)
             conv = fpn.fpn_convs[i]
             with ops.side_stream():
                 ops.conv3d_k3_wgrad(dy, lat, _gradbuf(conv.weight))
@@ -71,10 +72,12 @@ class _FPNFn(torch.autograd.Function):
         for i, (f, dl) in enumerate(zip(feats, dlats)):
             C = f.shape[-1]
             lconv = fpn.lateral_convs[i]
+            keep.append(dl)
             dfeats.append(ops.gemm_nt(dl.view(-1, Co), pk[f"l{i}.wT"].view(C, Co)).view(f.shape))
             with ops.side_stream():
                 ops.gemm_tn(dl.view(-1, Co), f.view(-1, C), _gradbuf(lconv.weight).view(Co, C), dbias=_gradbuf(lconv.bias))
         ops.join_side()
+        del keep
         return (None, *dfeats)
 
 

@@ -59,6 +59,19 @@ def relative_position_index(ws: int = WS) -> Tensor:
     return (rel[0] * m * m + rel[1] * m + rel[2]).flatten()
 
 
+def embed_capacity_rows(g: int, kept: Optional[int] = None, p_remove: Optional[float] = None, block: int = 4) -> int:
+    """rows per sample of the compact patch embed (_EmbedFn) on a g^3 token grid: the kept count rounded up to 64-row granules when the mask is known (eager
+    forward), or -- for a captured step, whose shapes are fixed before the masks are drawn -- the mean kept count of the block-Bernoulli mask
+    (swin_mae3d.py:1366-1373) plus eight standard deviations (GraphedTrainStep checks every mask against it and re-captures with full capacity should one
+    ever exceed it)"""
+    tps = g ** 3
+    if kept is None:
+        nb = max(0, (g - block) // block + 1) ** 3
+        keep = 1.0 - float(p_remove)
+        kept = int(math.ceil(block ** 3 * (nb * keep + 8.0 * math.sqrt(max(nb * keep * (1.0 - keep), 0.0)) + 1.0))) + (tps - nb * block ** 3)
+    return int(min(tps, max(64, -(-kept // 64) * 64)))
+
+
 def draw_block_bits(g: Sequence[int], p_remove: float, block: int = 4, rng=random) -> np.ndarray:
     """the draws of `draw_block_mask` only: uint8 array (nb0, nb1, nb2), 1 = block removed (same RNG stream, same order)"""
     nb = [max(0, (gi - block) // block + 1) for gi in g]
@@ -219,7 +232,10 @@ def _gradbuf(p: nn.Parameter) -> Tensor:
 # autograd Functions (one per block; explicit backward launching the HIP dgrad/wgrad kernels)
 # --------------------------------------------------------------------------------------------------
 class _EmbedFn(torch.autograd.Function):
-    """patch conv (im2row + GEMM) -> LayerNorm -> + pos_embed -> masked tokens <- mask_token (swin_mae3d.py:1455-1463)."""
+    """patch conv (im2row + GEMM) -> LayerNorm -> + pos_embed -> masked tokens <- mask_token (swin_mae3d.py:1455-1463).
+    With a mask (training) the embedding of a removed token is never read -- it is replaced by mask_token -- so the im2row, the GEMM rows, the LayerNorm rows and
+    the weight-gradient contraction run on the KEPT tokens only, in compact rows [B][cap][.] (ops.EMBED_KEPT; cap = model._embed_cap rows per sample, sized by
+    the caller that drew the mask).  Same values for every token that is read: the gradients differ from the full pass only by the order of fp32 sums."""
 
     @staticmethod
     def forward(ctx, anchor, mod, xb, mask_dev):
@@ -227,31 +243,46 @@ class _EmbedFn(torch.autograd.Function):
         m._wq.reset()   # first op of every forward pass: drops whatever a failed backward left queued
         B, R = xb.shape[0], xb.shape[2]
         g = R // 4
-        T, C, dtype = B * g ** 3, m.embed_dim, m.compute_dtype
-        A = torch.empty((T, 256), dtype=dtype, device=xb.device)
-        ops.patch_embed_gather(xb, A, B, R)
+        tps = g ** 3
+        T, C, dtype = B * tps, m.embed_dim, m.compute_dtype
+        use_mask = mask_dev is not None
+        kept = use_mask and ops.EMBED_KEPT and m._add_pos
+        cap = min(tps, int(m._embed_cap)) if (kept and m._embed_cap) else tps
+        rowmap = ops.embed_kept_rows(mask_dev, cap) if kept else None
+        rows = B * cap if kept else T
+        A = torch.empty((rows, 256), dtype=dtype, device=xb.device)
+        if kept:
+            ops.patch_embed_gather_kept(xb, A, B, R, rowmap, cap)
+        else:
+            ops.patch_embed_gather(xb, A, B, R)
         conv, ln = m.patch_partition[0], m.patch_partition[2]
         y0 = ops.gemm_nt(A, m._pk["pe.w"].view(C, 256), bias=conv.bias)
         tok = torch.empty((T, C), dtype=dtype, device=xb.device)
         mean, rstd = torch.empty(T, device=xb.device), torch.empty(T, device=xb.device)
-        use_mask = mask_dev is not None
-        ops.layernorm_fwd(y0, ln.weight, ln.bias, tok, mean, rstd, T, C, pos=m.pos_embed.view(-1, C) if m._add_pos else None,
-                          mask=mask_dev, mask_token=m.mask_token if use_mask else None, tokens_per_sample=g ** 3)
-        ctx.m, ctx.saved, ctx.dims = m, (A, y0, mean, rstd, mask_dev), (T, C, g)
+        if kept:
+            ops.embed_norm_fwd_kept(y0, ln.weight, ln.bias, tok, mean, rstd, T, C, m.pos_embed.view(-1, C), mask_dev, m.mask_token, tps, rowmap, cap)
+        else:
+            ops.layernorm_fwd(y0, ln.weight, ln.bias, tok, mean, rstd, T, C, pos=m.pos_embed.view(-1, C) if m._add_pos else None,
+                              mask=mask_dev, mask_token=m.mask_token if use_mask else None, tokens_per_sample=tps)
+        ctx.m, ctx.saved, ctx.dims = m, (A, y0, mean, rstd, mask_dev, rowmap), (T, C, g, cap)
         return tok
 
     @staticmethod
     def backward(ctx, dtok):
         m = ctx.m
-        A, y0, mean, rstd, mask_dev = ctx.saved
-        T, C, g = ctx.dims
+        A, y0, mean, rstd, mask_dev, rowmap = ctx.saved
+        T, C, g, cap = ctx.dims
         conv, ln = m.patch_partition[0], m.patch_partition[2]
         dy0 = torch.empty_like(y0)
-        ops.layernorm_bwd(dtok.contiguous(), y0, ln.weight, mean, rstd, dy0, _gradbuf(ln.weight), _gradbuf(ln.bias), T, C,
-                          mask=mask_dev, dmask_token=_gradbuf(m.mask_token) if mask_dev is not None else None, tokens_per_sample=g ** 3)
+        if rowmap is not None:
+            ops.embed_norm_bwd_kept(dtok.contiguous(), y0, ln.weight, mean, rstd, dy0, _gradbuf(ln.weight), _gradbuf(ln.bias), T, C, mask_dev, _gradbuf(m.mask_token),
+                                    g ** 3, rowmap, cap)
+        else:
+            ops.layernorm_bwd(dtok.contiguous(), y0, ln.weight, mean, rstd, dy0, _gradbuf(ln.weight), _gradbuf(ln.bias), T, C,
+                              mask=mask_dev, dmask_token=_gradbuf(m.mask_token) if mask_dev is not None else None, tokens_per_sample=g ** 3)
         q = m._wq if (ops.GROUPED_WGRAD and dy0.dtype == torch.bfloat16) else None
         if q is not None:
-            q.add(dy0, A, _gradbuf(conv.weight).view(C, 256), dbias=_gradbuf(conv.bias), rows_per_sample=g ** 3)
+            q.add(dy0, A, _gradbuf(conv.weight).view(C, 256), dbias=_gradbuf(conv.bias), rows_per_sample=cap if rowmap is not None else g ** 3)
             q.flush(foreground=True)
             q.join()      # the backward pass ends here: every deferred weight gradient has been issued and joined
         else:
@@ -905,6 +936,7 @@ class SwinTransformer_MAE3D_New(nn.Module):
         self._add_pos = True
         self._anchor = None
         self._reducer = None  # dist.GradReducer when data-parallel
+        self._embed_cap = None   # rows per sample of the compact patch embed of the kept tokens (_EmbedFn); None = every token has a row
 
     # ---- flat buffers + packed weights ------------------------------------------------------------
     def _trainable(self):
@@ -1147,7 +1179,12 @@ class SwinTransformer_MAE3D_New(nn.Module):
         if block_mask is None:
             block_mask = draw_block_mask((g, g, g), self.masking_prob)
         mask_dev = block_mask.to(torch.uint8).contiguous().view(-1).to(device, non_blocking=True)
-        tok = _EmbedFn.apply(self._anchor, self, xb, mask_dev).view(B, g, g, g, self.embed_dim)
+        # the mask was drawn on the host: the compact patch embed gets exactly the rows it needs (64-row granules)
+        cap_was, self._embed_cap = self._embed_cap, embed_capacity_rows(g, kept=int(g ** 3 - int(block_mask.to(torch.int64).sum())))
+        try:
+            tok = _EmbedFn.apply(self._anchor, self, xb, mask_dev).view(B, g, g, g, self.embed_dim)
+        finally:
+            self._embed_cap = cap_was
         feats = self.forward_encoder(tok, sd_noise)
         want_pred = is_eval or return_pred
         pred = torch.empty((B, 4, R, R, R), device=device) if want_pred else None

@@ -603,6 +603,37 @@ def layernorm_fwd(x, gamma, beta, out, mean, rstd, rows, C, src_mode=0, geom: Op
 
 
 LN_DEFER_PARAM_GRADS = __import__("os").environ.get("NMH_LN_DEFER", "1") != "0"
+EMBED_KEPT = __import__("os").environ.get("NMH_EMBED_KEPT", "1") != "0"   # patch embed (im2row, GEMM, LayerNorm, weight gradient) on the kept tokens only
+
+
+def embed_kept_rows(mask, cap_rows):
+    """token mask [n] uint8 (1 = removed) -> int32 rowmap [n + 2] (include/nerfmae_hip.h: nmh_patch_embed_kept_rows)"""
+    _chk(mask)
+    n = mask.numel()
+    rowmap = torch.empty(n + 2, dtype=torch.int32, device=mask.device)
+    lib().call("nmh_patch_embed_kept_rows", mask, n, int(cap_rows), rowmap, _st())
+    return rowmap
+
+
+def patch_embed_gather_kept(x, A, B, R, rowmap, cap_rows):
+    _chk(x, A, rowmap)
+    ev = _prof(("patch_embed_gather", B, R))
+    lib().call("nmh_patch_embed_gather_kept", dt_of(A), x, A, B, R, rowmap, int(cap_rows), _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return A
+
+
+def embed_norm_fwd_kept(y0, gamma, beta, tok, mean, rstd, rows, C, pos, mask, mask_token, tokens_per_sample, rowmap, cap_rows, eps=1e-5):
+    _chk(y0, gamma, beta, tok, mean, rstd, pos, mask, mask_token, rowmap)
+    lib().call("nmh_patch_embed_norm_fwd_kept", dt_of(y0), y0, tok, gamma, beta, eps, mean, rstd, rows, C, pos, mask, mask_token, tokens_per_sample, rowmap, int(cap_rows), _st())
+    return tok
+
+
+def embed_norm_bwd_kept(dtok, y0, gamma, mean, rstd, dy0, dgamma, dbeta, rows, C, mask, dmask_token, tokens_per_sample, rowmap, cap_rows):
+    _chk(dtok, y0, gamma, mean, rstd, dy0, dgamma, dbeta, mask, dmask_token, rowmap)
+    lib().call("nmh_patch_embed_norm_bwd_kept", dt_of(y0), dtok, y0, gamma, mean, rstd, dy0, dgamma, dbeta, rows, C, mask, dmask_token, tokens_per_sample, rowmap, int(cap_rows), _st())
+    return dy0
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, src_mode=0, geom: Optional[WinGeom] = None, dres=None,

@@ -138,6 +138,10 @@ class GraphedTrainStep:
         self.x = torch.zeros((batch, 4, R, R, R), device=dev)
         self.ext = torch.full((batch, 3), R, dtype=torch.int32, device=dev)
         self.mask = torch.zeros(g ** 3, dtype=torch.uint8, device=dev)
+        # rows per sample of the compact patch embed of the kept tokens (model._EmbedFn): fixed at capture from the mask distribution; every mask is checked
+        # against it in __call__ (a mask that keeps more tokens re-captures the step with a row for every token)
+        from .model import embed_capacity_rows
+        self._embed_cap = embed_capacity_rows(g, p_remove=model.masking_prob)
         self.losses = None
         self._ext_host = None
         self._g1 = self._g2 = self._gb1 = self._gb2 = None
@@ -168,6 +172,13 @@ class GraphedTrainStep:
         return out
 
     def _capture(self):
+        cap_was, self.model._embed_cap = self.model._embed_cap, self._embed_cap
+        try:
+            self._capture_graphs()
+        finally:
+            self.model._embed_cap = cap_was
+
+    def _capture_graphs(self):
         import os
         import torch.distributed as tdist
         ops.side_stream.auto(self.x.shape[0])
@@ -357,6 +368,12 @@ class GraphedTrainStep:
                     self._pin_mask = PinnedRing((self.mask.numel(),), torch.uint8)
                 self._pin_mask.upload(torch.from_numpy(full), self.mask)
                 bits = None
+        if block_mask is not None and self._embed_cap < g ** 3:
+            kept = g ** 3 - (64 * int(np.asarray(bits).sum()) if bits is not None else int(np.asarray(block_mask).sum()))
+            if kept > self._embed_cap:   # (eight standard deviations above the mean kept count: not expected to happen in a training run)
+                self._embed_cap = g ** 3
+                torch.cuda.synchronize()
+                self._capture()
         ext, self._ext_host = self._ext_host, None
         # mask bits + optimizer hyper-parameters + extents as kernel arguments of one launch: nothing in the step waits on a copy.
         # The argument struct holds 16 samples' extents (nmh_step_params): larger batches send the rest in further launches.

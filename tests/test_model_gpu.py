@@ -170,6 +170,55 @@ def test_stage_flush_behind_the_first_chain_kernel_changes_nothing(monkeypatch):
     assert torch.isfinite(grads[1][1]).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_patch_embed_of_the_kept_tokens_only_changes_nothing(monkeypatch, dtype):
+    """ops.EMBED_KEPT: im2row, GEMM, LayerNorm and weight gradient of the patch embed on the compact rows of the kept tokens (swin_mae3d.py:1375-1380 replaces
+    the others by mask_token).  Against the full pass: the same loss, and gradients that differ by the order of fp32 sums only -- with a ragged second sample,
+    with a capacity larger than the kept count (zeroed tail rows), with one block removed and with every block removed"""
+    from nerf_mae_amd import ops
+    from nerf_mae_amd.model import embed_capacity_rows
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(SWIN_T, dtype, res=32, init="default")
+    xs = [O.synthetic_grid((32, 32, 32), 41).cuda(), O.synthetic_grid((32, 30, 27), 42).cuda()]
+    one = torch.zeros(8, 8, 8, dtype=torch.uint8)
+    one[4:, :4, 4:] = 1   # one block removed (with none removed the reference's loss_alpha is 0 / 0)
+    masks = [O.draw_block_mask((8, 8, 8), 0.75, rng=random.Random(8)), one, torch.ones(8, 8, 8, dtype=torch.uint8)]
+    assert embed_capacity_rows(8, kept=130) == 192 and embed_capacity_rows(8, kept=0) == 64 and embed_capacity_rows(40, p_remove=0.75) < 0.4 * 64000
+    for bm in masks:
+        res = []
+        for flag in (False, True, False):
+            monkeypatch.setattr(ops, "EMBED_KEPT", flag)
+            hip.zero_grad()
+            out = hip(xs, block_mask=bm)
+            out[0].backward()
+            torch.cuda.synchronize()
+            res.append((out[0].item(), hip._flat_grad.clone()))
+        noise = relerr(res[0][1], res[2][1])
+        assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]), (res[0][0], res[1][0])
+        assert relerr(res[1][1], res[0][1]) <= max(4 * noise, 2e-6 if dtype == torch.float32 else 2e-3), (relerr(res[1][1], res[0][1]), noise)
+        assert torch.isfinite(res[1][1]).all()
+    # a capacity above the kept count (what a captured step runs with): forward_static with model._embed_cap set
+    monkeypatch.setattr(ops, "EMBED_KEPT", True)
+    bm = masks[0]
+    xb, ext = hip.transform(xs, torch.device("cuda"))
+    md = bm.to(torch.uint8).contiguous().view(-1).cuda()
+    outs = []
+    for cap in (None, 512, embed_capacity_rows(8, kept=int(512 - int(bm.sum())))):
+        hip._embed_cap = cap
+        try:
+            hip.zero_grad()
+            torch.manual_seed(3)
+            l = hip.forward_static(xb, ext, md)
+            l[0].backward()
+            torch.cuda.synchronize()
+            outs.append((l[0].item(), hip._flat_grad.clone()))
+        finally:
+            hip._embed_cap = None
+    for o in outs[1:]:
+        assert abs(o[0] - outs[0][0]) <= 1e-6 * abs(outs[0][0])
+        assert relerr(o[1], outs[0][1]) <= (2e-5 if dtype == torch.float32 else 5e-3)
+
+
 def test_bf16_close_to_oracle_and_eval_contract():
     from oracle import mae3d_oracle as O
     res = 96
