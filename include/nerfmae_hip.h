@@ -150,6 +150,17 @@ NMH_API int64_t nmh_cconv_pack_numel(void);
 NMH_API int64_t nmh_cconv_pack_ws_floats(void);
 NMH_API int nmh_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, void* stream);
 NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, int B, int v, double* stats_acc, void* stream);
+/* The CENTERED form of decoder1's conv1 -> InstanceNorm -> LeakyReLU -> conv2 (unetr_block.py:57-62), round 6.  y1 is linear in the coarse tensor x, so its mean
+ * per (sample, channel) is known before y1 exists: sum over the fine voxels = sum_n S_n . M[n] + border constant, S_n = sum of x over the source cells whose
+ * target cell lies in the grid, M[n] = the composed blocks summed over the phases (mean_table, [27][96][48] fp32, built by nmh_cconv_pack_centered next to the pack).
+ * nmh_cconv_output_mean: x [B][v^3][96] -> mean [B][48] (class_sums: [B][27][96] fp64 scratch).  nmh_cconv_fwd_centered then stores z = lrelu(y1 - mean) and
+ * accumulates the statistics of t = y1 - mean (stats_acc as nmh_cconv_fwd: nmh_instnorm_finalize turns them into (residual mean ~ 0, rstd)).  Since rstd > 0 commutes
+ * with the LeakyReLU, lrelu(InstanceNorm(y1)) = rstd * z: the scale goes into conv2's weights per sample (nmh_conv48_pack_scaled, nmh_conv3d_k3_c48_per_sample) and the
+ * stand-alone normalisation pass over the 160^3 tensor (nmh_instnorm_apply, 6.3 GB at 8 grids) is gone; the backward reads z (nmh_conv3d_k3_c48_bwd_reduce_centered,
+ * nmh_instnorm_bwd_apply_bg_centered, nmh_conv3d_k3_c48_wgrad_scaled). */
+NMH_API int nmh_cconv_pack_centered(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, float* mean_table, void* stream);
+NMH_API int nmh_cconv_output_mean(const void* x, const float* mean_table, const float* delta, double* class_sums, float* mean, int B, int v, void* stream);
+NMH_API int nmh_cconv_fwd_centered(const void* x, const void* Wcp, const float* delta, const float* mean, float slope, void* z, int B, int v, double* stats_acc, void* stream);
 /* Weight gradient of decoder1's conv1 THROUGH the composition above (backward of unetr_block.py:35-44 with respect to conv1.weight; replaces the
  * 48 -> 48 nmh_conv3d_k3_c48_wgrad launch on the up-sampled map): dW1[c][co][d] += sum_a sum_ci Wt[ci][co][(a+d) mod 4] . G[a][n(a,d)][ci][c] with
  * G[a][n] = sum_j x[j+n]^T dy1[4j+a] -- the same 216 blocks as the forward, a quarter of the FLOPs, contraction over the coarse cells.

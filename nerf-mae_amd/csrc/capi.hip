@@ -214,6 +214,24 @@ int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, void* y1, 
   if (B <= 0 || v <= 0) return 0;
   return k_cconv_fwd(x, Wcp, delta, y1, B, v, stats_acc, ST);
 }
+int nmh_cconv_pack_centered(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, float* mean_table, void* stream) {
+  CLR();
+  REQ(Wt, W1, bt, Wcp, delta, ws, mean_table);
+  return k_cconv_pack(Wt, W1, bt, Wcp, delta, ws, ST, mean_table);
+}
+int nmh_cconv_output_mean(const void* x, const float* mean_table, const float* delta, double* class_sums, float* mean, int B, int v, void* stream) {
+  CLR();
+  REQ(x, mean_table, delta, class_sums, mean);
+  if (B <= 0 || v <= 0) return 0;
+  return k_cconv_mean(x, mean_table, delta, class_sums, mean, B, v, ST);
+}
+int nmh_cconv_fwd_centered(const void* x, const void* Wcp, const float* delta, const float* mean, float slope, void* z, int B, int v, double* stats_acc, void* stream) {
+  CLR();
+  REQ(x, Wcp, delta, mean, z);
+  if (B <= 0 || v <= 0) return 0;
+  if (!(slope > 0.f && slope < 1.f)) return -2;
+  return k_cconv_fwd(x, Wcp, delta, z, B, v, stats_acc, ST, mean, slope);
+}
 int64_t nmh_cconv_wgrad_ws_floats(void) { return (int64_t)k_cconv_wgrad_ws_floats(); }
 int nmh_cconv_wgrad(const void* x, const void* dy1, const float* pack_ws, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, int phase, void* stream) {
   CLR();

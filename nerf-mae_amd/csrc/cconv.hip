@@ -30,7 +30,7 @@ namespace cc {
 constexpr int BZ = 4, BY = 8, BX = 8, HZ = BZ + 2, HY = BY + 2, HX = BX + 2;
 constexpr int CELL = 192, LINE = HX * CELL + 32, PLANE = HY * LINE, HALO = HZ * PLANE;
 constexpr int WCHUNK = 18 * 1024, NCHUNK = 108, WHALF = 9 * 1024, NHALF = 2 * NCHUNK;   // ring: 4 slots of half a chunk (9 fragments)
-constexpr int OFF_RING = HALO, OFF_SACC = OFF_RING + 2 * WCHUNK, OFF_DELTA = OFF_SACC + 2 * 96 * 4, LDS_BYTES = OFF_DELTA + 27 * 48 * 4;
+constexpr int OFF_RING = HALO, OFF_SACC = OFF_RING + 2 * WCHUNK, OFF_DELTA = OFF_SACC + 2 * 96 * 4, OFF_MHAT = OFF_DELTA + 27 * 48 * 4, LDS_BYTES = OFF_MHAT + 48 * 4;
 static_assert(LDS_BYTES <= 163840, "LDS budget");
 constexpr int HCH = HZ * HY * HX * 12;          // 16-byte chunks of the halo (7200)
 constexpr int HREG = (HCH + 511) / 512;         // 15
@@ -42,6 +42,9 @@ __device__ constexpr int BLK_NX[6] = {0, 1, 1, 1, 1, 2};   // index into xf[]: n
 struct CConvArgs {
   const bf16_t* X; const bf16_t* Wcp; const float* delta; bf16_t* Y; double* stats_acc;
   int B, v, nbz, nby, nbx; long total;
+  // centered variant (CZ): mhat [B][48] = the per-(sample, channel) mean of the output, known BEFORE the launch (k_cconv_mean: the output is linear in x);
+  // the kernel stores z = lrelu(y1 - mhat) and accumulates the statistics of t = y1 - mhat
+  const float* mhat; float slope;
 };
 
 // neighbour offsets of phase component a: count and first offset
@@ -49,7 +52,7 @@ __host__ __device__ __forceinline__ int cc_ncnt(int a) { return (a == 0 || a == 
 __host__ __device__ __forceinline__ int cc_nfirst(int a) { return a == 0 ? -1 : 0; }
 
 // DBG (diagnostic builds, NMH_CCONV_DBG): 1 = no output stores, 2 = no weight DMA / waits (stale weights), 4 = no MFMAs, 8 = no epilogue at all.  0 = product.
-template <int DBG>
+template <int DBG, bool CZ = false>
 __global__ __launch_bounds__(512) void cconv_fwd_kernel(CConvArgs a) {
   using namespace cc;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(512) void cconv_fwd_kernel(CConvArgs a) {
 
   long t = tbeg + jb;
   if (t >= tend) return;
+  int cz_b = -1;
   w_dma(0, 0); w_dma(1, 1); w_dma(2, 2);   // three half-chunks ahead
   for (; t < tend; t += jstride) {
     // ---- block origin
@@ -137,6 +141,10 @@ __global__ __launch_bounds__(512) void cconv_fwd_kernel(CConvArgs a) {
           *reinterpret_cast<uint4*>(halo + hz * PLANE + hy * LINE + hx * CELL + c12 * 16) = hv[i];
         }
       }
+      if constexpr (CZ) {   // minus the sample's predicted means: the accumulators of every group start from them (next to the halo stores: one drain for all)
+        if (b != cz_b && tid < 48) reinterpret_cast<float*>(smem + OFF_MHAT)[tid] = -a.mhat[(long)b * 48 + tid];
+        cz_b = b;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();     // the halo is complete before anyone reads it (the x fragments of a chunk are requested in front of its weight barrier)
@@ -150,12 +158,23 @@ __global__ __launch_bounds__(512) void cconv_fwd_kernel(CConvArgs a) {
     for (int gi = 0; gi < 16; ++gi) {
       const int az = gi >> 2, ay = gi & 3;
       f32x4 acc[4][3][2];
+      if constexpr (CZ) {   // rows 4 g + r of channel tile n <-> channel 12 g + 4 n + r: three raw 16-byte reads (a visible LDS read would drain the weight prefetch)
+        f32x4 m0, m1, m2;
+        const unsigned maddr = (unsigned)(OFF_MHAT + 12 * g * 4);
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(maddr) : "memory");
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) { acc[p][0][m] = m0; acc[p][1][m] = m1; acc[p][2][m] = m2; }
+      } else {
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int n = 0; n < 3; ++n)
 #pragma unroll
           for (int m = 0; m < 2; ++m) acc[p][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       const int cz = cc_ncnt(az), cy = cc_ncnt(ay), fz = cc_nfirst(az), fy = cc_nfirst(ay);
 #pragma unroll 1
       for (int iz = 0; iz < cz; ++iz)
@@ -252,6 +271,16 @@ __global__ __launch_bounds__(512) void cconv_fwd_kernel(CConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { vv[0][r] += d0[r]; vv[1][r] += d1[r]; vv[2][r] += d2[r]; }
           }
+#pragma unroll
+          for (int n = 0; n < 3; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st1[n][r] += vv[n][r]; st2[n][r] += vv[n][r] * vv[n][r]; }
+          if constexpr (CZ) {   // z = lrelu(t), t = y1 - mhat (the statistics above are those of t)
+#pragma unroll
+            for (int n = 0; n < 3; ++n)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) vv[n][r] = __builtin_fmaxf(vv[n][r], a.slope * vv[n][r]);
+          }
           unsigned w6[6];
 #pragma unroll
           for (int q = 0; q < 6; ++q) w6[q] = pk_bf16(vv[q >> 1][(q & 1) * 2], vv[q >> 1][(q & 1) * 2 + 1]);
@@ -261,10 +290,6 @@ __global__ __launch_bounds__(512) void cconv_fwd_kernel(CConvArgs a) {
             *reinterpret_cast<uint4*>(dst) = make_uint4(w6[0], w6[1], w6[2], w6[3]);
             *reinterpret_cast<uint2*>(dst + 8) = make_uint2(w6[4], w6[5]);
           } else asm volatile("" ::"v"(w6[0]), "v"(w6[1]), "v"(w6[2]), "v"(w6[3]), "v"(w6[4]), "v"(w6[5]));
-#pragma unroll
-          for (int n = 0; n < 3; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { st1[n][r] += vv[n][r]; st2[n][r] += vv[n][r] * vv[n][r]; }
         }
       }
       if (a.stats_acc) {
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(256) void cconv_tr_kernel(const float* __restrict__
 
 // one workgroup per fragment (16 channels x 32 input channels = 512 elements, one per thread); per contributing tap the 32 WtT rows and the
 // 16 W1T rows are staged in LDS (coalesced 16-byte loads) and every thread forms its 48-term dot product from there
-__global__ __launch_bounds__(512) void cconv_pack_kernel(const float* __restrict__ ws, const float* __restrict__ bt, bf16_t* __restrict__ Wcp, float* __restrict__ delta) {
+__global__ __launch_bounds__(512) void cconv_pack_kernel(const float* __restrict__ ws, const float* __restrict__ bt, bf16_t* __restrict__ Wcp, float* __restrict__ delta, float* __restrict__ Mtab) {
   constexpr int RSF = 52;                                  // padded row (floats)
   __shared__ __attribute__((aligned(16))) float swt[32 * RSF];
   __shared__ __attribute__((aligned(16))) float sw1[16 * RSF];
@@ -396,25 +421,120 @@ __global__ __launch_bounds__(512) void cconv_pack_kernel(const float* __restrict
       }
     }
   }
-  Wcp[((long)blk * 64 + lane) * 8 + j] = f2bf(acc);
+  const bf16_t wq = f2bf(acc);
+  Wcp[((long)blk * 64 + lane) * 8 + j] = wq;
+  // M[n][ci][c] = sum over the phases a with n in N(a) of the (bf16-rounded) composed weights: the output summed over a sample's fine voxels is
+  // sum_n (sum of x over the cells j with j + n inside the grid) . M[n]  (k_cconv_mean)
+  if (Mtab) atomicAdd(Mtab + (((long)((nz + 1) * 3 + (ny + 1)) * 3 + (nx + 1)) * 96 + 32 * s + cil) * 48 + 12 * (li >> 2) + 4 * nt + (li & 3), bf2f(wq));
 }
 
 long k_cconv_pack_ws_floats() { return CC_WTT + CC_W1T; }
 
-int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, hipStream_t st) {
+int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, hipStream_t st, float* Mtab) {
   hipLaunchKernelGGL(cconv_tr_kernel, dim3(96 + 48), dim3(256), 0, st, Wt, W1, ws);
   NMH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(cconv_pack_kernel, dim3(108 * 18 + 27), dim3(512), 0, st, (const float*)ws, bt, (bf16_t*)Wcp, delta);
+  if (Mtab) {
+    hipError_t e = nmh_zero_async(Mtab, sizeof(float) * 27 * 96 * 48, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(cconv_pack_kernel, dim3(108 * 18 + 27), dim3(512), 0, st, (const float*)ws, bt, (bf16_t*)Wcp, delta, Mtab);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- the mean of the composed output, per (sample, channel), from the COARSE tensor ------------------------------------------------
+// y1 is linear in x, so its sum over a sample's fine voxels is  sum_n S_n . M[n]  +  sum_class count(class) delta[class], with S_n[ci] the sum of x over
+// the source cells s for which s - n is a cell (n = 0: all cells; n_axis = +1: all but the first plane of that axis; -1: all but the last) and M from
+// the pack above.  (1) class sums C27[b][class][ci] of x by position class (first / interior / last per axis), one pass over the 98-MB coarse tensor;
+// (2) S_n from the classes, the 2592-term dot products and the border constant.  With the mean known BEFORE the fine tensor is written, the InstanceNorm
+// that follows needs no pass of its own over it: the producer stores lrelu(y1 - mean), the scale 1 / std goes into the consumer's weights (positive, so
+// it commutes with the LeakyReLU).
+__global__ __launch_bounds__(256) void cconv_class_sums_kernel(const bf16_t* __restrict__ x, double* __restrict__ C27, int v) {
+  // block = (z plane, sample); thread = (8-channel chunk cl of 12, cell lane vl of 21); 9 (y class, x class) accumulators of 8 channels in registers
+  __shared__ float red[9 * 96];
+  const int z = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, cl = tid % 12, vl = tid / 12;
+  for (int i = tid; i < 9 * 96; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float acc[9][8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+  if (vl < 21) {
+    const bf16_t* xp = x + (((long)b * v + z) * v * v) * 96 + cl * 8;
+    for (int c = vl; c < v * v; c += 21) {
+      const int y = c / v, xx = c - y * v;
+      const int ky = y == 0 ? 0 : (y == v - 1 ? 2 : 1), kx = xx == 0 ? 0 : (xx == v - 1 ? 2 : 1), k = ky * 3 + kx;
+      float f[8];
+      Vec8<bf16_t>::load(xp + (long)c * 96, f);
+#pragma unroll
+      for (int kk = 0; kk < 9; ++kk)
+        if (kk == k) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[kk][j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (acc[k][j] != 0.f) atomicAdd(&red[k * 96 + cl * 8 + j], acc[k][j]);
+  }
+  __syncthreads();
+  const int kz = z == 0 ? 0 : (z == v - 1 ? 2 : 1);
+  for (int i = tid; i < 9 * 96; i += 256) atomicAdd(C27 + ((long)b * 27 + kz * 9 + i / 96) * 96 + i % 96, (double)red[i]);
+}
+__global__ __launch_bounds__(256) void cconv_mean_kernel(const double* __restrict__ C27, const float* __restrict__ Mtab, const float* __restrict__ delta, float* __restrict__ mhat, int v) {
+  __shared__ float S[27 * 96];
+  __shared__ float part[5 * 48];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 27 * 96; i += 256) {
+    const int n = i / 96, ci = i - n * 96, nz = n / 9 - 1, ny = (n / 3) % 3 - 1, nx = n % 3 - 1;
+    double sum = 0.0;
+    for (int k = 0; k < 27; ++k) {
+      const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+      // a source cell s feeds the output cell j = s - n: counted when j is a cell.  n = +1: s >= 1 (not the first plane); n = -1: s <= v - 2 (not the last)
+      const bool in = !((nz > 0 && kz == 0) || (nz < 0 && kz == 2) || (ny > 0 && ky == 0) || (ny < 0 && ky == 2) || (nx > 0 && kx == 0) || (nx < 0 && kx == 2));
+      if (in) sum += C27[((long)b * 27 + k) * 96 + ci];
+    }
+    S[i] = (float)sum;
+  }
+  __syncthreads();
+  const int c = tid % 48, pt = tid / 48;
+  if (pt < 5) {
+    float acc = 0.f;
+    for (int r = pt; r < 27 * 96; r += 5) acc += S[r] * Mtab[(long)r * 48 + c];
+    part[pt * 48 + c] = acc;
+  }
+  __syncthreads();
+  if (tid < 48) {
+    const double F = 4.0 * v;
+    double tot = (double)part[tid] + part[48 + tid] + part[96 + tid] + part[144 + tid] + part[192 + tid];
+    for (int k = 0; k < 27; ++k) {
+      const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+      const double cnt = (kz == 1 ? F - 2 : 1.0) * (ky == 1 ? F - 2 : 1.0) * (kx == 1 ? F - 2 : 1.0);
+      tot += cnt * (double)delta[k * 48 + tid];
+    }
+    mhat[(long)b * 48 + tid] = (float)(tot / (F * F * F));
+  }
+}
+int k_cconv_mean(const void* x, const float* Mtab, const float* delta, double* C27, float* mhat, int B, int v, hipStream_t st) {
+  if (v < 2) return -2;
+  hipError_t e = nmh_zero_async(C27, sizeof(double) * 27 * 96 * B, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(cconv_class_sums_kernel, dim3(v, B), dim3(256), 0, st, (const bf16_t*)x, C27, v);
+  NMH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cconv_mean_kernel, dim3(B), dim3(256), 0, st, (const double*)C27, Mtab, delta, mhat, v);
   NMH_CHECK_LAUNCH();
   return 0;
 }
 
 long k_cconv_pack_numel() { return 108L * 18 * 512; }
 
-int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st) {
+int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st, const float* mhat, float slope) {
   using namespace cc;
   if (v % BY || v % BX || v % BZ) return -2;
   CConvArgs a;
+  a.mhat = mhat; a.slope = slope;
   a.X = (const bf16_t*)X; a.Wcp = (const bf16_t*)Wcp; a.delta = delta; a.Y = (bf16_t*)Y; a.stats_acc = stats_acc;
   a.B = B; a.v = v; a.nbz = v / BZ; a.nby = v / BY; a.nbx = v / BX;
   a.total = (long)B * a.nbz * a.nby * a.nbx;
@@ -427,6 +547,17 @@ int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int
   // a stride of 31 and the first workgroup of every range would run two blocks (the launch then takes two block times instead of one)
   long nb = (a.total + 7) / 8 * 8;
   if (nb > 256) nb = 256;
+  if (mhat) {
+    static NmhPerDeviceOnce attr_cz;
+    if (attr_cz.need()) {
+      hipError_t e = hipFuncSetAttribute((const void*)cconv_fwd_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      if (e != hipSuccess) return (int)e;
+      attr_cz.set();
+    }
+    hipLaunchKernelGGL((cconv_fwd_kernel<0, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
   static const int dbg = getenv("NMH_CCONV_DBG") ? atoi(getenv("NMH_CCONV_DBG")) : 0;
 #define CC_LAUNCH(D)                                                                                                              \
   {                                                                                                                               \

@@ -173,10 +173,11 @@ int k_window_scatter_residual(int dt, const void* yw, const void* x, void* out, 
 int k_window_gather_scale(int dt, const void* dx, void* dyw, const float* rowscale, int C, const WinMap& wm, hipStream_t st);
 
 // ---- cconv.hip: ConvTranspose3d(96 -> 48, k = s = 4) composed with the 3x3x3 conv that follows it (decoder1, forward) ----
-int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, hipStream_t st);
+int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, hipStream_t st, float* Mtab = nullptr);
+int k_cconv_mean(const void* x, const float* Mtab, const float* delta, double* C27, float* mhat, int B, int v, hipStream_t st);
 long k_cconv_pack_numel();
 long k_cconv_pack_ws_floats();
-int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st);
+int k_cconv_fwd(const void* X, const void* Wcp, const float* delta, void* Y, int B, int v, double* stats_acc, hipStream_t st, const float* mhat = nullptr, float slope = 0.f);
 int k_cconv_wgrad(const void* X, const void* dY, const float* WtT, const float* bt, float* dW1, float* dWt, float* dbt, float* ws, int B, int v, int phase, hipStream_t st);
 long k_cconv_dpack_numel();
 int k_cconv_dpack(const void* Wcp, void* Wdp, hipStream_t st);

@@ -391,6 +391,37 @@ def cconv_pack(Wt, W1, bt, Wcp, delta, ws=None):
     lib().call("nmh_cconv_pack", Wt, W1, bt, Wcp, delta, ws, _st())
 
 
+def cconv_pack_centered(Wt, W1, bt, Wcp, delta, ws, mean_table):
+    """cconv_pack + the [27,96,48] fp32 table of the composed blocks summed over the phases (include/nerfmae_hip.h: nmh_cconv_pack_centered)"""
+    _chk(Wt, W1, bt, Wcp, delta, ws, mean_table)
+    if mean_table.numel() < 27 * 96 * 48 or mean_table.dtype != torch.float32:
+        raise ValueError("cconv_pack_centered: mean_table must hold 27 x 96 x 48 floats")
+    lib().call("nmh_cconv_pack_centered", Wt, W1, bt, Wcp, delta, ws, mean_table, _st())
+
+
+def cconv_output_mean(x, mean_table, delta, B, v):
+    """per-(sample, channel) mean of cconv_fwd's output from the COARSE tensor (nmh_cconv_output_mean) -> fp32 [B,48]"""
+    _chk(x, mean_table, delta)
+    cls = torch.empty((B, 27, 96), dtype=torch.float64, device=x.device)
+    mean = torch.empty((B, 48), dtype=torch.float32, device=x.device)
+    lib().call("nmh_cconv_output_mean", x, mean_table, delta, cls, mean, B, v, _st())
+    return mean
+
+
+def cconv_fwd_centered(x, Wcp, delta, mean, B, v, out=None, stats_acc=None, slope=0.01):
+    """z = lrelu(cconv_fwd(x) - mean) + the statistics of cconv_fwd(x) - mean (nmh_cconv_fwd_centered)"""
+    _chk(x, Wcp, delta, mean, out, stats_acc)
+    if x.dtype != torch.bfloat16 or x.shape[-1] != 96 or v % 8:
+        raise RuntimeError("cconv_fwd_centered needs bf16 activations with 96 channels on a coarse grid whose edge is a multiple of 8")
+    if out is None:
+        out = torch.empty((B, 4 * v, 4 * v, 4 * v, 48), dtype=x.dtype, device=x.device)
+    ev = _prof(("cconv_fwd", B, 4 * v, 96, 48))
+    lib().call("nmh_cconv_fwd_centered", x, Wcp, delta, mean, float(slope), out, B, v, stats_acc, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 def cconv_pack_ws_floats() -> int:
     return int(lib().call("nmh_cconv_pack_ws_floats"))
 

@@ -1199,6 +1199,49 @@ def test_cconv_forward_matches_convtranspose_then_conv(B, v):
     assert_close(y.float().cpu(), y2.float().cpu() - const, 2e-2, "cconv vs two-step HIP path (interior + border)", elem_mult=2.0)
 
 
+@pytest.mark.parametrize("B,v", [(1, 8), (2, 8), (3, 16), (2, 24)])
+def test_cconv_output_mean_from_the_coarse_tensor_and_centered_forward(B, v):
+    """nmh_cconv_output_mean: the per-(sample, channel) mean of the composed conv's output computed from the COARSE tensor (the output is linear in it) == the mean
+    of what nmh_cconv_fwd stores, to the rounding of its bf16 outputs; nmh_cconv_fwd_centered: z == lrelu(y1 - mean) and the statistics of y1 - mean"""
+    ops = _ops()
+    dt = torch.bfloat16
+    x = q(rnd(B, v, v, v, 96, seed=1) + 0.3 * rnd(B, 1, 1, 1, 96, seed=5), dt)   # per-sample, per-channel offsets: the mean is far from zero
+    Wt = rnd(96, 48, 4, 4, 4, seed=2, scale=96 ** -0.5)
+    W1 = rnd(48, 48, 3, 3, 3, seed=3, scale=(27 * 48) ** -0.5)
+    bt = rnd(48, seed=4, scale=0.5)
+    Wcp = torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda")
+    delta = torch.empty(27, 48, device="cuda")
+    ws = torch.empty(ops.cconv_pack_ws_floats(), device="cuda")
+    mtab = torch.full((27, 96, 48), 3.0, device="cuda")     # zeroed by the entry
+    ops.cconv_pack_centered(dev(Wt), dev(W1), dev(bt), Wcp, delta, ws, mtab)
+    Wcp0 = torch.empty_like(Wcp)
+    ops.cconv_pack(dev(Wt), dev(W1), dev(bt), Wcp0, torch.empty_like(delta), ws)
+    assert torch.equal(Wcp, Wcp0)
+    xd = dev(x, dt)
+    acc = torch.zeros((B, 48, 2), dtype=torch.float64, device="cuda")
+    y = ops.cconv_fwd(xd, Wcp, delta, B, v, stats_acc=acc)
+    mean = ops.cconv_output_mean(xd, mtab, delta, B, v)
+    torch.cuda.synchronize()
+    V = (4 * v) ** 3
+    yd = y.double().reshape(B, V, 48)
+    std = yd.std(dim=1)
+    err = ((mean.double() - yd.mean(dim=1)).abs() / std).max().item()
+    assert err < 2e-4, err     # (bf16 rounding of 64 v^3 stored outputs averages out; the fp32 accumulator sums give the same to 1e-6)
+    err_acc = ((mean.double() - acc[:, :, 0] / V).abs() / std).max().item()
+    assert err_acc < 2e-5, err_acc
+    acc2 = torch.full((B, 48, 2), 9.0, dtype=torch.float64, device="cuda")
+    z = ops.cconv_fwd_centered(xd, Wcp, delta, mean, B, v, stats_acc=acc2)
+    torch.cuda.synchronize()
+    # z against the definition on the fp32 composed output: recomputed here from the reference ops
+    u = F.conv_transpose3d(x.permute(0, 4, 1, 2, 3), Wt, bt, stride=4)
+    ref = F.conv3d(u, W1, None, padding=1) - torch.einsum("o,codhw->c", bt, W1)[None, :, None, None, None]
+    t = ref.permute(0, 2, 3, 4, 1) - mean.cpu()[:, None, None, None, :]
+    check(z, F.leaky_relu(t, 0.01), dt, "cconv centered z", 2)
+    # statistics of t: sum ~ 0 (the predicted mean IS the mean), sum of squares = V * var
+    assert (acc2[:, :, 0].abs() / (V * std)).max().item() < 2e-5
+    check((acc2[:, :, 1] / V).float(), (yd.var(dim=1, unbiased=False)).float(), torch.float32, "cconv centered variance", 50)
+
+
 @pytest.mark.parametrize("B,D,H,W", [(1, 16, 16, 16), (2, 20, 24, 40), (3, 32, 32, 32), (1, 7, 9, 19)])
 def test_conv48_input_gradient_with_fused_instnorm_backward_sums(B, D, H, W):
     """nmh_conv3d_k3_c48_bwd_reduce (decoder1 conv2's input gradient, unetr_block.py:60-63 backward): the same dX as the plain launch, bit for bit, and
