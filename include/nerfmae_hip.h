@@ -153,13 +153,23 @@ NMH_API int nmh_cconv_fwd(const void* x, const void* Wcp, const float* delta, vo
 /* The CENTERED form of decoder1's conv1 -> InstanceNorm -> LeakyReLU -> conv2 (unetr_block.py:57-62), round 6.  y1 is linear in the coarse tensor x, so its mean
  * per (sample, channel) is known before y1 exists: sum over the fine voxels = sum_n S_n . M[n] + border constant, S_n = sum of x over the source cells whose
  * target cell lies in the grid, M[n] = the composed blocks summed over the phases (mean_table, [27][96][48] fp32, built by nmh_cconv_pack_centered next to the pack).
- * nmh_cconv_output_mean: x [B][v^3][96] -> mean [B][48] (class_sums: [B][27][96] fp64 scratch).  nmh_cconv_fwd_centered then stores z = lrelu(y1 - mean) and
+ * nmh_cconv_output_mean: x [B][v^3][96] -> mean [B][48] (class_sums: B * (27 * 96 + 48) doubles of scratch).  nmh_cconv_fwd_centered then stores z = lrelu(y1 - mean) and
  * accumulates the statistics of t = y1 - mean (stats_acc as nmh_cconv_fwd: nmh_instnorm_finalize turns them into (residual mean ~ 0, rstd)).  Since rstd > 0 commutes
  * with the LeakyReLU, lrelu(InstanceNorm(y1)) = rstd * z: the scale goes into conv2's weights per sample (nmh_conv48_pack_scaled, nmh_conv3d_k3_c48_per_sample) and the
  * stand-alone normalisation pass over the 160^3 tensor (nmh_instnorm_apply, 6.3 GB at 8 grids) is gone; the backward reads z (nmh_conv3d_k3_c48_bwd_reduce_centered,
  * nmh_instnorm_bwd_apply_bg_centered, nmh_conv3d_k3_c48_wgrad_scaled). */
 NMH_API int nmh_cconv_pack_centered(const float* Wt, const float* W1, const float* bt, void* Wcp, float* delta, float* ws, float* mean_table, void* stream);
 NMH_API int nmh_cconv_output_mean(const void* x, const float* mean_table, const float* delta, double* class_sums, float* mean, int B, int v, void* stream);
+/* conv2 of the centered decoder1: Wk_per_sample [B][41*3*512] bf16 = the forward fragment pack of W[co][ci][tap] * rstd[b][ci] (stats = (mean, rstd) pairs
+ * [B][48][2], fp32 master W [48][48][3][3][3]); nmh_conv3d_k3_c48_per_sample = nmh_conv3d_k3_c48 with the weight image of the tile's sample.
+ * Backward: _bwd_reduce_centered = nmh_conv3d_k3_c48_bwd_reduce reading z for y1 (y1 - mean = z > 0 ? z : z / slope); _wgrad_scaled = nmh_conv3d_k3_c48_wgrad on
+ * (dY, z) with every workgroup's partial scaled by its sample's rstd[ci] in the reduce (B in {1, 2, 4, 8} and whole tile ranges per sample: -2 otherwise);
+ * nmh_instnorm_bwd_apply_bg_centered = nmh_instnorm_bwd_apply_bg reading z. */
+NMH_API int nmh_conv48_pack_scaled(const float* W, const float* stats, void* Wk_per_sample, int B, void* stream);
+NMH_API int nmh_conv3d_k3_c48_per_sample(const void* X, const void* Wk_per_sample, void* Y, int B, int D, int H, int W, double* stats_acc, void* stream);
+NMH_API int nmh_conv3d_k3_c48_bwd_reduce_centered(const void* dY, const void* Wkd, void* dX, int B, int D, int H, int W, const void* Z, const float* stats1, float slope, double* sums, void* stream);
+NMH_API int nmh_conv3d_k3_c48_wgrad_scaled(const void* dY, const void* Z, const float* stats, float* dW, float* ws, int B, int D, int H, int W, void* stream);
+NMH_API int nmh_instnorm_bwd_apply_bg_centered(int dt, const void* dout, const void* z, const float* stats, const double* sums, void* dx, int B, int64_t V, int C, float slope, void* stream);
 NMH_API int nmh_cconv_fwd_centered(const void* x, const void* Wcp, const float* delta, const float* mean, float slope, void* z, int B, int v, double* stats_acc, void* stream);
 /* Weight gradient of decoder1's conv1 THROUGH the composition above (backward of unetr_block.py:35-44 with respect to conv1.weight; replaces the
  * 48 -> 48 nmh_conv3d_k3_c48_wgrad launch on the up-sampled map): dW1[c][co][d] += sum_a sum_ci Wt[ci][co][(a+d) mod 4] . G[a][n(a,d)][ci][c] with

@@ -138,6 +138,34 @@ int nmh_conv3d_k3_c48_bwd_reduce(const void* dY, const void* Wkd, void* dX, int 
   REQ(dY, Wkd, dX, Y1, stats1, sums);
   return k_conv48(dY, Wkd, dX, B, D, H, W, 0, sums, ST, Y1, stats1, slope);
 }
+int nmh_conv48_pack_scaled(const float* W, const float* stats, void* Wk_per_sample, int B, void* stream) {
+  CLR();
+  REQ(W, stats, Wk_per_sample);
+  if (B <= 0) return 0;
+  return k_conv48_pack_scaled(W, stats, Wk_per_sample, B, ST);
+}
+int nmh_conv3d_k3_c48_per_sample(const void* X, const void* Wk_per_sample, void* Y, int B, int D, int H, int W, double* stats_acc, void* stream) {
+  CLR();
+  REQ(X, Wk_per_sample, Y);
+  return k_conv48(X, Wk_per_sample, Y, B, D, H, W, 0, stats_acc, ST, nullptr, nullptr, 0.f, 41L * 3 * 512, 0);
+}
+int nmh_conv3d_k3_c48_bwd_reduce_centered(const void* dY, const void* Wkd, void* dX, int B, int D, int H, int W, const void* Z, const float* stats1, float slope,
+                                          double* sums, void* stream) {
+  CLR();
+  REQ(dY, Wkd, dX, Z, stats1, sums);
+  if (!(slope > 0.f && slope < 1.f)) return -2;
+  return k_conv48(dY, Wkd, dX, B, D, H, W, 0, sums, ST, Z, stats1, slope, 0, 1);
+}
+int nmh_conv3d_k3_c48_wgrad_scaled(const void* dY, const void* Z, const float* stats, float* dW, float* ws, int B, int D, int H, int W, void* stream) {
+  CLR();
+  REQ(dY, Z, stats, dW, ws);
+  return k_conv48_wgrad(dY, Z, dW, ws, B, D, H, W, ST, stats);
+}
+int nmh_instnorm_bwd_apply_bg_centered(int dt, const void* dout, const void* z, const float* stats, const double* sums, void* dx, int B, int64_t V, int C, float slope, void* stream) {
+  CLR();
+  REQ(dout, z, stats, sums, dx);
+  return k_in_bwd_apply_bg(dt, dout, z, stats, sums, dx, B, (long)V, C, slope, ST, 1);
+}
 int nmh_conv3d_k3_c48mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream) {
   CLR();
   if (!X || !Wk || !Y) return -4;

@@ -449,81 +449,109 @@ int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, f
 // (2) S_n from the classes, the 2592-term dot products and the border constant.  With the mean known BEFORE the fine tensor is written, the InstanceNorm
 // that follows needs no pass of its own over it: the producer stores lrelu(y1 - mean), the scale 1 / std goes into the consumer's weights (positive, so
 // it commutes with the LeakyReLU).
-__global__ __launch_bounds__(256) void cconv_class_sums_kernel(const bf16_t* __restrict__ x, double* __restrict__ C27, int v) {
-  // block = (z plane, sample); thread = (8-channel chunk cl of 12, cell lane vl of 21); 9 (y class, x class) accumulators of 8 channels in registers
-  __shared__ float red[9 * 96];
-  const int z = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, cl = tid % 12, vl = tid / 12;
-  for (int i = tid; i < 9 * 96; i += 256) red[i] = 0.f;
+__global__ __launch_bounds__(256) void cconv_class_sums_kernel(const bf16_t* __restrict__ x, double* __restrict__ C27, int v, int ysplit) {
+  // block = (z plane x y chunk, sample); wave = rows y of the chunk, lane = (8-channel chunk cl of 12, x lane xl of 5).  The row's (z, y) classes are wave-uniform
+  // (scalar branch into one of 9 accumulator sets of three x classes); only the first / last cell of a row leave the interior x class.
+  __shared__ float red[27 * 96];
+  const int zc = blockIdx.x, z = zc / ysplit, yc = zc - z * ysplit, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = lane % 12, xl = lane / 12;
+  for (int i = tid; i < 27 * 96; i += 256) red[i] = 0.f;
   __syncthreads();
-  float acc[9][8];
+  const int rows = (v + ysplit - 1) / ysplit, y0 = yc * rows, y1 = y0 + rows < v ? y0 + rows : v;
+  const int kz = z == 0 ? 0 : (z == v - 1 ? 2 : 1);
+  float acc[3][3][8];   // [y class][x class][channel]
 #pragma unroll
-  for (int k = 0; k < 9; ++k)
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
-  if (vl < 21) {
-    const bf16_t* xp = x + (((long)b * v + z) * v * v) * 96 + cl * 8;
-    for (int c = vl; c < v * v; c += 21) {
-      const int y = c / v, xx = c - y * v;
-      const int ky = y == 0 ? 0 : (y == v - 1 ? 2 : 1), kx = xx == 0 ? 0 : (xx == v - 1 ? 2 : 1), k = ky * 3 + kx;
-      float f[8];
-      Vec8<bf16_t>::load(xp + (long)c * 96, f);
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int kk = 0; kk < 9; ++kk)
-        if (kk == k) {
+      for (int j = 0; j < 8; ++j) acc[a][k][j] = 0.f;
+  if (xl < 5) {
+    for (int y = y0 + wave; y < y1; y += 4) {
+      const bf16_t* xp = x + ((((long)b * v + z) * v + y) * v) * 96 + cl * 8;
+      float r0[8], r1[8], r2[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[kk][j] += f[j];
-        }
+      for (int j = 0; j < 8; ++j) { r0[j] = 0.f; r1[j] = 0.f; r2[j] = 0.f; }
+      for (int xx = xl; xx < v; xx += 5) {
+        float f[8];
+        Vec8<bf16_t>::load(xp + (long)xx * 96, f);
+        const bool first = xx == 0, last = xx == v - 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r0[j] += first ? f[j] : 0.f; r2[j] += last ? f[j] : 0.f; r1[j] += (first || last) ? 0.f : f[j]; }
+      }
+      const int ky = __builtin_amdgcn_readfirstlane(y == 0 ? 0 : (y == v - 1 ? 2 : 1));
+      if (ky == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[0][0][j] += r0[j]; acc[0][1][j] += r1[j]; acc[0][2][j] += r2[j]; }
+      } else if (ky == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[2][0][j] += r0[j]; acc[2][1][j] += r1[j]; acc[2][2][j] += r2[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[1][0][j] += r0[j]; acc[1][1][j] += r1[j]; acc[1][2][j] += r2[j]; }
+      }
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (acc[k][j] != 0.f) atomicAdd(&red[k * 96 + cl * 8 + j], acc[k][j]);
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (acc[a][k][j] != 0.f) atomicAdd(&red[(a * 3 + k) * 96 + cl * 8 + j], acc[a][k][j]);
   }
   __syncthreads();
-  const int kz = z == 0 ? 0 : (z == v - 1 ? 2 : 1);
-  for (int i = tid; i < 9 * 96; i += 256) atomicAdd(C27 + ((long)b * 27 + kz * 9 + i / 96) * 96 + i % 96, (double)red[i]);
+  for (int i = tid; i < 9 * 96; i += 256) if (red[i] != 0.f) atomicAdd(C27 + ((long)b * 27 + kz * 9 + i / 96) * 96 + i % 96, (double)red[i]);
 }
-__global__ __launch_bounds__(256) void cconv_mean_kernel(const double* __restrict__ C27, const float* __restrict__ Mtab, const float* __restrict__ delta, float* __restrict__ mhat, int v) {
-  __shared__ float S[27 * 96];
+// block (n, b): S_n [96] from the class sums, then its 96 x 48 share of the dot products -> fp64 accumulators macc [B][48]
+__global__ __launch_bounds__(256) void cconv_mean_dot_kernel(const double* __restrict__ C27, const float* __restrict__ Mtab, double* __restrict__ macc) {
+  __shared__ float S[96];
   __shared__ float part[5 * 48];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < 27 * 96; i += 256) {
-    const int n = i / 96, ci = i - n * 96, nz = n / 9 - 1, ny = (n / 3) % 3 - 1, nx = n % 3 - 1;
+  const int n = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int nz = n / 9 - 1, ny = (n / 3) % 3 - 1, nx = n % 3 - 1;
+  if (tid < 96) {
     double sum = 0.0;
     for (int k = 0; k < 27; ++k) {
       const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
       // a source cell s feeds the output cell j = s - n: counted when j is a cell.  n = +1: s >= 1 (not the first plane); n = -1: s <= v - 2 (not the last)
       const bool in = !((nz > 0 && kz == 0) || (nz < 0 && kz == 2) || (ny > 0 && ky == 0) || (ny < 0 && ky == 2) || (nx > 0 && kx == 0) || (nx < 0 && kx == 2));
-      if (in) sum += C27[((long)b * 27 + k) * 96 + ci];
+      if (in) sum += C27[((long)b * 27 + k) * 96 + tid];
     }
-    S[i] = (float)sum;
+    S[tid] = (float)sum;
   }
   __syncthreads();
   const int c = tid % 48, pt = tid / 48;
   if (pt < 5) {
     float acc = 0.f;
-    for (int r = pt; r < 27 * 96; r += 5) acc += S[r] * Mtab[(long)r * 48 + c];
+    for (int r = pt; r < 96; r += 5) acc += S[r] * Mtab[((long)n * 96 + r) * 48 + c];
     part[pt * 48 + c] = acc;
   }
   __syncthreads();
-  if (tid < 48) {
-    const double F = 4.0 * v;
-    double tot = (double)part[tid] + part[48 + tid] + part[96 + tid] + part[144 + tid] + part[192 + tid];
-    for (int k = 0; k < 27; ++k) {
-      const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
-      const double cnt = (kz == 1 ? F - 2 : 1.0) * (ky == 1 ? F - 2 : 1.0) * (kx == 1 ? F - 2 : 1.0);
-      tot += cnt * (double)delta[k * 48 + tid];
-    }
-    mhat[(long)b * 48 + tid] = (float)(tot / (F * F * F));
+  if (tid < 48) atomicAdd(macc + (long)b * 48 + tid, (double)part[tid] + part[48 + tid] + part[96 + tid] + part[144 + tid] + part[192 + tid]);
+}
+__global__ void cconv_mean_final_kernel(const double* __restrict__ macc, const float* __restrict__ delta, float* __restrict__ mhat, int B, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 48) return;
+  const int c = i % 48;
+  const double F = 4.0 * v;
+  double tot = macc[i];
+  for (int k = 0; k < 27; ++k) {
+    const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+    const double cnt = (kz == 1 ? F - 2 : 1.0) * (ky == 1 ? F - 2 : 1.0) * (kx == 1 ? F - 2 : 1.0);
+    tot += cnt * (double)delta[k * 48 + c];
   }
+  mhat[i] = (float)(tot / (F * F * F));
 }
 int k_cconv_mean(const void* x, const float* Mtab, const float* delta, double* C27, float* mhat, int B, int v, hipStream_t st) {
+  // C27: [B][27][96] class sums followed by [B][48] dot-product accumulators (fp64)
   if (v < 2) return -2;
-  hipError_t e = nmh_zero_async(C27, sizeof(double) * 27 * 96 * B, st);
+  hipError_t e = nmh_zero_async(C27, sizeof(double) * (27 * 96 + 48) * B, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(cconv_class_sums_kernel, dim3(v, B), dim3(256), 0, st, (const bf16_t*)x, C27, v);
+  double* macc = C27 + (long)B * 27 * 96;
+  const int ysplit = v >= 16 ? 4 : 1;
+  hipLaunchKernelGGL(cconv_class_sums_kernel, dim3(v * ysplit, B), dim3(256), 0, st, (const bf16_t*)x, C27, v, ysplit);
   NMH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(cconv_mean_kernel, dim3(B), dim3(256), 0, st, (const double*)C27, Mtab, delta, mhat, v);
+  hipLaunchKernelGGL(cconv_mean_dot_kernel, dim3(27, B), dim3(256), 0, st, (const double*)C27, Mtab, macc);
+  NMH_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cconv_mean_final_kernel, dim3((B * 48 + 255) / 256), dim3(256), 0, st, (const double*)macc, delta, mhat, B, v);
   NMH_CHECK_LAUNCH();
   return 0;
 }

@@ -44,6 +44,9 @@ struct C48Args {
   // backward-reduce variant (RB: the launch is the input gradient of a conv whose INPUT was lrelu(InstanceNorm(Y1))): stats_acc receives the two
   // sums the InstanceNorm backward needs, sum g and sum g * yhat with g = out * lrelu'(Y1 - mean), yhat = (Y1 - mean) * rstd (nmh_instnorm_bwd_reduce)
   const bf16_t* Y1; const float* stats1; float slope;
+  // CZ (with RB): Y1 holds z = lrelu(y1 - mean) instead of y1 (centered decoder1, csrc/cconv.hip): y1 - mean = z > 0 ? z : z / slope; stats1 = (residual mean, rstd)
+  float inv_slope;
+  long wk_sample_stride;       // plain forward: elements between the weight images of consecutive samples (per-sample scaled weights, k_conv48_pack_scaled); 0 = one image
   // multi-block variant (MB): Cin = 48 ncib, Cout = 48 ncob; a work item is (tile, output block cob, input block cib), cib innermost:
   // the accumulators persist over cib, the epilogue runs after the last one; Wk holds one fragment-ordered image per (cob, cib)
   int ncib, ncob, ldx, ldy;    // ldx / ldy: channels per voxel of X / Y
@@ -67,7 +70,7 @@ __device__ __forceinline__ void c48_tile_origin(const C48Args& a, long t, int& b
 
 // DBG (diagnostic builds only, NMH_C48_DBG): 1 = no output stores, 2 = no halo prefetch / LDS refill, 4 = no weight DMA and no
 // chunk barriers, 8 = no MFMAs (operand traffic only), 16 = no operand reads in the k-loop (MFMAs only).  DBG = 0 is the product.
-template <int DBG, bool MB = false, bool RB = false>
+template <int DBG, bool MB = false, bool RB = false, bool CZ = false>
 __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   using namespace c48;
   constexpr long WBLK = (long)NSTEP * 3 * 512;   // elements of one (cob, cib) weight image
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   int cb, cz0, cy0, cx0;  // origin of the current tile; the next tile's origin is computed once (64-bit divisions) and carried over
   c48_tile_origin(a, split ? t / a.ncob : t, cb, cz0, cy0, cx0);
   int cob = split ? (int)(t % a.ncob) : 0, cib = 0;   // MB: output / input channel block of the current work item
-  const bf16_t* const wfirst = MB ? a.Wk + (long)cob * a.ncib * ((long)NSTEP * 3 * 512) : a.Wk;
+  const bf16_t* const wfirst = MB ? a.Wk + (long)cob * a.ncib * ((long)NSTEP * 3 * 512) : a.Wk + (long)cb * a.wk_sample_stride;
   halo_voff(cx0, 0);
 #pragma unroll
   for (int i = 0; i < HREG; ++i) halo_gload_one(i, cb, cz0, cy0, sample_bytes);
@@ -191,8 +194,12 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
   auto stats_flush = [&]() {
     if (st_b >= 0 && tid < 96) {
       float v = sacc[scur * 96 + tid];
+      const float sacc_even = (RB && CZ) ? __shfl(v, (tid & 63) & ~1, 64) : 0.f;   // sum g of the same channel (the even neighbour lane)
       sacc[scur * 96 + tid] = 0.f;
-      if (RB && (tid & 1)) v *= a.stats1[(long)st_b * 96 + tid];      // sum g (y - mean) -> sum g yhat: rstd of (sample, channel tid / 2)
+      if (RB && (tid & 1)) {
+        if constexpr (CZ) v -= a.stats1[(long)st_b * 96 + tid - 1] * sacc_even;   // minus (residual mean) x (sum g)
+        v *= a.stats1[(long)st_b * 96 + tid];      // sum g (y - mean) -> sum g yhat: rstd of (sample, channel tid / 2)
+      }
       atomicAdd(a.stats_acc + (long)st_b * 96 + tid, (double)v);
     }
   };
@@ -236,8 +243,8 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
     if (has_next && (!MB || tn != t)) c48_tile_origin(a, split ? tn / a.ncob : tn, nb, nz0, ny0, nx0);
     const unsigned nbytes = pf_next ? sample_bytes : 0u;
     halo_voff(nx0, nci);   // lane offsets of the next tile's requests
-    const bf16_t* const wcur = MB ? a.Wk + (long)(cob * a.ncib + cib) * WBLK : a.Wk;
-    const bf16_t* const wnxt = MB ? a.Wk + (long)(nco * a.ncib + nci) * WBLK : a.Wk;
+    const bf16_t* const wcur = MB ? a.Wk + (long)(cob * a.ncib + cib) * WBLK : a.Wk + (long)cb * a.wk_sample_stride;
+    const bf16_t* const wnxt = MB ? a.Wk + (long)(nco * a.ncib + nci) * WBLK : a.Wk + (long)nb * a.wk_sample_stride;
     if (!MB || cib == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -411,10 +418,19 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
               for (int q = 0; q < 6; ++q) {
                 const float d0 = __uint_as_float(wk[i][q] << 16), d1 = __uint_as_float(wk[i][q] & 0xffff0000u);
                 const float m0 = (q & 1) ? mu4[q >> 1].z : mu4[q >> 1].x, m1 = (q & 1) ? mu4[q >> 1].w : mu4[q >> 1].y;
-                const float t0 = __uint_as_float(yw[q] << 16) - m0, t1 = __uint_as_float(yw[q] & 0xffff0000u) - m1;
+                const float y0v = __uint_as_float(yw[q] << 16), y1v = __uint_as_float(yw[q] & 0xffff0000u);
+                if constexpr (CZ) {
+                  // y holds z = lrelu(t), t = y1 - mean: g = d lrelu'(t) has the sign test on z, and g t = d lrelu'(t) t = d z -- no inverse, no mean (the residual
+                  // mean of t enters at the flush: sum g (t - e) = sum d z - e sum g)
+                  const float g0 = d0 * (y0v > 0.f ? 1.0f : a.slope), g1 = d1 * (y1v > 0.f ? 1.0f : a.slope);
+                  st1[q >> 1][(q & 1) * 2] += g0; st1[q >> 1][(q & 1) * 2 + 1] += g1;
+                  st2[q >> 1][(q & 1) * 2] += d0 * y0v; st2[q >> 1][(q & 1) * 2 + 1] += d1 * y1v;
+                } else {
+                const float t0 = y0v - m0, t1 = y1v - m1;
                 const float g0 = d0 * (t0 > 0.f ? 1.0f : a.slope), g1 = d1 * (t1 > 0.f ? 1.0f : a.slope);
                 st1[q >> 1][(q & 1) * 2] += g0; st1[q >> 1][(q & 1) * 2 + 1] += g1;
                 st2[q >> 1][(q & 1) * 2] += g0 * t0; st2[q >> 1][(q & 1) * 2 + 1] += g1 * t1;
+                }
               }
             }
         }
@@ -456,11 +472,13 @@ __global__ __launch_bounds__(512) void conv48_kernel(C48Args a) {
 
 
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st,
-             const void* Y1, const float* stats1, float slope) {
+             const void* Y1, const float* stats1, float slope, long wk_sample_stride, int centered) {
   using namespace c48;
   C48Args a;
   a.Y1 = (const bf16_t*)Y1; a.stats1 = stats1; a.slope = slope;
+  a.inv_slope = slope != 0.f ? 1.0f / slope : 0.f; a.wk_sample_stride = wk_sample_stride;
   if (Y1 && (!stats1 || !stats_acc || accumulate)) return -1;
+  if ((centered && !Y1) || (wk_sample_stride && (Y1 || accumulate))) return -1;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
@@ -500,7 +518,15 @@ int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W,
       if (e != hipSuccess) return (int)e;
       attr_rb.set();
     }
-    hipLaunchKernelGGL((conv48_kernel<0, false, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
+    if (centered) {
+      static NmhPerDeviceOnce attr_cz;
+      if (attr_cz.need()) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv48_kernel<0, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_cz.set();
+      }
+      hipLaunchKernelGGL((conv48_kernel<0, false, true, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
+    } else hipLaunchKernelGGL((conv48_kernel<0, false, true>), dim3((unsigned)nb), dim3(512), LDS_BYTES, st, a);
     NMH_CHECK_LAUNCH();
     return 0;
   }
@@ -517,7 +543,7 @@ int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int
   if (Cin % 48 || Cout % 48 || Cin <= 0 || Cout <= 0) return -2;
   if ((long)D * H * W * Cin * 2 >= (1L << 31)) return -2;   // 32-bit buffer offsets inside one sample, below the out-of-range marker
   C48Args a;
-  a.Y1 = nullptr; a.stats1 = nullptr; a.slope = 0.f;
+  a.Y1 = nullptr; a.stats1 = nullptr; a.slope = 0.f; a.inv_slope = 0.f; a.wk_sample_stride = 0;
   a.X = (const bf16_t*)X; a.Wk = (const bf16_t*)Wk; a.Y = (bf16_t*)Y;
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.tz = (D + TZ - 1) / TZ; a.ty = (H + TY - 1) / TY; a.tx = (W + TX - 1) / TX;
@@ -827,27 +853,41 @@ __global__ __launch_bounds__(64 * NW) void conv48_wgrad_kernel(W48Args a) {
 }
 
 // dW[(co*Cin+ci)*27+tap] += sum_blocks ws[sub][block][u = tap*3+cit][ct][row][col], co = os*48+ct*16+row, ci = cs*48+cit*16+col
-__global__ void conv48_wgrad_reduce_kernel(const float* ws, float* dW, int nblocks, int nci, int Cin) {
+__global__ void conv48_wgrad_reduce_kernel(const float* ws, float* dW, int nblocks, int nci, int Cin, const float* stats = nullptr, int B = 0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w48::PARTIAL) return;
   const int sub = blockIdx.y, cs = sub % nci, os = sub / nci;
   // 8 independent partial sums: the loads of one thread are 249 KB apart, so memory-level parallelism has to come from unrolling
   float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* src = ws + (long)sub * nblocks * w48::PARTIAL + i;
-  int b = 0;
+  int b = stats ? nblocks : 0;
   for (; b + 8 <= nblocks; b += 8) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) s8[u] += src[(long)(b + u) * w48::PARTIAL];
   }
   for (; b < nblocks; ++b) s8[0] += src[(long)b * w48::PARTIAL];
-  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   const int col = i & 15, row = (i >> 4) & 15, uc = i >> 8, ct = uc % 3, u = uc / 3, tap = u / 3, cit = u - tap * 3;
+  if (stats) {
+    // scaled form (centered decoder1: the operand was z, the conv's input is rstd[sample][ci] * z): workgroup blk walked tiles of sample ((blk % 8) B) / 8 only
+    // (launch_wgrad_halo checks the alignment), so the per-sample scale is applied to its partial -- slot u of the 8-way unrolled sum always sees the same sample
+    float sc[8], t8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { sc[u] = stats[((long)((u * B) >> 3) * 48 + cit * 16 + col) * 2 + 1]; t8[u] = 0.f; }
+    int bb = 0;
+    for (; bb + 8 <= nblocks; bb += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t8[u] += src[(long)(bb + u) * w48::PARTIAL];
+    }
+    for (; bb < nblocks; ++bb) t8[bb & 7] += src[(long)bb * w48::PARTIAL];
+    s = ((t8[0] * sc[0] + t8[1] * sc[1]) + (t8[2] * sc[2] + t8[3] * sc[3])) + ((t8[4] * sc[4] + t8[5] * sc[5]) + (t8[6] * sc[6] + t8[7] * sc[7]));
+  }
   dW[((long)(os * 48 + ct * 16 + row) * Cin + cs * 48 + cit * 16 + col) * 27 + tap] += s;
 }
 
 long k_conv48_wgrad_ws_floats() { return 256L * w48::PARTIAL + 65536; }  // (+ room for the diagnostic phase counters)
 
-static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st) {
+static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st, const float* scale_stats = nullptr) {
   using namespace w48;
   W48Args a;
   a.X = (const bf16_t*)X; a.dY = (const bf16_t*)dY; a.ws = ws;
@@ -864,6 +904,10 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv48_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set.set();
+  }
+  if (scale_stats) {   // every one of the 8 tile ranges must lie inside ONE sample (the reduce scales a workgroup's partial by its sample's rstd)
+    const long tps = (long)a.tz * a.ty * a.tx;
+    if (nsub != 1 || B < 1 || 8 % B || tps % (8 / B) || a.total < 256) return -2;
   }
   int nb;
   if (nsub == 1) nb = a.total < 256 ? (int)((a.total + 7) / 8 * 8) : 256;   // 8 XCD-contiguous tile ranges
@@ -898,12 +942,36 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
   } else if (nw == 8) hipLaunchKernelGGL(conv48_wgrad_kernel<8>, dim3(nb, nsub), dim3(512), LDS_BYTES, st, a);
   else hipLaunchKernelGGL(conv48_wgrad_kernel<16>, dim3(nb, nsub), dim3(1024), LDS_BYTES, st, a);
   NMH_CHECK_LAUNCH();
-  hipLaunchKernelGGL(conv48_wgrad_reduce_kernel, dim3((PARTIAL + 255) / 256, nsub), dim3(256), 0, st, ws, dW, nb, a.nci, Cin);
+  hipLaunchKernelGGL(conv48_wgrad_reduce_kernel, dim3((PARTIAL + 255) / 256, nsub), dim3(256), 0, st, ws, dW, nb, a.nci, Cin, scale_stats, B);
   NMH_CHECK_LAUNCH();
   return 0;
 }
-int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st) {
-  return launch_wgrad_halo(dY, X, dW, ws, B, D, H, W, 48, 48, st);
+int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st, const float* scale_stats) {
+  return launch_wgrad_halo(dY, X, dW, ws, B, D, H, W, 48, 48, st, scale_stats);
+}
+
+// conv2's forward weights of the centered decoder1, per sample: Wk[b] = fragment-ordered image (pack mode 6) of W[co][ci][tap] * rstd[b][ci] -- the conv's input
+// is lrelu(InstanceNorm(y1)) = rstd * z (rstd > 0 commutes with the LeakyReLU), and z is what is stored
+__global__ void conv48_pack_scaled_kernel(const float* __restrict__ W, const float* __restrict__ stats, bf16_t* __restrict__ out) {
+  constexpr int IMG = c48::NSTEP * 3 * 512;
+  const int b = blockIdx.y;
+  for (int iw = blockIdx.x * 256 + threadIdx.x; iw < IMG; iw += gridDim.x * 256) {
+    const int j = iw & 7, lane = (iw >> 3) & 63, sn = iw >> 9;
+    const int nt = sn % 3, st = sn / 3, g = lane >> 4, li = lane & 15, n = 12 * (li >> 2) + 4 * nt + (li & 3);
+    int r, c;
+    if (st < 36) { r = 4 * (st / 18) + g; c = st % 18; } else { r = 8; c = 4 * (st - 36) + g; }
+    float v = 0.f;
+    if (c < 18) {
+      const int tap = r * 3 + c / 6, k = (c % 6) * 8 + j;
+      v = W[((long)n * 48 + k) * 27 + tap] * stats[((long)b * 48 + k) * 2 + 1];
+    }
+    out[(long)b * IMG + iw] = f2bf(v);
+  }
+}
+int k_conv48_pack_scaled(const float* W, const float* stats, void* out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(conv48_pack_scaled_kernel, dim3(62, B), dim3(256), 0, st, W, stats, (bf16_t*)out);
+  NMH_CHECK_LAUNCH();
+  return 0;
 }
 // any Cin, Cout that are multiples of 48 (the decoder levels 96..768): (Cin/48)*(Cout/48) sub-problems, <= 256 workgroups in total
 int k_conv3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st) {

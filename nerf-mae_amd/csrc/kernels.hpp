@@ -113,14 +113,15 @@ struct TnProblemHost {
 };
 int k_gemm_tn_grouped(const TnProblemHost* probs, int nprob, float* ws, long ws_floats, hipStream_t st, bool foreground = false);
 int k_conv48(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int accumulate, double* stats_acc, hipStream_t st,
-             const void* Y1 = nullptr, const float* stats1 = nullptr, float slope = 0.f);
+             const void* Y1 = nullptr, const float* stats1 = nullptr, float slope = 0.f, long wk_sample_stride = 0, int centered = 0);
+int k_conv48_pack_scaled(const float* W, const float* stats, void* out, int B, hipStream_t st);
 int k_conv48_mb(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, hipStream_t st);
 int k_conv64(const void* X, const void* Wk, void* Y, int B, int D, int H, int W, int Cin, int Cout, int accumulate, double* stats_acc, const float* bias, hipStream_t st);
 long k_conv64_pack_numel(int Cin, int Cout);
 int k_conv64_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st);
 long k_conv64_wgrad_ws_floats();
 int k_in_finalize(int dt, const double* acc, float* stats, int B, long V, int C, float eps, hipStream_t st);
-int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st);
+int k_conv48_wgrad(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, hipStream_t st, const float* scale_stats = nullptr);
 long k_conv48_wgrad_ws_floats();
 int k_conv3_wgrad_halo(const void* dY, const void* X, float* dW, float* ws, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st);
 int k_conv3_tn(int dt, const void* dY, const void* X, float* dW, int B, int D, int H, int W, int Cin, int Cout, hipStream_t st);
@@ -217,7 +218,7 @@ int k_in_bwd_reduce(int dt, const void* dout, const void* out, const void* x, co
 // dx = rstd*(g - S1/V - xhat*S2/V); rmode 1: dr (+)= g ; rmode 2: dr = IN-bwd wrt r
 int k_in_bwd_apply(int dt, const void* dout, const void* out, const void* x, const float* stats, const double* sums, const void* r, const float* stats_r,
                    const double* sums_r, int rmode, void* dx, void* dr, int dr_accumulate, int B, long V, int C, float slope, hipStream_t st);
-int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, long V, int C, float slope, hipStream_t st);
+int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, long V, int C, float slope, hipStream_t st, int centered = 0);
 
 // ---- attn.hip ----
 int k_attn_fwd(int dt, const void* qkv, const float* bias_table, void* out, float* lse, int heads, int C, const WinMap& wm, hipStream_t st, int tok_out = 0);

@@ -916,8 +916,74 @@ __global__ __launch_bounds__(256) void in_bwd_apply_bg_kernel(const bf16_t* __re
     }
   }
 }
-int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, long V, int C, float slope, hipStream_t st) {
+// The same background launch for the CENTERED decoder1 (csrc/cconv.hip): the stored tensor is z = lrelu(t), t = y - mean, stats = (e = residual mean of t, rstd).
+//   dx = rstd (g - m1 - xhat m2),  g = d lrelu'(t),  xhat = (t - e) rstd,  t = z (z > 0 ? 1 : 1 / slope)
+//      = d (z > 0 ? A : A slope)  -  z (z > 0 ? Cc : Cc / slope)  -  Bc,     A = rstd, Cc = rstd^2 m2, Bc = rstd m1 - rstd^2 m2 e
+// one compare, two selects between per-channel constants and two FMAs per element (the classic form needs eleven instructions: this launch lives on the issue
+// slots the weight gradient beside it leaves free).  40 constants per lane: unroll 4 keeps it under the 96 registers that are free there.
+template <int U>
+__global__ __launch_bounds__(256) void in_bwd_apply_bg_centered_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ z, const float* __restrict__ stats,
+                                                                        const double* __restrict__ sums, bf16_t* __restrict__ dx, long V, float slope, int wps) {
+  constexpr int C = 48, CL = 6, NV = 42;
+  const int b = blockIdx.x / wps, w = blockIdx.x - b * wps;
+  const int cl = threadIdx.x % CL, vl = threadIdx.x / CL;
+  if (vl >= NV) return;
+  const float invV = 1.0f / (float)V, inv_slope = 1.0f / slope;
+  float A1[8], A2[8], C1[8], C2[8], Bc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long sc = ((long)b * C + cl * 8 + j) * 2;
+    const float e = stats[sc], rs = stats[sc + 1], m1 = (float)sums[sc] * invV, m2 = (float)sums[sc + 1] * invV;
+    A1[j] = rs; A2[j] = rs * slope;
+    C1[j] = rs * rs * m2; C2[j] = C1[j] * inv_slope;
+    Bc[j] = rs * m1 - C1[j] * e;
+  }
+  const long per = (V + wps - 1) / wps, v0 = (long)w * per;
+  long v1 = v0 + per;
+  if (v1 > V) v1 = V;
+  const bf16_t* const db = dout + (long)b * V * C + cl * 8;
+  const bf16_t* const zb = z + (long)b * V * C + cl * 8;
+  bf16_t* const ob = dx + (long)b * V * C + cl * 8;
+  for (long vb = v0 + vl; vb < v1; vb += (long)NV * U) {
+    u32x4 dw[U], zw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long v = vb + (long)u * NV;
+      if (v < v1) {
+        dw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(db + v * C));
+        zw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(zb + v * C));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long v = vb + (long)u * NV;
+      if (v < v1) {
+        float od[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int j = 2 * i + h;
+            const float dv = __uint_as_float(h ? dw[u][i] & 0xffff0000u : dw[u][i] << 16), zv = __uint_as_float(h ? zw[u][i] & 0xffff0000u : zw[u][i] << 16);
+            const bool pos = zv > 0.f;
+            od[j] = __builtin_fmaf(-zv, pos ? C1[j] : C2[j], __builtin_fmaf(dv, pos ? A1[j] : A2[j], -Bc[j]));
+          }
+        }
+        Vec8<bf16_t>::store_nt(ob + v * C, od);
+      }
+    }
+  }
+}
+int k_in_bwd_apply_bg(int dt, const void* dout, const void* x, const float* stats, const double* sums, void* dx, int B, long V, int C, float slope, hipStream_t st, int centered) {
   if (dt != NMH_DT_BF16 || C != 48 || B < 1 || V < 1) return -2;
+  if (centered) {
+    if (!(slope > 0.f)) return -2;
+    int wps = 256 / B;
+    if (wps < 1) wps = 1;
+    hipLaunchKernelGGL(in_bwd_apply_bg_centered_kernel<4>, dim3((unsigned)(B * wps)), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, stats, sums, (bf16_t*)dx, V, slope, wps);
+    NMH_CHECK_LAUNCH();
+    return 0;
+  }
   int wps = 256 / B;
   if (wps < 1) wps = 1;
   static const int unroll = [] { const char* e = getenv("NMH_INBWD_BG_U"); const int u = e ? atoi(e) : 5; return u < 3 ? 3 : (u > 5 ? 5 : u); }();   // test-only override, clamped to {3, 4, 5}:   // 74 / 82 / 90 VGPRs: 96 are free beside the weight gradient

@@ -202,8 +202,11 @@ class _Packer:
             if sp < n:
                 ops.pack_weights(self.dt, self.descs, self.blk2desc[sp:], self.blkstart[sp:], n - sp)
             if self.cconv is not None:    # decoder1: ConvTranspose o conv1 composed weights (csrc/cconv.hip), from the fp32 masters
-                up, Wcp, delta, ws, Wup, Wdp = self.cconv
-                ops.cconv_pack(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws)
+                up, Wcp, delta, ws, Wup, Wdp, mtab = self.cconv
+                if mtab is not None:   # + the table the centered forward's mean comes from
+                    ops.cconv_pack_centered(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws, mtab)
+                else:
+                    ops.cconv_pack(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws)
                 if Wup is not None:
                     ops.upconv4_pack(ws, Wup)
                 if Wdp is not None:
@@ -562,7 +565,17 @@ class _UpBlockFn(torch.autograd.Function):
         halo_stats = c48 or c64    # InstanceNorm statistics come out of the conv epilogue
         st1 = torch.empty((B, Cout, 2), device=dev)
         cc = cc if c48 else None
-        if cc is not None:   # decoder1: y1 straight from the coarse map with the composed weights (4x fewer FLOPs; cat is only the residual)
+        # centered form (csrc/cconv.hip, round 6): the mean of conv1's output comes from the coarse tensor, conv1 stores z = lrelu(y1 - mean), 1 / std goes into conv2's
+        # weights per sample; the backward reads z.  Needs the launches that read it (fused sums in conv2's input gradient, the background InstanceNorm backward, the
+        # scaled weight-gradient reduce: B in {1, 2, 4, 8}) -- otherwise the classic form below
+        cz = (cc is not None and ops.CCONV_CENTERED and cc[6] is not None and B in (1, 2, 4, 8) and S % 16 == 0 and ops.C48_BWD_REDUCE and ops.INBWD_BG
+              and ops.side_stream.enabled and ops.CCONV_WGRAD and v <= 40 and cc[5] is not None)
+        ctx.cz = cz
+        if cz:
+            mhat = ops.cconv_output_mean(x.view(B, v, v, v, Cin), cc[6], cc[2], B, v)
+            y1 = ops.cconv_fwd_centered(x.view(B, v, v, v, Cin), cc[1], cc[2], mhat, B, v, stats_acc=scratch).view(B * V, Cout)   # (y1 holds z)
+            ops.instnorm_finalize(scratch, st1, B, V, Cout)    # (mean of y1 - mhat: ~ 0; rstd)
+        elif cc is not None:   # decoder1: y1 straight from the coarse map with the composed weights (4x fewer FLOPs; cat is only the residual)
             y1 = ops.cconv_fwd(x.view(B, v, v, v, Cin), cc[1], cc[2], B, v, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st1, B, V, Cout)
         elif halo_stats:   # InstanceNorm statistics come out of the conv epilogue (no extra pass over the 160^3 tensor)
@@ -571,11 +584,18 @@ class _UpBlockFn(torch.autograd.Function):
         else:
             y1 = conv(cat.view(B, S, S, S, Cc), "c1.w", Cout).view(B * V, Cout)
             ops.instnorm_stats(y1, st1, scratch, B, V, Cout)
-        a1 = torch.empty_like(y1)
-        ops.instnorm_apply(y1, st1, a1, B, V, Cout)
+        a1 = None
+        if not cz:
+            a1 = torch.empty_like(y1)
+            ops.instnorm_apply(y1, st1, a1, B, V, Cout)
         st2 = torch.empty((B, Cout, 2), device=dev)
         scratch = new_acc()
-        if halo_stats:
+        if cz:
+            wk2 = torch.empty(B * ops.C48_IMG, dtype=dtype, device=dev)
+            ops.conv48_pack_scaled(m.conv_block.conv2.weight, st1, wk2, B)
+            y2 = ops.conv3d_k3_c48_per_sample(y1.view(B, S, S, S, Cout), wk2, stats_acc=scratch).view(B * V, Cout)
+            ops.instnorm_finalize(scratch, st2, B, V, Cout)
+        elif halo_stats:
             y2 = conv(a1.view(B, S, S, S, Cout), "c2.w", Cout, stats_acc=scratch).view(B * V, Cout)
             ops.instnorm_finalize(scratch, st2, B, V, Cout)
         else:
@@ -647,7 +667,10 @@ class _UpBlockFn(torch.autograd.Function):
         wgrad = ops.conv3d_k3_c48_wgrad if ctx.c48 else ops.conv3d_k3_wgrad
         sums1 = ops.acc_zeros((B, Cout, 2), dev)
         fused_red = ctx.c48 and ops.C48_BWD_REDUCE and S % 16 == 0
-        if fused_red:   # the InstanceNorm-backward sums of (da1, y1) come out of the conv epilogue (no separate pass over both 160^3 tensors)
+        cz = getattr(ctx, "cz", False)
+        if cz:          # centered form: y1 holds z = lrelu(conv1's output - mean)
+            da1 = ops.conv3d_k3_c48_bwd_reduce_centered(dy2.view(B, S, S, S, Cout), pk[key + "c2.wkd"], y1, st1, sums1).view(B * V, Cout)
+        elif fused_red:   # the InstanceNorm-backward sums of (da1, y1) come out of the conv epilogue (no separate pass over both 160^3 tensors)
             da1 = ops.conv3d_k3_c48_bwd_reduce(dy2.view(B, S, S, S, Cout), pk[key + "c2.wkd"], y1, st1, sums1).view(B * V, Cout)
         else:
             da1 = conv(dy2.view(B, S, S, S, Cout), "c2.wd", Cout).view(B * V, Cout)
@@ -671,15 +694,20 @@ class _UpBlockFn(torch.autograd.Function):
                     fn()
         g_c2, g_c1 = _gradbuf(m.conv_block.conv2.weight), _gradbuf(m.conv_block.conv1.weight)
         dy1 = torch.empty_like(dy2)  # (dy2 is still being read by the side-stream wgrad)
-        bg = ops.INBWD_BG and ctx.c48 and fused_red and Cout == 48 and dtype == torch.bfloat16 and ops.side_stream.enabled
-        if bg:
+        bg = cz or (ops.INBWD_BG and ctx.c48 and fused_red and Cout == 48 and dtype == torch.bfloat16 and ops.side_stream.enabled)
+        if cz:
+            with ops.side_stream():
+                ops.instnorm_bwd_apply_bg_centered(da1, y1, st1, sums1, dy1, B, V, Cout)
+            ops.conv3d_k3_c48_wgrad_scaled(dy2.view(B, S, S, S, Cout), y1.view(B, S, S, S, Cout), st1, g_c2)
+        elif bg:
             # decoder1: the HBM-bound InstanceNorm backward (needs conv2's input gradient only) streams on a forked stream UNDER conv2's weight gradient, as one
             # small workgroup per CU beside the persistent kernel's (csrc/norm.hip: in_bwd_apply_bg_kernel); joined in front of its first consumer
             # (the transpose conv's input gradient, a 4000-workgroup GEMM, does not ride along: one of its workgroups per CU at a time crawls -- 2.7 ms for 0.64)
             with ops.side_stream():
                 ops.instnorm_bwd_apply_bg(da1, y1, st1, sums1, dy1, B, V, Cout)
-        side(lambda: wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), g_c2))
-        if not fused_red:
+        if not cz:
+            side(lambda: wgrad(dy2.view(B, S, S, S, Cout), a1.view(B, S, S, S, Cout), g_c2))
+        if not fused_red and not cz:
             ops.instnorm_bwd_reduce(da1, None, y1, st1, sums1, B, V, Cout, rmode=0)   # sign(a1) == sign(y1 - mean): a1 is not re-read
         if bg:
             ops.join_side()
@@ -1018,7 +1046,8 @@ class SwinTransformer_MAE3D_New(nn.Module):
             P.cconv = (d1, torch.empty(ops.cconv_pack_numel(), dtype=torch.bfloat16, device=device), torch.empty((27, 48), device=device),
                        torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device=device),
                        torch.empty(ops.upconv4_pack_numel(), dtype=torch.bfloat16, device=device) if ops.UPCONV4 else None,
-                       torch.empty(ops.cconv_dgrad_pack_numel(), dtype=torch.bfloat16, device=device) if (ops.CCONV_DGRAD and ops.CCONV_WGRAD) else None)
+                       torch.empty(ops.cconv_dgrad_pack_numel(), dtype=torch.bfloat16, device=device) if (ops.CCONV_DGRAD and ops.CCONV_WGRAD) else None,
+                       torch.empty((27, 96, 48), dtype=torch.float32, device=device) if ops.CCONV_CENTERED else None)
         self._packer = P
         self._pk = P
         self._wq = ops.WgradQueue()   # deferred encoder weight gradients (grouped launches, issued per stage)

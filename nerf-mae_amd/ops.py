@@ -377,6 +377,50 @@ def conv3d_k3_c48_bwd_reduce(dY, Wkd, y1, stats1, sums, out=None, slope=0.01):
     return out
 
 
+# decoder1 in the centered form (csrc/cconv.hip): the mean of conv1's output is computed from the coarse tensor before the launch, conv1 stores lrelu(y1 - mean), 1 / std goes
+# into conv2's weights per sample -- no normalisation pass over the 160^3 tensor, no second copy of it
+CCONV_CENTERED = __import__("os").environ.get("NMH_CCONV_CENTERED", "1") != "0"
+C48_IMG = 41 * 3 * 512
+
+
+def conv48_pack_scaled(W, stats, out, B):
+    _chk(W, stats, out)
+    if tuple(W.shape) != (48, 48, 3, 3, 3) or W.dtype != torch.float32 or out.numel() < B * C48_IMG or out.dtype != torch.bfloat16:
+        raise ValueError("conv48_pack_scaled: shapes")
+    lib().call("nmh_conv48_pack_scaled", W, stats, out, B, _st())
+    return out
+
+
+def conv3d_k3_c48_per_sample(X, Wk_per_sample, out=None, stats_acc=None):
+    """conv3d_k3_c48 with one weight image per sample (conv48_pack_scaled)"""
+    _chk(X, Wk_per_sample, out, stats_acc)
+    B, D, H, W, Cin = X.shape
+    if Cin != 48 or X.dtype != torch.bfloat16 or Wk_per_sample.numel() < B * C48_IMG:
+        raise RuntimeError("conv3d_k3_c48_per_sample needs bf16 activations with 48 channels and B weight images")
+    if out is None:
+        out = torch.empty((B, D, H, W, 48), dtype=X.dtype, device=X.device)
+    ev = _prof(("conv3d_k3_c48", B, D, 48, 48))
+    lib().call("nmh_conv3d_k3_c48_per_sample", X, Wk_per_sample, out, B, D, H, W, stats_acc, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
+def conv3d_k3_c48_bwd_reduce_centered(dY, Wkd, z, stats1, sums, out=None, slope=0.01):
+    """conv3d_k3_c48_bwd_reduce reading z = lrelu(y1 - mean) for y1"""
+    _chk(dY, Wkd, z, stats1, sums, out)
+    B, D, H, W, Cin = dY.shape
+    if Cin != 48 or dY.dtype != torch.bfloat16 or z.dtype != torch.bfloat16 or z.numel() != dY.numel() or sums.dtype != torch.float64:
+        raise RuntimeError("conv3d_k3_c48_bwd_reduce_centered needs bf16 tensors with 48 channels and fp64 sums")
+    if out is None:
+        out = torch.empty((B, D, H, W, 48), dtype=dY.dtype, device=dY.device)
+    ev = _prof(("conv3d_k3_c48_bwd_reduce", B, D, 48, 48))
+    lib().call("nmh_conv3d_k3_c48_bwd_reduce_centered", dY, Wkd, out, B, D, H, W, z, stats1, float(slope), sums, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return out
+
+
 CCONV = __import__("os").environ.get("NMH_CCONV", "1") != "0"   # decoder1 forward: ConvTranspose(k = s = 4) composed with conv1 (csrc/cconv.hip)
 
 
@@ -402,7 +446,7 @@ def cconv_pack_centered(Wt, W1, bt, Wcp, delta, ws, mean_table):
 def cconv_output_mean(x, mean_table, delta, B, v):
     """per-(sample, channel) mean of cconv_fwd's output from the COARSE tensor (nmh_cconv_output_mean) -> fp32 [B,48]"""
     _chk(x, mean_table, delta)
-    cls = torch.empty((B, 27, 96), dtype=torch.float64, device=x.device)
+    cls = torch.empty(B * (27 * 96 + 48), dtype=torch.float64, device=x.device)   # class sums + dot-product accumulators
     mean = torch.empty((B, 48), dtype=torch.float32, device=x.device)
     lib().call("nmh_cconv_output_mean", x, mean_table, delta, cls, mean, B, v, _st())
     return mean
@@ -588,6 +632,21 @@ def conv3d_k3_c48_wgrad(dY, X, dW):
         _C48_WS[key] = torch.empty(lib().call("nmh_conv3d_k3_c48_wgrad_ws_floats"), dtype=torch.float32, device=X.device)
     ev = _prof(("conv3d_k3_c48_wgrad", B, D, 48, 48))
     lib().call("nmh_conv3d_k3_c48_wgrad", dY, X, dW, _C48_WS[key], B, D, H, W, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return dW
+
+
+def conv3d_k3_c48_wgrad_scaled(dY, Z, stats, dW):
+    """conv3d_k3_c48_wgrad on (dY, Z) with every workgroup's partial scaled by rstd[sample][ci] (stats [B,48,2]) in the reduce: the weight gradient of a conv whose
+    input is rstd * Z (include/nerfmae_hip.h: nmh_conv3d_k3_c48_wgrad_scaled; B in {1, 2, 4, 8})"""
+    _chk(dY, Z, stats, dW)
+    B, D, H, W, Cin = Z.shape
+    key = Z.device.index
+    if key not in _C48_WS:
+        _C48_WS[key] = torch.empty(lib().call("nmh_conv3d_k3_c48_wgrad_ws_floats"), dtype=torch.float32, device=Z.device)
+    ev = _prof(("conv3d_k3_c48_wgrad", B, D, 48, 48))
+    lib().call("nmh_conv3d_k3_c48_wgrad_scaled", dY, Z, stats, dW, _C48_WS[key], B, D, H, W, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
     return dW
@@ -977,6 +1036,15 @@ def instnorm_bwd_apply_bg(dout, x, stats, sums, dx, B, V, C, slope=0.01):
     _chk(dout, x, stats, sums, dx)
     ev = _prof(("instnorm_bwd_apply_bg", B, V, C), 3 * x.numel() * x.element_size())
     lib().call("nmh_instnorm_bwd_apply_bg", dt_of(x), dout, x, stats, sums, dx, B, V, C, slope, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+
+
+def instnorm_bwd_apply_bg_centered(dout, z, stats, sums, dx, B, V, C, slope=0.01):
+    """instnorm_bwd_apply_bg reading z = lrelu(y - mean) for y (centered decoder1)"""
+    _chk(dout, z, stats, sums, dx)
+    ev = _prof(("instnorm_bwd_apply_bg", B, V, C), 3 * z.numel() * z.element_size())
+    lib().call("nmh_instnorm_bwd_apply_bg_centered", dt_of(z), dout, z, stats, sums, dx, B, V, C, slope, _st())
     if ev is not None:
         ev.record(torch.cuda.current_stream())
 

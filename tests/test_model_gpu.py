@@ -219,6 +219,39 @@ def test_patch_embed_of_the_kept_tokens_only_changes_nothing(monkeypatch, dtype)
         assert relerr(o[1], outs[0][1]) <= (2e-5 if dtype == torch.float32 else 5e-3)
 
 
+def test_centered_decoder1_agrees_with_the_classic_form(monkeypatch):
+    """ops.CCONV_CENTERED (csrc/cconv.hip): conv1 -> InstanceNorm -> LeakyReLU -> conv2 of decoder1 with the mean taken from the coarse tensor, z = lrelu(y1 - mean)
+    stored, 1 / std in conv2's weights.  The same function in real arithmetic, different rounding points (rstd * bf16(z) vs bf16(rstd * t)): loss and gradients agree
+    to bf16 accuracy with the classic form, at two samples per step (8 % B == 0: the scaled weight-gradient reduce) with one ragged"""
+    from nerf_mae_amd import ops
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(SWIN_T, torch.bfloat16, res=64, init="default")
+    xs = [O.synthetic_grid((64, 64, 64), 51).cuda(), O.synthetic_grid((64, 60, 51), 52).cuda()]
+    bm = O.draw_block_mask((16, 16, 16), ora.masking_prob, rng=random.Random(9))
+    res = []
+    for flag in (False, True, False):
+        monkeypatch.setattr(ops, "CCONV_CENTERED", flag)
+        hip.zero_grad()
+        out = hip(xs, block_mask=bm, return_pred=True)
+        out[0].backward()
+        torch.cuda.synchronize()
+        res.append((out[0].item(), hip._flat_grad.clone(), out[3].clone()))
+    assert abs(res[0][0] - res[1][0]) <= 2e-3 * abs(res[0][0]), (res[0][0], res[1][0])
+    assert_close(res[1][2], res[0][2].cpu(), 3e-2, "reconstructed grid, centered vs classic", elem_mult=BF16_ELEM_MULT)
+    a, b = res[1][1].double(), res[0][1].double()
+    assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.999
+    # per parameter: the decoder1 / head gradients are the ones the change touches
+    rows = []
+    for n, p in hip.named_parameters():
+        if n.startswith(("decoder1.", "out.")) and p.requires_grad:
+            off = hip._offsets[id(p)]
+            ga, gb = res[1][1][off:off + p.numel()].double(), res[0][1][off:off + p.numel()].double()
+            if gb.norm() > 0:   # (conv biases in front of the affine-free InstanceNorm have no gradient)
+                rows.append(((torch.dot(ga, gb) / (ga.norm() * gb.norm() + 1e-30)).item(), n, ga.norm().item(), gb.norm().item()))
+    assert min(rows)[0] > 0.995, sorted(rows)
+    assert torch.isfinite(res[1][1]).all()
+
+
 def test_bf16_close_to_oracle_and_eval_contract():
     from oracle import mae3d_oracle as O
     res = 96
