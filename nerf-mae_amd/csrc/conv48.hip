@@ -907,7 +907,7 @@ static int launch_wgrad_halo(const void* dY, const void* X, float* dW, float* ws
   }
   if (scale_stats) {   // every one of the 8 tile ranges must lie inside ONE sample (the reduce scales a workgroup's partial by its sample's rstd)
     const long tps = (long)a.tz * a.ty * a.tx;
-    if (nsub != 1 || B < 1 || 8 % B || tps % (8 / B) || a.total < 256) return -2;
+    if (nsub != 1 || B < 1 || 8 % B || tps % (8 / B)) return -2;   // (then B tps is a multiple of 8 and every range is tps B / 8 tiles of one sample)
   }
   int nb;
   if (nsub == 1) nb = a.total < 256 ? (int)((a.total + 7) / 8 * 8) : 256;   // 8 XCD-contiguous tile ranges

@@ -568,7 +568,8 @@ class _UpBlockFn(torch.autograd.Function):
         # centered form (csrc/cconv.hip, round 6): the mean of conv1's output comes from the coarse tensor, conv1 stores z = lrelu(y1 - mean), 1 / std goes into conv2's
         # weights per sample; the backward reads z.  Needs the launches that read it (fused sums in conv2's input gradient, the background InstanceNorm backward, the
         # scaled weight-gradient reduce: B in {1, 2, 4, 8}) -- otherwise the classic form below
-        cz = (cc is not None and ops.CCONV_CENTERED and cc[6] is not None and B in (1, 2, 4, 8) and S % 16 == 0 and ops.C48_BWD_REDUCE and ops.INBWD_BG
+        cz = (cc is not None and ops.CCONV_CENTERED and cc[6] is not None and B in (1, 2, 4, 8) and S % 16 == 0 and ((S // 4) ** 2 * (S // 16)) % (8 // B) == 0
+              and ops.C48_BWD_REDUCE and ops.INBWD_BG
               and ops.side_stream.enabled and ops.CCONV_WGRAD and v <= 40 and cc[5] is not None)
         ctx.cz = cz
         if cz:

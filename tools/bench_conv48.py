@@ -10,6 +10,7 @@ x = torch.randn(B, R, R, R, 48, device='cuda').to(dt)
 dy = torch.randn(B, R, R, R, 48, device='cuda').to(dt)
 w = torch.randn(48, 48, 3, 3, 3) * (27 * 48) ** -0.5
 wk = _pack_via_kernel(w, 6, dt, 41 * 3 * 64 * 8)
+wk8 = wk.repeat(B).contiguous()
 y = torch.empty_like(x)
 dW = torch.zeros(48, 48, 3, 3, 3, device='cuda')
 fl = 2.0 * 27 * 48 * 48 * R ** 3 * B
@@ -17,6 +18,9 @@ st = torch.empty(B, 48, 2, device='cuda'); sums = torch.zeros(B, 48, 2, dtype=to
 ops.instnorm_stats(x.view(-1, 48), st, ops.acc_zeros((B, 48, 2), 'cuda'), B, R ** 3, 48)
 for name, fn in (("conv48 fwd", lambda: ops.conv3d_k3_c48(x, wk, out=y)), ("conv48 fwd + stats", lambda: ops.conv3d_k3_c48(x, wk, out=y, stats_acc=sums)),
                  ("stand-alone InstanceNorm apply", lambda: ops.instnorm_apply(x.view(-1, 48), st, dy.view(-1, 48), B, R ** 3, 48)),
+                 ("conv48 fwd + stats, one weight image per sample (centered decoder1)", lambda: ops.conv3d_k3_c48_per_sample(x, wk8, out=y, stats_acc=sums)),
+                 ("conv48 dgrad + IN-backward sums, centered (reads z)", lambda: ops.conv3d_k3_c48_bwd_reduce_centered(dy, wk, x, st, sums, out=y)),
+                 ("conv48 wgrad, scaled reduce", lambda: ops.conv3d_k3_c48_wgrad_scaled(dy, x, st, dW)),
                  ("conv48 dgrad + IN-backward sums", lambda: ops.conv3d_k3_c48_bwd_reduce(dy, wk, x, st, sums, out=y)),
                  ("separate IN-backward reduce", lambda: ops.instnorm_bwd_reduce(y.view(-1, 48), None, x.view(-1, 48), st, sums, B, R ** 3, 48, rmode=0)),
                  ("conv48 wgrad", lambda: ops.conv3d_k3_c48_wgrad(dy, x, dW))):
