@@ -449,6 +449,11 @@ int k_cconv_pack(const float* Wt, const float* W1, const float* bt, void* Wcp, f
 // (2) S_n from the classes, the 2592-term dot products and the border constant.  With the mean known BEFORE the fine tensor is written, the InstanceNorm
 // that follows needs no pass of its own over it: the producer stores lrelu(y1 - mean), the scale 1 / std goes into the consumer's weights (positive, so
 // it commutes with the LeakyReLU).
+__device__ __forceinline__ void unpack8_cc(const uint4& u, float (&v)[8]) {
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
 __global__ __launch_bounds__(256) void cconv_class_sums_kernel(const bf16_t* __restrict__ x, double* __restrict__ C27, int v, int ysplit) {
   // block = (z plane x y chunk, sample); wave = rows y of the chunk, lane = (8-channel chunk cl of 12, x lane xl of 5).  The row's (z, y) classes are wave-uniform
   // (scalar branch into one of 9 accumulator sets of three x classes); only the first / last cell of a row leave the interior x class.
@@ -472,12 +477,23 @@ __global__ __launch_bounds__(256) void cconv_class_sums_kernel(const bf16_t* __r
       float r0[8], r1[8], r2[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { r0[j] = 0.f; r1[j] = 0.f; r2[j] = 0.f; }
-      for (int xx = xl; xx < v; xx += 5) {
-        float f[8];
-        Vec8<bf16_t>::load(xp + (long)xx * 96, f);
-        const bool first = xx == 0, last = xx == v - 1;
+      for (int xb = 0; xb < v; xb += 40) {   // eight cells per lane in flight (the row of a 40^3 grid in one go)
+        uint4 raw[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { r0[j] += first ? f[j] : 0.f; r2[j] += last ? f[j] : 0.f; r1[j] += (first || last) ? 0.f : f[j]; }
+        for (int k = 0; k < 8; ++k) {
+          const int xx = xb + xl + 5 * k;
+          raw[k] = make_uint4(0, 0, 0, 0);
+          if (xx < v) raw[k] = *reinterpret_cast<const uint4*>(xp + (long)xx * 96);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int xx = xb + xl + 5 * k;
+          float f[8];
+          unpack8_cc(raw[k], f);
+          const bool first = xx == 0, last = xx == v - 1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { r0[j] += first ? f[j] : 0.f; r2[j] += last ? f[j] : 0.f; r1[j] += (first || last) ? 0.f : f[j]; }
+        }
       }
       const int ky = __builtin_amdgcn_readfirstlane(y == 0 ? 0 : (y == v - 1 ? 2 : 1));
       if (ky == 0) {
@@ -546,7 +562,7 @@ int k_cconv_mean(const void* x, const float* Mtab, const float* delta, double* C
   hipError_t e = nmh_zero_async(C27, sizeof(double) * (27 * 96 + 48) * B, st);
   if (e != hipSuccess) return (int)e;
   double* macc = C27 + (long)B * 27 * 96;
-  const int ysplit = v >= 16 ? 4 : 1;
+  const int ysplit = v > 64 ? 4 : 1;   // few workgroups: each ends with 864 fp64 atomics onto the same 2592 addresses per sample (3200 workgroups: 82 us, the atomics)
   hipLaunchKernelGGL(cconv_class_sums_kernel, dim3(v * ysplit, B), dim3(256), 0, st, (const bf16_t*)x, C27, v, ysplit);
   NMH_CHECK_LAUNCH();
   hipLaunchKernelGGL(cconv_mean_dot_kernel, dim3(27, B), dim3(256), 0, st, (const double*)C27, Mtab, macc);
