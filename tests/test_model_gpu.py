@@ -194,7 +194,7 @@ def test_patch_embed_of_the_kept_tokens_only_changes_nothing(monkeypatch, dtype)
             torch.cuda.synchronize()
             res.append((out[0].item(), hip._flat_grad.clone()))
         noise = relerr(res[0][1], res[2][1])
-        assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]), (res[0][0], res[1][0])
+        assert abs(res[0][0] - res[1][0]) <= 5e-6 * abs(res[0][0]), (res[0][0], res[1][0])   # (run-to-run: the InstanceNorm statistics are sums of fp64 atomics of fp32 partials)
         assert relerr(res[1][1], res[0][1]) <= max(4 * noise, 2e-6 if dtype == torch.float32 else 2e-3), (relerr(res[1][1], res[0][1]), noise)
         assert torch.isfinite(res[1][1]).all()
     # a capacity above the kept count (what a captured step runs with): forward_static with model._embed_cap set
@@ -215,7 +215,7 @@ def test_patch_embed_of_the_kept_tokens_only_changes_nothing(monkeypatch, dtype)
         finally:
             hip._embed_cap = None
     for o in outs[1:]:
-        assert abs(o[0] - outs[0][0]) <= 1e-6 * abs(outs[0][0])
+        assert abs(o[0] - outs[0][0]) <= 5e-6 * abs(outs[0][0])
         assert relerr(o[1], outs[0][1]) <= (2e-5 if dtype == torch.float32 else 5e-3)
 
 
