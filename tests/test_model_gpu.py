@@ -324,6 +324,31 @@ def test_nerf_rpn_encoder_contract():
         assert relerr(a, b) < 1e-3
 
 
+def test_graphed_step_recaptures_when_a_mask_keeps_more_tokens_than_the_embed_capacity():
+    """trainer.GraphedTrainStep fixes the rows of the compact patch embed at capture (mean + 8 sigma of the mask distribution); a mask that keeps more tokens makes it
+    re-capture with a row for every token -- forced here with a capacity of 64 rows: the replayed losses equal the eager model's on the same masks, before and
+    after the overflow"""
+    from nerf_mae_amd.trainer import FusedAdamW, GraphedTrainStep
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(SWIN_T, torch.bfloat16, res=32, init="default")
+    _, ref = _pair(SWIN_T, torch.bfloat16, res=32, init="default")
+    ref.load_state_dict(hip.state_dict(), strict=True)
+    xs = [O.synthetic_grid((32, 32, 32), 61).cuda(), O.synthetic_grid((32, 30, 27), 62).cuda()]
+    opt = FusedAdamW(hip, lr=0.0, weight_decay=0.0, max_grad_norm=0.1)     # lr 0: the weights stay put, the losses depend on the mask only
+    step = GraphedTrainStep(hip, opt, 2)
+    step._embed_cap = 64
+    few = torch.ones(8, 8, 8, dtype=torch.uint8)
+    few[:4, :4, :4] = 0          # one block kept: 64 tokens, fits
+    many = torch.zeros(8, 8, 8, dtype=torch.uint8)
+    many[:4, :4, :4] = 1         # seven blocks kept: 448 tokens
+    for i, bm in enumerate((few, many, few)):
+        losses = step(xs if i == 0 else None, bm)
+        torch.cuda.synchronize()
+        want = ref(xs, block_mask=bm)
+        assert abs(losses[0].item() - want[0].item()) <= 2e-5 * abs(want[0].item()), (i, losses[0].item(), want[0].item())
+        assert step._embed_cap == (64 if i == 0 else 512)
+
+
 def test_training_trace_matches_reference_golden(golden):
     """10 optimizer steps of the whole training step (HIP forward + backward on two grids, one of them ragged; fused clip + AdamW, OneCycle
     schedule, python-random block masks) against the trace the REAL reference produced with torch.optim.AdamW / OneCycleLR /
