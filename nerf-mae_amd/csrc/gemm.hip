@@ -111,6 +111,50 @@ template <typename T> struct AConv3 {
   }
 };
 
+// The same operand for bf16 with Cin a multiple of 64 (every decoder level): a 64-deep k-tile then lies inside ONE tap, so the tap, its voxel offset and the
+// channel offset of the tile are wave-uniform (scalar unit: they go into the buffer descriptor's base), and what is left per lane is fixed for the whole
+// M tile -- the byte offset of (row voxel, the lane's 8-channel piece) and a 27-bit mask of the taps that stay inside the volume for that row.  A load costs
+// a bit test, a select and the buffer load (an out-of-range offset reads zero: the conv's padding), where AConv3 spends ~20 vector instructions per
+// 16-byte load on the tap decode, three range tests and 64-bit address arithmetic -- as many issue cycles per k-tile as its 24 MFMAs (the 10^3 / 20^3 decoder
+// convs ran at 0.19-0.25 of the MFMA peak).  Sample tensors must stay below 2 GiB (checked by the launcher).
+template <typename T> struct AConv3F {
+  const T* X; int Cin, D, H, W; FDiv dW, dH, dC;
+  struct Row { unsigned voff, mask; };
+  struct Kst { const T* base; int tap; };
+  __device__ __forceinline__ void init_row(Row& r, int m, int M, int zb) const {
+    const bool ok = m < M;
+    const unsigned q = fdiv((unsigned)m, dW);
+    const int x = m - q * W;
+    const unsigned q2 = fdiv(q, dH);
+    const int y = q - q2 * H, z = (int)q2;
+    r.voff = (unsigned)((((long)zb * M + m) * Cin + (threadIdx.x & 7) * 8) * (long)sizeof(T));
+    unsigned mk = 0;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      const int dz = t / 9 - 1, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+      const bool v = ok && (unsigned)(z + dz) < (unsigned)D && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+      mk |= v ? (1u << t) : 0u;
+    }
+    r.mask = mk;
+  }
+  __device__ __forceinline__ Kst init_k(int k, int K) const {
+    const int kb = __builtin_amdgcn_readfirstlane(k & ~63);   // the k-tile's first column: the same in every lane (k = kb + 8 (tid & 7))
+    Kst s;
+    int tap = (int)fdiv((unsigned)kb, dC);
+    const int ci = kb - tap * Cin;
+    const int t9 = tap / 9, r9 = tap - t9 * 9, t3 = r9 / 3;
+    const long off = ((long)(t9 - 1) * H + (t3 - 1)) * W + (r9 - t3 * 3 - 1);
+    s.base = X + off * Cin + ci;
+    s.tap = kb < K ? tap : 27;   // (bit 27 of a row mask is never set)
+    return s;
+  }
+  __device__ __forceinline__ uint4 load(const Row& r, const Kst& s) const {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)s.base, 0, 0x7fffffff, 0x00020000);
+    const unsigned vo = ((r.mask >> s.tap) & 1u) ? r.voff : 0x80000000u;
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0));
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // epilogue (runtime-flagged, wave-uniform branches); operates on 8 consecutive columns
 // ------------------------------------------------------------------------------------------------
@@ -777,7 +821,17 @@ int k_conv3_nt(int dt, const void* X, const void* Wp, int B, int D, int H, int W
     if (tiles <= ks_tiles && s > 1) { ep.ksplit = s; ep.kpart = ws; }
   }
   int rc;
-  if (dt == NMH_DT_BF16) {
+  static const int fast_on = getenv("NMH_CONV_FAST_A") ? atoi(getenv("NMH_CONV_FAST_A")) : 1;
+  if (dt == NMH_DT_BF16 && fast_on && Cin % 64 == 0 && (long)B * M * Cin * 2 < (1L << 31)) {
+    AConv3F<bf16_t> al{(const bf16_t*)X, Cin, D, H, W, make_fdiv(W), make_fdiv(H), make_fdiv(Cin)};
+    // 128 x 192 tiles where the output width allows (every decoder level: 192 / 384 / 768): the kernel is bound by L2 -> LDS traffic (1 / BM + 1 / BN per FLOP: the
+    // 128 x 96 tile moved 4.7 GB for the 255-GFLOP conv at 20^3), not by load latency (an LDS-DMA ring of 3-4 stages measured 10 % SLOWER at the same tile) and
+    // not by the address arithmetic alone (AConv3F at 128 x 96: -7 %); 256 x 192 spills.  NMH_CONV_TILE = 26: the tile of rounds 2-5.  Sum of the six 10^3 / 20^3
+    // shapes at 8 grids: 1622 -> 1261 us (tools/bench_aconv3_sweep.py)
+    static const int tile_cfg = getenv("NMH_CONV_TILE") ? atoi(getenv("NMH_CONV_TILE")) : 212;
+    if (tile_cfg == 212 && Cout % 192 == 0) rc = launch_nt<bf16_t, 2, 12, AConv3F<bf16_t>>(al, Wp, K, M, Cout, K, B, ep, st);
+    else rc = dispatch_nt<bf16_t>(al, Wp, K, M, Cout, K, B, ep, st);
+  } else if (dt == NMH_DT_BF16) {
     AConv3<bf16_t> al{(const bf16_t*)X, Cin, D, H, W, make_fdiv(W), make_fdiv(H), make_fdiv(Cin)};
     rc = dispatch_nt<bf16_t>(al, Wp, K, M, Cout, K, B, ep, st);
   } else {
