@@ -317,6 +317,14 @@ NMH_API int nmh_mae_loss_bwd(int dt, const void* d0, const float* Wout, const fl
  * [B*R^3][8] bytes (6 used), bit j of byte c = [d0[voxel][8c + j] > 0] -- with the backward's sums taken here, the sign is all nmh_mae_tail_bwd still needs of d0:
  * given the mask it reads 8 bytes per voxel instead of the residual row (r and d0 may then both be NULL there). */
 NMH_API int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, void* d0, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, double* bwd_sums, unsigned char* sign_mask, void* stream);
+/* The training form of nmh_mae_tail_fwd for decoder1, whose residual is r = ConvTranspose3d_{k=s=4}(xcoarse) + bt (unetr_block.py:151-158, 193-200): r is formed
+ * inside the pass from the coarse tensor xcoarse [B][(R/4)^3][96] (bf16) on the matrix cores instead of being written by nmh_upconv4_fwd and read back -- one
+ * 160^3 x 48 write and read less.  Wr: nmh_tail_residual_pack(pack_ws of nmh_cconv_pack) -> nmh_tail_residual_pack_numel() bf16 elements (the 64 phase
+ * weights as MFMA fragments).  bf16, C = 48, R a multiple of 4 with (R/4)^3 a multiple of 16, R <= 256; dpred, bwd_sums and sign_mask are required (-4 otherwise:
+ * the caller then stores r and uses nmh_mae_tail_fwd).  r enters the sum in fp32 (nmh_mae_tail_fwd reads it rounded to bf16). */
+NMH_API int64_t nmh_tail_residual_pack_numel(void);
+NMH_API int nmh_tail_residual_pack(const float* pack_ws, void* Wr, void* stream);
+NMH_API int nmh_mae_tail_fwd_from_coarse(int dt, const void* y, const float* stats, const void* xcoarse, const void* Wr, const float* bt, const float* Wout, const float* bout, const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred, float* dpred, float slope, double* bwd_sums, unsigned char* sign_mask, void* stream);
 /* Backward of the decoder tail d0 = lrelu(IN(y) + r) -> 1x1 head -> loss in two elementwise passes that never materialise d(d0)
  * (swin_mae3d.py:1496-1549 + unetr_block.py:62-71 backward): d(d0) = Wout^T dpred is recomputed per element from dpred/loss_sums
  * (both from nmh_mae_loss_fwd).  in_sums[b][c] = {sum g, sum g*yhat}, dy = IN-backward, dr = g; dWout/dbout accumulate the head

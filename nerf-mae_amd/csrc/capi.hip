@@ -460,6 +460,22 @@ int nmh_mae_tail_fwd(int dt, const void* y, const float* stats, const void* r, v
   if (rc) return rc;
   return k_loss_finalize(sums, losses, ST);
 }
+int64_t nmh_tail_residual_pack_numel(void) { return (int64_t)k_tail_r_pack_numel(); }
+int nmh_tail_residual_pack(const float* pack_ws, void* Wr, void* stream) {
+  CLR();
+  REQ(pack_ws, Wr);
+  return k_tail_r_pack(pack_ws, Wr, ST);
+}
+int nmh_mae_tail_fwd_from_coarse(int dt, const void* y, const float* stats, const void* xcoarse, const void* Wr, const float* bt, const float* Wout, const float* bout,
+                                 const float* target, const int* extents, const unsigned char* tokmask, int B, int R, int C, double* sums, float* losses, float* pred,
+                                 float* dpred, float slope, double* bwd_sums, unsigned char* sign_mask, void* stream) {
+  CLR();
+  REQ(y, stats, xcoarse, Wr, bt, Wout, bout, target, extents, tokmask, sums, losses, dpred, bwd_sums, sign_mask);
+  LossArgs a{dt, nullptr, Wout, bout, target, extents, tokmask, B, R, C, sums, pred, dpred, bwd_sums, sign_mask};
+  int rc = k_tail_fwd_coarse(a, y, stats, xcoarse, Wr, bt, slope, ST);
+  if (rc) return rc;
+  return k_loss_finalize(sums, losses, ST);
+}
 int nmh_mae_tail_bwd(int dt, const void* d0, const void* r, const void* y, const float* stats, const float* dpred, const double* loss_sums, const float* Wout, double* in_sums,
                      void* dy, void* dr, float slope, float* dWout, float* dbout, int B, int64_t V, int C, const double* bwd_sums, const unsigned char* sign_mask,
                      void* stream) {

@@ -248,6 +248,10 @@ int k_loss_finalize(const double* sums, float* losses, hipStream_t st);
 int k_loss_bwd(const LossArgs& a, void* dd0, float* dWout, float* dbout, hipStream_t st);
 // d0 = lrelu(IN(x)+r) -> out, fused with the 1x1 head and the loss terms (a.d0 unused; sums/pred/dp as in k_loss_fwd)
 int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void* r, void* out, float slope, hipStream_t st);
+// the training form of the pass with the residual r = ConvT_{k=s=4}(xcoarse) + bt formed inside from the coarse tensor (Wr: k_tail_r_pack); d(pred), bwd_sums, sign_mask required
+int k_tail_fwd_coarse(const LossArgs& a, const void* x, const float* stats, const void* xcoarse, const void* Wr, const float* bt, float slope, hipStream_t st);
+long k_tail_r_pack_numel();
+int k_tail_r_pack(const float* ws, void* Wr, hipStream_t st);
 // loss backward + backward of d0 = lrelu(IN(x)+r) in two elementwise passes over (d0, x, dp): dx, dr = g; also head weight/bias gradients
 int k_tail_bwd(int dt, const void* d0, const void* r, const void* xin, const float* in_stats, const float* dp, const double* loss_sums, const float* Wout, double* in_sums,
                void* dx, void* dr, float slope, float* dWout, float* dbout, int B, long V, int C, const double* bwd_sums, hipStream_t st, const unsigned char* sign_mask = nullptr);

@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // window maps.  Window-ordered row m = ((b*nwz+wz)*nwy+wy)*nwx+wx)*64 + tz*16+ty*4+tx.
@@ -1636,6 +1637,350 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
     atomicAdd(dst, (double)val);
   }
   if (tid < 8) atomicAdd(&a.sums[tid], (double)sacc[tid]);
+}
+// ---- the same pass with the residual formed from the COARSE tensor (round 6) -------------------------------------------------------------
+// The residual of decoder1 is r = ConvT_{k=s=4}(xc) + bt (unetr_block.py:151-158): 3072 outputs of 96 inputs per coarse cell.  Written by
+// upconv4_fwd (3.15 GB at 8 x 160^3) it was read back by this pass alone; here the pass forms it on the matrix cores from the 192-byte row of
+// the cell.  A 16-voxel MFMA tile needs one weight set, i.e. one phase (dz, dy, dx) of 16 DIFFERENT cells:
+//  * workgroup = (range of cells, (dz, dy), sample), 8 waves: waves 0-3 the phases dx = 0, 1 (two tiles of the same 16 consecutive cells per step:
+//    32 voxels, neighbours in pairs), waves 4-7 dx = 2, 3 -- the 384-byte run of a cell's fine line is consumed by ONE workgroup (its three 128-byte
+//    lines meet in one L2); the phase weights of the line, 4 x (96 x 48) bf16 = 36 KB in fragment order, sit in LDS;
+//  * r^T[channel][cell] = W_phase^T xc^T: A = weights (row m of channel block cb <-> channel chan(cb, m)), B = the cell rows as loaded (lane
+//    (cell, g): inputs 32 ks + 8 g ..), accumulators start at the bias.  With chan(0, m) = 8 (m >> 2) + (m & 3), chan(1, m) = chan(0, m) + 4,
+//    chan(2, m) = 32 + m the lane (cell vi, g) leaves with r of channels 8g .. 8g+7 and 32 + 4g .. 32 + 4g + 3 of ITS voxel in fp32 -- the channels of
+//    the 16-byte chunk g and the 8-byte chunk g of the voxel's row of y2, which the lane loads;
+//  * head transposed: P^T[o][voxel] = Wout d0^T (A = head weights, rows 0-3: tile 0, rows 4-7: tile 1; B = the packed d0 chunks as they sit; the
+//    third fragment carries tile 0 in k-slots 0-3 and tile 1 in 4-7 against weights that are zero on the other tile's slots): lane (vi, g < 2) holds
+//    the four outputs of voxel vi of tile g -- own target loads, one 16-byte d(pred) store, one sigmoid per voxel;
+//  * d(pred) goes through a 256-byte wave-private LDS image [o][tile][16] to become the A fragment of the reduction GEMMs, which are those of
+//    tail_fwd_mfma_kernel (same operand images, row = 16 tile + cell).
+// r is no longer rounded to bf16 before the sum; everything downstream (d0's rounding, the head, the sums, the sign mask) as above.
+__global__ __launch_bounds__(512) void tail_fwd_coarse_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ xcoarse,
+                                                              const bf16_t* __restrict__ Wr, const float* __restrict__ bt, LossArgs a, long V, float slope, int cpb,
+                                                              unsigned mg1, unsigned mg2) {
+  constexpr int C = 48, OPB = 32 * 96, WLDS = 4 * OPB, WBYTES = 36 * 1024, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float sacc[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), vi = lane & 15, g = lane >> 4;
+  const int h = wave >> 2, wq = wave & 3, cls = blockIdx.y, dz = cls >> 2, dy = cls & 3, b = blockIdx.z;
+  char* const wl = smem + WBYTES + wave * WLDS;
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(smem) + WBYTES + NW * WLDS + wave * 256;
+  char* const dT = smem + WBYTES + NW * WLDS + NW * 256 + wave * 256;
+  char* const hw = smem + WBYTES + NW * WLDS + 2 * NW * 256 + lane * 16;   // head-weight fragments [6][64 lanes][16 B], written below
+  if (tid < 8) sacc[tid] = 0.f;
+  {   // the four phase-weight sets of this (dz, dy): [h][t][cb][ks][lane][8]
+    const uint4* src = reinterpret_cast<const uint4*>(Wr) + (long)cls * (WBYTES / 16);
+    for (int i = tid; i < WBYTES / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = src[i];
+  }
+  __syncthreads();
+  const char* const wsm = smem + h * (18 * 1024) + lane * 16;
+  typedef float tf2 __attribute__((ext_vector_type(2)));
+  tf2 mu0[4], rs0[4], mu1[4], rs1[4];   // mu* = MINUS the mean; set 0: channels 8g + j, set 1: channels 32 + 4g + (j & 3)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ca = 8 * g + j, cb_ = 32 + 4 * g + (j & 3);
+    mu0[j >> 1][j & 1] = -stats[((long)b * C + ca) * 2]; rs0[j >> 1][j & 1] = stats[((long)b * C + ca) * 2 + 1];
+    mu1[j >> 1][j & 1] = -stats[((long)b * C + cb_) * 2]; rs1[j >> 1][j & 1] = stats[((long)b * C + cb_) * 2 + 1];
+  }
+  const tf2 slope2 = {slope, slope};
+  // head weights as A fragments (lane (m = vi, g), k-slot j), bf16 hi + lo parts: kept in LDS (24 registers), six 16-byte reads per step
+  if (wave == 0) {
+    Frag<bf16_t> A0h, A0l, A1h, A1l, A2h, A2l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ow = vi & 3;
+      const float wa = vi < 8 ? a.Wout[ow * C + 8 * g + j] : 0.f, wb = vi < 8 ? a.Wout[ow * C + 32 + 4 * g + (j & 3)] : 0.f;
+      const bf16_t ah = f2bf(wa), bh = f2bf(wb);
+      const bf16_t al = f2bf(wa - bf2f(ah)), bl = f2bf(wb - bf2f(bh));
+      const bool t0 = vi < 4, t1 = vi >= 4 && vi < 8;
+      A0h.v[j] = t0 ? (short)ah : (short)0; A0l.v[j] = t0 ? (short)al : (short)0;
+      A1h.v[j] = t1 ? (short)ah : (short)0; A1l.v[j] = t1 ? (short)al : (short)0;
+      const bool on2 = (t0 && j < 4) || (t1 && j >= 4);
+      A2h.v[j] = on2 ? (short)bh : (short)0; A2l.v[j] = on2 ? (short)bl : (short)0;
+    }
+    *reinterpret_cast<bf16x8*>(hw) = A0h.v; *reinterpret_cast<bf16x8*>(hw + 1024) = A0l.v; *reinterpret_cast<bf16x8*>(hw + 2048) = A1h.v;
+    *reinterpret_cast<bf16x8*>(hw + 3072) = A1l.v; *reinterpret_cast<bf16x8*>(hw + 4096) = A2h.v; *reinterpret_cast<bf16x8*>(hw + 5120) = A2l.v;
+  }
+  __syncthreads();
+  f32x4 bb[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { bb[0][i] = bt[8 * g + i]; bb[1][i] = bt[8 * g + 4 + i]; bb[2][i] = bt[32 + 4 * g + i]; }
+  const float bo0 = a.bout[0], bo1 = a.bout[1], bo2 = a.bout[2], bo3 = a.bout[3];
+  const int e0 = a.extents[b * 3], e1 = a.extents[b * 3 + 1], e2 = a.extents[b * 3 + 2];
+  const unsigned Ru = (unsigned)a.R, gd = (unsigned)(a.R >> 2), gd2 = gd * gd, ncell = gd2 * gd;
+  f32x4 S[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) S[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float l_rgb = 0.f, l_a = 0.f, n_rgb = 0.f, n_a = 0.f, ds0 = 0.f, ds1 = 0.f, ds2 = 0.f, ds3 = 0.f;
+  const char* const xs_ = reinterpret_cast<const char*>(x + (long)b * V * C);
+  const char* const cs_ = reinterpret_cast<const char*>(xcoarse + (long)b * ncell * 96);
+  const int tl = g & 1;   // the tile of the lane's loss part (lanes g >= 2 idle there)
+  // What a step reads from global memory, in three groups of two register sets each (step k uses set k & 1; no copies between sets, the loop is unrolled by two):
+  //   B: the cell rows (L2) and the token mask, requested at the start of step k - 1;  X: the rows of y2 (HBM), requested in step k - 2 right behind its own
+  //   chunk arithmetic;  T: the targets (HBM), requested in step k - 2 behind its loss part -- the HBM streams are a step and a half ahead
+  //   (round 6: with everything one step ahead the pass moved 2.3 TB/s -- fewer bytes in flight per wave than the pass that also read r, at the same latency)
+  struct OpsB { uint4 xc[3]; unsigned tm, vox; int ins; };
+  struct OpsX { uint4 xa[2]; uint2 xb[2]; unsigned v0; int ins; };   // v0 / ins: voxel index and extent test of the cells requested last (passed on to that step's B set)
+  struct OpsT { float tg[4]; };
+  OpsB Bq[2]; OpsX Xq[2]; OpsT Tq[2];
+  auto issueB = [&](unsigned c0, unsigned v0, int ins, OpsB& o) {   // (v0, ins): as computed when the step's y2 rows were requested
+    const unsigned cell = c0 + (unsigned)vi;
+    o.vox = v0; o.ins = ins;
+    const char* const pc = cs_ + (unsigned long)cell * 192u + 16 * g;
+    o.xc[0] = *reinterpret_cast<const uint4*>(pc); o.xc[1] = *reinterpret_cast<const uint4*>(pc + 64); o.xc[2] = *reinterpret_cast<const uint4*>(pc + 128);
+    o.tm = a.tokmask[cell];
+  };
+  auto issueX = [&](unsigned c0, OpsX& o) {
+    const unsigned cell = c0 + (unsigned)vi;
+    const unsigned zc = __umulhi(cell, mg2), rem = cell - zc * gd2, yc = __umulhi(rem, mg1), xc_ = rem - yc * gd;
+    const unsigned zf = 4u * zc + (unsigned)dz, yf = 4u * yc + (unsigned)dy, xf = 4u * xc_ + 2u * (unsigned)h;
+    const unsigned v0 = (zf * Ru + yf) * Ru + xf;
+    o.v0 = v0;
+    o.ins = ((int)zf < e0 && (int)yf < e1 && (int)xf + tl < e2) ? 1 : 0;
+    const char* const p = xs_ + (unsigned long)v0 * 96u;
+    o.xa[0] = *reinterpret_cast<const uint4*>(p + 16 * g); o.xa[1] = *reinterpret_cast<const uint4*>(p + 96 + 16 * g);
+    o.xb[0] = *reinterpret_cast<const uint2*>(p + 64 + 8 * g); o.xb[1] = *reinterpret_cast<const uint2*>(p + 160 + 8 * g);
+  };
+  auto issueT = [&](unsigned v0, OpsT& o) {
+#pragma unroll
+    for (int oo = 0; oo < 4; ++oo) o.tg[oo] = a.target[((long)b * 4 + oo) * V + v0 + tl];   // (lanes g >= 2 repeat the addresses of g - 2: no branch around a load)
+  };
+  const unsigned sh15 = 0x000f000fu;
+  auto chunk = [&](const uint4& xw, const f32x4& ra, const f32x4& rb, const tf2 (&nmu)[4], const tf2 (&rs)[4], uint4& ypk, uint4& mpk, uint4& mxpk, uint4& xpk, unsigned& bits) {
+    const unsigned xs[4] = {xw.x, xw.y, xw.z, xw.w};
+    const tf2 rr[4] = {tf2{ra[0], ra[1]}, tf2{ra[2], ra[3]}, tf2{rb[0], rb[1]}, tf2{rb[2], rb[3]}};
+    unsigned yo[4], mo[4], mxo[4], xo[4];
+    unsigned u = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const tf2 xv = {__uint_as_float(xs[i] << 16), __uint_as_float(xs[i] & 0xffff0000u)};
+      tf2 xh, y, ys;
+      asm("v_pk_add_f32 %0, %1, %2" : "=v"(xh) : "v"(xv), "v"(nmu[i]));
+      asm("v_pk_mul_f32 %0, %1, %2" : "=v"(xh) : "v"(xh), "v"(rs[i]));
+      y = xh + rr[i];   // NOT inline asm: rr comes straight out of an MFMA, and the compiler places the wait states of a matrix-core result only in front of
+      //                   instructions it knows (an asm v_pk_add_f32 right behind the last MFMA of the residual read the accumulator too early: wrong values)
+      asm("v_pk_mul_f32 %0, %1, %2" : "=v"(ys) : "v"(y), "v"(slope2));
+      float ya, yc;
+      asm("v_max_f32 %0, %1, %2" : "=v"(ya) : "v"(y.x), "v"(ys.x));
+      asm("v_max_f32 %0, %1, %2" : "=v"(yc) : "v"(y.y), "v"(ys.y));
+      const unsigned yp = pk_bf16(ya, yc), xp = pk_bf16(xh.x, xh.y);
+      unsigned nm;
+      asm("v_pk_sub_i16 %0, 0, %1 clamp\n\tv_pk_ashrrev_i16 %0, %2, %0" : "=&v"(nm) : "v"(yp), "v"(sh15));   // 0xffff / 0 per half
+      yo[i] = yp; xo[i] = xp;
+      mo[i] = nm & 0x3f803f80u;
+      mxo[i] = nm & xp;
+      u |= nm & (0x00010001u << (2 * i));
+    }
+    bits = (u | (u >> 15)) & 0xffu;
+    ypk = make_uint4(yo[0], yo[1], yo[2], yo[3]); mpk = make_uint4(mo[0], mo[1], mo[2], mo[3]);
+    mxpk = make_uint4(mxo[0], mxo[1], mxo[2], mxo[3]); xpk = make_uint4(xo[0], xo[1], xo[2], xo[3]);
+  };
+  auto put16 = [&](int row, const uint4& mpk, const uint4& mxpk, const uint4& xpk, const uint4& ypk) {
+    char* p = wl + row * 96 + 16 * g;
+    *reinterpret_cast<uint4*>(p) = mpk;
+    *reinterpret_cast<uint4*>(p + OPB) = mxpk;
+    *reinterpret_cast<uint4*>(p + 2 * OPB) = xpk;
+    *reinterpret_cast<uint4*>(p + 3 * OPB) = ypk;
+  };
+  auto put8 = [&](const uint4& mpk, const uint4& mxpk, const uint4& xpk, const uint4& ypk) {   // tile 0: row vi <- .xy, tile 1: row 16 + vi <- .zw
+    char* p = wl + vi * 96 + 64 + 8 * g;
+    *reinterpret_cast<uint2*>(p) = make_uint2(mpk.x, mpk.y); *reinterpret_cast<uint2*>(p + 16 * 96) = make_uint2(mpk.z, mpk.w);
+    *reinterpret_cast<uint2*>(p + OPB) = make_uint2(mxpk.x, mxpk.y); *reinterpret_cast<uint2*>(p + OPB + 16 * 96) = make_uint2(mxpk.z, mxpk.w);
+    *reinterpret_cast<uint2*>(p + 2 * OPB) = make_uint2(xpk.x, xpk.y); *reinterpret_cast<uint2*>(p + 2 * OPB + 16 * 96) = make_uint2(xpk.z, xpk.w);
+    *reinterpret_cast<uint2*>(p + 3 * OPB) = make_uint2(ypk.x, ypk.y); *reinterpret_cast<uint2*>(p + 3 * OPB + 16 * 96) = make_uint2(ypk.z, ypk.w);
+  };
+  const unsigned cbeg = blockIdx.x * (unsigned)cpb, cend = cbeg + (unsigned)cpb < ncell ? cbeg + (unsigned)cpb : ncell;
+  auto step = [&](unsigned c0, auto parity) {
+    constexpr int PS = decltype(parity)::value;
+    const OpsB& o = Bq[PS];
+    OpsX& ox = Xq[PS];
+    OpsT& ot = Tq[PS];
+    // (requests past the wave's last step re-read the current one's addresses: no branch around a load -- with one the compiler can no longer count the loads in
+    //  flight and waits for all but the newest in front of the first use of this step's operands)
+    issueB(c0 + 64u < cend ? c0 + 64u : c0, Xq[PS ^ 1].v0, Xq[PS ^ 1].ins, Bq[PS ^ 1]);   // (the other X set still holds the next step's cells)
+    // the residual of both tiles: r[t][cb] = lane (cell vi, g): channels chan(cb, 4g + i)
+    Frag<bf16_t> xcf[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) xcf[ks].v = __builtin_bit_cast(bf16x8, o.xc[ks]);
+    f32x4 r[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int cb = 0; cb < 3; ++cb) {
+        r[t][cb] = bb[cb];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          Frag<bf16_t> wf;
+          wf.v = *reinterpret_cast<const bf16x8*>(wsm + ((t * 3 + cb) * 3 + ks) * 1024);
+          mma(r[t][cb], wf, xcf[ks]);
+        }
+      }
+    uint4 y0, y1, y2, mp, mxp, xp;
+    unsigned sb0, sb1, sb2;
+    chunk(ox.xa[0], r[0][0], r[0][1], mu0, rs0, y0, mp, mxp, xp, sb0); put16(vi, mp, mxp, xp, y0);
+    chunk(ox.xa[1], r[1][0], r[1][1], mu0, rs0, y1, mp, mxp, xp, sb1); put16(16 + vi, mp, mxp, xp, y1);
+    chunk(make_uint4(ox.xb[0].x, ox.xb[0].y, ox.xb[1].x, ox.xb[1].y), r[0][2], r[1][2], mu1, rs1, y2, mp, mxp, xp, sb2); put8(mp, mxp, xp, y2);
+    issueX(c0 + 128u < cend ? c0 + 128u : c0, ox);   // (the set is free again: y2 of the step after next)
+    {   // [d0 > 0]: byte g of both voxels; the lane's nibbles of byte 4 + (g >> 1) meet those of lane g ^ 1
+      sm[vi * 8 + g] = (unsigned char)sb0;
+      sm[(16 + vi) * 8 + g] = (unsigned char)sb1;
+      const unsigned pn = (unsigned)__shfl_xor((int)sb2, 16, 64);
+      if (!(g & 1)) {
+        sm[vi * 8 + 4 + (g >> 1)] = (unsigned char)((sb2 & 15u) | ((pn & 15u) << 4));
+        sm[(16 + vi) * 8 + 4 + (g >> 1)] = (unsigned char)((sb2 >> 4) | ((pn >> 4) << 4));
+      }
+    }
+    // head: P^T[o][voxel], rows 0-3 tile 0, rows 4-7 tile 1
+    Frag<bf16_t> f0, f1, f2;
+    f0.v = __builtin_bit_cast(bf16x8, y0); f1.v = __builtin_bit_cast(bf16x8, y1); f2.v = __builtin_bit_cast(bf16x8, y2);
+    f32x4 P = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      Frag<bf16_t> hf[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) hf[i].v = *reinterpret_cast<const bf16x8*>(hw + i * 1024);
+      mma(P, hf[0], f0); mma(P, hf[1], f0); mma(P, hf[2], f1); mma(P, hf[3], f1); mma(P, hf[4], f2); mma(P, hf[5], f2);
+    }
+    if (g < 2) {   // lane (vi, g): the four outputs of voxel o.vox + g
+      const long vq = (long)o.vox + g;
+      const float p0 = P[0] + bo0, p1 = P[1] + bo1, p2 = P[2] + bo2, p3 = P[3] + bo3;
+      const bool occ = ot.tg[3] > 0.01f, rm = o.tm != 0u && o.ins != 0;
+      const float d0f = p0 - ot.tg[0], d1f = p1 - ot.tg[1], d2f = p2 - ot.tg[2];
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-p3)), d3f = sg - ot.tg[3];
+      const float q0 = occ ? 2.f * d0f : 0.f, q1 = occ ? 2.f * d1f : 0.f, q2 = occ ? 2.f * d2f : 0.f, q3 = rm ? 2.f * sg * (1.f - sg) * d3f : 0.f;
+      l_rgb += occ ? d0f * d0f + d1f * d1f + d2f * d2f : 0.f; l_a += rm ? d3f * d3f : 0.f;
+      n_rgb += occ ? 1.f : 0.f; n_a += rm ? 1.f : 0.f;
+      ds0 += q0; ds1 += q1; ds2 += q2; ds3 += q3;
+      *reinterpret_cast<float4*>(a.dp + ((long)b * V + vq) * 4) = make_float4(q0, q1, q2, q3);
+      if (a.pred) { a.pred[((long)b * 4 + 0) * V + vq] = p0; a.pred[((long)b * 4 + 1) * V + vq] = p1; a.pred[((long)b * 4 + 2) * V + vq] = p2; a.pred[((long)b * 4 + 3) * V + vq] = p3; }
+      bf16_t* const dt_ = reinterpret_cast<bf16_t*>(dT) + g * 16 + vi;   // [o][tile][16]
+      const unsigned q01 = pk_bf16(q0, q1), q23 = pk_bf16(q2, q3);
+      dt_[0] = (bf16_t)(q01 & 0xffffu); dt_[32] = (bf16_t)(q01 >> 16); dt_[64] = (bf16_t)(q23 & 0xffffu); dt_[96] = (bf16_t)(q23 >> 16);
+    }
+    issueT(ox.v0, ot);   // (ox.v0: already that of the step after next)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32)   // lane = 16 tile + cell
+      *reinterpret_cast<uint2*>(a.sign_mask + ((long)b * V + o.vox + g) * 8) = *reinterpret_cast<const uint2*>(sm + lane * 8);
+    Frag<bf16_t> df;
+    {
+      uint2 w = make_uint2(0u, 0u);
+      if (vi < 8) w = *reinterpret_cast<const uint2*>(dT + (((vi & 3) * 2 + (vi >> 2)) * 16 + 4 * g) * 2);
+      const bool t1 = (vi & 4) != 0;
+      df.v = __builtin_bit_cast(bf16x8, make_uint4(t1 ? 0u : w.x, t1 ? 0u : w.y, t1 ? w.x : 0u, t1 ? w.y : 0u));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const char* pa = wl + q * OPB + (4 * g + (vi >> 2)) * 96 + (n * 4 + (vi & 3)) * 8;
+        const bf16x4 lo = ds_read_tr16(pa), hi = ds_read_tr16(pa + 16 * 96);
+        Frag<bf16_t> bf;
+        bf.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        mma(S[q][n], df, bf);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  {
+    unsigned c0 = cbeg + 16u * (unsigned)wq;
+    if (c0 < cend) {
+      issueX(c0, Xq[0]); issueB(c0, Xq[0].v0, Xq[0].ins, Bq[0]); issueT(Xq[0].v0, Tq[0]);
+      issueX(c0 + 64u < cend ? c0 + 64u : c0, Xq[1]); issueT(Xq[1].v0, Tq[1]);
+      for (; c0 + 64u < cend; c0 += 128u) {   // two steps per trip: straight-line code between the requests and their uses
+        step(c0, std::integral_constant<int, 0>{});
+        step(c0 + 64u, std::integral_constant<int, 1>{});
+      }
+      if (c0 < cend) step(c0, std::integral_constant<int, 0>{});
+    }
+  }
+  // ---- block reduction (as tail_fwd_mfma_kernel, 8 waves) ----------------------------------------------------------------------------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);   // [wave * 2 + tile][q][o][48]
+  if (g < 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) red[(((wave * 2 + g) * 4 + q) * 4 + rr) * C + 16 * n + vi] = S[q][n][rr];
+  }
+  {
+    const float v8[8] = {l_rgb, n_rgb, l_a, n_a, ds0, ds1, ds2, ds3};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float s = wave_sum(v8[i]);
+      if (lane == 0) atomicAdd(&sacc[i], s);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 8 * C; i += 512) {
+    const int k = i / C, c = i - k * C;
+    float T[4][4];   // [operand][o]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int oo = 0; oo < 4; ++oo) {
+        float t = 0.f;
+        for (int w = 0; w < 2 * NW; ++w) t += red[((w * 4 + q) * 4 + oo) * C + c];
+        T[q][oo] = t;
+      }
+    float val;
+    if (k < 4) {
+      const bool xh = k & 1;
+      val = 0.f;
+      const int o_lo = k < 2 ? 0 : 3, o_hi = k < 2 ? 3 : 4;
+      for (int oo = o_lo; oo < o_hi; ++oo) {
+        const float plain = xh ? T[2][oo] : sacc[4 + oo], masked = xh ? T[1][oo] : T[0][oo];
+        val += a.Wout[oo * C + c] * (slope * plain + (1.0f - slope) * masked);
+      }
+    } else val = T[3][k - 4];
+    double* dst = k < 4 ? a.bwd_sums + ((long)b * C + c) * 4 + k : a.bwd_sums + (long)a.B * C * 4 + (long)(k - 4) * C + c;
+    atomicAdd(dst, (double)val);
+  }
+  if (tid < 8) atomicAdd(&a.sums[tid], (double)sacc[tid]);
+}
+// Wr bf16 [16 (dz, dy)][2 h][2 t][3 cb][3 ks][64 lanes][8] from WtT fp32 [64 phases][96][48] (the workspace of cconv_pack): A fragments of the phase dx = 2h + t
+__global__ __launch_bounds__(512) void tail_r_pack_kernel(const float* __restrict__ WtT, bf16_t* __restrict__ Wr) {
+  const int blk = blockIdx.x, tid = threadIdx.x;   // one workgroup per fragment
+  const int cls = blk / 36, f = blk - cls * 36, ht = f / 9, cb = (f - ht * 9) / 3, ks = f - ht * 9 - cb * 3;
+  const int lane = tid >> 3, j = tid & 7, li = lane & 15, kg = lane >> 4;
+  const int ph = cls * 4 + ht, ci = 32 * ks + 8 * kg + j;
+  const int co = cb == 2 ? 32 + li : 8 * (li >> 2) + (li & 3) + 4 * cb;
+  Wr[((long)blk * 64 + lane) * 8 + j] = f2bf(WtT[((long)ph * 96 + ci) * 48 + co]);
+}
+long k_tail_r_pack_numel() { return 16L * 36 * 512; }
+int k_tail_r_pack(const float* ws, void* Wr, hipStream_t st) {
+  hipLaunchKernelGGL(tail_r_pack_kernel, dim3(16 * 36), dim3(512), 0, st, ws, (bf16_t*)Wr);
+  NMH_CHECK_LAUNCH();
+  return 0;
+}
+// training pass only (d(pred), the backward sums and the sign mask are all written): bf16, 48 channels, R a multiple of 4 with (R/4)^3 a multiple of 16, R <= 256
+int k_tail_fwd_coarse(const LossArgs& a, const void* x, const float* stats, const void* xcoarse, const void* Wr, const float* bt, float slope, hipStream_t st) {
+  const long V = (long)a.R * a.R * a.R;
+  const int gd = a.R / 4;
+  if (a.dt != NMH_DT_BF16 || a.Cd != 48 || a.R % 4 || a.R > 256 || ((long)gd * gd * gd) % 16 || !a.dp || !a.bwd_sums || !a.sign_mask || !(slope > 0.f && slope < 1.f)) return -4;
+  hipError_t e = nmh_zero_async(a.sums, 8 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  e = nmh_zero_async(a.bwd_sums, sizeof(double) * ((size_t)a.B * 48 * 4 + 4 * 48), st);
+  if (e != hipSuccess) return (int)e;
+  constexpr int LDS = 36 * 1024 + 8 * 4 * 32 * 96 + 8 * 256 + 8 * 256 + 6 * 1024;
+  static NmhPerDeviceOnce attr_set;
+  if (attr_set.need()) {
+    e = hipFuncSetAttribute((const void*)tail_fwd_coarse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr_set.set();
+  }
+  static const int cpb_env = getenv("NMH_TAILC_CPB") ? atoi(getenv("NMH_TAILC_CPB")) : 0;
+  const int ncell = gd * gd * gd;
+  int cpb = cpb_env > 0 ? (cpb_env + 63) / 64 * 64 : 4096;   // (8 x 160^3 inside the step: 42.38 ms with 2048, 42.20 with 4096, 42.87 with 1024)
+  if (cpb > (ncell + 63) / 64 * 64) cpb = (ncell + 63) / 64 * 64;
+  const unsigned mg1 = (unsigned)((0x100000000ULL + (unsigned)gd - 1) / (unsigned)gd), mg2 = (unsigned)((0x100000000ULL + (unsigned)(gd * gd) - 1) / (unsigned)(gd * gd));
+  dim3 grid((unsigned)((ncell + cpb - 1) / cpb), 16, a.B);
+  hipLaunchKernelGGL(tail_fwd_coarse_kernel, grid, dim3(512), LDS, st, (const bf16_t*)x, stats, (const bf16_t*)xcoarse, (const bf16_t*)Wr, bt, a, V, slope, cpb, mg1, mg2);
+  NMH_CHECK_LAUNCH();
+  return 0;
 }
 int k_tail_fwd(const LossArgs& a, const void* x, const float* stats, const void* r, void* out, float slope, hipStream_t st) {
   const int C = a.Cd;

@@ -202,13 +202,15 @@ class _Packer:
             if sp < n:
                 ops.pack_weights(self.dt, self.descs, self.blk2desc[sp:], self.blkstart[sp:], n - sp)
             if self.cconv is not None:    # decoder1: ConvTranspose o conv1 composed weights (csrc/cconv.hip), from the fp32 masters
-                up, Wcp, delta, ws, Wup, Wdp, mtab = self.cconv
+                up, Wcp, delta, ws, Wup, Wdp, mtab, Wres = self.cconv
                 if mtab is not None:   # + the table the centered forward's mean comes from
                     ops.cconv_pack_centered(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws, mtab)
                 else:
                     ops.cconv_pack(up.transp_conv.weight, up.conv_block.conv1.weight, up.transp_conv.bias, Wcp, delta, ws)
                 if Wup is not None:
                     ops.upconv4_pack(ws, Wup)
+                if Wres is not None:   # the same weights as the fragments of the tail that forms the residual itself
+                    ops.tail_residual_pack(ws, Wres)
                 if Wdp is not None:
                     ops.cconv_dgrad_pack(Wcp, Wdp)
 
@@ -536,9 +538,17 @@ class _UpBlockFn(torch.autograd.Function):
         dev, dtype = x.device, x.dtype
         has_skip = skip is not None
         Cc = 2 * Cout if has_skip else Cout
-        cat = torch.empty((B * V, Cc), dtype=dtype, device=dev)
         cc = pk.cconv if ((key + "c1.wk") in pk.views and pk.cconv is not None and pk.cconv[0] is m and v % 8 == 0 and not has_skip) else None
-        if cc is not None and cc[4] is not None:   # decoder1: persistent kernel, coarse fragments in registers (csrc/cconv.hip)
+        # decoder1 in training (round 6): the residual u = ConvT(x) is read by the tail forward alone (the composed kernels take conv1's passes through the coarse
+        # tensor, the tail backward reads a sign mask), and the tail forms it from x on the matrix cores -- u is never stored (csrc/norm.hip: tail_fwd_coarse_kernel)
+        rx = (cc is not None and ops.TAIL_FROM_COARSE and cc[7] is not None and tail is not None and not m.has_proj and ctx.needs_input_grad[0]
+              and tail[0].fuse_tail_sums and ops.TAIL_SIGN_MASK and ops.CCONV_WGRAD and v <= 40 and cc[5] is not None and k == 4 and (key + "c2.wk") in pk.views
+              and ops.tail_from_coarse_ok(v * k, Cout, Cin, dtype))
+        ctx.rx = rx
+        cat = None if rx else torch.empty((B * V, Cc), dtype=dtype, device=dev)
+        if rx:
+            pass
+        elif cc is not None and cc[4] is not None:   # decoder1: persistent kernel, coarse fragments in registers (csrc/cconv.hip)
             ops.upconv4_fwd(x.view(B, v, v, v, Cin), cc[4], m.transp_conv.bias, cat, B, v)
         else:
             ops.upconv_fwd(x, pk[key + "t.w"].view(k3 * Cout, Cin), m.transp_conv.bias, cat, B, v, k, Cin, Cout)   # pixel shuffle in the epilogue
@@ -629,8 +639,13 @@ class _UpBlockFn(torch.autograd.Function):
             # with the backward's sums taken here, the sign of d0 is all the tail backward still needs of it: 6 bytes per voxel instead of the residual row
             smask = (torch.empty((B * V, 8), dtype=torch.uint8, device=dev)
                      if (bsum is not None and ops.TAIL_SIGN_MASK and dtype == torch.bfloat16 and Cout == 48 and out is None and S % 4 == 0) else None)
-            ops.mae_tail_fwd(y2, st2, cat, out, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask, B, S, Cout, lsums, losses,
-                             pred_out, dpred, bwd_sums=bsum, sign_mask=smask)
+            if rx:
+                assert smask is not None and bsum is not None and dpred is not None
+                ops.mae_tail_fwd_from_coarse(y2, st2, x.view(B, v, v, v, Cin), cc[7], m.transp_conv.bias, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask,
+                                             B, S, Cout, lsums, losses, dpred, bsum, smask, pred=pred_out)
+            else:
+                ops.mae_tail_fwd(y2, st2, cat, out, model.out.conv.weight, model.out.conv.bias, xb, extents, tokmask, B, S, Cout, lsums, losses,
+                                 pred_out, dpred, bwd_sums=bsum, sign_mask=smask)
             ctx.tail = (model, lsums, dpred, bsum, smask)
             return losses
         return out
@@ -644,11 +659,11 @@ class _UpBlockFn(torch.autograd.Function):
         k, Cin, Cout = m.k, m.cin, m.cout
         k3, S = k ** 3, v * k
         V = S ** 3
-        Cc = cat.shape[1]
+        Cc = cat.shape[1] if cat is not None else Cout
         dev, dtype = x.device, x.dtype
         sums2 = ops.acc_zeros((B, Cout, 2), dev)
         dy2 = torch.empty_like(y2)
-        dcat = torch.empty_like(cat)
+        dcat = torch.empty((B * V, Cc), dtype=dtype, device=dev)
         if ctx.tail is not None:   # d(loss)/d(losses[0]) == 1 (the reference calls loss.backward()); d(d0) is never materialised
             model, lsums, dpred, bsum, smask = ctx.tail
             ops.mae_tail_bwd(None, y2, st2, dpred, lsums, model.out.conv.weight, sums2, dy2, dcat,
@@ -1048,7 +1063,8 @@ class SwinTransformer_MAE3D_New(nn.Module):
                        torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device=device),
                        torch.empty(ops.upconv4_pack_numel(), dtype=torch.bfloat16, device=device) if ops.UPCONV4 else None,
                        torch.empty(ops.cconv_dgrad_pack_numel(), dtype=torch.bfloat16, device=device) if (ops.CCONV_DGRAD and ops.CCONV_WGRAD) else None,
-                       torch.empty((27, 96, 48), dtype=torch.float32, device=device) if ops.CCONV_CENTERED else None)
+                       torch.empty((27, 96, 48), dtype=torch.float32, device=device) if ops.CCONV_CENTERED else None,
+                       torch.empty(ops.tail_residual_pack_numel(), dtype=torch.bfloat16, device=device) if ops.TAIL_FROM_COARSE else None)
         self._packer = P
         self._pk = P
         self._wq = ops.WgradQueue()   # deferred encoder weight gradients (grouped launches, issued per stage)

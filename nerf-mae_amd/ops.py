@@ -1141,6 +1141,41 @@ def mae_tail_fwd(y, stats, r, d0, Wout, bout, target, extents, tokmask, B, R, C,
     return losses
 
 
+TAIL_FROM_COARSE = __import__("os").environ.get("NMH_TAIL_FROM_COARSE", "1") != "0"   # decoder1's tail forms the residual ConvT(x) from the coarse tensor (no 160^3 residual tensor)
+
+
+def tail_residual_pack_numel() -> int:
+    return int(lib().call("nmh_tail_residual_pack_numel"))
+
+
+def tail_residual_pack(pack_ws, Wr):
+    """the 64 phase weights of the k = s = 4 transpose conv as the MFMA fragments of mae_tail_fwd_from_coarse, from the scratch cconv_pack filled in this step"""
+    _chk(pack_ws, Wr)
+    if Wr.numel() < tail_residual_pack_numel() or Wr.dtype != torch.bfloat16:
+        raise ValueError("tail_residual_pack: shapes")
+    lib().call("nmh_tail_residual_pack", pack_ws, Wr, _st())
+
+
+def tail_from_coarse_ok(R: int, C: int, Cin: int, dtype) -> bool:
+    """shapes mae_tail_fwd_from_coarse takes (include/nerfmae_hip.h)"""
+    return dtype == torch.bfloat16 and C == 48 and Cin == 96 and R % 4 == 0 and R <= 256 and ((R // 4) ** 3) % 16 == 0
+
+
+def mae_tail_fwd_from_coarse(y, stats, xcoarse, Wr, bt, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, dpred, bwd_sums, sign_mask, pred=None, slope=0.01):
+    """mae_tail_fwd (training form: d(pred), the backward's sums and the sign mask are all written) with the residual ConvT_{k=s=4}(xcoarse) + bt formed inside"""
+    _chk(y, stats, xcoarse, Wr, bt, Wout, bout, target, extents, tokmask, sums, losses, pred, dpred, bwd_sums, sign_mask)
+    if not tail_from_coarse_ok(R, C, xcoarse.shape[-1], y.dtype) or xcoarse.dtype != torch.bfloat16 or xcoarse.numel() != B * (R // 4) ** 3 * 96:
+        raise ValueError("mae_tail_fwd_from_coarse: bf16, 48 channels from a 96-channel coarse tensor of edge R / 4, (R / 4)^3 a multiple of 16")
+    if sums.numel() < 8 or bwd_sums.numel() < B * C * 4 + 4 * C or sign_mask.dtype != torch.uint8 or sign_mask.numel() < B * R ** 3 * 8 or dpred.numel() < B * R ** 3 * 4:
+        raise ValueError("mae_tail_fwd_from_coarse: sums[8], bwd_sums[B*C*4 + 4*C], sign_mask[B*R^3*8], dpred[B*R^3*4]")
+    ev = _prof(("mae_tail_fwd", B, R, C), y.numel() * y.element_size() + xcoarse.numel() * 2 + B * R ** 3 * (16 * (2 + (pred is not None)) + 8))
+    lib().call("nmh_mae_tail_fwd_from_coarse", dt_of(y), y, stats, xcoarse, Wr, bt, Wout, bout, target, extents, tokmask, B, R, C, sums, losses, pred, dpred, slope,
+               bwd_sums, sign_mask, _st())
+    if ev is not None:
+        ev.record(torch.cuda.current_stream())
+    return losses
+
+
 def mae_tail_bwd(d0, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, B, V, C, slope=0.01, r=None, bwd_sums=None, sign_mask=None):
     """d0 may be None when r (the forward's residual input) is given: the kernel rebuilds d0 from y, stats and r"""
     _chk(d0, r, y, stats, dpred, loss_sums, Wout, in_sums, dy, dr, dWout, dbout, bwd_sums, sign_mask)

@@ -633,6 +633,79 @@ def test_tail_backward_fused(dt, R):
         assert torch.allclose(in_sums5, in_sums4, rtol=1e-6, atol=1e-9 * scale) and torch.allclose(dW5, dW4, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("R", [32, 48, 64])
+def test_tail_forward_with_the_residual_formed_from_the_coarse_tensor(R):
+    """decoder1's tail with r = ConvTranspose3d_{k=s=4}(x coarse) + bias formed INSIDE the pass (csrc/norm.hip: tail_fwd_coarse_kernel; unetr_block.py:62-71,
+    151-158 + swin_mae3d.py:1496-1549): against autograd of the same chain in fp32 on the bf16-rounded operands (forward values, and every gradient the tail backward
+    makes of the pass's d(pred), sums and sign mask), and against the pass that reads the stored residual (which sees r rounded to bf16).
+    R = 48: 12^3 cells (the cell -> (z, y, x) split by multiplication, rows of 12 cells against groups of 16), a sample with partial extents."""
+    from oracle import mae3d_oracle as O
+    ops = _ops()
+    dt = torch.bfloat16
+    B, Cd, gd = 2, 48, R // 4
+    V = R ** 3
+    x = torch.stack([O.synthetic_grid((R, R, R), 3), O.synthetic_grid((R, R, R), 4)])
+    valid = torch.ones_like(x)
+    valid[1, :, R - 4:] = 0
+    valid[1, :, :, :, R - 6:] = 0
+    x = x * valid
+    ext = torch.tensor([[R, R, R], [R - 4, R, R - 6]], dtype=torch.int32)
+    y = q(rnd(B, V, Cd) * 1.3 + 0.2, dt)
+    xc = q(rnd(B, gd, gd, gd, 96, seed=11), dt)
+    Wt = rnd(96, 48, 4, 4, 4, seed=12, scale=96 ** -0.5)
+    bt = rnd(48, seed=13, scale=0.5)
+    Wo, bo = rnd(4, Cd, seed=1, scale=0.2), rnd(4, seed=2, scale=0.1)
+    tm = O.draw_block_mask((gd,) * 3, 0.6, rng=__import__("random").Random(5))
+    yr, Wr, br_ = (t.clone().requires_grad_(True) for t in (y, Wo, bo))
+    r_ref = F.conv_transpose3d(xc.permute(0, 4, 1, 2, 3), q(Wt, dt), bt, stride=4).permute(0, 2, 3, 4, 1).reshape(B, V, Cd).clone().requires_grad_(True)
+    inorm = lambda t: F.instance_norm(t.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+    d0_ref = F.leaky_relu(inorm(yr) + r_ref, 0.01)
+    d0q = q(d0_ref.detach(), dt)
+    d0s = d0_ref + (d0q - d0_ref).detach()
+    pred = (d0s.reshape(B, R, R, R, Cd) @ Wr.T + br_).permute(0, 4, 1, 2, 3)
+    l, lr, la, *_ = O.mae_loss(x, pred, valid, tm[None, ..., None].expand(B, -1, -1, -1, 1))
+    l.backward()
+    # packed phase weights from the scratch of the composed-weight pack, as the model makes them
+    ws = torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device="cuda")
+    ops.cconv_pack(dev(Wt), dev(rnd(48, 48, 3, 3, 3, seed=3)), dev(bt), torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda"), torch.empty(27, 48, device="cuda"), ws)
+    Wres = torch.empty(ops.tail_residual_pack_numel(), dtype=dt, device="cuda")
+    ops.tail_residual_pack(ws, Wres)
+    yd = dev(y, dt)
+    stats, scratch = torch.empty(B, Cd, 2, device="cuda"), torch.empty(B, Cd, 2, dtype=torch.float64, device="cuda")
+    ops.instnorm_stats(yd, stats, scratch, B, V, Cd)
+    Wod, bod, xd, extd, tmd = dev(Wo), dev(bo), dev(x), dev(ext), dev(tm.to(torch.uint8))
+    lsums, losses, dpred = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda"), torch.full((B * V, 4), 7.0, device="cuda")
+    bsum = torch.empty(B * Cd * 4 + 4 * Cd, dtype=torch.float64, device="cuda")
+    smask = torch.full((B * V, 8), 0xAA, dtype=torch.uint8, device="cuda")
+    predk = torch.empty(B, 4, R, R, R, device="cuda")
+    ops.mae_tail_fwd_from_coarse(yd.view(-1, Cd), stats, dev(xc, dt), Wres, dev(bt), Wod, bod, xd, extd, tmd, B, R, Cd, lsums, losses, dpred, bsum, smask, pred=predk)
+    torch.cuda.synchronize()
+    check(predk, pred.detach(), dt, "pred", 2)
+    np.testing.assert_allclose(losses.cpu().numpy(), [l.item(), lr.item(), la.item()], rtol=TOL[dt])
+    # the pass that reads the stored residual (bf16): same thing up to the rounding of r
+    rd = dev(r_ref.detach(), dt)
+    lsums2, losses2, dpred2 = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda"), torch.empty(B * V, 4, device="cuda")
+    bsum2, smask2 = torch.empty_like(bsum), torch.empty_like(smask)
+    ops.mae_tail_fwd(yd.view(-1, Cd), stats, rd.view(-1, Cd), None, Wod, bod, xd, extd, tmd, B, R, Cd, lsums2, losses2, None, dpred2, bwd_sums=bsum2, sign_mask=smask2)
+    np.testing.assert_allclose(losses.cpu().numpy(), losses2.cpu().numpy(), rtol=2e-3)
+    np.testing.assert_allclose(lsums.cpu().numpy(), lsums2.cpu().numpy(), rtol=5e-3, atol=1e-3 * float(lsums2.abs().max()))
+    check(dpred, dpred2.cpu(), dt, "dpred against the stored-residual pass", 2)
+    sc = float(bsum2.abs().max())
+    assert torch.allclose(bsum, bsum2, rtol=2e-2, atol=2e-3 * sc), ((bsum - bsum2).abs().max().item(), sc)
+    bits = ((smask[:, :6].reshape(B * V, 6, 1) >> torch.arange(8, device="cuda", dtype=torch.uint8).view(1, 1, 8)) & 1).view(B * V, Cd).bool().cpu()
+    mism = bits != (d0_ref.detach().reshape(B * V, Cd) > 0)
+    assert mism.float().mean().item() < 1e-5 and (mism.sum().item() == 0 or d0_ref.detach().reshape(B * V, Cd).abs()[mism].max().item() < 1e-4), \
+        ("sign mask", mism.sum().item(), d0_ref.detach().reshape(B * V, Cd).abs()[mism].max().item() if mism.any() else 0.0)
+    # the backward made of this pass's outputs against autograd
+    dy, dr = torch.empty(B * V, Cd, dtype=dt, device="cuda"), torch.empty(B * V, Cd, dtype=dt, device="cuda")
+    dW, db, in_sums = torch.zeros(4, Cd, device="cuda"), torch.zeros(4, device="cuda"), torch.empty(B, Cd, 2, dtype=torch.float64, device="cuda")
+    ops.mae_tail_bwd(None, yd.view(-1, Cd), stats, dpred, lsums, Wod, in_sums, dy, dr, dW, db, B, V, Cd, bwd_sums=bsum, sign_mask=smask)
+    check(dr, r_ref.grad.reshape(-1, Cd), dt, "dr", 3)
+    check(dy, yr.grad.reshape(-1, Cd), dt, "dy", 3)
+    check(dW, Wr.grad, dt, "dWout", 2)
+    check(db, br_.grad, dt, "dbout", 2)
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_instnorm_bwd_without_out(dt):
     """rmode 0: sign(out) == sign(x - mean), so `out` may be omitted."""

@@ -228,14 +228,19 @@ def test_centered_decoder1_agrees_with_the_classic_form(monkeypatch):
     ora, hip = _pair(SWIN_T, torch.bfloat16, res=64, init="default")
     xs = [O.synthetic_grid((64, 64, 64), 51).cuda(), O.synthetic_grid((64, 60, 51), 52).cuda()]
     bm = O.draw_block_mask((16, 16, 16), ora.masking_prob, rng=random.Random(9))
-    res = []
-    for flag in (False, True, False):
+    calls = []
+    real = ops.cconv_fwd_centered
+    monkeypatch.setattr(ops, "cconv_fwd_centered", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    res = {}
+    for flag in (True, False):   # (the packer allocates the mean table at the first forward: the flag is on there)
         monkeypatch.setattr(ops, "CCONV_CENTERED", flag)
+        n0 = len(calls)
         hip.zero_grad()
         out = hip(xs, block_mask=bm, return_pred=True)
         out[0].backward()
         torch.cuda.synchronize()
-        res.append((out[0].item(), hip._flat_grad.clone(), out[3].clone()))
+        assert len(calls) - n0 == (1 if flag else 0)   # the form under test is the one that ran
+        res[int(flag)] = (out[0].item(), hip._flat_grad.clone(), out[3].clone())
     assert abs(res[0][0] - res[1][0]) <= 2e-3 * abs(res[0][0]), (res[0][0], res[1][0])
     assert_close(res[1][2], res[0][2].cpu(), 3e-2, "reconstructed grid, centered vs classic", elem_mult=BF16_ELEM_MULT)
     a, b = res[1][1].double(), res[0][1].double()
@@ -249,6 +254,43 @@ def test_centered_decoder1_agrees_with_the_classic_form(monkeypatch):
             if gb.norm() > 0:   # (conv biases in front of the affine-free InstanceNorm have no gradient)
                 rows.append(((torch.dot(ga, gb) / (ga.norm() * gb.norm() + 1e-30)).item(), n, ga.norm().item(), gb.norm().item()))
     assert min(rows)[0] > 0.995, sorted(rows)
+    assert torch.isfinite(res[1][1]).all()
+
+
+def test_tail_that_forms_the_residual_from_the_coarse_tensor_agrees_with_the_stored_residual(monkeypatch):
+    """ops.TAIL_FROM_COARSE (csrc/norm.hip: tail_fwd_coarse_kernel): decoder1's residual ConvT(x) is formed inside the tail forward instead of being stored by
+    upconv4_fwd and read back.  Same function; the residual enters the sum in fp32 instead of rounded to bf16: loss, reconstruction and gradients agree to bf16
+    accuracy with the stored form (two samples, one ragged), and the new launch is the one that runs."""
+    from nerf_mae_amd import ops
+    from oracle import mae3d_oracle as O
+    ora, hip = _pair(SWIN_T, torch.bfloat16, res=64, init="default")
+    xs = [O.synthetic_grid((64, 64, 64), 51).cuda(), O.synthetic_grid((64, 60, 51), 52).cuda()]
+    bm = O.draw_block_mask((16, 16, 16), ora.masking_prob, rng=random.Random(9))
+    calls = []
+    real = ops.mae_tail_fwd_from_coarse
+    monkeypatch.setattr(ops, "mae_tail_fwd_from_coarse", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    res = {}
+    for flag in (True, False):   # (the packer allocates the fragment buffer at the first forward: the flag is on there)
+        monkeypatch.setattr(ops, "TAIL_FROM_COARSE", flag)
+        n0 = len(calls)
+        hip.zero_grad()
+        out = hip(xs, block_mask=bm, return_pred=True)
+        out[0].backward()
+        torch.cuda.synchronize()
+        assert len(calls) - n0 == (1 if flag else 0)
+        res[int(flag)] = (out[0].item(), hip._flat_grad.clone(), out[3].clone())
+    assert abs(res[0][0] - res[1][0]) <= 2e-3 * abs(res[0][0]), (res[0][0], res[1][0])
+    assert_close(res[1][2], res[0][2].cpu(), 3e-2, "reconstructed grid, residual formed in the tail vs stored", elem_mult=BF16_ELEM_MULT)
+    a, b = res[1][1].double(), res[0][1].double()
+    assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.999
+    rows = []
+    for n, p in hip.named_parameters():
+        if p.requires_grad:
+            off = hip._offsets[id(p)]
+            ga, gb = res[1][1][off:off + p.numel()].double(), res[0][1][off:off + p.numel()].double()
+            if gb.norm() > 0:
+                rows.append(((torch.dot(ga, gb) / (ga.norm() * gb.norm() + 1e-30)).item(), n, ga.norm().item(), gb.norm().item()))
+    assert min(rows)[0] > 0.99, sorted(rows)[:5]
     assert torch.isfinite(res[1][1]).all()
 
 
