@@ -1655,11 +1655,14 @@ __global__ __launch_bounds__(256) void tail_fwd_mfma_kernel(const bf16_t* __rest
 //  * d(pred) goes through a 256-byte wave-private LDS image [o][tile][16] to become the A fragment of the reduction GEMMs, which are those of
 //    tail_fwd_mfma_kernel (same operand images, row = 16 tile + cell).
 // r is no longer rounded to bf16 before the sum; everything downstream (d0's rounding, the head, the sums, the sign mask) as above.
+#ifndef TAILC_RS
+#define TAILC_RS 112
+#endif
 template <int DBG>
 __global__ __launch_bounds__(512) void tail_fwd_coarse_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats, const bf16_t* __restrict__ xcoarse,
                                                               const bf16_t* __restrict__ Wr, const float* __restrict__ bt, LossArgs a, long V, float slope, int cpb,
                                                               unsigned mg1, unsigned mg2) {
-  constexpr int C = 48, OPB = 32 * 96, WLDS = 4 * OPB, WBYTES = 36 * 1024, NW = 8;
+  constexpr int C = 48, RS = TAILC_RS, OPB = 32 * RS, WLDS = 4 * OPB, WBYTES = 36 * 1024, NW = 8;   // RS: row stride of the operand images
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float sacc[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), vi = lane & 15, g = lane >> 4;
@@ -1779,18 +1782,18 @@ __global__ __launch_bounds__(512) void tail_fwd_coarse_kernel(const bf16_t* __re
     mxpk = make_uint4(mxo[0], mxo[1], mxo[2], mxo[3]); xpk = make_uint4(xo[0], xo[1], xo[2], xo[3]);
   };
   auto put16 = [&](int row, const uint4& mpk, const uint4& mxpk, const uint4& xpk, const uint4& ypk) {
-    char* p = wl + row * 96 + 16 * g;
+    char* p = wl + row * RS + 16 * g;
     *reinterpret_cast<uint4*>(p) = mpk;
     *reinterpret_cast<uint4*>(p + OPB) = mxpk;
     *reinterpret_cast<uint4*>(p + 2 * OPB) = xpk;
     *reinterpret_cast<uint4*>(p + 3 * OPB) = ypk;
   };
   auto put8 = [&](const uint4& mpk, const uint4& mxpk, const uint4& xpk, const uint4& ypk) {   // tile 0: row vi <- .xy, tile 1: row 16 + vi <- .zw
-    char* p = wl + vi * 96 + 64 + 8 * g;
-    *reinterpret_cast<uint2*>(p) = make_uint2(mpk.x, mpk.y); *reinterpret_cast<uint2*>(p + 16 * 96) = make_uint2(mpk.z, mpk.w);
-    *reinterpret_cast<uint2*>(p + OPB) = make_uint2(mxpk.x, mxpk.y); *reinterpret_cast<uint2*>(p + OPB + 16 * 96) = make_uint2(mxpk.z, mxpk.w);
-    *reinterpret_cast<uint2*>(p + 2 * OPB) = make_uint2(xpk.x, xpk.y); *reinterpret_cast<uint2*>(p + 2 * OPB + 16 * 96) = make_uint2(xpk.z, xpk.w);
-    *reinterpret_cast<uint2*>(p + 3 * OPB) = make_uint2(ypk.x, ypk.y); *reinterpret_cast<uint2*>(p + 3 * OPB + 16 * 96) = make_uint2(ypk.z, ypk.w);
+    char* p = wl + vi * RS + 64 + 8 * g;
+    *reinterpret_cast<uint2*>(p) = make_uint2(mpk.x, mpk.y); *reinterpret_cast<uint2*>(p + 16 * RS) = make_uint2(mpk.z, mpk.w);
+    *reinterpret_cast<uint2*>(p + OPB) = make_uint2(mxpk.x, mxpk.y); *reinterpret_cast<uint2*>(p + OPB + 16 * RS) = make_uint2(mxpk.z, mxpk.w);
+    *reinterpret_cast<uint2*>(p + 2 * OPB) = make_uint2(xpk.x, xpk.y); *reinterpret_cast<uint2*>(p + 2 * OPB + 16 * RS) = make_uint2(xpk.z, xpk.w);
+    *reinterpret_cast<uint2*>(p + 3 * OPB) = make_uint2(ypk.x, ypk.y); *reinterpret_cast<uint2*>(p + 3 * OPB + 16 * RS) = make_uint2(ypk.z, ypk.w);
   };
   const unsigned cbeg = blockIdx.x * (unsigned)cpb, cend = cbeg + (unsigned)cpb < ncell ? cbeg + (unsigned)cpb : ncell;
   auto step = [&](unsigned c0, auto parity) {
@@ -1878,8 +1881,8 @@ __global__ __launch_bounds__(512) void tail_fwd_coarse_kernel(const bf16_t* __re
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int n = 0; n < 3; ++n) {
-        const char* pa = wl + q * OPB + (4 * g + (vi >> 2)) * 96 + (n * 4 + (vi & 3)) * 8;
-        const bf16x4 lo = ds_read_tr16(pa), hi = ds_read_tr16(pa + 16 * 96);
+        const char* pa = wl + q * OPB + (4 * g + (vi >> 2)) * RS + (n * 4 + (vi & 3)) * 8;
+        const bf16x4 lo = ds_read_tr16(pa), hi = ds_read_tr16(pa + 16 * RS);
         Frag<bf16_t> bf;
         bf.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         mma(S[q][n], df, bf);
@@ -1969,7 +1972,7 @@ int k_tail_fwd_coarse(const LossArgs& a, const void* x, const float* stats, cons
   if (e != hipSuccess) return (int)e;
   e = nmh_zero_async(a.bwd_sums, sizeof(double) * ((size_t)a.B * 48 * 4 + 4 * 48), st);
   if (e != hipSuccess) return (int)e;
-  constexpr int LDS = 36 * 1024 + 8 * 4 * 32 * 96 + 8 * 256 + 8 * 256 + 6 * 1024;
+  constexpr int LDS = 36 * 1024 + 8 * 4 * 32 * TAILC_RS + 8 * 256 + 8 * 256 + 6 * 1024;
   static NmhPerDeviceOnce attr_set;
   if (attr_set.need()) {
     e = hipFuncSetAttribute((const void*)tail_fwd_coarse_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
