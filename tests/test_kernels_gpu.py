@@ -706,6 +706,62 @@ def test_tail_forward_with_the_residual_formed_from_the_coarse_tensor(R):
     check(db, br_.grad, dt, "dbout", 2)
 
 
+def test_tail_from_coarse_at_full_size_and_outside_its_domain():
+    """tail_fwd_coarse_kernel at the benched volume (160^3: 40^3 cells, rows of 40 cells against groups of 16, 16 cell ranges per (dz, dy) class, two ragged samples)
+    against the pass that reads the stored residual -- same losses, d(pred), backward sums and sign mask up to the bf16 rounding of r -- and the entry's refusal (-4) of a
+    volume whose cell count is not a multiple of 16 (the caller then stores the residual)."""
+    from nerf_mae_amd._lib import NmhError
+    ops = _ops()
+    dt, B, R, Cd = torch.bfloat16, 2, 160, 48
+    gd, V = R // 4, R ** 3
+    g = torch.Generator(device="cuda").manual_seed(7)
+    y = (torch.randn(B * V, Cd, device="cuda", generator=g) * 1.3 + 0.2).to(dt)
+    xc = torch.randn(B, gd, gd, gd, 96, device="cuda", generator=g).to(dt)
+    Wt, bt = torch.randn(96, 48, 4, 4, 4, device="cuda", generator=g) * 96 ** -0.5, torch.randn(48, device="cuda", generator=g) * 0.5
+    ws = torch.empty(ops.cconv_pack_ws_floats(), dtype=torch.float32, device="cuda")
+    ops.cconv_pack(Wt, torch.randn(48, 48, 3, 3, 3, device="cuda", generator=g), bt, torch.empty(ops.cconv_pack_numel(), dtype=dt, device="cuda"), torch.empty(27, 48, device="cuda"), ws)
+    Wres, Wup = torch.empty(ops.tail_residual_pack_numel(), dtype=dt, device="cuda"), torch.empty(ops.upconv4_pack_numel(), dtype=dt, device="cuda")
+    ops.tail_residual_pack(ws, Wres)
+    ops.upconv4_pack(ws, Wup)
+    r = torch.empty(B * V, Cd, dtype=dt, device="cuda")
+    ops.upconv4_fwd(xc, Wup, bt, r, B, gd)
+    stats = torch.empty(B, Cd, 2, device="cuda")
+    ops.instnorm_stats(y, stats, torch.empty(B, Cd, 2, dtype=torch.float64, device="cuda"), B, V, Cd)
+    Wo, bo = torch.randn(4, Cd, device="cuda", generator=g) * 0.2, torch.randn(4, device="cuda", generator=g) * 0.1
+    x = torch.rand(B, 4, R, R, R, device="cuda", generator=g)
+    ext = torch.tensor([[R, R, R], [R - 7, R - 12, R - 1]], dtype=torch.int32, device="cuda")
+    tm = (torch.rand(gd ** 3, device="cuda", generator=g) < 0.75).to(torch.uint8)
+    outs = []
+    for coarse in (True, False):
+        lsums, losses, dpred = torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda"), torch.full((B * V, 4), 7.0, device="cuda")
+        bsum, smask = torch.empty(B * Cd * 4 + 4 * Cd, dtype=torch.float64, device="cuda"), torch.full((B * V, 8), 0xAA, dtype=torch.uint8, device="cuda")
+        if coarse:
+            ops.mae_tail_fwd_from_coarse(y, stats, xc, Wres, bt, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, dpred, bsum, smask)
+        else:
+            ops.mae_tail_fwd(y, stats, r, None, Wo, bo, x, ext, tm, B, R, Cd, lsums, losses, None, dpred, bwd_sums=bsum, sign_mask=smask)
+        torch.cuda.synchronize()
+        outs.append((lsums, losses, dpred, bsum, smask))
+    (ls1, lo1, dp1, bs1, sm1), (ls0, lo0, dp0, bs0, sm0) = outs
+    np.testing.assert_allclose(lo1.cpu().numpy(), lo0.cpu().numpy(), rtol=2e-3)
+    np.testing.assert_allclose(ls1.cpu().numpy(), ls0.cpu().numpy(), rtol=5e-3, atol=1e-3 * float(ls0.abs().max()))
+    assert (dp1 == 7.0).sum().item() == 0                      # every voxel written
+    diff = (dp1 - dp0).abs()
+    assert diff.max().item() < 0.25 and diff.mean().item() < 2e-3 * dp0.abs().mean().item() + 1e-4, (diff.max().item(), diff.mean().item(), dp0.abs().mean().item())
+    assert ((dp1 != 0) != (dp0 != 0)).float().mean().item() < 1e-5   # the same voxels are inside the loss regions
+    assert torch.allclose(bs1, bs0, rtol=2e-2, atol=2e-3 * float(bs0.abs().max()))
+    assert ((sm1[:, :6] != sm0[:, :6]).sum().item()) < 2e-3 * B * V * 6   # sign bits differ only where x-hat + r cancels to the rounding of r
+    # outside the domain: 24^3 has 216 cells -- the host wrapper and the C entry both refuse
+    from nerf_mae_amd._lib import lib
+    R2 = 24
+    a2 = (y[:R2 ** 3], stats[:1], xc.view(-1, 96)[:216].contiguous(), Wres, bt, Wo, bo, x[:1, :, :R2, :R2, :R2].contiguous(), ext[:1], tm[:216])
+    o2 = (torch.empty(8, dtype=torch.float64, device="cuda"), torch.empty(3, device="cuda"), torch.empty(R2 ** 3, 4, device="cuda"),
+          torch.empty(Cd * 4 + 4 * Cd, dtype=torch.float64, device="cuda"), torch.empty(R2 ** 3, 8, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.mae_tail_fwd_from_coarse(*a2[:2], a2[2].view(1, 6, 6, 6, 96), *a2[3:], 1, R2, Cd, *o2)
+    with pytest.raises(NmhError):
+        lib().call("nmh_mae_tail_fwd_from_coarse", ops.dt_of(y), *a2, 1, R2, Cd, o2[0], o2[1], None, o2[2], 0.01, o2[3], o2[4], ops._st())
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_instnorm_bwd_without_out(dt):
     """rmode 0: sign(out) == sign(x - mean), so `out` may be omitted."""
